@@ -1,0 +1,117 @@
+"""ctypes loader for ``libcnmf_hip.so`` (the C-ABI declared in include/cnmf_hip.h).
+
+The library is built IN-TREE (``cnmf_amd/libcnmf_hip.so``) by ``build()`` below /
+``__graft_entry__.build()`` with ``hipcc --offload-arch=gfx950``.  There is no CPU
+fallback anywhere in this package: if the shared object is missing or no GPU is
+visible, the product path raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcnmf_hip.so")
+SRC_DIR = os.path.join(_HERE, "csrc")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+# every symbol include/cnmf_hip.h declares (tests/test_abi.py checks the header against this)
+SYMBOLS = [
+    "cnmf_device_count", "cnmf_create", "cnmf_destroy", "cnmf_last_error", "cnmf_version",
+    "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_get_shape",
+    "cnmf_nmf_cd_batch", "cnmf_nmf_cd_batch_resident", "cnmf_nnls",
+    "cnmf_debug_gemm", "cnmf_debug_standard_normal",
+]
+
+CNMF_KMAX = 32
+
+
+class CdParams(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("kc_max", C.c_int),
+                ("l1_reg_W", C.c_double), ("l2_reg_W", C.c_double),
+                ("l1_reg_H", C.c_double), ("l2_reg_H", C.c_double),
+                ("lag", C.c_int), ("reserved", C.c_int)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("outer_iterations", C.c_int64), ("restart_iterations", C.c_int64),
+                ("column_iterations", C.c_int64), ("gpu_ms", C.c_double),
+                ("passA_ms", C.c_double), ("passB_ms", C.c_double),
+                ("passA_launches", C.c_int64), ("passB_launches", C.c_int64),
+                ("kc", C.c_int32), ("nsplit", C.c_int32)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+def sources():
+    return sorted(os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR))
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + [os.path.join(INCLUDE_DIR, "cnmf_hip.h")]
+    return any(os.path.getmtime(s) > t for s in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/cnmf_hip.hip for gfx950 into cnmf_amd/libcnmf_hip.so (in-tree)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-value", "-Wno-unused-result",
+           os.path.join(SRC_DIR, "cnmf_hip.hip"), "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the shared object and declare the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "cnmf_amd: %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32p, dblp = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_double)
+    i32p, u32p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    lib.cnmf_device_count.restype = i32
+    lib.cnmf_create.restype = vp
+    lib.cnmf_create.argtypes = [i32]
+    lib.cnmf_destroy.restype = None
+    lib.cnmf_destroy.argtypes = [vp]
+    lib.cnmf_last_error.restype = C.c_char_p
+    lib.cnmf_last_error.argtypes = [vp]
+    lib.cnmf_version.restype = C.c_char_p
+    lib.cnmf_set_matrix.restype = i32
+    lib.cnmf_set_matrix.argtypes = [vp, f32p, i64, i64]
+    lib.cnmf_set_matrix_csr.restype = i32
+    lib.cnmf_set_matrix_csr.argtypes = [vp, i32p, i32p, f32p, i64, i64]
+    lib.cnmf_get_shape.restype = i32
+    lib.cnmf_get_shape.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    lib.cnmf_nmf_cd_batch.restype = i32
+    lib.cnmf_nmf_cd_batch.argtypes = [vp, i32, i32p, i32, u32p, dblp, f32p, f32p,
+                                      C.POINTER(CdParams), f32p, f32p, i32p, dblp,
+                                      C.POINTER(BatchStats)]
+    lib.cnmf_nmf_cd_batch_resident.restype = i32
+    lib.cnmf_nmf_cd_batch_resident.argtypes = [vp, i32, i32p, i32, u32p, dblp, f32p, f32p,
+                                               C.POINTER(CdParams), i32p, dblp,
+                                               C.POINTER(BatchStats)]
+    lib.cnmf_nnls.restype = i32
+    lib.cnmf_nnls.argtypes = [vp, i32, f32p, C.POINTER(CdParams), f32p, i32p, dblp]
+    lib.cnmf_debug_gemm.restype = i32
+    lib.cnmf_debug_gemm.argtypes = [vp, i32, i32, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
+    lib.cnmf_debug_standard_normal.restype = i32
+    lib.cnmf_debug_standard_normal.argtypes = [vp, C.c_uint32, i64, dblp]
+    _lib = lib
+    return lib

@@ -1,0 +1,795 @@
+// libcnmf_hip.so : C-ABI + host runtime of the MI355X-native consensus-NMF engine.
+//
+// Runtime model (one context per GPU, one host thread per context):
+//   * X lives zero-padded in HBM for the life of the context ([N_pad][G_pad] fp32).
+//   * A batch call packs as many restarts as fit into KC component columns
+//     ("slots"), and runs the coordinate-descent outer iteration for ALL of them with
+//     two MFMA passes over X per iteration (kernels_gemm.hip.h) + lane-per-row sweeps
+//     (kernels_sweep.hip.h).  The stopping rule runs on the device; a converged slot
+//     freezes itself at exactly sklearn's iteration.  The host looks at a pinned
+//     snapshot `lag` iterations behind the GPU, retires finished slots and refills
+//     them from the pending list (a persistent work queue of restarts), so the batch
+//     never runs at the speed of its slowest member.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cnmf_hip.h"
+#include "kernels_gemm.hip.h"
+#include "kernels_rng.hip.h"
+#include "kernels_sweep.hip.h"
+
+using namespace cnmf;
+
+static thread_local std::string g_last_error;
+
+struct cnmf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // data matrix
+    int64_t N = 0, G = 0;
+    int N_pad = 0, G_pad = 0;
+    float* X = nullptr;
+
+    // batch buffers (sized for kc_alloc columns)
+    int kc_alloc = 0, nsplit_alloc = 0, parts_alloc = 0;
+    float *H = nullptr, *Wt = nullptr, *XHt = nullptr, *XtW = nullptr;
+    float *gramH = nullptr, *gramW = nullptr, *gram_part = nullptr;
+    double* viol_part = nullptr;
+    SlotDesc* d_slots = nullptr;
+    int* d_slot_list = nullptr;
+    SlotDesc* h_slots = nullptr;      // pinned: per-slot install descriptors
+    SlotDesc* h_snap = nullptr;       // pinned: snapshot ring [RING][kc_alloc]
+    int* h_slot_list = nullptr;       // pinned ring of new-slot lists
+    float *stageW = nullptr, *stageH = nullptr;
+    size_t stageW_sz = 0, stageH_sz = 0;
+
+    // resident spectra store (device) for the gather / consensus
+    float* spectra = nullptr;
+    size_t spectra_cap = 0, spectra_rows = 0;
+};
+
+static constexpr int RING = 8;
+
+#define SET_ERR(ctx, ...)                                                   \
+    do {                                                                    \
+        char buf_[512];                                                     \
+        snprintf(buf_, sizeof buf_, __VA_ARGS__);                           \
+        if (ctx) (ctx)->err = buf_;                                         \
+        g_last_error = buf_;                                                \
+    } while (0)
+
+#define HIP_TRY(ctx, call)                                                  \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) {                                             \
+            SET_ERR(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? CNMF_ENOMEM : CNMF_EHIP;   \
+        }                                                                   \
+    } while (0)
+
+static inline int round_up(int64_t v, int m) { return (int)(((v + m - 1) / m) * m); }
+
+// ------------------------------------------------------------------ GEMM dispatch
+// variant : 0 = auto; 1 = "S" (waves split components, 32 j per workgroup);
+//           2 = "T" (every wave owns all the workgroup's components, 128 j per workgroup)
+//           3 = 2x2 wave grid (64 j per workgroup)
+struct GemmPlan { int variant; int mw; int jw; };
+
+template <int MTW, int WM, int WN, bool NN>
+static hipError_t launch_gemm_t(hipStream_t st, const float* A, int lda, const float* B, int ldb,
+                                float* C, int ldc, long long cstride, int KC, int Ktot, int J,
+                                int nsplit)
+{
+    constexpr int MW = WM * MTW * 32, JW = WN * 32;
+    const int Kper = round_up((Ktot + nsplit - 1) / nsplit, BK);
+    dim3 grid((J + JW - 1) / JW, KC / MW, nsplit);
+    static bool attr_set = false;
+    constexpr size_t lds = gemm_lds_bytes<MTW, WM, WN, NN>();
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_kernel<MTW, WM, WN, NN>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    gemm_kernel<MTW, WM, WN, NN><<<grid, 256, lds, st>>>(A, lda, B, ldb, C, ldc, cstride, Kper,
+                                                        Ktot, J);
+    return hipGetLastError();
+}
+
+template <bool NN>
+static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int lda, const float* B,
+                              int ldb, float* C, int ldc, long long cstride, int KC, int Ktot,
+                              int J, int nsplit)
+{
+#define GO(MTW, WM, WN) \
+    return launch_gemm_t<MTW, WM, WN, NN>(st, A, lda, B, ldb, C, ldc, cstride, KC, Ktot, J, nsplit)
+    if (variant == 0) variant = NN ? 2 : (KC >= 128 ? 1 : 2);
+    if (variant == 1 && KC < 128) variant = (KC >= 64) ? 3 : 2;
+    if (variant == 3 && KC < 64) variant = 2;
+    switch (variant) {
+        case 1:  // S: 4 waves x (MTW tiles of 32 comps), 32 j
+            if (KC % 256 == 0 && KC >= 256 && getenv("CNMF_S_MTW2")) GO(2, 4, 1);
+            GO(1, 4, 1);
+        case 3:  // 2x2
+            if (KC % 128 == 0) GO(2, 2, 2);
+            GO(1, 2, 2);
+        default:  // T: every wave all comps of the M group, 128 j
+            if (KC % 128 == 0) GO(4, 1, 4);
+            if (KC % 64 == 0) GO(2, 1, 4);
+            GO(1, 1, 4);
+    }
+#undef GO
+}
+
+// ------------------------------------------------------------------ sweep dispatch
+static hipError_t launch_sweep(hipStream_t st, unsigned kp_mask, int nslots, float* V, int ldv,
+                               int L, const float* P, int nsplit, long long pstride,
+                               const float* gram, const SlotDesc* slots, float l1,
+                               float* gram_part, double* viol_part, int chunks, int parts,
+                               int want_gram)
+{
+    dim3 grid(parts, nslots);
+#define SW(KP)                                                                                   \
+    if (kp_mask & (1u << (KP / 4)))                                                              \
+        sweep_kernel<KP><<<grid, 256, 0, st>>>(V, ldv, L, P, nsplit, pstride, gram, slots, l1,   \
+                                               gram_part, viol_part, chunks, want_gram);
+    SW(4) SW(8) SW(12) SW(16) SW(20) SW(24) SW(28) SW(32)
+#undef SW
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ lifecycle
+extern "C" int cnmf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* cnmf_version(void) { return "cnmf_hip 0.1.0 (gfx950)"; }
+
+extern "C" const char* cnmf_last_error(const cnmf_ctx* ctx)
+{
+    return ctx ? ctx->err.c_str() : g_last_error.c_str();
+}
+
+extern "C" cnmf_ctx* cnmf_create(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        SET_ERR((cnmf_ctx*)nullptr, "no HIP device available (%s)", hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        SET_ERR((cnmf_ctx*)nullptr, "device %d out of range (have %d)", device, n);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        SET_ERR((cnmf_ctx*)nullptr, "hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    cnmf_ctx* ctx = new cnmf_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        SET_ERR((cnmf_ctx*)nullptr, "hipStreamCreate failed");
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+static void free_batch(cnmf_ctx* c)
+{
+    hipFree(c->H); hipFree(c->Wt); hipFree(c->XHt); hipFree(c->XtW);
+    hipFree(c->gramH); hipFree(c->gramW); hipFree(c->gram_part); hipFree(c->viol_part);
+    hipFree(c->d_slots); hipFree(c->d_slot_list);
+    if (c->h_slots) hipHostFree(c->h_slots);
+    if (c->h_snap) hipHostFree(c->h_snap);
+    if (c->h_slot_list) hipHostFree(c->h_slot_list);
+    c->H = c->Wt = c->XHt = c->XtW = c->gramH = c->gramW = c->gram_part = nullptr;
+    c->viol_part = nullptr; c->d_slots = nullptr; c->d_slot_list = nullptr;
+    c->h_slots = c->h_snap = nullptr; c->h_slot_list = nullptr;
+    c->kc_alloc = 0;
+}
+
+extern "C" void cnmf_destroy(cnmf_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    free_batch(ctx);
+    hipFree(ctx->X); hipFree(ctx->stageW); hipFree(ctx->stageH); hipFree(ctx->spectra);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+// ------------------------------------------------------------------ data matrix
+static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
+{
+    if (N <= 0 || G <= 0 || N > (1ll << 30) || G > (1ll << 24)) {
+        SET_ERR(ctx, "bad matrix shape %lld x %lld", (long long)N, (long long)G);
+        return CNMF_EINVAL;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    free_batch(ctx);
+    hipFree(ctx->X); ctx->X = nullptr;
+    ctx->N = N; ctx->G = G;
+    ctx->N_pad = round_up(N, 128);
+    ctx->G_pad = round_up(G, 32);
+    // +128 columns of slack so pass B's last 128-gene tile may be addressed (never read: guarded)
+    const size_t bytes = (size_t)ctx->N_pad * ctx->G_pad * sizeof(float);
+    HIP_TRY(ctx, hipMalloc(&ctx->X, bytes));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->X, 0, bytes, ctx->stream));
+    return CNMF_OK;
+}
+
+extern "C" int cnmf_set_matrix(cnmf_ctx* ctx, const float* X, int64_t N, int64_t G)
+{
+    if (!ctx || !X) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    int rc = alloc_matrix(ctx, N, G);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->X, (size_t)ctx->G_pad * sizeof(float), X,
+                                  (size_t)G * sizeof(float), (size_t)G * sizeof(float), (size_t)N,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNMF_OK;
+}
+
+__global__ void csr_densify_kernel(const int* __restrict__ indptr, const int* __restrict__ indices,
+                                   const float* __restrict__ data, float* __restrict__ X, int ld,
+                                   int n_rows)
+{
+    const int row = blockIdx.x;
+    if (row >= n_rows) return;
+    const int b = indptr[row], e = indptr[row + 1];
+    for (int p = b + threadIdx.x; p < e; p += blockDim.x)
+        atomicAdd(&X[(size_t)row * ld + indices[p]], data[p]);   // duplicates sum, like .toarray()
+}
+
+extern "C" int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const int32_t* indices,
+                                   const float* data, int64_t N, int64_t G)
+{
+    if (!ctx || !indptr || (!indices && indptr[N] > 0) || (!data && indptr[N] > 0)) {
+        SET_ERR(ctx, "null argument");
+        return CNMF_EINVAL;
+    }
+    int rc = alloc_matrix(ctx, N, G);
+    if (rc) return rc;
+    const int64_t nnz = indptr[N];
+    int *d_ptr = nullptr, *d_idx = nullptr;
+    float* d_val = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_ptr, (size_t)(N + 1) * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc(&d_idx, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc(&d_val, (size_t)std::max<int64_t>(nnz, 1) * sizeof(float)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_ptr, indptr, (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if (nnz > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_idx, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_val, data, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        csr_densify_kernel<<<(unsigned)N, 64, 0, ctx->stream>>>(d_ptr, d_idx, d_val, ctx->X, ctx->G_pad, (int)N);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d_ptr); hipFree(d_idx); hipFree(d_val);
+    return CNMF_OK;
+}
+
+extern "C" int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* N, int64_t* G)
+{
+    if (!ctx) return CNMF_EINVAL;
+    if (N) *N = ctx->N;
+    if (G) *G = ctx->G;
+    return ctx->X ? CNMF_OK : CNMF_ESTATE;
+}
+
+// ------------------------------------------------------------------ batch buffers
+static int sweep_chunks(int L) { return std::max(1, (int)(((int64_t)L + 256 * 64 - 1) / (256 * 64))); }
+static int sweep_parts(int L) { int c = sweep_chunks(L); return (L + 256 * c - 1) / (256 * c); }
+
+static int pick_nsplit(const cnmf_ctx* ctx, int KC)
+{
+    if (const char* s = getenv("CNMF_NSPLIT")) { int v = atoi(s); if (v > 0) return v; }
+    // pass B grid = ceil(G_pad/128) x (KC/128 or 1) x nsplit ; aim at ~2 workgroups per CU
+    const int jt = (ctx->G_pad + 127) / 128;
+    const int mg = std::max(1, KC / 128);
+    int s = std::max(1, 512 / (jt * mg));
+    const int max_by_k = std::max(1, ctx->N_pad / 256);   // at least 256 cells of K per split
+    return std::min(s, max_by_k);
+}
+
+static int ensure_batch(cnmf_ctx* ctx, int KC)
+{
+    const int nsplit = pick_nsplit(ctx, KC);
+    const int parts = std::max(sweep_parts((int)ctx->N), sweep_parts((int)ctx->G));
+    if (ctx->kc_alloc == KC && ctx->nsplit_alloc == nsplit && ctx->parts_alloc == parts) return CNMF_OK;
+    free_batch(ctx);
+    const size_t hb = (size_t)KC * ctx->G_pad * sizeof(float);
+    const size_t wb = (size_t)KC * ctx->N_pad * sizeof(float);
+    HIP_TRY(ctx, hipMalloc(&ctx->H, hb));
+    HIP_TRY(ctx, hipMalloc(&ctx->Wt, wb));
+    HIP_TRY(ctx, hipMalloc(&ctx->XHt, wb));
+    HIP_TRY(ctx, hipMalloc(&ctx->XtW, hb * nsplit));
+    HIP_TRY(ctx, hipMalloc(&ctx->gramH, (size_t)KC * GRAM_SZ * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(&ctx->gramW, (size_t)KC * GRAM_SZ * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(&ctx->gram_part, (size_t)KC * parts * GRAM_SZ * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(&ctx->viol_part, (size_t)KC * parts * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_slots, (size_t)KC * sizeof(SlotDesc)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_slot_list, (size_t)KC * RING * sizeof(int)));
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_slots, (size_t)KC * sizeof(SlotDesc)));
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_snap, (size_t)KC * RING * sizeof(SlotDesc)));
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_slot_list, (size_t)KC * RING * sizeof(int)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, hb, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->Wt, 0, wb, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->XHt, 0, wb, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->XtW, 0, hb * nsplit, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_slots, 0, (size_t)KC * sizeof(SlotDesc), ctx->stream));
+    ctx->kc_alloc = KC; ctx->nsplit_alloc = nsplit; ctx->parts_alloc = parts;
+    return CNMF_OK;
+}
+
+static int ensure_stage(cnmf_ctx* ctx, size_t wfloats, size_t hfloats)
+{
+    if (wfloats > ctx->stageW_sz) {
+        hipFree(ctx->stageW); ctx->stageW = nullptr;
+        HIP_TRY(ctx, hipMalloc(&ctx->stageW, wfloats * sizeof(float)));
+        ctx->stageW_sz = wfloats;
+    }
+    if (hfloats > ctx->stageH_sz) {
+        hipFree(ctx->stageH); ctx->stageH = nullptr;
+        HIP_TRY(ctx, hipMalloc(&ctx->stageH, hfloats * sizeof(float)));
+        ctx->stageH_sz = hfloats;
+    }
+    return CNMF_OK;
+}
+
+// simple first-fit interval allocator over the packed component columns
+struct ColAlloc {
+    std::vector<std::pair<int, int>> free_;   // (begin, length), sorted by begin
+    explicit ColAlloc(int n) { free_.push_back({0, n}); }
+    int alloc(int k) {
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].second >= k) {
+                int b = free_[i].first;
+                free_[i].first += k; free_[i].second -= k;
+                if (free_[i].second == 0) free_.erase(free_.begin() + i);
+                return b;
+            }
+        return -1;
+    }
+    void release(int b, int k) {
+        auto it = std::lower_bound(free_.begin(), free_.end(), std::make_pair(b, 0));
+        it = free_.insert(it, {b, k});
+        if (it + 1 != free_.end() && it->first + it->second == (it + 1)->first) {
+            it->second += (it + 1)->second; free_.erase(it + 1);
+        }
+        if (it != free_.begin() && (it - 1)->first + (it - 1)->second == it->first) {
+            (it - 1)->second += it->second; free_.erase(it);
+        }
+    }
+};
+
+struct HostSlot { int state = 0; int restart = -1; int off = 0; int k = 0; int64_t installed_at = 0; };
+
+static int pick_kc(int64_t total_k, int max_k, int kc_max)
+{
+    if (kc_max <= 0) kc_max = 256;
+    if (const char* s = getenv("CNMF_KC")) { int v = atoi(s); if (v >= 32) kc_max = v; }
+    kc_max = std::max(32, std::min(256, (kc_max / 32) * 32));
+    int kc = 32;
+    while (kc < kc_max && kc < total_k) kc *= 2;
+    kc = std::min(kc, kc_max);
+    if (kc < max_k) kc = round_up(max_k, 32);
+    return kc;
+}
+
+static int validate_params(cnmf_ctx* ctx, const cnmf_cd_params* p)
+{
+    if (!p) { SET_ERR(ctx, "params is NULL"); return CNMF_EINVAL; }
+    if (!(p->tol >= 0) || p->max_iter < 1) { SET_ERR(ctx, "bad tol/max_iter"); return CNMF_EINVAL; }
+    if (p->l1_reg_W < 0 || p->l2_reg_W < 0 || p->l1_reg_H < 0 || p->l2_reg_H < 0) {
+        SET_ERR(ctx, "negative regularisation"); return CNMF_EINVAL;
+    }
+    return CNMF_OK;
+}
+
+// ------------------------------------------------------------------ the restart hot loop
+static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, const uint32_t* seeds,
+                     const double* avg, const float* W0, const float* H0, const cnmf_cd_params* prm,
+                     float* H_out, float* W_out, bool resident, int32_t* n_iter_out,
+                     double* viol_out, cnmf_batch_stats* stats)
+{
+    if (!ctx) { SET_ERR(ctx, "ctx is NULL"); return CNMF_EINVAL; }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    int rc = validate_params(ctx, prm);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !kk)) { SET_ERR(ctx, "bad restart list"); return CNMF_EINVAL; }
+    if (init_mode == 0 && n > 0 && (!W0 || !H0)) { SET_ERR(ctx, "init_mode 0 needs W0 and H0"); return CNMF_EINVAL; }
+    if (init_mode == 1 && n > 0 && (!seeds || !avg)) { SET_ERR(ctx, "init_mode 1 needs seeds and avg"); return CNMF_EINVAL; }
+    if (init_mode != 0 && init_mode != 1) { SET_ERR(ctx, "unknown init_mode %d", init_mode); return CNMF_EINVAL; }
+    if (!resident && n > 0 && !H_out) { SET_ERR(ctx, "H_out is NULL"); return CNMF_EINVAL; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (n == 0) return CNMF_OK;
+
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    int64_t total_k = 0; int max_k = 0;
+    std::vector<size_t> hoff(n + 1, 0), woff(n + 1, 0);
+    for (int r = 0; r < n; ++r) {
+        if (kk[r] < 1) { SET_ERR(ctx, "n_components must be >= 1 (restart %d)", r); return CNMF_EINVAL; }
+        if (kk[r] > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d is not supported by the device sweep", kk[r], KMAX); return CNMF_EUNSUPPORTED; }
+        total_k += kk[r]; max_k = std::max(max_k, (int)kk[r]);
+        hoff[r + 1] = hoff[r] + (size_t)kk[r] * G;
+        woff[r + 1] = woff[r] + (size_t)kk[r] * N;
+    }
+    const int KC = pick_kc(total_k, max_k, prm->kc_max);
+    rc = ensure_batch(ctx, KC);
+    if (rc) return rc;
+    rc = ensure_stage(ctx, (size_t)N * KMAX, (size_t)G * KMAX);
+    if (rc) return rc;
+    const int nsplit = ctx->nsplit_alloc;
+    const int lag = std::max(1, std::min(RING - 2, prm->lag > 0 ? prm->lag : 2));
+    hipStream_t st = ctx->stream;
+
+    // device result buffers
+    float* d_Hres = nullptr; float* d_Wres = nullptr;
+    if (resident) {
+        const size_t need = (ctx->spectra_rows + (size_t)total_k) * G;
+        if (need > ctx->spectra_cap) {
+            float* nb = nullptr;
+            const size_t cap = std::max(need, ctx->spectra_cap * 2);
+            HIP_TRY(ctx, hipMalloc(&nb, cap * sizeof(float)));
+            if (ctx->spectra_rows)
+                HIP_TRY(ctx, hipMemcpyAsync(nb, ctx->spectra, ctx->spectra_rows * G * sizeof(float), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            hipFree(ctx->spectra);
+            ctx->spectra = nb; ctx->spectra_cap = cap;
+        }
+        d_Hres = ctx->spectra + ctx->spectra_rows * G;
+    } else {
+        HIP_TRY(ctx, hipMalloc(&d_Hres, hoff[n] * sizeof(float)));
+    }
+    if (W_out) HIP_TRY(ctx, hipMalloc(&d_Wres, woff[n] * sizeof(float)));
+
+    // init_mode 1: sklearn's init='random' for EVERY restart of the call, generated up front on the
+    // device (one workgroup per restart) into a component-major store; install = row copy.
+    float *d_H0 = nullptr, *d_Wt0 = nullptr;
+    RngJob* d_jobs = nullptr;
+    if (init_mode == 1) {
+        HIP_TRY(ctx, hipMalloc(&d_H0, hoff[n] * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(&d_Wt0, woff[n] * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(&d_jobs, (size_t)n * sizeof(RngJob)));
+        std::vector<RngJob> jobs(n);
+        int rowoff = 0;
+        for (int r = 0; r < n; ++r) {
+            jobs[r] = RngJob{seeds[r], kk[r], rowoff, avg[r], (long long)kk[r] * ((long long)G + N)};
+            rowoff += kk[r];
+        }
+        HIP_TRY(ctx, hipMemcpy(d_jobs, jobs.data(), (size_t)n * sizeof(RngJob), hipMemcpyHostToDevice));
+        rng_kernel<1><<<n, 256, 0, st>>>(d_jobs, nullptr, d_H0, G, G, d_Wt0, N, N);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+
+    // restarts in descending rank so that freed slots can always be reused
+    std::vector<int> order(n);
+    for (int r = 0; r < n; ++r) order[r] = r;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kk[a] > kk[b]; });
+    size_t next = 0;
+
+    ColAlloc cols(KC);
+    std::vector<HostSlot> hs(KC);
+    int nslots = 0;          // highest used slot index + 1
+    int n_active = 0;
+    int64_t it = 0;          // batch iterations enqueued so far
+    std::vector<hipEvent_t> ev(RING);
+    for (auto& e : ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t ev_begin, ev_end;
+    HIP_TRY(ctx, hipEventCreate(&ev_begin));
+    HIP_TRY(ctx, hipEventCreate(&ev_end));
+    HIP_TRY(ctx, hipEventRecord(ev_begin, st));
+    const bool time_gemm = stats && getenv("CNMF_TIME_GEMM");
+    std::vector<hipEvent_t> gev;   // (a0,a1,b0,b1) per iteration when timing is requested
+
+    const int chunksW = sweep_chunks(N), partsW = sweep_parts(N);
+    const int chunksH = sweep_chunks(G), partsH = sweep_parts(G);
+    const float l1W = (float)prm->l1_reg_W, l2W = (float)prm->l2_reg_W;
+    const float l1H = (float)prm->l1_reg_H, l2H = (float)prm->l2_reg_H;
+    const int gvarA = getenv("CNMF_GEMM_A") ? atoi(getenv("CNMF_GEMM_A")) : 0;
+    const int gvarB = getenv("CNMF_GEMM_B") ? atoi(getenv("CNMF_GEMM_B")) : 0;
+    int64_t restart_iters = 0, column_iters = 0;
+    int n_done = 0;
+
+    auto retire = [&](int s, const SlotDesc& snap) -> int {
+        HostSlot& h = hs[s];
+        const int r = h.restart, k = h.k;
+        dim3 gH((G + 255) / 256, k), gW((N + 255) / 256, k);
+        extract_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, G, h.off, k, d_Hres + hoff[r], 0);
+        if (d_Wres) extract_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, h.off, k, d_Wres + woff[r], 1);
+        clear_rows_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, h.off, k);
+        clear_rows_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, h.off, k);
+        HIP_TRY(ctx, hipGetLastError());
+        if (n_iter_out) n_iter_out[r] = snap.iter;
+        if (viol_out) viol_out[r] = snap.viol_last;
+        restart_iters += snap.iter;
+        cols.release(h.off, k);
+        h.state = 0; h.restart = -1;
+        --n_active; ++n_done;
+        return CNMF_OK;
+    };
+
+    while (true) {
+        // ---- refill free columns from the pending list
+        int n_new = 0;
+        int* new_list = ctx->h_slot_list + (size_t)(it % RING) * KC;
+        while (next < order.size()) {
+            const int r = order[next], k = kk[r];
+            const int off = cols.alloc(k);
+            if (off < 0) break;
+            int s = 0;
+            while (s < KC && hs[s].state != 0) ++s;
+            hs[s].state = 1; hs[s].restart = r; hs[s].off = off; hs[s].k = k; hs[s].installed_at = it;
+            nslots = std::max(nslots, s + 1);
+            dim3 gI((std::max(N, G) + 255) / 256, k);
+            if (init_mode == 0) {
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->stageH, H0 + hoff[r], (size_t)k * G * sizeof(float), hipMemcpyHostToDevice, st));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->stageW, W0 + woff[r], (size_t)k * N * sizeof(float), hipMemcpyHostToDevice, st));
+                install_kernel<<<gI, 256, 0, st>>>(ctx->stageH, ctx->stageW, ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, off, k);
+            } else {
+                install_cm_kernel<<<gI, 256, 0, st>>>(d_H0 + hoff[r], d_Wt0 + woff[r], ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, off);
+            }
+            HIP_TRY(ctx, hipGetLastError());
+            SlotDesc* d = &ctx->h_slots[s];
+            memset(d, 0, sizeof *d);
+            d->off = off; d->k = k; d->active = 1; d->iter = 0; d->restart = r;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots + s, d, sizeof(SlotDesc), hipMemcpyHostToDevice, st));
+            new_list[n_new++] = s;
+            ++n_active; ++next;
+        }
+        if (n_new) {
+            int* dl = ctx->d_slot_list + (size_t)(it % RING) * KC;
+            HIP_TRY(ctx, hipMemcpyAsync(dl, new_list, n_new * sizeof(int), hipMemcpyHostToDevice, st));
+            gram_rows_kernel<<<n_new, 256, 0, st>>>(ctx->H, ctx->G_pad, G, ctx->d_slots, dl, ctx->gramH, l2W);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        if (n_active == 0 && next >= order.size()) break;
+
+        // ---- one coordinate-descent outer iteration for every slot in flight
+        unsigned kp_mask = 0;
+        for (int s = 0; s < nslots; ++s)
+            if (hs[s].state) kp_mask |= 1u << ((hs[s].k + 3) / 4);
+        if (time_gemm) { gev.resize(gev.size() + 4); for (int i = 0; i < 4; ++i) hipEventCreate(&gev[gev.size() - 4 + i]); hipEventRecord(gev[gev.size() - 4], st); }
+        // pass A : XHt[KC][N] = H_all . X^T                       (sklearn _nmf.py:387)
+        HIP_TRY(ctx, launch_gemm<false>(st, gvarA, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt,
+                                        ctx->N_pad, 0, KC, ctx->G_pad, ctx->N_pad, 1));
+        if (time_gemm) hipEventRecord(gev[gev.size() - 3], st);
+        // W half-step                                             (sklearn _nmf.py:500)
+        HIP_TRY(ctx, launch_sweep(st, kp_mask, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, 1, 0,
+                                  ctx->gramH, ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part,
+                                  chunksW, partsW, 1));
+        finalize_kernel<<<nslots, 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
+                                                ctx->d_slots, 0, prm->tol, prm->max_iter, 1);
+        if (time_gemm) hipEventRecord(gev[gev.size() - 2], st);
+        // pass B : XtW[S][KC][G] = Wt_all . X  (split over cells)  (sklearn _nmf.py:505-507)
+        HIP_TRY(ctx, launch_gemm<true>(st, gvarB, ctx->Wt, ctx->N_pad, ctx->X, ctx->G_pad, ctx->XtW,
+                                       ctx->G_pad, (long long)KC * ctx->G_pad, KC, ctx->N_pad,
+                                       ctx->G_pad, nsplit));
+        if (time_gemm) hipEventRecord(gev[gev.size() - 1], st);
+        // H half-step
+        HIP_TRY(ctx, launch_sweep(st, kp_mask, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, nsplit,
+                                  (long long)KC * ctx->G_pad, ctx->gramW, ctx->d_slots, l1H,
+                                  ctx->gram_part, ctx->viol_part, chunksH, partsH, 1));
+        finalize_kernel<<<nslots, 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W,
+                                                ctx->d_slots, 1, prm->tol, prm->max_iter, 1);
+        HIP_TRY(ctx, hipGetLastError());
+        column_iters += KC;
+
+        // ---- snapshot of the slot table, examined `lag` iterations later
+        SlotDesc* snap = ctx->h_snap + (size_t)(it % RING) * KC;
+        HIP_TRY(ctx, hipMemcpyAsync(snap, ctx->d_slots, (size_t)nslots * sizeof(SlotDesc), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipEventRecord(ev[it % RING], st));
+        ++it;
+        // catch up: everything older than `lag` must be inspected; drain fully when idle
+        {
+            const int64_t si = it - 1 - lag;   // snapshot index to inspect now
+            if (si >= 0) {
+                HIP_TRY(ctx, hipEventSynchronize(ev[si % RING]));
+                const SlotDesc* sp = ctx->h_snap + (size_t)(si % RING) * KC;
+                for (int s = 0; s < nslots; ++s)
+                    if (hs[s].state == 1 && hs[s].installed_at <= si && sp[s].active == 0 && sp[s].restart == hs[s].restart) {
+                        rc = retire(s, sp[s]);
+                        if (rc) return rc;
+                    }
+            }
+        }
+    }
+
+    HIP_TRY(ctx, hipEventRecord(ev_end, st));
+    if (!resident)
+        HIP_TRY(ctx, hipMemcpyAsync(H_out, d_Hres, hoff[n] * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (W_out)
+        HIP_TRY(ctx, hipMemcpyAsync(W_out, d_Wres, woff[n] * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (resident) ctx->spectra_rows += (size_t)total_k;
+    else hipFree(d_Hres);
+    hipFree(d_Wres);
+    hipFree(d_H0); hipFree(d_Wt0); hipFree(d_jobs);
+    if (stats) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, ev_begin, ev_end);
+        stats->gpu_ms = ms;
+        stats->outer_iterations = it;
+        stats->restart_iterations = restart_iters;
+        stats->column_iterations = column_iters;
+        stats->kc = KC; stats->nsplit = nsplit;
+        for (size_t i = 0; i + 3 < gev.size(); i += 4) {
+            float a = 0.f, b = 0.f;
+            hipEventElapsedTime(&a, gev[i], gev[i + 1]);
+            hipEventElapsedTime(&b, gev[i + 2], gev[i + 3]);
+            stats->passA_ms += a; stats->passB_ms += b;
+            stats->passA_launches++; stats->passB_launches++;
+        }
+    }
+    for (auto& e : gev) hipEventDestroy(e);
+    for (auto& e : ev) hipEventDestroy(e);
+    hipEventDestroy(ev_begin); hipEventDestroy(ev_end);
+    return CNMF_OK;
+}
+
+extern "C" int cnmf_nmf_cd_batch(cnmf_ctx* ctx, int n, const int32_t* k, int init_mode,
+                                 const uint32_t* seeds, const double* avg, const float* W0,
+                                 const float* H0, const cnmf_cd_params* prm, float* H_out,
+                                 float* W_out, int32_t* n_iter_out, double* viol_out,
+                                 cnmf_batch_stats* stats)
+{
+    return run_batch(ctx, n, k, init_mode, seeds, avg, W0, H0, prm, H_out, W_out, false, n_iter_out, viol_out, stats);
+}
+
+extern "C" int cnmf_nmf_cd_batch_resident(cnmf_ctx* ctx, int n, const int32_t* k, int init_mode,
+                                          const uint32_t* seeds, const double* avg, const float* W0,
+                                          const float* H0, const cnmf_cd_params* prm,
+                                          int32_t* n_iter_out, double* viol_out,
+                                          cnmf_batch_stats* stats)
+{
+    return run_batch(ctx, n, k, init_mode, seeds, avg, W0, H0, prm, nullptr, nullptr, true, n_iter_out, viol_out, stats);
+}
+
+// ------------------------------------------------------------------ NNLS refit
+extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_params* prm,
+                         float* W_out, int32_t* n_iter_out, double* viol_out)
+{
+    if (!ctx) { SET_ERR(ctx, "ctx is NULL"); return CNMF_EINVAL; }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    int rc = validate_params(ctx, prm);
+    if (rc) return rc;
+    if (!Hin || !W_out || k < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    const int KC = 32;
+    rc = ensure_batch(ctx, KC);
+    if (rc) return rc;
+    rc = ensure_stage(ctx, (size_t)N * KMAX, (size_t)G * KMAX);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageH, Hin, (size_t)k * G * sizeof(float), hipMemcpyHostToDevice, st));
+    dim3 gI((std::max(N, G) + 255) / 256, k);
+    install_kernel<<<gI, 256, 0, st>>>(ctx->stageH, nullptr, ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, 0, k);
+    if (k < KC) {   // unused component rows of the 32-wide tile must be zero
+        dim3 gc((ctx->G_pad + 255) / 256, KC - k), gw((ctx->N_pad + 255) / 256, KC - k);
+        clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, k, KC - k);
+        clear_rows_kernel<<<gw, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, k, KC - k);
+    }
+    SlotDesc* d = &ctx->h_slots[0];
+    memset(d, 0, sizeof *d);
+    d->off = 0; d->k = k; d->active = 1; d->restart = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots, d, sizeof(SlotDesc), hipMemcpyHostToDevice, st));
+    ctx->h_slot_list[0] = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slot_list, ctx->h_slot_list, sizeof(int), hipMemcpyHostToDevice, st));
+    gram_rows_kernel<<<1, 256, 0, st>>>(ctx->H, ctx->G_pad, G, ctx->d_slots, ctx->d_slot_list, ctx->gramH, (float)prm->l2_reg_W);
+    HIP_TRY(ctx, launch_gemm<false>(st, 0, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt, ctx->N_pad, 0, KC, ctx->G_pad, ctx->N_pad, 1));
+    const int chunksW = sweep_chunks(N), partsW = sweep_parts(N);
+    const unsigned kp_mask = 1u << ((k + 3) / 4);
+    hipEvent_t ev;
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const int burst = 8;        // sweeps enqueued between two looks at the slot state
+    int done = 0;
+    SlotDesc* snap = ctx->h_snap;
+    for (int it = 0; it < prm->max_iter && !done; it += burst) {
+        for (int b = 0; b < burst; ++b) {
+            HIP_TRY(ctx, launch_sweep(st, kp_mask, 1, ctx->Wt, ctx->N_pad, N, ctx->XHt, 1, 0, ctx->gramH,
+                                      ctx->d_slots, (float)prm->l1_reg_W, ctx->gram_part, ctx->viol_part,
+                                      chunksW, partsW, 0));
+            finalize_kernel<<<1, 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, 0.f,
+                                               ctx->d_slots, 2, prm->tol, prm->max_iter, 0);
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(snap, ctx->d_slots, sizeof(SlotDesc), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipEventRecord(ev, st));
+        HIP_TRY(ctx, hipEventSynchronize(ev));
+        done = (snap->active == 0);
+    }
+    hipEventDestroy(ev);
+    float* d_W = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_W, (size_t)N * k * sizeof(float)));
+    dim3 gW((N + 255) / 256, k);
+    extract_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, 0, k, d_W, 1);
+    HIP_TRY(ctx, hipMemcpyAsync(W_out, d_W, (size_t)N * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    dim3 gH((ctx->G_pad + 255) / 256, k), gWc((ctx->N_pad + 255) / 256, k);
+    clear_rows_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, 0, k);
+    clear_rows_kernel<<<gWc, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, 0, k);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    hipFree(d_W);
+    if (n_iter_out) *n_iter_out = snap->iter;
+    if (viol_out) *viol_out = snap->viol_last;
+    return CNMF_OK;
+}
+
+// ------------------------------------------------------------------ diagnostics
+extern "C" int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float* A, const float* B,
+                               float* C, int KC, int K, int J, int nsplit, double* ms_out, int reps)
+{
+    if (!ctx || !A || !B || !C) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    if (KC % 32 || K % 32 || J % 32 || nsplit < 1 || (mode != 0 && mode != 1)) {
+        SET_ERR(ctx, "debug_gemm needs KC,K,J multiples of 32"); return CNMF_EINVAL;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int Jp = round_up(J, 128);           // J padded like N_pad so any tile shape is addressable
+    const int Kp = K;
+    float *dA, *dB, *dC;
+    const size_t bA = (size_t)KC * Kp * sizeof(float);
+    const size_t bB = (mode == 0 ? (size_t)Jp * Kp : (size_t)Kp * J) * sizeof(float);
+    const size_t bC = (size_t)nsplit * KC * Jp * sizeof(float);
+    HIP_TRY(ctx, hipMalloc(&dA, bA)); HIP_TRY(ctx, hipMalloc(&dB, bB)); HIP_TRY(ctx, hipMalloc(&dC, bC));
+    HIP_TRY(ctx, hipMemsetAsync(dB, 0, bB, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dA, A, bA, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dB, B, (size_t)(mode == 0 ? J : Kp) * (mode == 0 ? Kp : J) * sizeof(float), hipMemcpyHostToDevice, st));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    reps = std::max(1, reps);
+    for (int i = 0; i < reps + 1; ++i) {
+        if (i == 1) hipEventRecord(e0, st);
+        hipError_t e = (mode == 0)
+            ? launch_gemm<false>(st, variant, dA, Kp, dB, Kp, dC, Jp, (long long)KC * Jp, KC, Kp, Jp, 1)
+            : launch_gemm<true>(st, variant, dA, Kp, dB, J, dC, Jp, (long long)KC * Jp, KC, Kp, J, nsplit);
+        HIP_TRY(ctx, e);
+    }
+    hipEventRecord(e1, st);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (reps >= 1) hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) *ms_out = (reps >= 1) ? ms / reps : 0.0;
+    std::vector<float> hc((size_t)(mode == 0 ? 1 : nsplit) * KC * Jp);
+    HIP_TRY(ctx, hipMemcpy(hc.data(), dC, hc.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int c = 0; c < KC; ++c)
+        for (int j = 0; j < J; ++j) {
+            float s = hc[(size_t)c * Jp + j];
+            if (mode == 1)
+                for (int z = 1; z < nsplit; ++z) s += hc[((size_t)z * KC + c) * Jp + j];
+            C[(size_t)c * J + j] = s;
+        }
+    hipFree(dA); hipFree(dB); hipFree(dC);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return CNMF_OK;
+}
+
+extern "C" int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t n, double* out)
+{
+    if (!ctx || !out || n < 0) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, (size_t)std::max<int64_t>(n, 1) * sizeof(double)));
+    launch_standard_normal(ctx->stream, seed, n, d);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(d);
+    return CNMF_OK;
+}

@@ -1,0 +1,297 @@
+// Coordinate-descent sweep + bookkeeping kernels of the batched NMF engine.
+//
+// sweep_kernel restates sklearn's `_update_cdnmf_fast`
+// (sklearn/decomposition/_cdnmf_fast.pyx:8-38) with one LANE per row: rows are
+// independent inside the sweep, components are visited in order t = 0..k-1 and
+// every update sees the already-updated components r < t, exactly as the Cython
+// loop.  All factors are stored component-major ([KC][L], L = cells or genes) so
+// that a wave's 64 lanes read 64 consecutive rows of one component (coalesced).
+//
+// The same kernel serves both half-steps (sklearn _nmf.py:500 and :505):
+//   W half-step : V = Wt_all [KC][N],  P = X.Ht products [1][KC][N],   gram = HHt (+l2_reg_W)
+//   H half-step : V = H_all  [KC][G],  P = Xt.W split-K partials [S][KC][G], gram = WtW (+l2_reg_H)
+// and additionally produces, on the otherwise idle matrix pipe, the Gram matrix of the
+// UPDATED rows (V_slot . V_slot^T, needed by the next half-step, sklearn _nmf.py:386) and
+// the projected-gradient violation, both as per-workgroup partials that
+// finalize_kernel reduces in a fixed order (deterministic, no float atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels_gemm.hip.h"
+
+namespace cnmf {
+
+constexpr int KMAX = 32;            // largest rank handled by the register-resident sweep
+constexpr int GRAM_LD = KMAX;       // gram matrices are stored [slot][32][32]
+constexpr int GRAM_SZ = KMAX * KMAX;
+
+struct SlotDesc {                   // one restart in flight (device + host mirror)
+    int off;                        // first packed component column
+    int k;                          // rank
+    int active;                     // 1 while iterating, 0 once converged / empty
+    int iter;                       // completed outer iterations
+    int restart;                    // index into the caller's restart list (-1 = empty)
+    int pad_;
+    double viol;                    // violation accumulated in the current outer iteration
+    double viol_init;               // violation of outer iteration 1
+    double viol_last;               // violation/viol_init at the last completed iteration
+};
+
+// KP = k rounded up to a multiple of 4 (compile-time register array size).
+template <int KP>
+__global__ __launch_bounds__(256) void sweep_kernel(
+    float* __restrict__ V, int ldv, int L,
+    const float* __restrict__ P, int nsplit, long long p_split_stride,
+    const float* __restrict__ gram,          // [nslots][32][32], regularised diagonal included
+    const SlotDesc* __restrict__ slots,
+    float l1_reg,
+    float* __restrict__ gram_part,           // [nslots][gridDim.x][32][32]
+    double* __restrict__ viol_part,          // [nslots][gridDim.x]
+    int chunks_per_block, int want_gram)
+{
+    const int slot = blockIdx.y;
+    const SlotDesc sd = slots[slot];
+    if (!sd.active || sd.k > KP || sd.k <= KP - 4) return;   // other KP instantiation handles it
+    const int k = sd.k, off = sd.off;
+
+    __shared__ __attribute__((aligned(16))) float Gs[KMAX][KMAX + 4];
+    __shared__ __attribute__((aligned(16))) float Ws[4][64][KMAX + 1];
+    __shared__ double vred[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < KMAX * KMAX; e += 256) {
+        const int r = e / KMAX, c = e % KMAX;
+        Gs[r][c] = (r < k && c < k) ? gram[(size_t)slot * GRAM_SZ + r * GRAM_LD + c] : 0.f;
+    }
+    __syncthreads();
+
+    f32x16 gacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+    float viol = 0.f;
+
+    for (int ch = 0; ch < chunks_per_block; ++ch) {
+        const int row = (blockIdx.x * chunks_per_block + ch) * 256 + tid;
+        const bool live = row < L;
+        float w[KP], p[KP];
+#pragma unroll
+        for (int c = 0; c < KP; ++c) {
+            w[c] = 0.f; p[c] = 0.f;
+            if (live && c < k) {
+                const size_t idx = (size_t)(off + c) * ldv + row;
+                w[c] = V[idx];
+                float acc = P[idx];
+                for (int s = 1; s < nsplit; ++s) acc += P[(size_t)s * p_split_stride + idx];
+                p[c] = acc - l1_reg;
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < KP; ++t) {
+                if (t < k) {
+                    float grad = -p[t];
+#pragma unroll
+                    for (int r = 0; r < KP; ++r) grad = fmaf(Gs[t][r], w[r], grad);
+                    const float pg = (w[t] == 0.f) ? fminf(0.f, grad) : grad;
+                    viol += fabsf(pg);
+                    const float hess = Gs[t][t];
+                    if (hess != 0.f) w[t] = fmaxf(w[t] - grad / hess, 0.f);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < KP; ++c)
+                if (c < k) V[(size_t)(off + c) * ldv + row] = w[c];
+        }
+        if (want_gram) {
+            // Gram of the updated rows on the matrix pipe: gacc += Wrows^T . Wrows
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) Ws[wave][lane][c] = (c < KP) ? w[c < KP ? c : 0] : 0.f;
+            // (wave-private tile: no workgroup barrier needed, only LDS write->read order)
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            const int li = lane & 31, h = lane >> 5;
+#pragma unroll 8
+            for (int s = 0; s < 32; ++s) {
+                const float a = Ws[wave][2 * s + h][li];
+                gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, gacc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- violation: wave reduce (double) -> block partial
+    double dv = (double)viol;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dv += __shfl_xor(dv, o, 64);
+    if (lane == 0) vred[wave] = dv;
+
+    // ---- gram: sum the 4 waves' accumulators through LDS, write the block partial
+    __syncthreads();
+    float* gred = &Ws[0][0][0];          // reuse as [4][32][33]? -> needs 4*32*33 <= 4*64*33 : ok
+    if (want_gram) {
+        const int li = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            gred[(wave * 32 + rr) * 33 + li] = gacc[r];
+        }
+    }
+    __syncthreads();
+    if (want_gram) {
+        for (int e = tid; e < GRAM_SZ; e += 256) {
+            const int r = e / 32, c = e % 32;
+            const float s = gred[(0 * 32 + r) * 33 + c] + gred[(1 * 32 + r) * 33 + c] +
+                            gred[(2 * 32 + r) * 33 + c] + gred[(3 * 32 + r) * 33 + c];
+            gram_part[((size_t)slot * gridDim.x + blockIdx.x) * GRAM_SZ + e] = s;
+        }
+    }
+    if (tid == 0)
+        viol_part[(size_t)slot * gridDim.x + blockIdx.x] = vred[0] + vred[1] + vred[2] + vred[3];
+}
+
+// One workgroup per slot: reduce the sweep's partials in a fixed order, add the
+// l2 regulariser to the diagonal (sklearn _nmf.py:389-392) and run the stopping rule
+// of _fit_coordinate_descent (sklearn _nmf.py:496-521) on the device.
+//   phase 0 : after the W half-step (update_H=True)  -> store violation, no decision
+//   phase 1 : after the H half-step                  -> total violation, decide
+//   phase 2 : after the W half-step (update_H=False) -> decide on the W violation alone
+__global__ __launch_bounds__(256) void finalize_kernel(
+    const float* __restrict__ gram_part, const double* __restrict__ viol_part, int nparts,
+    float* __restrict__ gram_out, float l2_reg,
+    SlotDesc* __restrict__ slots, int phase, double tol, int max_iter, int want_gram)
+{
+    const int slot = blockIdx.x;
+    SlotDesc* sd = &slots[slot];
+    if (!sd->active) return;
+    const int tid = threadIdx.x;
+    if (want_gram) {
+        for (int e = tid; e < GRAM_SZ; e += 256) {
+            float s = 0.f;
+            for (int pI = 0; pI < nparts; ++pI)
+                s += gram_part[((size_t)slot * nparts + pI) * GRAM_SZ + e];
+            if ((e / 32) == (e % 32)) s += l2_reg;
+            gram_out[(size_t)slot * GRAM_SZ + e] = s;
+        }
+    }
+    __shared__ double red[256];
+    double v = 0.0;
+    for (int pI = tid; pI < nparts; pI += 256) v += viol_part[(size_t)slot * nparts + pI];
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double vsum = red[0];
+        if (phase == 0) {
+            sd->viol = vsum;
+        } else {
+            const double viol = (phase == 1) ? sd->viol + vsum : vsum;
+            const int it = sd->iter + 1;
+            sd->iter = it;
+            if (it == 1) sd->viol_init = viol;
+            bool done = false;
+            if (sd->viol_init == 0.0) { done = true; sd->viol_last = 0.0; }
+            else {
+                sd->viol_last = viol / sd->viol_init;
+                if (sd->viol_last <= tol) done = true;
+            }
+            if (it >= max_iter) done = true;
+            if (done) sd->active = 0;
+            sd->viol = 0.0;
+        }
+    }
+}
+
+// Gram matrix of the k rows [off, off+k) of a component-major factor (used once
+// per restart, for the initial HHt of H0; sklearn _nmf.py:386).  One workgroup per slot.
+__global__ __launch_bounds__(256) void gram_rows_kernel(
+    const float* __restrict__ V, int ldv, int L,
+    const SlotDesc* __restrict__ slots, const int* __restrict__ slot_list,
+    float* __restrict__ gram_out, float l2_reg)
+{
+    const int slot = slot_list[blockIdx.x];
+    const SlotDesc sd = slots[slot];
+    const int k = sd.k, off = sd.off;
+    __shared__ float tile[KMAX][257];
+    const int tid = threadIdx.x;
+    // thread owns up to 4 (a,b) pairs: e = tid + 256*i
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int g0 = 0; g0 < L; g0 += 256) {
+        for (int c = 0; c < k; ++c)
+            tile[c][tid] = (g0 + tid < L) ? V[(size_t)(off + c) * ldv + g0 + tid] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, a = e / 32, b = e % 32;
+            if (a < k && b < k) {
+                float s = 0.f;
+                for (int g = 0; g < 256; ++g) s = fmaf(tile[a][g], tile[b][g], s);
+                acc[i] += (double)s;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, a = e / 32, b = e % 32;
+        float s = (a < k && b < k) ? (float)acc[i] : 0.f;
+        if (a == b && a < k) s += l2_reg;
+        gram_out[(size_t)slot * GRAM_SZ + e] = s;
+    }
+}
+
+// Install a restart into its slot: H0 [k][G] row-major -> H_all rows, W0 [N][k]
+// row-major (sklearn layout) -> Wt_all rows (transposed).  Also clears the slot's
+// padding.  grid = (ceil(max(N,G)/256), k)
+__global__ void install_kernel(const float* __restrict__ H0, const float* __restrict__ W0,
+                               float* __restrict__ H, int ldh, int G,
+                               float* __restrict__ Wt, int ldw, int N, int off, int k)
+{
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < G) H[(size_t)(off + c) * ldh + i] = H0 ? H0[(size_t)c * G + i] : 0.f;
+    if (i < N) Wt[(size_t)(off + c) * ldw + i] = W0 ? W0[(size_t)i * k + c] : 0.f;
+}
+
+// Same from a component-major source (the device-generated init store): H0 [k][G], Wt0 [k][N].
+__global__ void install_cm_kernel(const float* __restrict__ H0, const float* __restrict__ Wt0,
+                                  float* __restrict__ H, int ldh, int G,
+                                  float* __restrict__ Wt, int ldw, int N, int off)
+{
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < G) H[(size_t)(off + c) * ldh + i] = H0[(size_t)c * G + i];
+    if (i < N) Wt[(size_t)(off + c) * ldw + i] = Wt0[(size_t)c * N + i];
+}
+
+// Zero a range of packed component rows (freed slot -> contributes nothing to the GEMMs).
+__global__ void clear_rows_kernel(float* __restrict__ V, int ldv, int L, int off, int k)
+{
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < k && i < L) V[(size_t)(off + c) * ldv + i] = 0.f;
+}
+
+// Copy k packed rows out to a dense [k][L] result block (optionally transposed to [L][k]).
+__global__ void extract_kernel(const float* __restrict__ V, int ldv, int L, int off, int k,
+                               float* __restrict__ out, int transpose)
+{
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < k && i < L) {
+        const float v = V[(size_t)(off + c) * ldv + i];
+        if (transpose) out[(size_t)i * k + c] = v; else out[(size_t)c * L + i] = v;
+    }
+}
+
+// fp32 copy of the caller's matrix into the zero-padded device layout.
+__global__ void pad_copy_kernel(const float* __restrict__ src, int rows, int cols,
+                                float* __restrict__ dst, int ld)
+{
+    const int r = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows && c < cols) dst[(size_t)r * ld + c] = src[(size_t)r * cols + c];
+}
+
+}  // namespace cnmf

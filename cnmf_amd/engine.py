@@ -1,0 +1,237 @@
+"""Python face of the C-ABI: one ``Engine`` = one ``cnmf_ctx`` = one MI355X.
+
+The engine keeps the cells x genes matrix resident in HBM and runs batches of
+NMF restarts / NNLS refits on it.  Everything numeric happens in
+``libcnmf_hip.so``; this module only marshals numpy buffers through ctypes and
+maps status codes to the exception types the reference path raises
+(scikit-learn raises ValueError / TypeError).
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib
+
+_ERR = {-1: ValueError, -2: RuntimeError, -3: MemoryError, -4: RuntimeError,
+        -5: NotImplementedError, -6: RuntimeError}
+
+
+class ConvergenceWarning(UserWarning):
+    """Mirror of sklearn.exceptions.ConvergenceWarning (sklearn _nmf.py:1727-1732)."""
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def regularization(n_samples, n_features, alpha_W=0.0, alpha_H=0.0, l1_ratio=0.0):
+    """sklearn's scaling of the penalties, decomposition/_nmf.py:1254-1265."""
+    return (n_features * alpha_W * l1_ratio, n_samples * alpha_H * l1_ratio,
+            n_features * alpha_W * (1.0 - l1_ratio), n_samples * alpha_H * (1.0 - l1_ratio))
+
+
+class Engine:
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        if self._lib.cnmf_device_count() <= 0:
+            raise RuntimeError("cnmf_amd: no HIP device visible -- the engine has no CPU fallback")
+        self._ctx = self._lib.cnmf_create(int(device))
+        if not self._ctx:
+            raise RuntimeError("cnmf_create failed: %s" % self._lib.cnmf_last_error(None).decode())
+        self.device = int(device)
+        self.shape = None
+        self.x_mean = None
+        self.x_dtype = None
+        self.last_stats = None
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.cnmf_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.cnmf_last_error(self._ctx).decode()
+            raise _ERR.get(rc, RuntimeError)("cnmf_hip: %s (code %d)" % (msg, rc))
+
+    def _params(self, tol, max_iter, alpha_W, alpha_H, l1_ratio, kc_max=0, lag=0):
+        N, G = self.shape
+        l1W, l1H, l2W, l2H = regularization(N, G, alpha_W, alpha_H, l1_ratio)
+        return _lib.CdParams(float(tol), int(max_iter), int(kc_max), l1W, l2W, l1H, l2H, int(lag), 0)
+
+    # ------------------------------------------------------------------ data matrix
+    def set_matrix(self, X):
+        """Upload the cells x genes matrix (dense ndarray or scipy CSR), once per context.
+
+        Mirrors sklearn's input validation for NMF (check_array + check_non_negative,
+        decomposition/_nmf.py:1126,283): NaN/inf and negative entries raise ValueError."""
+        import scipy.sparse as sp
+        if sp.issparse(X):
+            X = X.tocsr()
+            data = X.data
+            if not np.isfinite(data).all():
+                raise ValueError("Input X contains NaN or infinity.")
+            if data.size and data.min() < 0:
+                raise ValueError("Negative values in data passed to NMF (input X)")
+            self.x_dtype = np.dtype(X.dtype) if X.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+            self.x_mean = X.mean() if X.dtype in (np.float32, np.float64) else X.astype(np.float64).mean()
+            indptr = np.ascontiguousarray(X.indptr, dtype=np.int32)
+            indices = np.ascontiguousarray(X.indices, dtype=np.int32)
+            vals = np.ascontiguousarray(data, dtype=np.float32)
+            ip = C.POINTER(C.c_int32)
+            self._check(self._lib.cnmf_set_matrix_csr(self._ctx, indptr.ctypes.data_as(ip),
+                                                      indices.ctypes.data_as(ip), _fp(vals),
+                                                      X.shape[0], X.shape[1]))
+        else:
+            X = np.asarray(X)
+            if X.ndim != 2:
+                raise ValueError("Expected 2D array, got %dD array instead" % X.ndim)
+            if X.dtype not in (np.float32, np.float64):
+                X = X.astype(np.float64)            # sklearn: ints -> float64
+            if not np.isfinite(X).all():
+                raise ValueError("Input X contains NaN or infinity.")
+            if X.size and X.min() < 0:
+                raise ValueError("Negative values in data passed to NMF (input X)")
+            self.x_dtype = X.dtype
+            self.x_mean = X.mean()                  # numpy scalar of X's dtype, like sklearn's X.mean()
+            Xf = np.ascontiguousarray(X, dtype=np.float32)
+            self._check(self._lib.cnmf_set_matrix(self._ctx, _fp(Xf), Xf.shape[0], Xf.shape[1]))
+        self.shape = (int(X.shape[0]), int(X.shape[1]))
+        return self
+
+    def init_scale(self, k):
+        """``avg = sqrt(X.mean() / n_components)`` exactly as sklearn computes it
+        (numpy scalar arithmetic in X's dtype; decomposition/_nmf.py:303)."""
+        return float(np.sqrt(self.x_mean / k))
+
+    # ------------------------------------------------------------------ restarts
+    def nmf_batch(self, ks, seeds=None, W0=None, H0=None, tol=1e-4, max_iter=1000,
+                  alpha_W=0.0, alpha_H=0.0, l1_ratio=0.0, return_W=False, kc_max=0, lag=0,
+                  resident=False, warn=True):
+        """Run ``len(ks)`` independent CD-NMF restarts on the resident matrix.
+
+        Either ``seeds`` (sklearn ``init='random'`` reproduced on the device) or the lists
+        ``W0`` / ``H0`` of explicit initial factors (sklearn layouts N x k and k x G).
+        Returns ``(H_list, W_list_or_None, n_iter, violation)``."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        ks = np.ascontiguousarray(ks, dtype=np.int32).ravel()
+        n = int(ks.size)
+        if n and ks.min() < 1:
+            raise ValueError("n_components must be >= 1")
+        prm = self._params(tol, max_iter, alpha_W, alpha_H, l1_ratio, kc_max, lag)
+        i32p, u32p, dblp = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+        if seeds is not None:
+            seeds_a = np.ascontiguousarray(np.asarray(seeds, dtype=np.int64).astype(np.uint32)).ravel()
+            if seeds_a.size != n:
+                raise ValueError("need one seed per restart")
+            avg = np.ascontiguousarray([self.init_scale(int(k)) for k in ks], dtype=np.float64)
+            mode, w0p, h0p = 1, None, None
+            seedp, avgp = seeds_a.ctypes.data_as(u32p), avg.ctypes.data_as(dblp)
+        else:
+            if W0 is None or H0 is None or len(W0) != n or len(H0) != n:
+                raise ValueError("need seeds, or W0 and H0 lists with one entry per restart")
+            for r in range(n):
+                if np.shape(W0[r]) != (N, ks[r]) or np.shape(H0[r]) != (ks[r], G):
+                    raise ValueError("Array with wrong shape passed to NMF (input W/H) for restart %d" % r)
+                if np.min(W0[r]) < 0 or np.min(H0[r]) < 0:
+                    raise ValueError("Negative values in data passed to NMF (input W/H)")
+            w0 = (np.concatenate([np.ascontiguousarray(w, dtype=np.float32).ravel() for w in W0])
+                  if n else np.zeros(1, np.float32))
+            h0 = (np.concatenate([np.ascontiguousarray(h, dtype=np.float32).ravel() for h in H0])
+                  if n else np.zeros(1, np.float32))
+            mode, w0p, h0p, seedp, avgp = 0, _fp(w0), _fp(h0), None, None
+        tot_k = int(ks.sum()) if n else 0
+        n_iter = np.zeros(max(n, 1), dtype=np.int32)
+        viol = np.zeros(max(n, 1), dtype=np.float64)
+        stats = _lib.BatchStats()
+        if resident:
+            rc = self._lib.cnmf_nmf_cd_batch_resident(self._ctx, n, ks.ctypes.data_as(i32p), mode, seedp,
+                                                      avgp, w0p, h0p, C.byref(prm),
+                                                      n_iter.ctypes.data_as(i32p), viol.ctypes.data_as(dblp),
+                                                      C.byref(stats))
+            self._check(rc)
+            H_list = W_list = None
+        else:
+            H_out = np.empty((max(tot_k, 1), G), dtype=np.float32)
+            W_out = np.empty(max(tot_k, 1) * N, dtype=np.float32) if return_W else None
+            rc = self._lib.cnmf_nmf_cd_batch(self._ctx, n, ks.ctypes.data_as(i32p), mode, seedp, avgp,
+                                             w0p, h0p, C.byref(prm), _fp(H_out),
+                                             _fp(W_out) if return_W else None,
+                                             n_iter.ctypes.data_as(i32p), viol.ctypes.data_as(dblp),
+                                             C.byref(stats))
+            self._check(rc)
+            offs = np.concatenate([[0], np.cumsum(ks)]).astype(np.int64)
+            H_list = [H_out[offs[r]:offs[r + 1]] for r in range(n)]
+            W_list = None
+            if return_W:
+                W_list = [W_out[offs[r] * N:offs[r + 1] * N].reshape(N, ks[r]) for r in range(n)]
+        self.last_stats = stats.as_dict()
+        n_iter, viol = n_iter[:n], viol[:n]
+        if warn and n and tol > 0 and (n_iter == max_iter).any():
+            warnings.warn("Maximum number of iterations %d reached. Increase it to improve convergence."
+                          % max_iter, ConvergenceWarning)
+        return H_list, W_list, n_iter, viol
+
+    # ------------------------------------------------------------------ NNLS refit
+    def nnls(self, H, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0, warn=True):
+        """``non_negative_factorization(X, H=H, update_H=False, solver='cd')`` on the
+        resident matrix: returns ``(W [N x k], n_iter)``."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        H = np.asarray(H)
+        if H.ndim != 2 or H.shape[1] != G:
+            raise ValueError("Array with wrong shape passed to NMF (input H). Expected (k, %d), but got %s"
+                             % (G, (H.shape,)))
+        if not np.isfinite(H).all():
+            raise ValueError("Input H contains NaN or infinity.")
+        if H.min() < 0:
+            raise ValueError("Negative values in data passed to NMF (input H)")
+        if H.max() == 0:
+            raise ValueError("Array passed to NMF (input H) is full of zeros.")
+        k = int(H.shape[0])
+        Hf = np.ascontiguousarray(H, dtype=np.float32)
+        prm = self._params(tol, max_iter, alpha_W, 0.0, l1_ratio)
+        W = np.empty((N, k), dtype=np.float32)
+        n_iter = C.c_int32(0)
+        viol = C.c_double(0.0)
+        self._check(self._lib.cnmf_nnls(self._ctx, k, _fp(Hf), C.byref(prm), _fp(W),
+                                        C.byref(n_iter), C.byref(viol)))
+        if warn and tol > 0 and n_iter.value == max_iter:
+            warnings.warn("Maximum number of iterations %d reached. Increase it to improve convergence."
+                          % max_iter, ConvergenceWarning)
+        return W, int(n_iter.value)
+
+    # ------------------------------------------------------------------ diagnostics
+    def debug_gemm(self, mode, A, B, variant=0, nsplit=1, reps=0):
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        B = np.ascontiguousarray(B, dtype=np.float32)
+        KC, K = A.shape
+        J = B.shape[0] if mode == 0 else B.shape[1]
+        Cout = np.empty((KC, J), dtype=np.float32)
+        ms = C.c_double(0.0)
+        self._check(self._lib.cnmf_debug_gemm(self._ctx, mode, variant, _fp(A), _fp(B), _fp(Cout),
+                                              KC, K, J, nsplit, C.byref(ms), reps))
+        return Cout, ms.value
+
+    def debug_standard_normal(self, seed, n):
+        out = np.empty(max(n, 1), dtype=np.float64)
+        self._check(self._lib.cnmf_debug_standard_normal(self._ctx, C.c_uint32(seed), n,
+                                                         out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out[:n]

@@ -1,0 +1,136 @@
+/* libcnmf_hip.so -- C ABI of the MI355X-native consensus-NMF engine.
+ *
+ * The reference (dylkot/cNMF v1.7.1) has no FFI: its hot path is Python method
+ * dispatch on `class cNMF` that bottoms out in scikit-learn.  The entry points
+ * below are what a ctypes binding behind those methods calls; each one names the
+ * reference interface it replaces (paths are /root/reference/src/cnmf/cnmf.py
+ * unless prefixed sklearn:).  See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the CALLER owns every host buffer (numpy),
+ *     the library owns all device memory behind the opaque context;
+ *   - every call returns 0 on success or a negative CNMF_E* code; the message is
+ *     available from cnmf_last_error() (the Python wrapper maps codes to the same
+ *     exception types the reference path raises);
+ *   - one context per GPU, one host thread per context; no global mutable state
+ *     (multiprocessing fan-out with one process per GPU = one `worker_i` works);
+ *   - matrices are C-order float32.  Factor packing for a batch of restarts
+ *     r = 0..n-1 with ranks k[r]:  H blocks [k[r]][G] concatenated in r order,
+ *     W blocks [N][k[r]] concatenated in r order (sklearn's own layouts).
+ */
+#ifndef CNMF_HIP_H
+#define CNMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNMF_OK            0
+#define CNMF_EINVAL       -1   /* bad argument (ValueError on the Python side)   */
+#define CNMF_EHIP         -2   /* HIP runtime failure (RuntimeError)             */
+#define CNMF_ENOMEM       -3   /* device allocation failed (MemoryError)         */
+#define CNMF_ESTATE       -4   /* call order violated, e.g. no matrix set        */
+#define CNMF_EUNSUPPORTED -5   /* e.g. rank > CNMF_KMAX (NotImplementedError)    */
+#define CNMF_ECOMM        -6   /* RCCL failure                                   */
+
+#define CNMF_KMAX 32           /* largest rank handled by the device sweep       */
+
+typedef struct cnmf_ctx cnmf_ctx;
+
+/* Solver parameters = the yaml kwargs the reference persists (cnmf.py:618-631)
+ * after sklearn's scaling of the regularisers (sklearn:decomposition/_nmf.py:1254-1265):
+ *   l1_reg_W = G*alpha_W*l1_ratio   l2_reg_W = G*alpha_W*(1-l1_ratio)
+ *   l1_reg_H = N*alpha_H*l1_ratio   l2_reg_H = N*alpha_H*(1-l1_ratio)        */
+typedef struct cnmf_cd_params {
+    double tol;          /* 1e-4 in the reference (cnmf.py:624)                  */
+    int    max_iter;     /* 1000 (cnmf.py:567,625)                               */
+    int    kc_max;       /* max packed component columns in flight: 32..256, 0 = auto */
+    double l1_reg_W, l2_reg_W, l1_reg_H, l2_reg_H;
+    int    lag;          /* host polls convergence `lag` iterations behind the GPU; 0 = default (2) */
+    int    reserved;
+} cnmf_cd_params;
+
+/* Per-call statistics (optional, may be NULL). */
+typedef struct cnmf_batch_stats {
+    int64_t outer_iterations;      /* batch iterations enqueued (each = pass A + pass B)        */
+    int64_t restart_iterations;    /* sum over restarts of their n_iter                         */
+    int64_t column_iterations;     /* sum over batch iterations of KC (incl. idle columns)      */
+    double  gpu_ms;                /* device time of the whole call (hipEvent)                  */
+    double  passA_ms, passB_ms;    /* summed hipEvent time of the two MFMA GEMM passes          */
+    int64_t passA_launches, passB_launches;
+    int32_t kc;                    /* packed column count used                                  */
+    int32_t nsplit;                /* split-K factor of pass B                                  */
+} cnmf_batch_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+int         cnmf_device_count(void);
+cnmf_ctx*   cnmf_create(int device);           /* NULL on failure; see cnmf_last_error(NULL) */
+void        cnmf_destroy(cnmf_ctx* ctx);
+const char* cnmf_last_error(const cnmf_ctx* ctx);
+const char* cnmf_version(void);
+
+/* ---- data matrix ------------------------------------------------------------------
+ * Replaces the per-worker `norm_counts = sc.read(...)` + `norm_counts.X` hand-off of
+ * cNMF.factorize (cnmf.py:726,741) and cNMF.consensus (cnmf.py:873,919): X (cells x
+ * high-variance genes) is uploaded ONCE per context and stays resident in HBM.       */
+int cnmf_set_matrix(cnmf_ctx* ctx, const float* X, int64_t n_cells, int64_t n_genes);
+/* CSR input (scipy.sparse.csr_matrix of float32, int32 indices/indptr): densify on device. */
+int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const int32_t* indices,
+                        const float* data, int64_t n_cells, int64_t n_genes);
+int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* n_cells, int64_t* n_genes);
+
+/* ---- the restart hot loop ---------------------------------------------------------
+ * Replaces the loop body of cNMF.factorize (cnmf.py:735-741): for every restart r,
+ *   (usages, spectra, n_iter) = non_negative_factorization(X, n_components=k[r],
+ *        init='random'|custom, solver='cd', beta_loss='frobenius', tol, max_iter, ...)
+ * i.e. cNMF._nmf (cnmf.py:661-674) -> sklearn:decomposition/_nmf.py:905-1131,
+ * _fit_coordinate_descent :406-523, _update_cdnmf_fast sklearn:_cdnmf_fast.pyx:8-38.
+ * All restarts share each pass over X.
+ *
+ *   init_mode 0 (custom): W0 / H0 hold the packed initial factors (what sklearn's
+ *       _initialize_nmf :302-314 returns for the restart's seed).
+ *   init_mode 1 (random): the library reproduces sklearn's init='random' on the device
+ *       from `seeds` (numpy RandomState(seed): MT19937 + legacy polar gauss, H drawn
+ *       before W) scaled by avg[r] = sqrt(X.mean()/k[r]); W0/H0 are ignored.
+ *
+ *   H_out  [sum k][G]   required.   W_out packed [N][k[r]] blocks, may be NULL
+ *   (cNMF.factorize drops the usages, cnmf.py:741-745).
+ *   n_iter_out[r] = sklearn's n_iter;  viol_out[r] = final violation/violation_init.  */
+int cnmf_nmf_cd_batch(cnmf_ctx* ctx, int n_restarts, const int32_t* k,
+                      int init_mode, const uint32_t* seeds, const double* avg,
+                      const float* W0, const float* H0,
+                      const cnmf_cd_params* params,
+                      float* H_out, float* W_out,
+                      int32_t* n_iter_out, double* viol_out,
+                      cnmf_batch_stats* stats);
+
+/* Same, but the spectra stay on the device (for the RCCL gather / on-device consensus):
+ * results are appended to the context's spectra store in restart order.               */
+int cnmf_nmf_cd_batch_resident(cnmf_ctx* ctx, int n_restarts, const int32_t* k,
+                               int init_mode, const uint32_t* seeds, const double* avg,
+                               const float* W0, const float* H0,
+                               const cnmf_cd_params* params,
+                               int32_t* n_iter_out, double* viol_out,
+                               cnmf_batch_stats* stats);
+
+/* ---- NNLS refit ---------------------------------------------------------------------
+ * Replaces cNMF.refit_usage (cnmf.py:776-802): non_negative_factorization(X, H=spectra,
+ * update_H=False, n_components=k, solver='cd', ...) with W0 = 0 (sklearn:_nmf.py:1232-1233).
+ * X.Ht is computed once (sklearn recomputes it every outer iteration although H is fixed). */
+int cnmf_nnls(cnmf_ctx* ctx, int k, const float* H /*[k][G]*/, const cnmf_cd_params* params,
+              float* W_out /*[N][k]*/, int32_t* n_iter_out, double* viol_out);
+
+/* ---- diagnostics used by the tests ---------------------------------------------------- */
+/* C[KC][J] = A[KC][K] . B  through the engine's MFMA GEMM; mode 0: B is [J][K] (pass A),
+ * mode 1: B is [K][J] (pass B, split-K partials summed in split order).                  */
+int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float* A, const float* B,
+                    float* C, int KC, int K, int J, int nsplit, double* ms_out, int reps);
+/* numpy RandomState(seed).standard_normal(n) reproduced on the device. */
+int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t n, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNMF_HIP_H */
