@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py -- NMF restarts/s of the MI355X-native cNMF hot path (BASELINE.json metric).
+
+Workload (default, ``config.workload``): the north-star headline shape -- 50 000 cells x
+2000 high-variance genes (synthetic gamma-Poisson counts, reference `prepare` scaling,
+cnmf_amd/synth.py "C3"), K in {5..13}.  One STEP = one pass of the hot path over one
+batch of restarts: ``--restarts-per-k`` restarts for every K (default 3 -> 27 restarts,
+243 packed component columns), run to sklearn's stopping rule (tol 1e-4, max_iter 1000)
+with sklearn's init='random' generated on the device from the cNMF ledger seeds
+(master seed 14).  X is resident in HBM before the timed region.
+
+Multi-GPU (weak scaling, one process per GPU via torch.distributed.run): every rank holds
+a replica of X and runs its own batch of restarts per step (ledger rows sharded
+round-robin like the reference's worker_filter, cnmf.py:52-53); the only exchange is one
+all-gather of the per-restart spectra at the end of the step (RCCL over xGMI).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
+  roofline     -- the dominant kernel (MFMA GEMM passes): algorithmic flops / launch
+                  duration measured with HIP events inside the library, vs the fp32 MFMA peak
+  cpu_baseline -- scikit-learn's non_negative_factorization (the call the reference makes,
+                  cnmf.py:672) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C3", help="C1|C2|C3 (cnmf_amd/synth.py)")
+    ap.add_argument("--n-cells", type=int, default=None, help="truncate the workload (debug only)")
+    ap.add_argument("--restarts-per-k", type=int, default=3)
+    ap.add_argument("--kmin", type=int, default=5)
+    ap.add_argument("--kmax", type=int, default=13)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=40)
+    return ap.parse_args()
+
+
+def cpu_baseline(X32, mean_iters_per_restart, max_iter):
+    """scikit-learn CD-NMF (float64, the reference dtype, cnmf.py:534) on the host cores."""
+    from oracle import sklearn_ref
+    X64 = X32.astype(np.float64)
+    ks = (5, 9, 13)
+    t0 = time.perf_counter()
+    iters = 0
+    for k in ks:
+        _, _, n_it = sklearn_ref.nmf(X64, k, seed=1000 + k, max_iter=max_iter)
+        iters += n_it
+    dt = time.perf_counter() - t0
+    it_per_s = iters / dt
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {
+        "value": it_per_s / max(mean_iters_per_restart, 1.0),
+        "unit": "restarts/s",
+        "cores": int(threads),
+        "kind": "reference",
+        "restart_iterations_per_s": it_per_s,
+        "sample": ("sklearn.decomposition.non_negative_factorization (solver=cd, float64, init=random) on the same "
+                   "X for k=5,9,13, capped at %d outer iterations each: %d iterations in %.1f s; restarts/s = "
+                   "iterations/s / mean iterations per restart of the GPU run (%.1f)"
+                   % (max_iter, iters, dt, mean_iters_per_restart)),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")
+
+    from cnmf_amd import synth
+    from cnmf_amd.engine import Engine
+    from oracle import sklearn_ref   # ledger seeds only (numpy legacy RNG), not on the timed path
+
+    X = synth.make_config(args.workload, dtype=np.float32, n_cells=args.n_cells)
+    N, G = X.shape
+    eng = Engine(local_rank)
+    eng.set_matrix(X)
+
+    ks_all = list(range(args.kmin, args.kmax + 1))
+    n_steps_total = args.warmup + args.steps
+    led = sklearn_ref.ledger(ks_all, args.restarts_per_k * n_steps_total * world, 14)
+    by_k = {k: [s for (kk, _, s) in led if kk == k] for k in ks_all}
+
+    def step_jobs(step):
+        ks, seeds = [], []
+        for k in ks_all:
+            base = (step * world + rank) * args.restarts_per_k
+            for j in range(args.restarts_per_k):
+                ks.append(k)
+                seeds.append(by_k[k][base + j])
+        return ks, seeds
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def gather(H_list):
+        if dist is None:
+            return
+        import torch
+        mine = torch.from_numpy(np.concatenate(H_list, axis=0)).cuda()
+        out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device="cuda")
+        dist.all_gather_into_tensor(out, mine)
+        torch.cuda.synchronize()
+
+    agg = dict(restarts=0, restart_iters=0, rc_iters=0, outer=0, col_iters=0, passA_ms=0.0,
+               passB_ms=0.0, nA=0, nB=0, gpu_ms=0.0, kc=0, nsplit=0)
+    for step in range(args.warmup):
+        ks, seeds = step_jobs(step)
+        H, _, _, _ = eng.nmf_batch(ks, seeds=seeds, warn=False)
+        gather(H)
+    barrier()
+    t0 = time.perf_counter()
+    for step in range(args.warmup, n_steps_total):
+        ks, seeds = step_jobs(step)
+        H, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=True)
+        gather(H)
+        st = eng.last_stats
+        agg["restarts"] += len(ks)
+        agg["restart_iters"] += int(st["restart_iterations"])
+        agg["rc_iters"] += int(st["restart_column_iterations"])
+        agg["outer"] += int(st["outer_iterations"])
+        agg["col_iters"] += int(st["column_iterations"])
+        agg["passA_ms"] += st["passA_ms"]; agg["passB_ms"] += st["passB_ms"]
+        agg["nA"] += int(st["passA_launches"]); agg["nB"] += int(st["passB_launches"])
+        agg["gpu_ms"] += st["gpu_ms"]; agg["kc"] = int(st["kc"]); agg["nsplit"] = int(st["nsplit"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([agg["restarts"], agg["restart_iters"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_restarts, total_riters = float(cnt[0].item()), float(cnt[1].item())
+    else:
+        total_restarts, total_riters = float(agg["restarts"]), float(agg["restart_iters"])
+
+    if rank == 0:
+        # roofline of the dominant kernel (rank 0's launches): the MFMA GEMM pass
+        flops_per_col_iter = 2.0 * N * G                        # one pass, one component column
+        alg_flops_A = flops_per_col_iter * agg["rc_iters"]      # algorithmic (converged columns excluded)
+        tfA = alg_flops_A / max(agg["passA_ms"], 1e-9) / 1e9
+        tfB = alg_flops_A / max(agg["passB_ms"], 1e-9) / 1e9
+        dom = "A" if agg["passA_ms"] >= agg["passB_ms"] else "B"
+        ach = tfA if dom == "A" else tfB
+        roof = {
+            "bound": "mfma",
+            "kernel": "gemm_kernel<NT> (pass A: X.Ht)" if dom == "A" else "gemm_kernel<NN> (pass B: Xt.W)",
+            "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "avg_launch_ms": {"passA": agg["passA_ms"] / max(agg["nA"], 1), "passB": agg["passB_ms"] / max(agg["nB"], 1)},
+            "achieved_passA": tfA, "achieved_passB": tfB,
+            "alg_flops_per_launch": alg_flops_A / max(agg["nA"], 1),
+            "issued_flops_per_launch": flops_per_col_iter * agg["kc"],
+            "x_stream_GBs": {"passA": N * G * 4 / (agg["passA_ms"] / max(agg["nA"], 1)) / 1e6,
+                             "passB": N * G * 4 / (agg["passB_ms"] / max(agg["nB"], 1)) / 1e6,
+                             "peak": HBM_PEAK_GBS},
+            "gemm_share_of_gpu_time": (agg["passA_ms"] + agg["passB_ms"]) / max(agg["gpu_ms"], 1e-9),
+        }
+        mean_it = total_riters / max(total_restarts, 1.0)
+        out = {
+            "metric": "NMF restarts/sec (%dx%dxK%d..%d)" % (N, G, args.kmin, args.kmax),
+            "value": total_restarts / elapsed,
+            "unit": "restarts/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d cells x %d HVGs synthetic dense, K=%d..%d, %d restarts per K per step "
+                                   "per GPU, sklearn CD solver tol=1e-4 max_iter=1000, init=random from ledger seeds"
+                                   % (args.workload, N, G, args.kmin, args.kmax, args.restarts_per_k),
+                       "restarts_per_step_per_gpu": len(ks_all) * args.restarts_per_k,
+                       "packed_columns": agg["kc"], "splitk_passB": agg["nsplit"],
+                       "mean_iterations_per_restart": mean_it,
+                       "restart_iterations_per_s": total_riters / elapsed,
+                       "column_utilisation": agg["rc_iters"] / max(agg["col_iters"], 1),
+                       "parallelism": "restart-sharded x%d" % world},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(X, mean_it, args.cpu_iters)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,12 +29,13 @@ class CdParams(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("kc_max", C.c_int),
                 ("l1_reg_W", C.c_double), ("l2_reg_W", C.c_double),
                 ("l1_reg_H", C.c_double), ("l2_reg_H", C.c_double),
-                ("lag", C.c_int), ("reserved", C.c_int)]
+                ("lag", C.c_int), ("profile", C.c_int)]
 
 
 class BatchStats(C.Structure):
     _fields_ = [("outer_iterations", C.c_int64), ("restart_iterations", C.c_int64),
-                ("column_iterations", C.c_int64), ("gpu_ms", C.c_double),
+                ("column_iterations", C.c_int64), ("restart_column_iterations", C.c_int64),
+                ("gpu_ms", C.c_double),
                 ("passA_ms", C.c_double), ("passB_ms", C.c_double),
                 ("passA_launches", C.c_int64), ("passB_launches", C.c_int64),
                 ("kc", C.c_int32), ("nsplit", C.c_int32)]

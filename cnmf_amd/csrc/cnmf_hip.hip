@@ -495,7 +495,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     HIP_TRY(ctx, hipEventCreate(&ev_begin));
     HIP_TRY(ctx, hipEventCreate(&ev_end));
     HIP_TRY(ctx, hipEventRecord(ev_begin, st));
-    const bool time_gemm = stats && getenv("CNMF_TIME_GEMM");
+    const bool time_gemm = stats && (prm->profile || getenv("CNMF_TIME_GEMM"));
     std::vector<hipEvent_t> gev;   // (a0,a1,b0,b1) per iteration when timing is requested
 
     const int chunksW = sweep_chunks(N), partsW = sweep_parts(N);
@@ -504,7 +504,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     const float l1H = (float)prm->l1_reg_H, l2H = (float)prm->l2_reg_H;
     const int gvarA = getenv("CNMF_GEMM_A") ? atoi(getenv("CNMF_GEMM_A")) : 0;
     const int gvarB = getenv("CNMF_GEMM_B") ? atoi(getenv("CNMF_GEMM_B")) : 0;
-    int64_t restart_iters = 0, column_iters = 0;
+    int64_t restart_iters = 0, column_iters = 0, restart_col_iters = 0;
     int n_done = 0;
 
     auto retire = [&](int s, const SlotDesc& snap) -> int {
@@ -519,6 +519,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (n_iter_out) n_iter_out[r] = snap.iter;
         if (viol_out) viol_out[r] = snap.viol_last;
         restart_iters += snap.iter;
+        restart_col_iters += (int64_t)snap.iter * k;
         cols.release(h.off, k);
         h.state = 0; h.restart = -1;
         --n_active; ++n_done;
@@ -628,6 +629,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         stats->outer_iterations = it;
         stats->restart_iterations = restart_iters;
         stats->column_iterations = column_iters;
+        stats->restart_column_iterations = restart_col_iters;
         stats->kc = KC; stats->nsplit = nsplit;
         for (size_t i = 0; i + 3 < gev.size(); i += 4) {
             float a = 0.f, b = 0.f;

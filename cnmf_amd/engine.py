@@ -68,10 +68,10 @@ class Engine:
             msg = self._lib.cnmf_last_error(self._ctx).decode()
             raise _ERR.get(rc, RuntimeError)("cnmf_hip: %s (code %d)" % (msg, rc))
 
-    def _params(self, tol, max_iter, alpha_W, alpha_H, l1_ratio, kc_max=0, lag=0):
+    def _params(self, tol, max_iter, alpha_W, alpha_H, l1_ratio, kc_max=0, lag=0, profile=0):
         N, G = self.shape
         l1W, l1H, l2W, l2H = regularization(N, G, alpha_W, alpha_H, l1_ratio)
-        return _lib.CdParams(float(tol), int(max_iter), int(kc_max), l1W, l2W, l1H, l2H, int(lag), 0)
+        return _lib.CdParams(float(tol), int(max_iter), int(kc_max), l1W, l2W, l1H, l2H, int(lag), int(profile))
 
     # ------------------------------------------------------------------ data matrix
     def set_matrix(self, X):
@@ -121,7 +121,7 @@ class Engine:
     # ------------------------------------------------------------------ restarts
     def nmf_batch(self, ks, seeds=None, W0=None, H0=None, tol=1e-4, max_iter=1000,
                   alpha_W=0.0, alpha_H=0.0, l1_ratio=0.0, return_W=False, kc_max=0, lag=0,
-                  resident=False, warn=True):
+                  resident=False, warn=True, profile=False):
         """Run ``len(ks)`` independent CD-NMF restarts on the resident matrix.
 
         Either ``seeds`` (sklearn ``init='random'`` reproduced on the device) or the lists
@@ -134,7 +134,7 @@ class Engine:
         n = int(ks.size)
         if n and ks.min() < 1:
             raise ValueError("n_components must be >= 1")
-        prm = self._params(tol, max_iter, alpha_W, alpha_H, l1_ratio, kc_max, lag)
+        prm = self._params(tol, max_iter, alpha_W, alpha_H, l1_ratio, kc_max, lag, profile)
         i32p, u32p, dblp = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_double)
         if seeds is not None:
             seeds_a = np.ascontiguousarray(np.asarray(seeds, dtype=np.int64).astype(np.uint32)).ravel()

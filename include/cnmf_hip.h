@@ -49,7 +49,7 @@ typedef struct cnmf_cd_params {
     int    kc_max;       /* max packed component columns in flight: 32..256, 0 = auto */
     double l1_reg_W, l2_reg_W, l1_reg_H, l2_reg_H;
     int    lag;          /* host polls convergence `lag` iterations behind the GPU; 0 = default (2) */
-    int    reserved;
+    int    profile;      /* 1: bracket the two GEMM passes with HIP events (fills passA_ms/passB_ms) */
 } cnmf_cd_params;
 
 /* Per-call statistics (optional, may be NULL). */
@@ -57,6 +57,7 @@ typedef struct cnmf_batch_stats {
     int64_t outer_iterations;      /* batch iterations enqueued (each = pass A + pass B)        */
     int64_t restart_iterations;    /* sum over restarts of their n_iter                         */
     int64_t column_iterations;     /* sum over batch iterations of KC (incl. idle columns)      */
+    int64_t restart_column_iterations; /* sum over restarts of n_iter*k (algorithmic columns)  */
     double  gpu_ms;                /* device time of the whole call (hipEvent)                  */
     double  passA_ms, passB_ms;    /* summed hipEvent time of the two MFMA GEMM passes          */
     int64_t passA_launches, passB_launches;
