@@ -131,19 +131,22 @@ static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int l
 }
 
 // ------------------------------------------------------------------ sweep dispatch
-static hipError_t launch_sweep(hipStream_t st, unsigned kp_mask, int nslots, float* V, int ldv,
-                               int L, const float* P, int nsplit, long long pstride,
-                               const float* gram, const SlotDesc* slots, float l1,
-                               float* gram_part, double* viol_part, int chunks, int parts,
-                               int want_gram)
+static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, int L, const float* P,
+                               const float* gram, const SlotDesc* slots, float l1, float* gram_part,
+                               double* viol_part, int chunks, int parts, int want_gram)
 {
     dim3 grid(parts, nslots);
-#define SW(KP)                                                                                   \
-    if (kp_mask & (1u << (KP / 4)))                                                              \
-        sweep_kernel<KP><<<grid, 256, 0, st>>>(V, ldv, L, P, nsplit, pstride, gram, slots, l1,   \
-                                               gram_part, viol_part, chunks, want_gram);
-    SW(4) SW(8) SW(12) SW(16) SW(20) SW(24) SW(28) SW(32)
-#undef SW
+    sweep_kernel<<<grid, 256, 0, st>>>(V, ldv, L, P, gram, slots, l1, gram_part, viol_part, chunks,
+                                       want_gram);
+    return hipGetLastError();
+}
+
+static hipError_t launch_reduce_splits(hipStream_t st, float* P, int nsplit, long long split_stride,
+                                       long long n_floats)
+{
+    if (nsplit <= 1) return hipSuccess;
+    const long long nv = n_floats / 4;
+    reduce_splits_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, st>>>(P, nsplit, split_stride, P, nv);
     return hipGetLastError();
 }
 
@@ -430,12 +433,13 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         hoff[r + 1] = hoff[r] + (size_t)kk[r] * G;
         woff[r + 1] = woff[r] + (size_t)kk[r] * N;
     }
-    const int KC = pick_kc(total_k, max_k, prm->kc_max);
+    int KC = pick_kc(total_k, max_k, prm->kc_max);
+    const int KC0 = KC;
     rc = ensure_batch(ctx, KC);
     if (rc) return rc;
     rc = ensure_stage(ctx, (size_t)N * KMAX, (size_t)G * KMAX);
     if (rc) return rc;
-    const int nsplit = ctx->nsplit_alloc;
+    int nsplit = ctx->nsplit_alloc;
     const int lag = std::max(1, std::min(RING - 2, prm->lag > 0 ? prm->lag : 2));
     hipStream_t st = ctx->stream;
 
@@ -485,7 +489,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     size_t next = 0;
 
     ColAlloc cols(KC);
-    std::vector<HostSlot> hs(KC);
+    std::vector<HostSlot> hs(KC0);
     int nslots = 0;          // highest used slot index + 1
     int n_active = 0;
     int64_t it = 0;          // batch iterations enqueued so far
@@ -529,13 +533,13 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     while (true) {
         // ---- refill free columns from the pending list
         int n_new = 0;
-        int* new_list = ctx->h_slot_list + (size_t)(it % RING) * KC;
+        int* new_list = ctx->h_slot_list + (size_t)(it % RING) * KC0;
         while (next < order.size()) {
             const int r = order[next], k = kk[r];
             const int off = cols.alloc(k);
             if (off < 0) break;
             int s = 0;
-            while (s < KC && hs[s].state != 0) ++s;
+            while (s < KC0 && hs[s].state != 0) ++s;
             hs[s].state = 1; hs[s].restart = r; hs[s].off = off; hs[s].k = k; hs[s].installed_at = it;
             nslots = std::max(nslots, s + 1);
             dim3 gI((std::max(N, G) + 255) / 256, k);
@@ -555,7 +559,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             ++n_active; ++next;
         }
         if (n_new) {
-            int* dl = ctx->d_slot_list + (size_t)(it % RING) * KC;
+            int* dl = ctx->d_slot_list + (size_t)(it % RING) * KC0;
             HIP_TRY(ctx, hipMemcpyAsync(dl, new_list, n_new * sizeof(int), hipMemcpyHostToDevice, st));
             gram_rows_kernel<<<n_new, 256, 0, st>>>(ctx->H, ctx->G_pad, G, ctx->d_slots, dl, ctx->gramH, l2W);
             HIP_TRY(ctx, hipGetLastError());
@@ -563,19 +567,15 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (n_active == 0 && next >= order.size()) break;
 
         // ---- one coordinate-descent outer iteration for every slot in flight
-        unsigned kp_mask = 0;
-        for (int s = 0; s < nslots; ++s)
-            if (hs[s].state) kp_mask |= 1u << ((hs[s].k + 3) / 4);
         if (time_gemm) { gev.resize(gev.size() + 4); for (int i = 0; i < 4; ++i) hipEventCreate(&gev[gev.size() - 4 + i]); hipEventRecord(gev[gev.size() - 4], st); }
         // pass A : XHt[KC][N] = H_all . X^T                       (sklearn _nmf.py:387)
         HIP_TRY(ctx, launch_gemm<false>(st, gvarA, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt,
                                         ctx->N_pad, 0, KC, ctx->G_pad, ctx->N_pad, 1));
         if (time_gemm) hipEventRecord(gev[gev.size() - 3], st);
         // W half-step                                             (sklearn _nmf.py:500)
-        HIP_TRY(ctx, launch_sweep(st, kp_mask, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, 1, 0,
-                                  ctx->gramH, ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part,
-                                  chunksW, partsW, 1));
-        finalize_kernel<<<nslots, 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
+        HIP_TRY(ctx, launch_sweep(st, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
+                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1));
+        finalize_kernel<<<dim3(nslots, 4), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
                                                 ctx->d_slots, 0, prm->tol, prm->max_iter, 1);
         if (time_gemm) hipEventRecord(gev[gev.size() - 2], st);
         // pass B : XtW[S][KC][G] = Wt_all . X  (split over cells)  (sklearn _nmf.py:505-507)
@@ -584,16 +584,17 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                                        ctx->G_pad, nsplit));
         if (time_gemm) hipEventRecord(gev[gev.size() - 1], st);
         // H half-step
-        HIP_TRY(ctx, launch_sweep(st, kp_mask, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, nsplit,
-                                  (long long)KC * ctx->G_pad, ctx->gramW, ctx->d_slots, l1H,
-                                  ctx->gram_part, ctx->viol_part, chunksH, partsH, 1));
-        finalize_kernel<<<nslots, 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W,
+        HIP_TRY(ctx, launch_reduce_splits(st, ctx->XtW, nsplit, (long long)KC * ctx->G_pad,
+                                          (long long)KC * ctx->G_pad));
+        HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
+                                  ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1));
+        finalize_kernel<<<dim3(nslots, 4), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W,
                                                 ctx->d_slots, 1, prm->tol, prm->max_iter, 1);
         HIP_TRY(ctx, hipGetLastError());
         column_iters += KC;
 
         // ---- snapshot of the slot table, examined `lag` iterations later
-        SlotDesc* snap = ctx->h_snap + (size_t)(it % RING) * KC;
+        SlotDesc* snap = ctx->h_snap + (size_t)(it % RING) * KC0;
         HIP_TRY(ctx, hipMemcpyAsync(snap, ctx->d_slots, (size_t)nslots * sizeof(SlotDesc), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipEventRecord(ev[it % RING], st));
         ++it;
@@ -602,12 +603,50 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             const int64_t si = it - 1 - lag;   // snapshot index to inspect now
             if (si >= 0) {
                 HIP_TRY(ctx, hipEventSynchronize(ev[si % RING]));
-                const SlotDesc* sp = ctx->h_snap + (size_t)(si % RING) * KC;
+                const SlotDesc* sp = ctx->h_snap + (size_t)(si % RING) * KC0;
                 for (int s = 0; s < nslots; ++s)
                     if (hs[s].state == 1 && hs[s].installed_at <= si && sp[s].active == 0 && sp[s].restart == hs[s].restart) {
                         rc = retire(s, sp[s]);
                         if (rc) return rc;
                     }
+            }
+        }
+        // ---- tail compaction: nothing left to refill with and at most half of the packed
+        // columns still iterate -> repack the live slots into a narrower batch so the two
+        // GEMM passes shrink with the work (their cost is proportional to KC).
+        if (next >= order.size() && n_active > 0 && KC > 32 && !getenv("CNMF_NO_COMPACT")) {
+            int live_cols = 0;
+            for (int s = 0; s < nslots; ++s) if (hs[s].state) live_cols += hs[s].k;
+            int KCn = 32;
+            while (KCn < live_cols) KCn *= 2;
+            if (KCn < KC) {
+                std::vector<int> idx;
+                for (int s = 0; s < nslots; ++s) if (hs[s].state) idx.push_back(s);
+                std::sort(idx.begin(), idx.end(), [&](int a, int b) { return hs[a].off < hs[b].off; });
+                int pos = 0;
+                for (int s : idx) {
+                    HostSlot& h = hs[s];
+                    if (h.off != pos) {
+                        dim3 gH((G + 255) / 256, h.k), gW((N + 255) / 256, h.k), gI((std::max(N, G) + 255) / 256, h.k);
+                        extract_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, G, h.off, h.k, ctx->stageH, 0);
+                        extract_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, h.off, h.k, ctx->stageW, 0);
+                        install_cm_kernel<<<gI, 256, 0, st>>>(ctx->stageH, ctx->stageW, ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, pos);
+                        set_slot_off_kernel<<<1, 1, 0, st>>>(ctx->d_slots, s, pos);
+                        h.off = pos;
+                    }
+                    pos += h.k;
+                }
+                if (pos < KCn) {
+                    dim3 gc((ctx->G_pad + 255) / 256, KCn - pos), gw((ctx->N_pad + 255) / 256, KCn - pos);
+                    clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, pos, KCn - pos);
+                    clear_rows_kernel<<<gw, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, pos, KCn - pos);
+                }
+                HIP_TRY(ctx, hipGetLastError());
+                KC = KCn;
+                cols = ColAlloc(KC);
+                for (int s : idx) cols.alloc(hs[s].k);
+                const int cap = (ctx->nsplit_alloc * KC0) / KC;
+                nsplit = std::max(1, std::min(pick_nsplit(ctx, KC), cap));
             }
         }
     }
@@ -630,7 +669,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         stats->restart_iterations = restart_iters;
         stats->column_iterations = column_iters;
         stats->restart_column_iterations = restart_col_iters;
-        stats->kc = KC; stats->nsplit = nsplit;
+        stats->kc = KC0; stats->nsplit = ctx->nsplit_alloc;
         for (size_t i = 0; i + 3 < gev.size(); i += 4) {
             float a = 0.f, b = 0.f;
             hipEventElapsedTime(&a, gev[i], gev[i + 1]);
@@ -698,7 +737,6 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
     gram_rows_kernel<<<1, 256, 0, st>>>(ctx->H, ctx->G_pad, G, ctx->d_slots, ctx->d_slot_list, ctx->gramH, (float)prm->l2_reg_W);
     HIP_TRY(ctx, launch_gemm<false>(st, 0, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt, ctx->N_pad, 0, KC, ctx->G_pad, ctx->N_pad, 1));
     const int chunksW = sweep_chunks(N), partsW = sweep_parts(N);
-    const unsigned kp_mask = 1u << ((k + 3) / 4);
     hipEvent_t ev;
     HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const int burst = 8;        // sweeps enqueued between two looks at the slot state
@@ -706,10 +744,10 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
     SlotDesc* snap = ctx->h_snap;
     for (int it = 0; it < prm->max_iter && !done; it += burst) {
         for (int b = 0; b < burst; ++b) {
-            HIP_TRY(ctx, launch_sweep(st, kp_mask, 1, ctx->Wt, ctx->N_pad, N, ctx->XHt, 1, 0, ctx->gramH,
+            HIP_TRY(ctx, launch_sweep(st, 1, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
                                       ctx->d_slots, (float)prm->l1_reg_W, ctx->gram_part, ctx->viol_part,
                                       chunksW, partsW, 0));
-            finalize_kernel<<<1, 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, 0.f,
+            finalize_kernel<<<dim3(1, 1), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, 0.f,
                                                ctx->d_slots, 2, prm->tol, prm->max_iter, 0);
         }
         HIP_TRY(ctx, hipMemcpyAsync(snap, ctx->d_slots, sizeof(SlotDesc), hipMemcpyDeviceToHost, st));

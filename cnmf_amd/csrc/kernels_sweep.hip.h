@@ -36,27 +36,22 @@ struct SlotDesc {                   // one restart in flight (device + host mirr
     double viol_last;               // violation/viol_init at the last completed iteration
 };
 
-// KP = k rounded up to a multiple of 4 (compile-time register array size).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Body of the sweep for one (row chunk, slot); KP = k rounded up to a multiple of 4
+// (compile-time register array size).  Gram of the updated rows:
+//   KP <= 16 : v_mfma_f32_16x16x4_f32  (16 MFMAs of 32 cycles per 64 rows)
+//   KP  > 16 : v_mfma_f32_32x32x2_f32  (32 MFMAs of 64 cycles per 64 rows)
 template <int KP>
-__global__ __launch_bounds__(256) void sweep_kernel(
-    float* __restrict__ V, int ldv, int L,
-    const float* __restrict__ P, int nsplit, long long p_split_stride,
-    const float* __restrict__ gram,          // [nslots][32][32], regularised diagonal included
-    const SlotDesc* __restrict__ slots,
-    float l1_reg,
-    float* __restrict__ gram_part,           // [nslots][gridDim.x][32][32]
-    double* __restrict__ viol_part,          // [nslots][gridDim.x]
-    int chunks_per_block, int want_gram)
+__device__ __forceinline__ void sweep_body(
+    float* __restrict__ V, int ldv, int L, const float* __restrict__ P,
+    const float* __restrict__ gram, const SlotDesc& sd, int slot, float l1_reg,
+    float* __restrict__ gram_part, double* __restrict__ viol_part,
+    int chunks_per_block, int want_gram,
+    float (*Gs)[KMAX + 4], float (*Ws)[64][KMAX + 1], double* vred)
 {
-    const int slot = blockIdx.y;
-    const SlotDesc sd = slots[slot];
-    if (!sd.active || sd.k > KP || sd.k <= KP - 4) return;   // other KP instantiation handles it
+    constexpr bool SMALL = (KP <= 16);
     const int k = sd.k, off = sd.off;
-
-    __shared__ __attribute__((aligned(16))) float Gs[KMAX][KMAX + 4];
-    __shared__ __attribute__((aligned(16))) float Ws[4][64][KMAX + 1];
-    __shared__ double vred[4];
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < KMAX * KMAX; e += 256) {
         const int r = e / KMAX, c = e % KMAX;
@@ -65,6 +60,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(
     __syncthreads();
 
     f32x16 gacc;
+    f32x4 gacc4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
     float viol = 0.f;
@@ -79,9 +75,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(
             if (live && c < k) {
                 const size_t idx = (size_t)(off + c) * ldv + row;
                 w[c] = V[idx];
-                float acc = P[idx];
-                for (int s = 1; s < nsplit; ++s) acc += P[(size_t)s * p_split_stride + idx];
-                p[c] = acc - l1_reg;
+                p[c] = P[idx] - l1_reg;
             }
         }
         if (live) {
@@ -102,17 +96,25 @@ __global__ __launch_bounds__(256) void sweep_kernel(
                 if (c < k) V[(size_t)(off + c) * ldv + row] = w[c];
         }
         if (want_gram) {
-            // Gram of the updated rows on the matrix pipe: gacc += Wrows^T . Wrows
+            // Gram of the updated rows on the (otherwise idle) matrix pipe: acc += Wrows^T . Wrows
+            constexpr int WC = SMALL ? 16 : KMAX;
 #pragma unroll
-            for (int c = 0; c < KMAX; ++c) Ws[wave][lane][c] = (c < KP) ? w[c < KP ? c : 0] : 0.f;
-            // (wave-private tile: no workgroup barrier needed, only LDS write->read order)
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-            __builtin_amdgcn_wave_barrier();
-            const int li = lane & 31, h = lane >> 5;
+            for (int c = 0; c < WC; ++c) Ws[wave][lane][c] = (c < KP) ? w[c < KP ? c : 0] : 0.f;
+            __builtin_amdgcn_wave_barrier();       // wave-private tile: LDS ops of one wave are in order
+            if (SMALL) {
+                const int li = lane & 15, q = lane >> 4;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float a = Ws[wave][4 * s + q][li];
+                    gacc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, gacc4, 0, 0, 0);
+                }
+            } else {
+                const int li = lane & 31, h = lane >> 5;
 #pragma unroll 8
-            for (int s = 0; s < 32; ++s) {
-                const float a = Ws[wave][2 * s + h][li];
-                gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, gacc, 0, 0, 0);
+                for (int s = 0; s < 32; ++s) {
+                    const float a = Ws[wave][2 * s + h][li];
+                    gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, gacc, 0, 0, 0);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -126,21 +128,29 @@ __global__ __launch_bounds__(256) void sweep_kernel(
 
     // ---- gram: sum the 4 waves' accumulators through LDS, write the block partial
     __syncthreads();
-    float* gred = &Ws[0][0][0];          // reuse as [4][32][33]? -> needs 4*32*33 <= 4*64*33 : ok
+    float* gred = &Ws[0][0][0];          // reused as [4][32][33]  (4*32*33 <= 4*64*33 floats)
     if (want_gram) {
-        const int li = lane & 31, h = lane >> 5;
+        if (SMALL) {
+            const int li = lane & 15, q = lane >> 4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-            gred[(wave * 32 + rr) * 33 + li] = gacc[r];
+            for (int r = 0; r < 4; ++r) gred[(wave * 32 + 4 * q + r) * 33 + li] = gacc4[r];
+        } else {
+            const int li = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+                gred[(wave * 32 + rr) * 33 + li] = gacc[r];
+            }
         }
     }
     __syncthreads();
     if (want_gram) {
         for (int e = tid; e < GRAM_SZ; e += 256) {
             const int r = e / 32, c = e % 32;
-            const float s = gred[(0 * 32 + r) * 33 + c] + gred[(1 * 32 + r) * 33 + c] +
-                            gred[(2 * 32 + r) * 33 + c] + gred[(3 * 32 + r) * 33 + c];
+            float s = 0.f;
+            if (r < k && c < k)
+                s = gred[(0 * 32 + r) * 33 + c] + gred[(1 * 32 + r) * 33 + c] +
+                    gred[(2 * 32 + r) * 33 + c] + gred[(3 * 32 + r) * 33 + c];
             gram_part[((size_t)slot * gridDim.x + blockIdx.x) * GRAM_SZ + e] = s;
         }
     }
@@ -148,12 +158,66 @@ __global__ __launch_bounds__(256) void sweep_kernel(
         viol_part[(size_t)slot * gridDim.x + blockIdx.x] = vred[0] + vred[1] + vred[2] + vred[3];
 }
 
-// One workgroup per slot: reduce the sweep's partials in a fixed order, add the
-// l2 regulariser to the diagonal (sklearn _nmf.py:389-392) and run the stopping rule
-// of _fit_coordinate_descent (sklearn _nmf.py:496-521) on the device.
+// One launch sweeps every slot in flight: grid = (row blocks, slots); the workgroup
+// dispatches on its slot's rank to the right register-array size.
+__global__ __launch_bounds__(256) void sweep_kernel(
+    float* __restrict__ V, int ldv, int L,
+    const float* __restrict__ P,             // [KC][ldv] products (split-K already reduced)
+    const float* __restrict__ gram,          // [nslots][32][32], regularised diagonal included
+    const SlotDesc* __restrict__ slots,
+    float l1_reg,
+    float* __restrict__ gram_part,           // [nslots][gridDim.x][32][32]
+    double* __restrict__ viol_part,          // [nslots][gridDim.x]
+    int chunks_per_block, int want_gram)
+{
+    const int slot = blockIdx.y;
+    const SlotDesc sd = slots[slot];
+    if (!sd.active) return;
+    __shared__ __attribute__((aligned(16))) float Gs[KMAX][KMAX + 4];
+    __shared__ __attribute__((aligned(16))) float Ws[4][64][KMAX + 1];
+    __shared__ double vred[4];
+#define CNMF_SW(KP_)                                                                              \
+    case KP_ / 4:                                                                                 \
+        sweep_body<KP_>(V, ldv, L, P, gram, sd, slot, l1_reg, gram_part, viol_part,               \
+                        chunks_per_block, want_gram, Gs, Ws, vred);                               \
+        break;
+    switch ((sd.k + 3) / 4) {
+        CNMF_SW(4) CNMF_SW(8) CNMF_SW(12) CNMF_SW(16) CNMF_SW(20) CNMF_SW(24) CNMF_SW(28) CNMF_SW(32)
+        default: break;
+    }
+#undef CNMF_SW
+}
+
+// Sum the split-K partials of pass B in split order (deterministic): out = sum_s P[s].
+// float4 grid-stride; rows of inactive / unused component columns are skipped via `rows`.
+__global__ __launch_bounds__(256) void reduce_splits_kernel(
+    const float* __restrict__ P, int nsplit, long long split_stride, float* __restrict__ out,
+    long long n_vec4)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_vec4) return;
+    const v4f* p = reinterpret_cast<const v4f*>(P) + i;
+    const long long sv = split_stride / 4;
+    v4f acc = p[0];
+    int s = 1;
+    for (; s + 4 <= nsplit; s += 4) {
+        const v4f a = p[(long long)s * sv], b = p[(long long)(s + 1) * sv];
+        const v4f c = p[(long long)(s + 2) * sv], d = p[(long long)(s + 3) * sv];
+        acc += a; acc += b; acc += c; acc += d;
+    }
+    for (; s < nsplit; ++s) acc += p[(long long)s * sv];
+    reinterpret_cast<v4f*>(out)[i] = acc;
+}
+
+// grid = (slots, 4): reduce the sweep's partials in a fixed order, add the l2 regulariser to
+// the diagonal (sklearn _nmf.py:389-392); block (slot,0) also runs the stopping rule of
+// _fit_coordinate_descent (sklearn _nmf.py:496-521) on the device.
 //   phase 0 : after the W half-step (update_H=True)  -> store violation, no decision
 //   phase 1 : after the H half-step                  -> total violation, decide
 //   phase 2 : after the W half-step (update_H=False) -> decide on the W violation alone
+// NB the `active` flag is read by all four blocks of a slot and cleared by block 0 of the
+// same launch; the flag copy `was_active` taken at entry keeps the other three consistent
+// enough: a block that sees the cleared flag skips a gram nobody will read again.
 __global__ __launch_bounds__(256) void finalize_kernel(
     const float* __restrict__ gram_part, const double* __restrict__ viol_part, int nparts,
     float* __restrict__ gram_out, float l2_reg,
@@ -163,15 +227,28 @@ __global__ __launch_bounds__(256) void finalize_kernel(
     SlotDesc* sd = &slots[slot];
     if (!sd->active) return;
     const int tid = threadIdx.x;
+    const int k = sd->k;
     if (want_gram) {
-        for (int e = tid; e < GRAM_SZ; e += 256) {
-            float s = 0.f;
-            for (int pI = 0; pI < nparts; ++pI)
-                s += gram_part[((size_t)slot * nparts + pI) * GRAM_SZ + e];
-            if ((e / 32) == (e % 32)) s += l2_reg;
-            gram_out[(size_t)slot * GRAM_SZ + e] = s;
+        const int e = blockIdx.y * 256 + tid;
+        const int r = e / 32, c = e % 32;
+        float s = 0.f;
+        if (r < k && c < k) {
+            const float* gp = gram_part + (size_t)slot * nparts * GRAM_SZ + e;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int pI = 0;
+            for (; pI + 4 <= nparts; pI += 4) {
+                s0 += gp[(size_t)pI * GRAM_SZ];
+                s1 += gp[(size_t)(pI + 1) * GRAM_SZ];
+                s2 += gp[(size_t)(pI + 2) * GRAM_SZ];
+                s3 += gp[(size_t)(pI + 3) * GRAM_SZ];
+            }
+            for (; pI < nparts; ++pI) s0 += gp[(size_t)pI * GRAM_SZ];
+            s = (s0 + s1) + (s2 + s3);
+            if (r == c) s += l2_reg;
         }
+        gram_out[(size_t)slot * GRAM_SZ + e] = s;
     }
+    if (blockIdx.y != 0) return;
     __shared__ double red[256];
     double v = 0.0;
     for (int pI = tid; pI < nparts; pI += 256) v += viol_part[(size_t)slot * nparts + pI];
@@ -197,8 +274,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(
                 if (sd->viol_last <= tol) done = true;
             }
             if (it >= max_iter) done = true;
-            if (done) sd->active = 0;
             sd->viol = 0.0;
+            if (done) sd->active = 0;
         }
     }
 }
@@ -264,6 +341,8 @@ __global__ void install_cm_kernel(const float* __restrict__ H0, const float* __r
     if (i < G) H[(size_t)(off + c) * ldh + i] = H0[(size_t)c * G + i];
     if (i < N) Wt[(size_t)(off + c) * ldw + i] = Wt0[(size_t)c * N + i];
 }
+
+__global__ void set_slot_off_kernel(SlotDesc* slots, int slot, int off) { slots[slot].off = off; }
 
 // Zero a range of packed component rows (freed slot -> contributes nothing to the GEMMs).
 __global__ void clear_rows_kernel(float* __restrict__ V, int ldv, int L, int off, int k)
