@@ -226,3 +226,39 @@ def consensus_core(merged_spectra, X, k, density_threshold=0.5, local_neighborho
         out["silhouette"] = silhouette_score(l2, labels)
         out["prediction_error"] = float(((np.asarray(X, dtype=np.float64) - W @ med) ** 2).sum())
     return out
+
+
+# ------------------------------------------------------------------ the consensus tail
+def ols_all_cols(Xd, Y):
+    """efficient_ols_all_cols(X, Y, normalize_y=True) (cnmf.py:55-125) for dense Y:
+    z-score the columns of Y (population variance, eps floor), solve the normal equations."""
+    mean = Y.mean(axis=0)
+    var = Y.var(axis=0)
+    var[var < 1e-12] = 1e-12
+    Yn = (Y - mean) / np.sqrt(var)
+    beta, *_ = np.linalg.lstsq(Xd.T @ Xd, Xd.T @ Yn, rcond=None)
+    return beta
+
+
+def consensus_tail(core, tpm, tpm_std, hvg_idx, refit_usage=True, normalize_tpm_spectra=False):
+    """cnmf.py:939-975 on arrays: re-order programmes by total normalised usage, refit
+    spectra on the TPM matrix, z-score OLS spectra, final usage refit on std-scaled HVG TPM."""
+    rf = core["rf_usages"]
+    med = core["median_spectra"]
+    norm = rf / rf.sum(axis=1, keepdims=True)
+    order = np.argsort(-norm.sum(axis=0), kind="stable")
+    rf, norm, med = rf[:, order], norm[:, order], med[order]
+    tpm = np.asarray(tpm, dtype=np.float64)
+    Wt, _ = nmf_cd.nnls(tpm.T, norm.T)                       # refit_spectra(tpm.X, norm_usages)
+    spectra_tpm = Wt.T
+    if normalize_tpm_spectra:
+        spectra_tpm = spectra_tpm / spectra_tpm.sum(axis=1, keepdims=True) * 1e6
+    usage_coef = ols_all_cols(rf, tpm)
+    out = dict(order=order, median_spectra=med, spectra_tpm=spectra_tpm, usage_coef=usage_coef,
+               rf_usages=rf)
+    if refit_usage:
+        norm_tpm = tpm[:, hvg_idx]
+        norm_tpm = norm_tpm / norm_tpm.std(axis=0, ddof=1)
+        srf = spectra_tpm[:, hvg_idx] / tpm_std[hvg_idx]
+        out["rf_usages"], _ = nmf_cd.nnls(norm_tpm, srf)
+    return out
