@@ -19,6 +19,7 @@ SYMBOLS = [
     "cnmf_device_count", "cnmf_create", "cnmf_destroy", "cnmf_last_error", "cnmf_version",
     "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_get_shape",
     "cnmf_nmf_cd_batch", "cnmf_nmf_cd_batch_resident", "cnmf_nnls",
+    "cnmf_consensus", "cnmf_prediction_error",
     "cnmf_debug_gemm", "cnmf_debug_standard_normal",
 ]
 
@@ -42,6 +43,12 @@ class BatchStats(C.Structure):
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class ConsensusParams(C.Structure):
+    _fields_ = [("k", C.c_int), ("n_neighbors", C.c_int), ("density_threshold", C.c_double),
+                ("skip_density", C.c_int), ("want_silhouette", C.c_int), ("n_init", C.c_int),
+                ("max_iter", C.c_int), ("tol", C.c_double)]
 
 
 def sources():
@@ -110,6 +117,11 @@ def load():
                                                C.POINTER(BatchStats)]
     lib.cnmf_nnls.restype = i32
     lib.cnmf_nnls.argtypes = [vp, i32, f32p, C.POINTER(CdParams), f32p, i32p, dblp]
+    lib.cnmf_consensus.restype = i32
+    lib.cnmf_consensus.argtypes = [vp, dblp, i32, i32, C.POINTER(ConsensusParams), dblp,
+                                   dblp, i32p, i32p, dblp, dblp, dblp]
+    lib.cnmf_prediction_error.restype = i32
+    lib.cnmf_prediction_error.argtypes = [vp, i32, dblp, dblp, dblp]
     lib.cnmf_debug_gemm.restype = i32
     lib.cnmf_debug_gemm.argtypes = [vp, i32, i32, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
     lib.cnmf_debug_standard_normal.restype = i32

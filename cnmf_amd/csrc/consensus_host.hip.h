@@ -1,0 +1,312 @@
+// Host orchestration of the consensus step (included by cnmf_hip.hip).
+//
+// cnmf_consensus() restates cNMF.consensus' numerical core (cnmf.py:871-916, stats
+// 922-923) on the device: L2-normalise -> all-pairs distances -> KNN local density ->
+// density filter -> KMeans(k, n_init, random_state) -> per-cluster medians -> rows / sum.
+// KMeans' random draws (numpy RandomState(1): one uniform for the first centre, then
+// 2+int(log k) per further centre, per init; the count is data independent) are passed in
+// by the caller so that seeds match scikit-learn exactly (SURVEY.md "hard parts").
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "kernels_consensus.hip.h"
+
+namespace cnmf {
+
+struct DevPool {               // frees everything it handed out when it goes out of scope
+    std::vector<void*> ptrs;
+    hipError_t err = hipSuccess;
+    template <typename T> T* get(size_t n, bool zero = false, hipStream_t st = nullptr) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) { err = e; return nullptr; }
+        ptrs.push_back(p);
+        if (zero) hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(T), st);
+        return (T*)p;
+    }
+    ~DevPool() { for (void* p : ptrs) hipFree(p); }
+};
+
+static inline bool same_clustering(const std::vector<int>& a, const std::vector<int>& b, int k)
+{   // sklearn _k_means_common.pyx:314-330
+    std::vector<int> map(k, -1);
+    for (size_t i = 0; i < a.size(); ++i) {
+        if (map[a[i]] == -1) map[a[i]] = b[i];
+        else if (map[a[i]] != b[i]) return false;
+    }
+    return true;
+}
+
+// numpy RandomState.choice(n, p=ones(n)/n) for one uniform draw u:
+//   cdf = cumsum(p); cdf /= cdf[-1]; idx = searchsorted(cdf, u, side='right')
+static inline int first_center_index(int n, double u)
+{
+    std::vector<double> cdf(n);
+    const double p = 1.0 / (double)n;
+    double run = 0.0;
+    for (int i = 0; i < n; ++i) { run += p; cdf[i] = run; }
+    const double last = cdf[n - 1];
+    for (int i = 0; i < n; ++i) cdf[i] /= last;
+    return (int)(std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+}
+
+}  // namespace cnmf
+
+#define CONS_TRY(call)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            SET_ERR(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? CNMF_ENOMEM : CNMF_EHIP;                       \
+        }                                                                                       \
+    } while (0)
+
+extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G,
+                              const cnmf_consensus_params* prm, const double* uniforms,
+                              double* density_out, int32_t* keep_out, int32_t* labels_out,
+                              double* median_out, double* dist_out, double* stats_out)
+{
+    using namespace cnmf;
+    if (!ctx || !spectra || !prm || !labels_out || !median_out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    const int k = prm->k;
+    if (R < 1 || G < 1 || k < 1 || k > R) { SET_ERR(ctx, "bad shape R=%d G=%d k=%d", R, G, k); return CNMF_EINVAL; }
+    if (k > 64) { SET_ERR(ctx, "k=%d > 64 clusters is not supported", k); return CNMF_EUNSUPPORTED; }
+    const int n_init = prm->n_init > 0 ? prm->n_init : 10;
+    const int max_iter = prm->max_iter > 0 ? prm->max_iter : 300;
+    const double tol = prm->tol >= 0 ? prm->tol : 1e-4;
+    const int L = 2 + (int)std::log((double)k);
+    if (!uniforms) { SET_ERR(ctx, "uniforms (n_init x (1+(k-1)*(2+int(log k)))) is NULL"); return CNMF_EINVAL; }
+    if (L > 8) { SET_ERR(ctx, "too many local trials"); return CNMF_EUNSUPPORTED; }
+    if (!prm->skip_density && prm->n_neighbors < 1) { SET_ERR(ctx, "n_neighbors must be >= 1"); return CNMF_EINVAL; }
+    if (!prm->skip_density && prm->n_neighbors + 1 > R) { SET_ERR(ctx, "n_neighbors+1 > number of spectra"); return CNMF_EINVAL; }
+    CONS_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevPool pool;
+    const int ld = round_up(G, 16);
+    const int Rp = round_up(R, 64);
+
+    // ---- L2-normalised spectra (cnmf.py:882)
+    double* dS = pool.get<double>((size_t)R * G);
+    double* dL2 = pool.get<double>((size_t)Rp * ld, true, st);
+    double* dsq = pool.get<double>(Rp, true, st);
+    if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+    CONS_TRY(hipMemcpyAsync(dS, spectra, (size_t)R * G * sizeof(double), hipMemcpyHostToDevice, st));
+    l2_rows_kernel<<<R, 256, 0, st>>>(dS, R, G, dL2, ld, dsq);
+
+    // ---- all-pairs distances + KNN local density (cnmf.py:891-898)
+    const bool need_dist = !prm->skip_density || prm->want_silhouette || dist_out;
+    double* dD = nullptr;
+    std::vector<double> density(R, 0.0);
+    std::vector<int> keep_idx;
+    if (need_dist) {
+        dD = pool.get<double>((size_t)Rp * Rp);
+        if (pool.err) { SET_ERR(ctx, "device allocation failed (distance matrix)"); return CNMF_ENOMEM; }
+        dgemm_nt_kernel<<<dim3(Rp / 64, Rp / 64), 256, 0, st>>>(dL2, ld, dL2, ld, dD, Rp, ld);
+        dist_epilogue_kernel<<<dim3((R + 255) / 256, R), 256, 0, st>>>(dD, Rp, R, dsq);
+        CONS_TRY(hipGetLastError());
+        if (dist_out)
+            CONS_TRY(hipMemcpy2DAsync(dist_out, (size_t)R * sizeof(double), dD, (size_t)Rp * sizeof(double),
+                                      (size_t)R * sizeof(double), R, hipMemcpyDeviceToHost, st));
+    }
+    if (!prm->skip_density) {
+        double* ddens = pool.get<double>(R);
+        if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+        const size_t lds = (size_t)R * sizeof(double);
+        if (lds > 150 * 1024) { SET_ERR(ctx, "R=%d spectra exceed the single-pass KNN row buffer", R); return CNMF_EUNSUPPORTED; }
+        CONS_TRY(hipFuncSetAttribute((const void*)knn_density_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        knn_density_kernel<<<R, 256, lds, st>>>(dD, Rp, R, prm->n_neighbors + 1, prm->n_neighbors, ddens);
+        CONS_TRY(hipGetLastError());
+        CONS_TRY(hipMemcpyAsync(density.data(), ddens, (size_t)R * sizeof(double), hipMemcpyDeviceToHost, st));
+        CONS_TRY(hipStreamSynchronize(st));
+        for (int r = 0; r < R; ++r) if (density[r] < prm->density_threshold) keep_idx.push_back(r);   // strict <, cnmf.py:903
+    } else {
+        for (int r = 0; r < R; ++r) keep_idx.push_back(r);
+    }
+    if (density_out) memcpy(density_out, density.data(), (size_t)R * sizeof(double));
+    if (keep_out) { for (int r = 0; r < R; ++r) keep_out[r] = 0; for (int r : keep_idx) keep_out[r] = 1; }
+    for (int r = 0; r < R; ++r) labels_out[r] = -1;
+    const int Rk = (int)keep_idx.size();
+    if (stats_out) { stats_out[0] = Rk; stats_out[1] = stats_out[2] = stats_out[3] = 0.0; }
+    if (Rk == 0) { SET_ERR(ctx, "Zero components remain after density filtering. Consider increasing density threshold"); return CNMF_ESTATE; }
+    if (Rk < k) { SET_ERR(ctx, "n_samples=%d should be >= n_clusters=%d.", Rk, k); return CNMF_EINVAL; }
+
+    // ---- KMeans on the kept rows (cnmf.py:908-909; sklearn _kmeans.py:1427-1555)
+    const int Rkp = round_up(Rk, 64);
+    int* dkeep = pool.get<int>(Rk);
+    double* dX = pool.get<double>((size_t)Rkp * ld, true, st);
+    double* dxsq = pool.get<double>(Rkp, true, st);
+    double* dmean = pool.get<double>(ld, true, st);
+    double* dvar = pool.get<double>(ld, true, st);
+    double* dcA = pool.get<double>((size_t)64 * ld, true, st);
+    double* dcB = pool.get<double>((size_t)64 * ld, true, st);
+    double* dcand = pool.get<double>((size_t)64 * ld, true, st);
+    double* ddots = pool.get<double>((size_t)64 * Rkp, true, st);
+    double* dclosest = pool.get<double>(Rkp);
+    double* dcum = pool.get<double>(Rkp);
+    double* ddmin = pool.get<double>((size_t)8 * Rkp);
+    double* dcpot = pool.get<double>(8);
+    double* dcsq = pool.get<double>(64);
+    int* dlabels = pool.get<int>(Rkp);
+    const int rows_per_chunk = std::max(32, (Rk + 31) / 32);
+    const int nchunks = (Rk + rows_per_chunk - 1) / rows_per_chunk;
+    double* dpartial = pool.get<double>((size_t)nchunks * k * ld);
+    int* dpcount = pool.get<int>((size_t)nchunks * k);
+    double* dsums = pool.get<double>((size_t)k * ld);
+    int* dcounts = pool.get<int>(k);
+    double* ddist = pool.get<double>(Rkp);
+    int* dcids = pool.get<int>(64);
+    KmState* dst = pool.get<KmState>(1, true, st);
+    const size_t nu = (size_t)n_init * (1 + (size_t)(k - 1) * L);
+    double* du = pool.get<double>(nu);
+    KmState* hst = nullptr;
+    if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+    CONS_TRY(hipHostMalloc(&hst, sizeof(KmState)));
+    struct HostFree { void* p; ~HostFree() { hipHostFree(p); } } hf{hst};
+    CONS_TRY(hipMemcpyAsync(dkeep, keep_idx.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
+    CONS_TRY(hipMemcpyAsync(du, uniforms, nu * sizeof(double), hipMemcpyHostToDevice, st));
+    gather_rows_kernel<<<dim3((G + 255) / 256, Rk), 256, 0, st>>>(dL2, ld, dkeep, Rk, G, dX, ld);
+    col_stats_kernel<<<(G + 255) / 256, 256, 0, st>>>(dX, ld, Rk, G, dmean, dvar);
+    center_rows_kernel<<<Rk, 256, 0, st>>>(dX, ld, G, dmean, dxsq);
+    std::vector<double> hvar(G);
+    CONS_TRY(hipMemcpyAsync(hvar.data(), dvar, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, st));
+    CONS_TRY(hipStreamSynchronize(st));
+    double vsum = 0.0;
+    for (int g = 0; g < G; ++g) vsum += hvar[g];
+    const double tol_ = (vsum / G) * tol;                      // _tolerance, sklearn _kmeans.py:279-288
+
+    const size_t acc_lds = (size_t)k * 256 * sizeof(double);
+    CONS_TRY(hipFuncSetAttribute((const void*)accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
+    auto dots = [&](const double* A) {     // ddots[64][Rkp] = A[64][ld] . X^T
+        dgemm_nt_kernel<<<dim3(Rkp / 64, 1), 256, 0, st>>>(A, ld, dX, ld, ddots, Rkp, ld);
+    };
+
+    std::vector<int> best_labels, labels(Rk);
+    double best_inertia = 0.0; int best_iter = 0; bool have_best = false;
+    for (int init = 0; init < n_init; ++init) {
+        const double* hu = uniforms + (size_t)init * (1 + (size_t)(k - 1) * L);
+        const double* dui = du + (size_t)init * (1 + (size_t)(k - 1) * L);
+        // -- k-means++ (sklearn _kmeans.py:174-272)
+        const int c0 = std::min(first_center_index(Rk, hu[0]), Rk - 1);
+        CONS_TRY(hipMemsetAsync(dcA, 0, (size_t)64 * ld * sizeof(double), st));
+        copy_row_kernel<<<(ld + 255) / 256, 256, 0, st>>>(dX, ld, G, c0, dcA, 0);
+        dots(dcA);
+        pp_first_kernel<<<1, 256, 0, st>>>(ddots, Rk, dxsq, c0, dclosest, dst);
+        for (int c = 1; c < k; ++c) {
+            pp_candidates_kernel<<<1, 256, 0, st>>>(dclosest, Rk, dui + 1 + (size_t)(c - 1) * L, L, dcum, dst);
+            gather_rows_kernel<<<dim3((G + 255) / 256, L), 256, 0, st>>>(dX, ld, &dst->cand[0], L, G, dcand, ld);
+            dots(dcand);
+            pp_update_kernel<<<L, 256, 0, st>>>(ddots, Rkp, Rk, dxsq, dclosest, dst, ddmin, dcpot);
+            pp_pick_kernel<<<1, 256, 0, st>>>(dcpot, L, Rk, ddmin, dclosest, dst, dX, ld, G, dcA, c, dcids);
+        }
+        CONS_TRY(hipGetLastError());
+        // -- Lloyd (sklearn _kmeans.py:624-752)
+        double* cur = dcA; double* nxt = dcB;
+        CONS_TRY(hipMemsetAsync(dlabels, 0xff, (size_t)Rkp * sizeof(int), st));     // labels = -1
+        bool strict = false; int it = 0;
+        for (it = 0; it < max_iter; ++it) {
+            center_norms_kernel<<<k, 256, 0, st>>>(cur, ld, G, dcsq);
+            dots(cur);
+            CONS_TRY(hipMemsetAsync(&dst->changed, 0, 2 * sizeof(int), st));         // changed, n_empty
+            assign_kernel<<<(Rk + 255) / 256, 256, 0, st>>>(ddots, Rkp, Rk, k, dcsq, dlabels, dst, 1);
+            accumulate_kernel<<<dim3((G + 255) / 256, nchunks), 256, acc_lds, st>>>(dX, ld, Rk, G, dlabels, k, rows_per_chunk, dpartial, dpcount);
+            reduce_partial_kernel<<<dim3((G + 255) / 256, k), 256, 0, st>>>(dpartial, dpcount, nchunks, k, ld, G, dsums, dcounts, dst);
+            row_center_dist_kernel<<<Rk, 256, 0, st>>>(dX, ld, G, cur, dlabels, ddist, dst);
+            relocate_empty_kernel<<<1, 256, 0, st>>>(dX, ld, G, Rk, k, dlabels, ddist, dsums, dcounts, dst);
+            finish_centers_kernel<<<1, 256, 0, st>>>(dsums, dcounts, k, ld, G, cur, nxt, dst);
+            CONS_TRY(hipGetLastError());
+            CONS_TRY(hipMemcpyAsync(hst, dst, sizeof(KmState), hipMemcpyDeviceToHost, st));
+            CONS_TRY(hipStreamSynchronize(st));
+            std::swap(cur, nxt);
+            if (hst->changed == 0) { strict = true; break; }
+            if (hst->shift_tot <= tol_) break;
+        }
+        const int n_it = std::min(it + 1, max_iter);
+        if (!strict) {      // re-run the E step so that labels match the final centres
+            center_norms_kernel<<<k, 256, 0, st>>>(cur, ld, G, dcsq);
+            dots(cur);
+            assign_kernel<<<(Rk + 255) / 256, 256, 0, st>>>(ddots, Rkp, Rk, k, dcsq, dlabels, dst, 0);
+        }
+        row_center_dist_kernel<<<Rk, 256, 0, st>>>(dX, ld, G, cur, dlabels, ddist, nullptr);
+        sum_kernel<<<1, 256, 0, st>>>(ddist, Rk, &dst->inertia);
+        CONS_TRY(hipGetLastError());
+        CONS_TRY(hipMemcpyAsync(hst, dst, sizeof(KmState), hipMemcpyDeviceToHost, st));
+        CONS_TRY(hipMemcpyAsync(labels.data(), dlabels, (size_t)Rk * sizeof(int), hipMemcpyDeviceToHost, st));
+        CONS_TRY(hipStreamSynchronize(st));
+        const double inertia = hst->inertia;
+        if (!have_best || (inertia < best_inertia && !same_clustering(labels, best_labels, k))) {
+            best_labels = labels; best_inertia = inertia; best_iter = n_it; have_best = true;
+        }
+    }
+    for (int q = 0; q < Rk; ++q) labels_out[keep_idx[q]] = best_labels[q];
+
+    // ---- per-cluster per-gene median, rows normalised to sum 1 (cnmf.py:913-916)
+    std::vector<int> seg(k + 1, 0), order(Rk), order_rows(Rk);
+    for (int q = 0; q < Rk; ++q) seg[best_labels[q] + 1]++;
+    for (int j = 0; j < k; ++j) seg[j + 1] += seg[j];
+    { std::vector<int> pos(seg.begin(), seg.end() - 1);
+      for (int q = 0; q < Rk; ++q) { const int p = pos[best_labels[q]]++; order[p] = q; order_rows[p] = keep_idx[q]; } }
+    for (int j = 0; j < k; ++j)
+        if (seg[j + 1] == seg[j]) { SET_ERR(ctx, "k-means produced an empty cluster (%d)", j); return CNMF_ESTATE; }
+    int* dorder_rows = pool.get<int>(Rk);
+    int* dorder = pool.get<int>(Rk);
+    int* dseg = pool.get<int>(k + 1);
+    double* dmed = pool.get<double>((size_t)k * G);
+    if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+    CONS_TRY(hipMemcpyAsync(dorder_rows, order_rows.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
+    CONS_TRY(hipMemcpyAsync(dorder, order.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
+    CONS_TRY(hipMemcpyAsync(dseg, seg.data(), (size_t)(k + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    cluster_median_kernel<<<dim3((G + 63) / 64, k), 64, 0, st>>>(dL2, ld, G, dorder_rows, dseg, dmed);
+    normalise_rows_sum_kernel<<<k, 256, 0, st>>>(dmed, G);
+    CONS_TRY(hipGetLastError());
+    CONS_TRY(hipMemcpyAsync(median_out, dmed, (size_t)k * G * sizeof(double), hipMemcpyDeviceToHost, st));
+
+    // ---- silhouette (cnmf.py:923)
+    double sil = 0.0;
+    if (prm->want_silhouette) {
+        double* dsil = pool.get<double>(Rk);
+        double* dsum = pool.get<double>(1);
+        if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+        CONS_TRY(hipMemcpyAsync(dlabels, best_labels.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
+        // sample order = kept order q; silhouette_kernel wants sample index in kept space
+        silhouette_kernel<<<Rk, 256, 0, st>>>(dD, Rp, dkeep, dorder, dseg, dlabels, Rk, k, dsil);
+        sum_kernel<<<1, 256, 0, st>>>(dsil, Rk, dsum);
+        CONS_TRY(hipGetLastError());
+        CONS_TRY(hipMemcpyAsync(&sil, dsum, sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    CONS_TRY(hipStreamSynchronize(st));
+    if (stats_out) { stats_out[0] = Rk; stats_out[1] = best_inertia; stats_out[2] = sil / Rk; stats_out[3] = best_iter; }
+    return CNMF_OK;
+}
+
+// Replaces the dense residual of cnmf.py:926-930: sum((X - W.H)^2) with X the resident matrix.
+extern "C" int cnmf_prediction_error(cnmf_ctx* ctx, int k, const double* W, const double* H, double* err_out)
+{
+    using namespace cnmf;
+    if (!ctx || !W || !H || !err_out || k < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (k > 64) { SET_ERR(ctx, "k > 64"); return CNMF_EUNSUPPORTED; }
+    CONS_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    DevPool pool;
+    double* dW = pool.get<double>((size_t)N * k);
+    double* dH = pool.get<double>((size_t)k * G);
+    const int rpb = 512;
+    dim3 grid((G + 255) / 256, (N + rpb - 1) / rpb);
+    double* dpart = pool.get<double>((size_t)grid.x * grid.y);
+    double* dsum = pool.get<double>(1);
+    if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+    CONS_TRY(hipMemcpyAsync(dW, W, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, st));
+    CONS_TRY(hipMemcpyAsync(dH, H, (size_t)k * G * sizeof(double), hipMemcpyHostToDevice, st));
+    const size_t lds = (size_t)k * 256 * sizeof(double);
+    CONS_TRY(hipFuncSetAttribute((const void*)residual_sq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    residual_sq_kernel<<<grid, 256, lds, st>>>(ctx->X, ctx->G_pad, N, G, dW, dH, k, rpb, dpart);
+    sum_kernel<<<1, 256, 0, st>>>(dpart, (int)(grid.x * grid.y), dsum);
+    CONS_TRY(hipGetLastError());
+    CONS_TRY(hipMemcpyAsync(err_out, dsum, sizeof(double), hipMemcpyDeviceToHost, st));
+    CONS_TRY(hipStreamSynchronize(st));
+    return CNMF_OK;
+}

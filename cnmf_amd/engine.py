@@ -218,6 +218,68 @@ class Engine:
                           % max_iter, ConvergenceWarning)
         return W, int(n_iter.value)
 
+    # ------------------------------------------------------------------ consensus core
+    def consensus(self, spectra, k, density_threshold=0.5, local_neighborhood_size=0.30,
+                  skip_density=False, want_silhouette=False, random_state=1, n_init=10,
+                  max_iter=300, tol=1e-4, return_dist=False):
+        """Numerical core of ``cNMF.consensus`` (cnmf.py:871-916) on the device, float64.
+
+        ``spectra``: the merged per-restart spectra (R x G).  Returns a dict with
+        ``local_density`` (R,), ``density_filter`` (R,) bool, ``labels`` (R,) int (0-based,
+        -1 = filtered), ``median_spectra`` (k x G, rows sum to 1), ``inertia``,
+        ``silhouette`` (if requested), ``topics_dist`` (R x R, if requested)."""
+        S = np.ascontiguousarray(spectra, dtype=np.float64)
+        if S.ndim != 2:
+            raise ValueError("spectra must be 2-D")
+        R, G = S.shape
+        k = int(k)
+        n_neighbors = int(local_neighborhood_size * R / k)                 # cnmf.py:879
+        L = 2 + int(np.log(k))
+        # the draws KMeans(random_state=1) takes: data-independent count, so the whole
+        # stream is generated up front with numpy's legacy RNG (bit-identical to sklearn)
+        u = np.random.RandomState(random_state).random_sample(n_init * (1 + (k - 1) * L))
+        prm = _lib.ConsensusParams(k, n_neighbors, float(density_threshold), int(bool(skip_density)),
+                                   int(bool(want_silhouette)), int(n_init), int(max_iter), float(tol))
+        dens = np.zeros(R, dtype=np.float64)
+        keep = np.zeros(R, dtype=np.int32)
+        labels = np.zeros(R, dtype=np.int32)
+        med = np.zeros((k, G), dtype=np.float64)
+        dist = np.zeros((R, R), dtype=np.float64) if return_dist else None
+        stats = np.zeros(4, dtype=np.float64)
+        dblp, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        rc = self._lib.cnmf_consensus(self._ctx, S.ctypes.data_as(dblp), R, G, C.byref(prm),
+                                      u.ctypes.data_as(dblp), dens.ctypes.data_as(dblp),
+                                      keep.ctypes.data_as(i32p), labels.ctypes.data_as(i32p),
+                                      med.ctypes.data_as(dblp),
+                                      dist.ctypes.data_as(dblp) if return_dist else None,
+                                      stats.ctypes.data_as(dblp))
+        if rc == -4 and b"Zero components remain" in self._lib.cnmf_last_error(self._ctx):
+            raise RuntimeError("Zero components remain after density filtering. Consider increasing density threshold")
+        self._check(rc)
+        out = dict(local_density=dens, density_filter=keep.astype(bool), labels=labels,
+                   median_spectra=med, inertia=float(stats[1]), n_kept=int(stats[0]),
+                   kmeans_n_iter=int(stats[3]), n_neighbors=n_neighbors)
+        if want_silhouette:
+            out["silhouette"] = float(stats[2])
+        if return_dist:
+            out["topics_dist"] = dist
+        return out
+
+    def prediction_error(self, W, H):
+        """``((X - W @ H)**2).sum()`` over the resident matrix (cnmf.py:926-930)."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        if W.shape[0] != N or H.shape[1] != G or W.shape[1] != H.shape[0]:
+            raise ValueError("shape mismatch: W %s, H %s, X %s" % (W.shape, H.shape, (N, G)))
+        err = C.c_double(0.0)
+        dblp = C.POINTER(C.c_double)
+        self._check(self._lib.cnmf_prediction_error(self._ctx, int(H.shape[0]), W.ctypes.data_as(dblp),
+                                                    H.ctypes.data_as(dblp), C.byref(err)))
+        return float(err.value)
+
     # ------------------------------------------------------------------ diagnostics
     def debug_gemm(self, mode, A, B, variant=0, nsplit=1, reps=0):
         A = np.ascontiguousarray(A, dtype=np.float32)

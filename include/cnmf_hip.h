@@ -123,6 +123,40 @@ int cnmf_nmf_cd_batch_resident(cnmf_ctx* ctx, int n_restarts, const int32_t* k,
 int cnmf_nnls(cnmf_ctx* ctx, int k, const float* H /*[k][G]*/, const cnmf_cd_params* params,
               float* W_out /*[N][k]*/, int32_t* n_iter_out, double* viol_out);
 
+/* ---- consensus core ---------------------------------------------------------------------
+ * Replaces the numerical core of cNMF.consensus (cnmf.py:871-916 + the silhouette of the stats
+ * branch, :923), float64 on the device:
+ *   l2 = spectra / |spectra|_2 (:882) -> euclidean_distances (:891; sklearn:metrics/pairwise.py:
+ *   391-438) -> local density = sum of the n_neighbors+1 smallest per row / n_neighbors (:893-898)
+ *   -> keep density < threshold (:903) -> KMeans(k, n_init, random_state=1) on the kept rows
+ *   (:908-909; sklearn:cluster/_kmeans.py:1427-1555) -> per-cluster per-gene median (:913) ->
+ *   rows / row sum (:916).
+ * `uniforms` = the draws KMeans takes from numpy RandomState(random_state):
+ *   [n_init][1 + (k-1)*(2+int(log k))] doubles (first centre, then the local trials).
+ * Outputs: density_out[R] (NULL ok; zeros when skip_density), keep_out[R] 0/1 (NULL ok),
+ *   labels_out[R] (0..k-1, -1 for filtered rows), median_out[k][G], dist_out[R][R] (NULL ok),
+ *   stats_out[4] = {rows kept, best inertia, silhouette (0 unless want_silhouette), n_iter of best run}.
+ * Returns CNMF_ESTATE with the reference's message when the filter removes every row (:905-906). */
+typedef struct cnmf_consensus_params {
+    int    k;
+    int    n_neighbors;        /* int(local_neighborhood_size * R / k), cnmf.py:879 */
+    double density_threshold;
+    int    skip_density;       /* 1 = skip_density_and_return_after_stats (k_selection_plot)  */
+    int    want_silhouette;
+    int    n_init;             /* 10 */
+    int    max_iter;           /* 300 (sklearn default) */
+    double tol;                /* 1e-4 (sklearn default) */
+} cnmf_consensus_params;
+
+int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G,
+                   const cnmf_consensus_params* params, const double* uniforms,
+                   double* density_out, int32_t* keep_out, int32_t* labels_out,
+                   double* median_out, double* dist_out, double* stats_out);
+
+/* sum((X - W.H)^2) over the resident matrix: the prediction error of cnmf.py:926-930
+ * (W [N][k], H [k][G], float64). */
+int cnmf_prediction_error(cnmf_ctx* ctx, int k, const double* W, const double* H, double* err_out);
+
 /* ---- diagnostics used by the tests ---------------------------------------------------- */
 /* C[KC][J] = A[KC][K] . B  through the engine's MFMA GEMM; mode 0: B is [J][K] (pass A),
  * mode 1: B is [K][J] (pass B, split-K partials summed in split order).                  */
