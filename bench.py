@@ -122,13 +122,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def gather(H_list):
+    def gather(H_list, ks=None, step=0):
+        """The one data-path collective: all-gather of the packed per-restart spectra."""
         if dist is None:
             return
         import torch
-        mine = torch.from_numpy(np.concatenate(H_list, axis=0)).cuda()
-        out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device="cuda")
-        dist.all_gather_into_tensor(out, mine)
+        from cnmf_amd import dist as cd
+        rows = [(i, int(H.shape[0]), step) for i, H in enumerate(H_list)]
+        hdr, blk = cd.pack_local(rows, H_list, G)
+        cd.allgather_spectra(hdr, blk, G, device="cuda:%d" % local_rank)
         torch.cuda.synchronize()
 
     agg = dict(restarts=0, restart_iters=0, rc_iters=0, outer=0, col_iters=0, passA_ms=0.0,

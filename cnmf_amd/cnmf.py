@@ -1,0 +1,442 @@
+"""Host-side mirror of the reference's ``class cNMF`` for the accelerated hot path.
+
+Same method names, argument meaning, on-disk artefacts and error behaviour as
+/root/reference/src/cnmf/cnmf.py for ``factorize`` (:692-745), ``combine`` / ``combine_nmf``
+(:462-483, :748-773), ``refit_usage`` / ``refit_spectra`` (:776-820), ``consensus``
+(:823-985, without the plotting block) and the statistics loop of ``k_selection_plot``
+(:1119-1135) -- but every numerical step runs on the MI355X through ``Engine``
+(libcnmf_hip.so).  There is no CPU fallback.
+
+What is different by design
+* all restarts of a worker run as ONE batched device call (X is uploaded once, not re-read
+  per worker process; cnmf.py:726), and the spectra come back in one transfer;
+* ``factorize`` can keep the merged spectra in memory (``self.spectra_cache``) so that
+  ``combine`` becomes a gather instead of n_iter file reads; the per-restart
+  ``.df.npz`` files are still written (``write_iter_files=True``) so that the reference's
+  ``completed`` ledger / ``skip_completed_runs`` / ``skip_missing_files`` semantics survive;
+* ``prepare`` (HVG selection, TPM, scanpy I/O) is out of scope:
+  ``prepare_from_matrix`` takes the normalised cells x genes matrix the reference's
+  ``prepare`` would have written and produces the same ledger / yaml.  The matrix itself is
+  stored as ``.df.npz`` (the reference's own DataFrame container, cnmf.py:31-40) because
+  scanpy/anndata do not exist in this image.
+"""
+import errno
+import itertools
+import os
+import warnings
+
+import numpy as np
+import pandas as pd
+import yaml
+
+from .engine import Engine
+
+
+# ---------------------------------------------------------------- reference I/O helpers
+def save_df_to_npz(obj, filename):
+    """cnmf.py:31-32"""
+    np.savez_compressed(filename, data=obj.values, index=obj.index.values, columns=obj.columns.values)
+
+
+def save_df_to_text(obj, filename):
+    """cnmf.py:34-35"""
+    obj.to_csv(filename, sep="\t")
+
+
+def load_df_from_npz(filename):
+    """cnmf.py:37-40"""
+    with np.load(filename, allow_pickle=True) as f:
+        obj = pd.DataFrame(**f)
+    return obj
+
+
+def check_dir_exists(path):
+    """cnmf.py:42-50"""
+    try:
+        os.makedirs(path)
+    except OSError as exception:
+        if exception.errno != errno.EEXIST:
+            raise
+
+
+def worker_filter(iterable, worker_index, total_workers):
+    """cnmf.py:52-53: static round-robin shard of the restart ledger."""
+    return (p for i, p in enumerate(iterable) if (i - worker_index) % total_workers == 0)
+
+
+class cNMF:
+    def __init__(self, output_dir=".", name=None, device=0, engine=None):
+        """Same constructor semantics as the reference (cnmf.py:268-296) plus the GPU index."""
+        self.output_dir = output_dir
+        if name is None:
+            import datetime
+            import uuid
+            now = datetime.datetime.now()
+            rand_hash = uuid.uuid4().hex[:6]
+            name = "%s_%s" % (now.strftime("%Y_%m_%d"), rand_hash)
+        self.name = name
+        self.paths = None
+        self._initialize_dirs()
+        self.device = device
+        self._engine = engine
+        self._engine_key = None
+        self.spectra_cache = {}          # (k, iter) -> spectra ndarray kept from factorize
+        self.last_factorize_stats = None
+
+    # ------------------------------------------------------------------ paths (cnmf.py:298-330)
+    def _initialize_dirs(self):
+        if self.paths is None:
+            check_dir_exists(self.output_dir)
+            check_dir_exists(os.path.join(self.output_dir, self.name))
+            check_dir_exists(os.path.join(self.output_dir, self.name, "cnmf_tmp"))
+            d, n = self.output_dir, self.name
+            t = lambda s: os.path.join(d, n, "cnmf_tmp", n + s)      # noqa: E731
+            o = lambda s: os.path.join(d, n, n + s)                  # noqa: E731
+            self.paths = {
+                "normalized_counts": t(".norm_counts.df.npz"),
+                "nmf_replicate_parameters": t(".nmf_params.df.npz"),
+                "nmf_run_parameters": t(".nmf_idvrun_params.yaml"),
+                "nmf_genes_list": o(".overdispersed_genes.txt"),
+                "tpm": t(".tpm.df.npz"),
+                "tpm_stats": t(".tpm_stats.df.npz"),
+                "iter_spectra": t(".spectra.k_%d.iter_%d.df.npz"),
+                "iter_usages": t(".usages.k_%d.iter_%d.df.npz"),
+                "merged_spectra": t(".spectra.k_%d.merged.df.npz"),
+                "local_density_cache": t(".local_density_cache.k_%d.merged.df.npz"),
+                "consensus_spectra": t(".spectra.k_%d.dt_%s.consensus.df.npz"),
+                "consensus_spectra__txt": o(".spectra.k_%d.dt_%s.consensus.txt"),
+                "consensus_usages": t(".usages.k_%d.dt_%s.consensus.df.npz"),
+                "consensus_usages__txt": o(".usages.k_%d.dt_%s.consensus.txt"),
+                "consensus_stats": t(".stats.k_%d.dt_%s.df.npz"),
+                "k_selection_stats": o(".k_selection_stats.df.npz"),
+                "gene_spectra_score": t(".gene_spectra_score.k_%d.dt_%s.df.npz"),
+                "gene_spectra_score__txt": o(".gene_spectra_score.k_%d.dt_%s.txt"),
+                "gene_spectra_tpm": t(".gene_spectra_tpm.k_%d.dt_%s.df.npz"),
+                "gene_spectra_tpm__txt": o(".gene_spectra_tpm.k_%d.dt_%s.txt"),
+            }
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _get_engine(self, X, key):
+        """One resident upload per distinct matrix (X is NOT re-read per restart/worker)."""
+        if self._engine is None:
+            self._engine = Engine(self.device)
+        if self._engine_key != key:
+            self._engine.set_matrix(X)
+            self._engine_key = key
+        return self._engine
+
+    def _load_norm_counts(self):
+        df = load_df_from_npz(self.paths["normalized_counts"])
+        return df
+
+    # ------------------------------------------------------------------ ledger (cnmf.py:564-658)
+    def get_nmf_iter_params(self, ks, n_iter=100, random_state_seed=None, beta_loss="kullback-leibler",
+                            alpha_usage=0.0, alpha_spectra=0.0, init="random", max_iter=1000):
+        if type(ks) is int:
+            ks = [ks]
+        k_list = sorted(set(list(ks)))
+        n_runs = len(ks) * n_iter
+        np.random.seed(seed=random_state_seed)
+        nmf_seeds = np.random.randint(low=1, high=(2 ** 31) - 1, size=n_runs)
+        replicate_params = []
+        for i, (k, r) in enumerate(itertools.product(k_list, range(n_iter))):
+            done = os.path.exists(self.paths["iter_spectra"] % (k, r))
+            replicate_params.append([k, r, nmf_seeds[i], done])
+        replicate_params = pd.DataFrame(replicate_params, columns=["n_components", "iter", "nmf_seed", "completed"])
+        n_completed = replicate_params["completed"].sum()
+        if n_completed > 0:
+            warnings.warn("%d runs already appear completed. If this is unexpected, consider re-initializing "
+                          "the cnmf object with a different run name or output directory" % n_completed, UserWarning)
+        _nmf_kwargs = dict(alpha_W=alpha_usage, alpha_H=alpha_spectra, l1_ratio=0.0, beta_loss=beta_loss,
+                           solver="mu", tol=1e-4, max_iter=max_iter, init=init)
+        if beta_loss == "frobenius":
+            _nmf_kwargs["solver"] = "cd"
+        return replicate_params, _nmf_kwargs
+
+    def update_nmf_iter_params(self):
+        _nmf_kwargs = yaml.load(open(self.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
+        replicate_params = load_df_from_npz(self.paths["nmf_replicate_parameters"])
+        for i in replicate_params.index:
+            replicate_params.at[i, "completed"] = os.path.exists(
+                self.paths["iter_spectra"] % (replicate_params.at[i, "n_components"], replicate_params.at[i, "iter"]))
+        remaining = (replicate_params["completed"] == False).sum()      # noqa: E712
+        print("{n} NMF runs are currently incomplete".format(n=remaining))
+        self.save_nmf_iter_params(replicate_params, _nmf_kwargs)
+
+    def save_nmf_iter_params(self, replicate_params, run_params):
+        self._initialize_dirs()
+        save_df_to_npz(replicate_params, self.paths["nmf_replicate_parameters"])
+        with open(self.paths["nmf_run_parameters"], "w") as F:
+            yaml.dump(run_params, F)
+
+    def prepare_from_matrix(self, norm_counts, components, n_iter=100, seed=None, beta_loss="frobenius",
+                            alpha_usage=0.0, alpha_spectra=0.0, init="random", max_NMF_iter=1000,
+                            tpm=None):
+        """Stand-in for the tail of ``prepare`` (cnmf.py:452-459): persist the already
+        normalised cells x HVG matrix (DataFrame or ndarray) and write the restart ledger +
+        run parameters exactly as the reference does.  Raises the reference's zero-count
+        error (cnmf.py:551-554)."""
+        if not isinstance(norm_counts, pd.DataFrame):
+            norm_counts = pd.DataFrame(np.asarray(norm_counts),
+                                       index=["cell%d" % i for i in range(np.shape(norm_counts)[0])],
+                                       columns=["gene%d" % j for j in range(np.shape(norm_counts)[1])])
+        zerocells = np.array(norm_counts.values.sum(axis=1) == 0).reshape(-1)
+        if zerocells.sum() > 0:
+            examples = norm_counts.index[np.ravel(zerocells)]
+            raise Exception("Error: %d cells have zero counts of overdispersed genes. E.g. %s. Filter those cells "
+                            "and re-run or adjust the number of overdispersed genes. Quitting!"
+                            % (zerocells.sum(), ", ".join(map(str, examples[:4]))))
+        self._initialize_dirs()
+        save_df_to_npz(norm_counts, self.paths["normalized_counts"])
+        with open(self.paths["nmf_genes_list"], "w") as F:
+            F.write("\n".join(map(str, norm_counts.columns)))
+        if tpm is not None:
+            save_df_to_npz(tpm, self.paths["tpm"])
+            stats = pd.DataFrame([tpm.values.mean(axis=0), tpm.values.std(axis=0, ddof=0)],
+                                 index=["__mean", "__std"], columns=tpm.columns).T
+            save_df_to_npz(stats, self.paths["tpm_stats"])
+        replicate_params, run_params = self.get_nmf_iter_params(
+            ks=components, n_iter=n_iter, random_state_seed=seed, beta_loss=beta_loss,
+            alpha_usage=alpha_usage, alpha_spectra=alpha_spectra, init=init, max_iter=max_NMF_iter)
+        self.save_nmf_iter_params(replicate_params, run_params)
+
+    # ------------------------------------------------------------------ the NMF call-site
+    def _check_kwargs(self, kw):
+        if kw.get("beta_loss", "frobenius") != "frobenius" or kw.get("solver", "cd") != "cd":
+            raise NotImplementedError("the device engine implements solver='cd' (beta_loss='frobenius'); "
+                                      "got solver=%r beta_loss=%r" % (kw.get("solver"), kw.get("beta_loss")))
+        if kw.get("init", "random") not in ("random", "custom", None) and "H" not in kw:
+            raise NotImplementedError("init=%r is not implemented on the device (random / custom only)" % kw.get("init"))
+
+    def _nmf(self, X, nmf_kwargs):
+        """Mirror of cNMF._nmf (cnmf.py:661-674): ``(spectra, usages)`` for one restart, or the
+        NNLS refit when ``update_H=False`` (then ``H`` must have X's dtype, sklearn _nmf.py:1221)."""
+        kw = dict(nmf_kwargs)
+        self._check_kwargs(kw)
+        Xv = X.values if isinstance(X, pd.DataFrame) else X
+        eng = self._get_engine(Xv, ("obj", id(X), getattr(Xv, "shape", None)))
+        if kw.get("update_H", True) is False:
+            H = np.asarray(kw["H"])
+            xdt = Xv.dtype if Xv.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+            if H.dtype != xdt:
+                raise TypeError("H should have the same dtype as X. Got H.dtype = {}.".format(H.dtype))
+            W, _ = eng.nnls(H, tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 200),
+                            alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
+            return H, W.astype(xdt, copy=False)
+        k = int(kw["n_components"])
+        if kw.get("init") == "custom":
+            Hl, Wl, _, _ = eng.nmf_batch([k], W0=[kw["W"]], H0=[kw["H"]], tol=kw.get("tol", 1e-4),
+                                         max_iter=kw.get("max_iter", 200), alpha_W=kw.get("alpha_W", 0.0),
+                                         alpha_H=kw.get("alpha_H", 0.0), l1_ratio=kw.get("l1_ratio", 0.0),
+                                         return_W=True)
+        else:
+            Hl, Wl, _, _ = eng.nmf_batch([k], seeds=[int(kw["random_state"])], tol=kw.get("tol", 1e-4),
+                                         max_iter=kw.get("max_iter", 200), alpha_W=kw.get("alpha_W", 0.0),
+                                         alpha_H=kw.get("alpha_H", 0.0), l1_ratio=kw.get("l1_ratio", 0.0),
+                                         return_W=True)
+        xdt = Xv.dtype if Xv.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+        return Hl[0].astype(xdt), Wl[0].astype(xdt)
+
+    # ------------------------------------------------------------------ factorize (cnmf.py:692-745)
+    def factorize(self, worker_i=0, total_workers=1, skip_completed_runs=False, write_iter_files=True,
+                  kc_max=0):
+        run_params = load_df_from_npz(self.paths["nmf_replicate_parameters"])
+        norm_counts = self._load_norm_counts()
+        _nmf_kwargs = yaml.load(open(self.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
+        self._check_kwargs(_nmf_kwargs)
+        if not skip_completed_runs:
+            jobs = list(worker_filter(range(len(run_params)), worker_i, total_workers))
+        else:
+            jobs = list(worker_filter(run_params.index[run_params["completed"] == False],   # noqa: E712
+                                      worker_i, total_workers))
+        if not jobs:
+            return
+        eng = self._get_engine(norm_counts.values, ("norm_counts", self.paths["normalized_counts"],
+                                                    os.path.getmtime(self.paths["normalized_counts"])))
+        ks = [int(run_params.iloc[idx]["n_components"]) for idx in jobs]
+        seeds = [int(run_params.iloc[idx]["nmf_seed"]) for idx in jobs]
+        for idx in jobs:
+            print("[Worker %d]. Starting task %d." % (worker_i, idx))
+        H_list, _, n_iter, _ = eng.nmf_batch(
+            ks, seeds=seeds, tol=_nmf_kwargs.get("tol", 1e-4), max_iter=_nmf_kwargs.get("max_iter", 1000),
+            alpha_W=_nmf_kwargs.get("alpha_W", 0.0), alpha_H=_nmf_kwargs.get("alpha_H", 0.0),
+            l1_ratio=_nmf_kwargs.get("l1_ratio", 0.0), kc_max=kc_max)
+        self.last_factorize_stats = dict(eng.last_stats, n_iter=n_iter)
+        xdt = norm_counts.values.dtype if norm_counts.values.dtype in (np.float32, np.float64) else np.float64
+        for idx, H in zip(jobs, H_list):
+            p = run_params.iloc[idx, :]
+            k, it = int(p["n_components"]), int(p["iter"])
+            spectra = pd.DataFrame(H.astype(xdt), index=np.arange(1, k + 1), columns=norm_counts.columns)
+            self.spectra_cache[(k, it)] = spectra
+            if write_iter_files:
+                save_df_to_npz(spectra, self.paths["iter_spectra"] % (k, it))
+
+    # ------------------------------------------------------------------ combine (cnmf.py:462-483, 748-773)
+    def combine(self, components=None, skip_missing_files=False):
+        if type(components) is int:
+            ks = [components]
+        elif components is None:
+            run_params = load_df_from_npz(self.paths["nmf_replicate_parameters"])
+            ks = sorted(set(run_params.n_components))
+        else:
+            ks = components
+        for k in ks:
+            self.combine_nmf(k, skip_missing_files=skip_missing_files)
+
+    def combine_nmf(self, k, skip_missing_files=False, remove_individual_iterations=False):
+        run_params = load_df_from_npz(self.paths["nmf_replicate_parameters"])
+        print("Combining factorizations for k=%d." % k)
+        run_params_subset = run_params[run_params.n_components == k].sort_values("iter")
+        combined_spectra = []
+        for i, p in run_params_subset.iterrows():
+            key = (int(p["n_components"]), int(p["iter"]))
+            current_file = self.paths["iter_spectra"] % key
+            if key in self.spectra_cache:
+                spectra = self.spectra_cache[key].copy()
+            elif os.path.exists(current_file):
+                spectra = load_df_from_npz(current_file)
+            else:
+                if not skip_missing_files:
+                    print("Missing file: %s, run with skip_missing=True to override" % current_file)
+                    raise FileNotFoundError(errno.ENOENT, os.strerror(errno.ENOENT), current_file)
+                print("Missing file: %s. Skipping." % current_file)
+                continue
+            spectra.index = ["iter%d_topic%d" % (p["iter"], t + 1) for t in range(k)]
+            combined_spectra.append(spectra)
+        if len(combined_spectra) > 0:
+            combined_spectra = pd.concat(combined_spectra, axis=0)
+            save_df_to_npz(combined_spectra, self.paths["merged_spectra"] % k)
+            if remove_individual_iterations:
+                for i, p in run_params_subset.iterrows():
+                    f = self.paths["iter_spectra"] % (int(p["n_components"]), int(p["iter"]))
+                    if os.path.exists(f):
+                        os.remove(f)
+        else:
+            print("No spectra found for k=%d" % k)
+        return combined_spectra
+
+    # ------------------------------------------------------------------ refits (cnmf.py:776-820)
+    def refit_usage(self, X, spectra):
+        refit_nmf_kwargs = yaml.load(open(self.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
+        Hv = spectra.values if type(spectra) is pd.DataFrame else spectra
+        refit_nmf_kwargs.update(dict(n_components=Hv.shape[0], H=Hv, update_H=False))
+        _, rf_usages = self._nmf(X, nmf_kwargs=refit_nmf_kwargs)
+        if (type(X) is pd.DataFrame) and (type(spectra) is pd.DataFrame):
+            rf_usages = pd.DataFrame(rf_usages, index=X.index, columns=spectra.index)
+        return rf_usages
+
+    def refit_spectra(self, X, usage):
+        return self.refit_usage(X.T, usage.T).T
+
+    # ------------------------------------------------------------------ consensus (cnmf.py:823-985)
+    def consensus(self, k, density_threshold=0.5, local_neighborhood_size=0.30, show_clustering=False,
+                  build_ref=False, skip_density_and_return_after_stats=False, close_clustergram_fig=False,
+                  refit_usage=True, normalize_tpm_spectra=False, norm_counts=None):
+        merged_spectra = load_df_from_npz(self.paths["merged_spectra"] % k)
+        if norm_counts is None:
+            norm_counts = self._load_norm_counts()
+        density_threshold_str = str(density_threshold)
+        if skip_density_and_return_after_stats:
+            density_threshold_str = "2"
+        density_threshold_repl = density_threshold_str.replace(".", "_")
+        eng = self._get_engine(norm_counts.values, ("norm_counts", self.paths["normalized_counts"],
+                                                    os.path.getmtime(self.paths["normalized_counts"])))
+        cached = os.path.isfile(self.paths["local_density_cache"] % k) and not skip_density_and_return_after_stats
+        out = eng.consensus(merged_spectra.values, k, density_threshold=density_threshold,
+                            local_neighborhood_size=local_neighborhood_size,
+                            skip_density=skip_density_and_return_after_stats,
+                            want_silhouette=skip_density_and_return_after_stats,
+                            return_dist=show_clustering)
+        if not skip_density_and_return_after_stats and not cached:
+            local_density = pd.DataFrame(out["local_density"], columns=["local_density"], index=merged_spectra.index)
+            save_df_to_npz(local_density, self.paths["local_density_cache"] % k)
+        # artefacts the (unchanged) plotting block of the reference consumes (cnmf.py:986-1079)
+        self.topics_dist = out.get("topics_dist")
+        self.density_filter = pd.Series(out["density_filter"], index=merged_spectra.index)
+        kept = out["density_filter"]
+        self.kmeans_cluster_labels = pd.Series(out["labels"][kept] + 1, index=merged_spectra.index[kept])
+        self.local_density = out["local_density"]
+        median_spectra = pd.DataFrame(out["median_spectra"], index=np.arange(1, k + 1), columns=merged_spectra.columns)
+        xdt = norm_counts.values.dtype
+        rf_usages = self.refit_usage(norm_counts, median_spectra.astype(xdt))
+        rf_usages = pd.DataFrame(np.asarray(rf_usages), index=norm_counts.index, columns=median_spectra.index)
+
+        if skip_density_and_return_after_stats:
+            prediction_error = eng.prediction_error(rf_usages.values, median_spectra.values)
+            return pd.DataFrame([k, density_threshold, out["silhouette"], prediction_error],
+                                index=["k", "local_density_threshold", "silhouette", "prediction_error"],
+                                columns=["stats"])
+
+        # re-order by total contribution (cnmf.py:939-946)
+        norm_usages = rf_usages.div(rf_usages.sum(axis=1), axis=0)
+        reorder = norm_usages.sum(axis=0).sort_values(ascending=False)
+        rf_usages = rf_usages.loc[:, reorder.index]
+        norm_usages = norm_usages.loc[:, reorder.index]
+        median_spectra = median_spectra.loc[reorder.index, :]
+        rf_usages.columns = np.arange(1, rf_usages.shape[1] + 1)
+        norm_usages.columns = rf_usages.columns
+        median_spectra.index = rf_usages.columns
+
+        spectra_tpm = usage_coef = None
+        if os.path.exists(self.paths["tpm"]):
+            # consensus tail (cnmf.py:948-975): TPM spectra by NNLS on the transposed TPM matrix,
+            # z-score spectra by OLS, final usage refit on std-scaled HVG TPM
+            tpm = load_df_from_npz(self.paths["tpm"])
+            tpm_stats = load_df_from_npz(self.paths["tpm_stats"])
+            tdt = tpm.values.dtype if tpm.values.dtype in (np.float32, np.float64) else np.float64
+            spectra_tpm = self.refit_spectra(tpm.values.astype(tdt), norm_usages.values.astype(tdt))
+            spectra_tpm = pd.DataFrame(spectra_tpm, index=rf_usages.columns, columns=tpm.columns)
+            if normalize_tpm_spectra:
+                spectra_tpm = spectra_tpm.div(spectra_tpm.sum(axis=1), axis=0) * 1e6
+            usage_coef = _ols_all_cols(rf_usages.values.astype(np.float64), tpm.values.astype(np.float64))
+            usage_coef = pd.DataFrame(usage_coef, index=rf_usages.columns, columns=tpm.columns)
+            if refit_usage:
+                hvgs = open(self.paths["nmf_genes_list"]).read().split("\n")
+                norm_tpm = tpm.loc[:, hvgs].astype(np.float64)
+                norm_tpm = norm_tpm / norm_tpm.values.std(axis=0, ddof=1)
+                spectra_tpm_rf = spectra_tpm.loc[:, hvgs].div(tpm_stats.loc[hvgs, "__std"], axis=1)
+                rf = self.refit_usage(norm_tpm, spectra_tpm_rf.astype(norm_tpm.values.dtype))
+                rf_usages = pd.DataFrame(np.asarray(rf), index=norm_counts.index, columns=spectra_tpm_rf.index)
+
+        save_df_to_npz(median_spectra, self.paths["consensus_spectra"] % (k, density_threshold_repl))
+        save_df_to_npz(rf_usages, self.paths["consensus_usages"] % (k, density_threshold_repl))
+        save_df_to_text(median_spectra, self.paths["consensus_spectra__txt"] % (k, density_threshold_repl))
+        save_df_to_text(rf_usages, self.paths["consensus_usages__txt"] % (k, density_threshold_repl))
+        if spectra_tpm is not None:
+            save_df_to_npz(spectra_tpm, self.paths["gene_spectra_tpm"] % (k, density_threshold_repl))
+            save_df_to_text(spectra_tpm, self.paths["gene_spectra_tpm__txt"] % (k, density_threshold_repl))
+            save_df_to_npz(usage_coef, self.paths["gene_spectra_score"] % (k, density_threshold_repl))
+            save_df_to_text(usage_coef, self.paths["gene_spectra_score__txt"] % (k, density_threshold_repl))
+        return median_spectra, rf_usages
+
+    # ------------------------------------------------------------------ k selection (cnmf.py:1119-1135)
+    def k_selection_stats(self):
+        """The numerical half of ``k_selection_plot``: one stats-mode consensus per k; writes
+        ``k_selection_stats.df.npz`` like the reference (plotting is out of scope)."""
+        run_params = load_df_from_npz(self.paths["nmf_replicate_parameters"])
+        norm_counts = self._load_norm_counts()
+        stats = []
+        for k in sorted(set(run_params.n_components)):
+            stats.append(self.consensus(k, skip_density_and_return_after_stats=True,
+                                        show_clustering=False, norm_counts=norm_counts).stats)
+        stats = pd.DataFrame(stats)
+        stats.reset_index(drop=True, inplace=True)
+        save_df_to_npz(stats, self.paths["k_selection_stats"])
+        return stats
+
+
+def _ols_all_cols(X, Y, batch_size=1024):
+    """efficient_ols_all_cols(X, Y, normalize_y=True) (cnmf.py:55-125), dense Y."""
+    mean = Y.mean(axis=0)
+    var = Y.var(axis=0)
+    var[var < 1e-12] = 1e-12
+    std = np.sqrt(var)
+    XtX = np.zeros((X.shape[1], X.shape[1]))
+    XtY = np.zeros((X.shape[1], Y.shape[1]))
+    for s in range(0, X.shape[0], batch_size):
+        e = min(s + batch_size, X.shape[0])
+        Xb = X[s:e]
+        XtX += Xb.T @ Xb
+        XtY += Xb.T @ ((Y[s:e] - mean) / std)
+    beta, *_ = np.linalg.lstsq(XtX, XtY, rcond=None)
+    return beta

@@ -1,0 +1,116 @@
+"""End-to-end drop-in test: the host-side mirror of the reference's cNMF object
+(cnmf_amd/cnmf.py) run on the GPU against what the UNMODIFIED reference produced for the
+same normalised matrix, ledger seed and parameters (tests/golden/ref_small.npz):
+
+    prepare_from_matrix -> factorize (2 workers) -> combine -> k_selection_stats -> consensus
+
+The reference's own test bar is sum of squared differences < 1e-4
+(/root/reference/tests/test_reproducibility.py:12)."""
+import errno
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from cnmf_amd.cnmf import cNMF, load_df_from_npz
+from oracle import nmf_cd
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_small.npz")
+TOLERANCE = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(GOLD, allow_pickle=False))
+
+
+@pytest.fixture(scope="module")
+def run(tmp_path_factory, gold, engine):
+    g = gold
+    out = tmp_path_factory.mktemp("cnmf_run")
+    obj = cNMF(output_dir=str(out), name="t", engine=engine)
+    nc = pd.DataFrame(g["norm_counts"], index=["c%d" % i for i in range(g["norm_counts"].shape[0])],
+                      columns=list(g["genes"]))
+    tpm = pd.DataFrame(g["tpm"], index=nc.index, columns=list(g["tpm_genes"]))
+    obj.prepare_from_matrix(nc, components=[4, 5, 6], n_iter=12, seed=14, beta_loss="frobenius", tpm=tpm)
+    return obj
+
+
+def test_ledger_and_yaml_match_reference(run, gold):
+    led = load_df_from_npz(run.paths["nmf_replicate_parameters"])
+    assert np.array_equal(led[["n_components", "iter", "nmf_seed"]].values.astype(np.int64), gold["ledger"])
+    import yaml
+    kw = yaml.load(open(run.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
+    assert kw == dict(alpha_W=0.0, alpha_H=0.0, l1_ratio=0.0, beta_loss="frobenius", solver="cd",
+                      tol=1e-4, max_iter=1000, init="random")
+
+
+def test_factorize_shards_and_resume(run, gold):
+    # worker 1 of 2 first: only its ledger rows get files (cnmf.py:52-53)
+    run.factorize(worker_i=1, total_workers=2)
+    led = load_df_from_npz(run.paths["nmf_replicate_parameters"])
+    have = [os.path.exists(run.paths["iter_spectra"] % (int(r.n_components), int(r.iter))) for r in led.itertuples()]
+    assert have == [(i - 1) % 2 == 0 for i in range(len(led))]
+    with pytest.raises(FileNotFoundError) as ei:
+        run.combine_nmf(4)
+    assert ei.value.errno == errno.ENOENT
+    # resume: mark completed, run the rest with skip_completed_runs on a single worker
+    run.update_nmf_iter_params()
+    run.factorize(worker_i=0, total_workers=1, skip_completed_runs=True)
+    run.combine()
+    for k in (4, 5, 6):
+        merged = load_df_from_npz(run.paths["merged_spectra"] % k)
+        ref = gold["merged_k%d" % k]
+        assert merged.shape == ref.shape
+        assert list(merged.index[:k + 1]) == ["iter0_topic%d" % (t + 1) for t in range(k)] + ["iter1_topic1"]
+        # per restart: same components in the same order (same seed, same init)
+        for it in range(12):
+            maxabs, relfro = nmf_cd.spectra_error(ref[it * k:(it + 1) * k], merged.values[it * k:(it + 1) * k])
+            assert maxabs <= 5e-4 and relfro <= 1e-3, (k, it, maxabs, relfro)
+
+
+def test_k_selection_stats_match_reference(run, gold):
+    stats = run.k_selection_stats()
+    for row, k in zip(stats.itertuples(), (4, 5, 6)):
+        kk, thr, sil, err = gold["stats_k%d" % k]
+        assert row.k == k
+        assert abs(row.silhouette - sil) < 5e-3
+        assert abs(row.prediction_error - err) <= 1e-3 * err
+
+
+@pytest.mark.parametrize("k,thr", [(5, 0.5), (4, 2.0)])
+def test_consensus_matches_reference(run, gold, k, thr):
+    med, usages = run.consensus(k, density_threshold=thr)
+    rep = str(thr).replace(".", "_")
+    assert ((med.values - gold["consensus_spectra_k%d" % k]) ** 2).sum() < TOLERANCE
+    assert ((usages.values - gold["consensus_usages_k%d" % k]) ** 2).sum() < TOLERANCE * usages.size
+    tpm_sp = load_df_from_npz(run.paths["gene_spectra_tpm"] % (k, rep)).values
+    ref = gold["gene_spectra_tpm_k%d" % k]
+    assert np.abs(tpm_sp - ref).max() <= 2e-3 * np.abs(ref).max()
+    score = load_df_from_npz(run.paths["gene_spectra_score"] % (k, rep)).values
+    assert np.abs(score - gold["gene_spectra_score_k%d" % k]).max() < 5e-3
+    assert os.path.exists(run.paths["consensus_spectra__txt"] % (k, rep))
+    assert os.path.exists(run.paths["local_density_cache"] % k)
+
+
+def test_zero_count_cell_raises_like_prepare(tmp_path, engine):
+    X = np.ones((10, 6))
+    X[3] = 0
+    obj = cNMF(output_dir=str(tmp_path), name="z", engine=engine)
+    with pytest.raises(Exception, match="Error: .* cells have zero counts of overdispersed genes.*"):
+        obj.prepare_from_matrix(X, components=[2], n_iter=2, seed=1)
+
+
+def test_nmf_callsite_dtype_contract(run, gold):
+    """cNMF._nmf returns arrays of X's dtype and rejects an H of another dtype like sklearn."""
+    X = gold["norm_counts"]
+    spectra, usages = run._nmf(X, dict(n_components=4, random_state=5, tol=1e-4, max_iter=50, solver="cd",
+                                       beta_loss="frobenius", alpha_W=0.0, alpha_H=0.0, l1_ratio=0.0, init="random"))
+    assert spectra.shape == (4, X.shape[1]) and usages.shape == (X.shape[0], 4) and spectra.dtype == X.dtype
+    with pytest.raises(TypeError):
+        run._nmf(X, dict(H=spectra.astype(np.float32), update_H=False, n_components=4, solver="cd",
+                         beta_loss="frobenius", tol=1e-4, max_iter=50))
+    with pytest.raises(NotImplementedError):
+        run._nmf(X, dict(n_components=4, random_state=5, solver="mu", beta_loss="kullback-leibler"))
