@@ -42,7 +42,8 @@ struct cnmf_ctx {
 
     // batch buffers (sized for kc_alloc columns)
     int kc_alloc = 0, nsplit_alloc = 0, parts_alloc = 0;
-    float *H = nullptr, *Wt = nullptr, *XHt = nullptr, *XtW = nullptr;
+    float *H = nullptr, *Wt = nullptr, *XHt = nullptr, *XHt1 = nullptr, *XtW = nullptr;
+    unsigned char* d_split = nullptr;   // stream-K cut flags of the current plan
     float *gramH = nullptr, *gramW = nullptr, *gram_part = nullptr;
     double* viol_part = nullptr;
     SlotDesc* d_slots = nullptr;
@@ -112,7 +113,7 @@ static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int l
 {
 #define GO(MTW, WM, WN) \
     return launch_gemm_t<MTW, WM, WN, NN>(st, A, lda, B, ldb, C, ldc, cstride, KC, Ktot, J, nsplit)
-    if (variant == 0) variant = NN ? 2 : (KC >= 128 ? 1 : 2);
+    if (variant == 0) variant = 2;
     if (variant == 1 && KC < 128) variant = (KC >= 64) ? 3 : 2;
     if (variant == 3 && KC < 64) variant = 2;
     switch (variant) {
@@ -133,11 +134,54 @@ static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int l
 // ------------------------------------------------------------------ sweep dispatch
 static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, int L, const float* P,
                                const float* gram, const SlotDesc* slots, float l1, float* gram_part,
-                               double* viol_part, int chunks, int parts, int want_gram)
+                               double* viol_part, int chunks, int parts, int want_gram,
+                               SplitInfo sp = SplitInfo{nullptr, nullptr, 1, 1, 1})
 {
     dim3 grid(parts, nslots);
-    sweep_kernel<<<grid, 256, 0, st>>>(V, ldv, L, P, gram, slots, l1, gram_part, viol_part, chunks,
+    sweep_kernel<<<grid, 256, 0, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks,
                                        want_gram);
+    return hipGetLastError();
+}
+
+// ---- stream-K pass A (T layout: 128 components x 128 cells per tile)
+struct StreamK {
+    bool on = false;
+    int MG = 1, T = 0, nk = 0, P = 0;
+    std::vector<unsigned char> split;
+};
+
+static StreamK plan_streamk(int KC, int N_pad, int G_pad, int n_wg_slots)
+{
+    StreamK sk;
+    if (KC % 128 != 0 || getenv("CNMF_NO_STREAMK")) return sk;
+    sk.MG = KC / 128;
+    sk.T = sk.MG * (N_pad / 128);
+    sk.nk = G_pad / BK;
+    sk.P = n_wg_slots;
+    if (sk.T <= sk.P) sk.P = n_wg_slots / 2;              // one workgroup per CU
+    if (sk.T <= sk.P || sk.T % sk.P == 0) return sk;      // nothing to balance
+    sk.on = true;
+    sk.split.assign(sk.T, 0);
+    const long long U = (long long)sk.T * sk.nk;
+    for (int p = 1; p < sk.P; ++p) {
+        const long long b = U * p / sk.P;                  // first unit of workgroup p
+        if (b % sk.nk) sk.split[b / sk.nk] = 1;            // boundary inside a tile -> that tile is cut
+    }
+    return sk;
+}
+
+static hipError_t launch_streamk_passA(hipStream_t st, const StreamK& sk, const float* A, int lda,
+                                       const float* B, int ldb, float* C0, float* C1, int ldc, int Jtot)
+{
+    constexpr size_t lds = gemm_lds_bytes<4, 1, 4, false>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_streamk_kernel<4, 1, 4, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    gemm_streamk_kernel<4, 1, 4, false><<<sk.P, 256, lds, st>>>(A, lda, B, ldb, C0, C1, ldc, sk.MG, sk.T,
+                                                               sk.nk, Jtot);
     return hipGetLastError();
 }
 
@@ -193,7 +237,8 @@ extern "C" cnmf_ctx* cnmf_create(int device)
 
 static void free_batch(cnmf_ctx* c)
 {
-    hipFree(c->H); hipFree(c->Wt); hipFree(c->XHt); hipFree(c->XtW);
+    hipFree(c->H); hipFree(c->Wt); hipFree(c->XHt); hipFree(c->XHt1); hipFree(c->XtW); hipFree(c->d_split);
+    c->XHt1 = nullptr; c->d_split = nullptr;
     hipFree(c->gramH); hipFree(c->gramW); hipFree(c->gram_part); hipFree(c->viol_part);
     hipFree(c->d_slots); hipFree(c->d_slot_list);
     if (c->h_slots) hipHostFree(c->h_slots);
@@ -229,8 +274,9 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     ctx->N = N; ctx->G = G;
     ctx->N_pad = round_up(N, 128);
     ctx->G_pad = round_up(G, 32);
-    // +128 columns of slack so pass B's last 128-gene tile may be addressed (never read: guarded)
-    const size_t bytes = (size_t)ctx->N_pad * ctx->G_pad * sizeof(float);
+    // one extra row of slack: pass B's last 128-gene tile runs past G_pad into the next row
+    // (values that only feed never-stored output columns), so the last row needs a successor
+    const size_t bytes = ((size_t)ctx->N_pad + 1) * ctx->G_pad * sizeof(float);
     HIP_TRY(ctx, hipMalloc(&ctx->X, bytes));
     HIP_TRY(ctx, hipMemsetAsync(ctx->X, 0, bytes, ctx->stream));
     return CNMF_OK;
@@ -320,6 +366,8 @@ static int ensure_batch(cnmf_ctx* ctx, int KC)
     HIP_TRY(ctx, hipMalloc(&ctx->H, hb));
     HIP_TRY(ctx, hipMalloc(&ctx->Wt, wb));
     HIP_TRY(ctx, hipMalloc(&ctx->XHt, wb));
+    HIP_TRY(ctx, hipMalloc(&ctx->XHt1, wb));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_split, (size_t)(KC / 32 + 1) * (ctx->N_pad / 128 + 1)));
     HIP_TRY(ctx, hipMalloc(&ctx->XtW, hb * nsplit));
     HIP_TRY(ctx, hipMalloc(&ctx->gramH, (size_t)KC * GRAM_SZ * sizeof(float)));
     HIP_TRY(ctx, hipMalloc(&ctx->gramW, (size_t)KC * GRAM_SZ * sizeof(float)));
@@ -509,6 +557,9 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     const int gvarA = getenv("CNMF_GEMM_A") ? atoi(getenv("CNMF_GEMM_A")) : 0;
     const int gvarB = getenv("CNMF_GEMM_B") ? atoi(getenv("CNMF_GEMM_B")) : 0;
     int64_t restart_iters = 0, column_iters = 0, restart_col_iters = 0;
+    const int wg_slots = 2 * 256;                    // T-layout pass A: 2 workgroups per CU (73.7 KB LDS each)
+    StreamK sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
+    if (sk.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
     int n_done = 0;
 
     auto retire = [&](int s, const SlotDesc& snap) -> int {
@@ -569,12 +620,18 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         // ---- one coordinate-descent outer iteration for every slot in flight
         if (time_gemm) { gev.resize(gev.size() + 4); for (int i = 0; i < 4; ++i) hipEventCreate(&gev[gev.size() - 4 + i]); hipEventRecord(gev[gev.size() - 4], st); }
         // pass A : XHt[KC][N] = H_all . X^T                       (sklearn _nmf.py:387)
-        HIP_TRY(ctx, launch_gemm<false>(st, gvarA, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt,
-                                        ctx->N_pad, 0, KC, ctx->G_pad, ctx->N_pad, 1));
+        if (sk.on && gvarA == 0)
+            HIP_TRY(ctx, launch_streamk_passA(st, sk, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt,
+                                              ctx->XHt1, ctx->N_pad, ctx->N_pad));
+        else
+            HIP_TRY(ctx, launch_gemm<false>(st, gvarA, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt,
+                                            ctx->N_pad, 0, KC, ctx->G_pad, ctx->N_pad, 1));
         if (time_gemm) hipEventRecord(gev[gev.size() - 3], st);
         // W half-step                                             (sklearn _nmf.py:500)
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
-                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1));
+                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1,
+                                  (sk.on && gvarA == 0) ? SplitInfo{ctx->XHt1, ctx->d_split, 128, 128, sk.MG}
+                                                        : SplitInfo{nullptr, nullptr, 1, 1, 1}));
         finalize_kernel<<<dim3(nslots, 4), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
                                                 ctx->d_slots, 0, prm->tol, prm->max_iter, 1);
         if (time_gemm) hipEventRecord(gev[gev.size() - 2], st);
@@ -647,6 +704,11 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                 for (int s : idx) cols.alloc(hs[s].k);
                 const int cap = (ctx->nsplit_alloc * KC0) / KC;
                 nsplit = std::max(1, std::min(pick_nsplit(ctx, KC), cap));
+                sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
+                if (sk.on) {
+                    // the flags of the old plan may still be read by an in-flight sweep: same stream -> ordered
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
+                }
             }
         }
     }
@@ -788,7 +850,7 @@ extern "C" int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float
     const int Kp = K;
     float *dA, *dB, *dC;
     const size_t bA = (size_t)KC * Kp * sizeof(float);
-    const size_t bB = (mode == 0 ? (size_t)Jp * Kp : (size_t)Kp * J) * sizeof(float);
+    const size_t bB = (mode == 0 ? (size_t)Jp * Kp : ((size_t)Kp + 1) * J + 128) * sizeof(float);
     const size_t bC = (size_t)nsplit * KC * Jp * sizeof(float);
     HIP_TRY(ctx, hipMalloc(&dA, bA)); HIP_TRY(ctx, hipMalloc(&dB, bB)); HIP_TRY(ctx, hipMalloc(&dC, bC));
     HIP_TRY(ctx, hipMemsetAsync(dB, 0, bB, st));

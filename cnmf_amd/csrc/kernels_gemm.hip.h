@@ -40,11 +40,11 @@ constexpr int LDK = BK + 4;   // padded row length of a K-contiguous LDS tile
 // MTW : 32-row component tiles per wave        WM x WN : wave grid (WM*WN == 4)
 // NN  : false -> B is [J][ldb] K-contiguous (pass A); true -> B is [K][ldb] J-contiguous (pass B)
 template <int MTW, int WM, int WN, bool NN>
-__global__ __launch_bounds__(256) void gemm_kernel(
+__device__ __forceinline__ void gemm_segment(
     const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb,
-    float* __restrict__ C, int ldc, long long c_split_stride,
-    int Kper, int Ktot, int Jtot)
+    float* __restrict__ C, int ldc,
+    int m0, int j0, int kbeg, int nk, int Jtot, float* smem)
 {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int MW = WM * MTW * 32;   // component rows per workgroup
@@ -54,7 +54,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(
     constexpr int A_TILE = MW * LDK;
     constexpr int B_TILE = NN ? (BK * JW) : (JW * LDK);
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                   // [2][A_TILE]
     float* Bs = smem + 2 * A_TILE;      // [2][B_TILE]
 
@@ -64,12 +63,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, h = lane >> 5;
 
-    const int j0 = blockIdx.x * JW;
-    const int m0 = blockIdx.y * MW;
-    const int kbeg = blockIdx.z * Kper;
-    const int kend = min(kbeg + Kper, Ktot);
-    const int nk = (kend - kbeg) / BK;
-
     // ---- global -> register staging addresses
     const int a_row = tid >> 3, a_kq = tid & 7;            // A: 8 float4 per 32-k row
     const float* a_src = A + (size_t)(m0 + a_row) * lda + kbeg + a_kq * 4;
@@ -78,13 +71,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 
     const float* b_src;
     int b_jq = 0, b_kr = 0;
-    bool b_ok = true;
     if (!NN) {
         b_src = B + (size_t)(j0 + a_row) * ldb + kbeg + a_kq * 4;
     } else {
         constexpr int QPR = JW / 4;                        // float4 per k row
         b_kr = tid / QPR; b_jq = tid % QPR;
-        b_ok = (j0 + b_jq * 4) < Jtot;
+        // columns j >= Jtot read into the next row of the (over-allocated) buffer; they only
+        // feed output columns that are never stored, so no guard (= no branch) is needed
         b_src = B + (size_t)(kbeg + b_kr) * ldb + j0 + b_jq * 4;
     }
 
@@ -97,8 +90,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(
                 b_reg[i] = *reinterpret_cast<const v4f*>(b_src + (size_t)(32 * i) * ldb + (kt_) * BK); \
         } else {                                                                                     \
             _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                         \
-                b_reg[i] = b_ok ? *reinterpret_cast<const v4f*>(b_src + (size_t)((kt_) * BK + RPI * i) * ldb) \
-                                : v4f{0.f, 0.f, 0.f, 0.f};                                          \
+                b_reg[i] = *reinterpret_cast<const v4f*>(b_src + (size_t)((kt_) * BK + RPI * i) * ldb); \
         }                                                                                            \
     }
 #define CNMF_STORE_STAGE(buf_)                                                                       \
@@ -132,10 +124,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(
     }
     __syncthreads();
 
+    // Branch-free main loop: the prefetch of the last stage is clamped (re-loads the final
+    // tile) and every wave computes, live or not -- a conditional around the MFMA block makes
+    // the compiler shuttle all accumulators VGPR<->AGPR on every stage.
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) CNMF_LOAD_STAGE(kt + 1)
-        if (wave_live) {
+        const int ktn = min(kt + 1, nk - 1);
+        CNMF_LOAD_STAGE(ktn)
+        // keep the prefetch at the top of the stage (hipcc otherwise sinks the loads next to
+        // their ds_write consumers and exposes the whole HBM latency every stage)
+        __builtin_amdgcn_sched_barrier(0);
+        {
             const float* as = As + buf * A_TILE + (wm * MTW * 32 + li) * LDK + h * 4;
             const float* bs = NN ? (Bs + buf * B_TILE + (h * 4) * JW + wn * 32 + li)
                                  : (Bs + buf * B_TILE + (wn * 32 + li) * LDK + h * 4);
@@ -162,12 +161,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(
                 }
             }
         }
-        if (kt + 1 < nk) CNMF_STORE_STAGE(buf ^ 1)
+        CNMF_STORE_STAGE(buf ^ 1)
         __syncthreads();
     }
 
     if (wave_live) {
-        float* c = C + (size_t)blockIdx.z * c_split_stride;
+        float* c = C;
         const int j = j0 + wn * 32 + li;
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
@@ -183,6 +182,50 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 
 #undef CNMF_LOAD_STAGE
 #undef CNMF_STORE_STAGE
+
+// grid-mapped launch: blockIdx = (j tile, component group, K split)
+template <int MTW, int WM, int WN, bool NN>
+__global__ __launch_bounds__(256) void gemm_kernel(
+    const float* __restrict__ A, int lda,
+    const float* __restrict__ B, int ldb,
+    float* __restrict__ C, int ldc, long long c_split_stride,
+    int Kper, int Ktot, int Jtot)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int MW = WM * MTW * 32, JW = WN * 32;
+    const int kbeg = blockIdx.z * Kper;
+    const int kend = min(kbeg + Kper, Ktot);
+    gemm_segment<MTW, WM, WN, NN>(A, lda, B, ldb, C + (size_t)blockIdx.z * c_split_stride, ldc,
+                                  blockIdx.y * MW, blockIdx.x * JW, kbeg, (kend - kbeg) / BK, Jtot, smem);
+}
+
+// stream-K launch (pass A): `gridDim.x` persistent workgroups share T tiles x nk stages evenly.
+// Unit u = tile * nk + stage, tile = jt * MG + mg (component group fastest, so the groups of one
+// j tile sit in the same / neighbouring workgroup and share the X tile in L2).  With at least nk
+// units per workgroup a tile is cut at most once: the piece that starts at stage 0 goes to plane 0,
+// the piece that ends at stage nk to plane 1 (sweep_kernel adds plane 1 where `split[tile]`).
+template <int MTW, int WM, int WN, bool NN>
+__global__ __launch_bounds__(256) void gemm_streamk_kernel(
+    const float* __restrict__ A, int lda,
+    const float* __restrict__ B, int ldb,
+    float* __restrict__ C0, float* __restrict__ C1, int ldc,
+    int MG, int T, int nk, int Jtot)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int MW = WM * MTW * 32, JW = WN * 32;
+    const long long U = (long long)T * nk;
+    long long u = U * blockIdx.x / gridDim.x;
+    const long long u1 = U * (blockIdx.x + 1) / gridDim.x;
+    while (u < u1) {
+        const int tile = (int)(u / nk), kb = (int)(u % nk);
+        const int ke = (int)min((long long)nk, kb + (u1 - u));
+        const int jt = tile / MG, mg = tile % MG;
+        gemm_segment<MTW, WM, WN, NN>(A, lda, B, ldb, (kb == 0) ? C0 : C1, ldc, mg * MW, jt * JW,
+                                      kb * BK, ke - kb, Jtot, smem);
+        u += ke - kb;
+        __syncthreads();                 // LDS stages are reused by the next segment
+    }
+}
 
 template <int MTW, int WM, int WN, bool NN>
 constexpr size_t gemm_lds_bytes() {

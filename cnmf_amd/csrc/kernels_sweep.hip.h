@@ -38,13 +38,19 @@ struct SlotDesc {                   // one restart in flight (device + host mirr
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+struct SplitInfo {                  // second partial plane of a stream-K product (or plane1 == nullptr)
+    const float* plane1;
+    const unsigned char* split;     // [tiles] 1 = the tile was cut, add plane 1
+    int tile_rows, tile_cols, mgroups;
+};
+
 // Body of the sweep for one (row chunk, slot); KP = k rounded up to a multiple of 4
 // (compile-time register array size).  Gram of the updated rows:
 //   KP <= 16 : v_mfma_f32_16x16x4_f32  (16 MFMAs of 32 cycles per 64 rows)
 //   KP  > 16 : v_mfma_f32_32x32x2_f32  (32 MFMAs of 64 cycles per 64 rows)
 template <int KP>
 __device__ __forceinline__ void sweep_body(
-    float* __restrict__ V, int ldv, int L, const float* __restrict__ P,
+    float* __restrict__ V, int ldv, int L, const float* __restrict__ P, const SplitInfo& sp,
     const float* __restrict__ gram, const SlotDesc& sd, int slot, float l1_reg,
     float* __restrict__ gram_part, double* __restrict__ viol_part,
     int chunks_per_block, int want_gram,
@@ -75,7 +81,12 @@ __device__ __forceinline__ void sweep_body(
             if (live && c < k) {
                 const size_t idx = (size_t)(off + c) * ldv + row;
                 w[c] = V[idx];
-                p[c] = P[idx] - l1_reg;
+                float pv = P[idx];
+                if (sp.plane1) {       // stream-K pass A: tiles cut between two workgroups
+                    const int tile = (row / sp.tile_rows) * sp.mgroups + (off + c) / sp.tile_cols;
+                    if (sp.split[tile]) pv += sp.plane1[idx];
+                }
+                p[c] = pv - l1_reg;
             }
         }
         if (live) {
@@ -163,6 +174,7 @@ __device__ __forceinline__ void sweep_body(
 __global__ __launch_bounds__(256) void sweep_kernel(
     float* __restrict__ V, int ldv, int L,
     const float* __restrict__ P,             // [KC][ldv] products (split-K already reduced)
+    SplitInfo sp,
     const float* __restrict__ gram,          // [nslots][32][32], regularised diagonal included
     const SlotDesc* __restrict__ slots,
     float l1_reg,
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(
     __shared__ double vred[4];
 #define CNMF_SW(KP_)                                                                              \
     case KP_ / 4:                                                                                 \
-        sweep_body<KP_>(V, ldv, L, P, gram, sd, slot, l1_reg, gram_part, viol_part,               \
+        sweep_body<KP_>(V, ldv, L, P, sp, gram, sd, slot, l1_reg, gram_part, viol_part,           \
                         chunks_per_block, want_gram, Gs, Ws, vred);                               \
         break;
     switch ((sd.k + 3) / 4) {
