@@ -4,7 +4,7 @@
 Workload (default, ``config.workload``): the north-star headline shape -- 50 000 cells x
 2000 high-variance genes (synthetic gamma-Poisson counts, reference `prepare` scaling,
 cnmf_amd/synth.py "C3"), K in {5..13}.  One STEP = one pass of the hot path over one
-batch of restarts: ``--restarts-per-k`` restarts for every K (default 10 -> 90 restarts
+batch of restarts: ``--restarts-per-k`` restarts for every K (default 20 -> 180 restarts
 streamed through 256 packed component columns by the slot work-queue), run to sklearn's stopping rule (tol 1e-4, max_iter 1000)
 with sklearn's init='random' generated on the device from the cNMF ledger seeds
 (master seed 14).  X is resident in HBM before the timed region.
@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C3", help="C1|C2|C3 (cnmf_amd/synth.py)")
     ap.add_argument("--n-cells", type=int, default=None, help="truncate the workload (debug only)")
-    ap.add_argument("--restarts-per-k", type=int, default=10)
+    ap.add_argument("--restarts-per-k", type=int, default=20)
     ap.add_argument("--kmin", type=int, default=5)
     ap.add_argument("--kmax", type=int, default=13)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -134,12 +134,12 @@ static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int l
 // ------------------------------------------------------------------ sweep dispatch
 static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, int L, const float* P,
                                const float* gram, const SlotDesc* slots, float l1, float* gram_part,
-                               double* viol_part, int chunks, int parts, int want_gram,
+                               double* viol_part, int chunks, int parts, int want_gram, int kmax,
                                SplitInfo sp = SplitInfo{nullptr, nullptr, 1, 1, 1})
 {
     dim3 grid(parts, nslots);
-    sweep_kernel<<<grid, 256, 0, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks,
-                                       want_gram);
+    sweep_kernel<<<grid, 256, sweep_lds_bytes(kmax), st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part,
+                                                           viol_part, chunks, want_gram, sweep_wstride(kmax));
     return hipGetLastError();
 }
 
@@ -534,7 +534,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     std::vector<int> order(n);
     for (int r = 0; r < n; ++r) order[r] = r;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kk[a] > kk[b]; });
-    size_t next = 0;
+    size_t next = 0;                 // first queue position that may still be pending
+    int n_pending = n;
 
     ColAlloc cols(KC);
     std::vector<HostSlot> hs(KC0);
@@ -557,6 +558,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     const int gvarA = getenv("CNMF_GEMM_A") ? atoi(getenv("CNMF_GEMM_A")) : 0;
     const int gvarB = getenv("CNMF_GEMM_B") ? atoi(getenv("CNMF_GEMM_B")) : 0;
     int64_t restart_iters = 0, column_iters = 0, restart_col_iters = 0;
+    const bool dbg = getenv("CNMF_DEBUG") != nullptr;
+    int64_t dbg_it[9] = {0}, dbg_live[9] = {0};
     const int wg_slots = 2 * 256;                    // T-layout pass A: 2 workgroups per CU (73.7 KB LDS each)
     StreamK sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
     if (sk.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
@@ -585,10 +588,19 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         // ---- refill free columns from the pending list
         int n_new = 0;
         int* new_list = ctx->h_slot_list + (size_t)(it % RING) * KC0;
-        while (next < order.size()) {
-            const int r = order[next], k = kk[r];
+        // pending restarts are sorted by descending rank; a hole too small for the head of the
+        // queue is filled with the largest pending rank that fits (restarts are independent, so
+        // the order they run in is free) -> the packed columns stay full in the main phase
+        int failed_k = 1 << 30;                       // smallest rank that did not fit in this pass
+        for (size_t pi = next; pi < order.size() && n_pending > 0; ++pi) {
+            const int r = order[pi];
+            if (r < 0) { if (pi == next) ++next; continue; }      // already taken
+            const int k = kk[r];
+            if (k >= failed_k) continue;
             const int off = cols.alloc(k);
-            if (off < 0) break;
+            if (off < 0) { failed_k = k; continue; }
+            order[pi] = -1; --n_pending;
+            if (pi == next) ++next;
             int s = 0;
             while (s < KC0 && hs[s].state != 0) ++s;
             hs[s].state = 1; hs[s].restart = r; hs[s].off = off; hs[s].k = k; hs[s].installed_at = it;
@@ -607,7 +619,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             d->off = off; d->k = k; d->active = 1; d->iter = 0; d->restart = r;
             HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots + s, d, sizeof(SlotDesc), hipMemcpyHostToDevice, st));
             new_list[n_new++] = s;
-            ++n_active; ++next;
+            ++n_active;
         }
         if (n_new) {
             int* dl = ctx->d_slot_list + (size_t)(it % RING) * KC0;
@@ -615,7 +627,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             gram_rows_kernel<<<n_new, 256, 0, st>>>(ctx->H, ctx->G_pad, G, ctx->d_slots, dl, ctx->gramH, l2W);
             HIP_TRY(ctx, hipGetLastError());
         }
-        if (n_active == 0 && next >= order.size()) break;
+        if (n_active == 0 && n_pending == 0) break;
 
         // ---- one coordinate-descent outer iteration for every slot in flight
         if (time_gemm) { gev.resize(gev.size() + 4); for (int i = 0; i < 4; ++i) hipEventCreate(&gev[gev.size() - 4 + i]); hipEventRecord(gev[gev.size() - 4], st); }
@@ -629,7 +641,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (time_gemm) hipEventRecord(gev[gev.size() - 3], st);
         // W half-step                                             (sklearn _nmf.py:500)
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
-                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1,
+                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k,
                                   (sk.on && gvarA == 0) ? SplitInfo{ctx->XHt1, ctx->d_split, 128, 128, sk.MG}
                                                         : SplitInfo{nullptr, nullptr, 1, 1, 1}));
         finalize_kernel<<<dim3(nslots, 4), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
@@ -644,11 +656,16 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         HIP_TRY(ctx, launch_reduce_splits(st, ctx->XtW, nsplit, (long long)KC * ctx->G_pad,
                                           (long long)KC * ctx->G_pad));
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
-                                  ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1));
+                                  ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k));
         finalize_kernel<<<dim3(nslots, 4), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W,
                                                 ctx->d_slots, 1, prm->tol, prm->max_iter, 1);
         HIP_TRY(ctx, hipGetLastError());
         column_iters += KC;
+        if (dbg) {
+            int live = 0;
+            for (int s2 = 0; s2 < nslots; ++s2) if (hs[s2].state) live += hs[s2].k;
+            dbg_it[KC / 32] += 1; dbg_live[KC / 32] += live;
+        }
 
         // ---- snapshot of the slot table, examined `lag` iterations later
         SlotDesc* snap = ctx->h_snap + (size_t)(it % RING) * KC0;
@@ -671,7 +688,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         // ---- tail compaction: nothing left to refill with and at most half of the packed
         // columns still iterate -> repack the live slots into a narrower batch so the two
         // GEMM passes shrink with the work (their cost is proportional to KC).
-        if (next >= order.size() && n_active > 0 && KC > 32 && !getenv("CNMF_NO_COMPACT")) {
+        if (n_pending == 0 && n_active > 0 && KC > 32 && !getenv("CNMF_NO_COMPACT")) {
             int live_cols = 0;
             for (int s = 0; s < nslots; ++s) if (hs[s].state) live_cols += hs[s].k;
             int KCn = 32;
@@ -713,6 +730,10 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         }
     }
 
+    if (dbg)
+        for (int i = 1; i <= 8; ++i)
+            if (dbg_it[i]) fprintf(stderr, "[cnmf] KC=%d: %lld iterations, mean host-live columns %.1f\n", i * 32,
+                                   (long long)dbg_it[i], (double)dbg_live[i] / dbg_it[i]);
     HIP_TRY(ctx, hipEventRecord(ev_end, st));
     if (!resident)
         HIP_TRY(ctx, hipMemcpyAsync(H_out, d_Hres, hoff[n] * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -808,7 +829,7 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
         for (int b = 0; b < burst; ++b) {
             HIP_TRY(ctx, launch_sweep(st, 1, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
                                       ctx->d_slots, (float)prm->l1_reg_W, ctx->gram_part, ctx->viol_part,
-                                      chunksW, partsW, 0));
+                                      chunksW, partsW, 0, k));
             finalize_kernel<<<dim3(1, 1), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, 0.f,
                                                ctx->d_slots, 2, prm->tol, prm->max_iter, 0);
         }

@@ -24,6 +24,13 @@ constexpr int KMAX = 32;            // largest rank handled by the register-resi
 constexpr int GRAM_LD = KMAX;       // gram matrices are stored [slot][32][32]
 constexpr int GRAM_SZ = KMAX * KMAX;
 
+// dynamic LDS of sweep_kernel for a batch whose largest rank is kmax
+static inline int sweep_wstride(int kmax) { return kmax <= 16 ? 17 : KMAX + 1; }
+static inline size_t sweep_lds_bytes(int kmax)
+{
+    return sizeof(float) * (size_t)(KMAX * (KMAX + 4) + 8 + 4 * 64 * sweep_wstride(kmax));
+}
+
 struct SlotDesc {                   // one restart in flight (device + host mirror)
     int off;                        // first packed component column
     int k;                          // rank
@@ -53,10 +60,14 @@ __device__ __forceinline__ void sweep_body(
     float* __restrict__ V, int ldv, int L, const float* __restrict__ P, const SplitInfo& sp,
     const float* __restrict__ gram, const SlotDesc& sd, int slot, float l1_reg,
     float* __restrict__ gram_part, double* __restrict__ viol_part,
-    int chunks_per_block, int want_gram,
-    float (*Gs)[KMAX + 4], float (*Ws)[64][KMAX + 1], double* vred)
+    int chunks_per_block, int want_gram, float* lds, int wstride)
 {
     constexpr bool SMALL = (KP <= 16);
+    // dynamic LDS: Gs [32][36] | vred [4] doubles | Ws [4][64][wstride]
+    float (*Gs)[KMAX + 4] = reinterpret_cast<float (*)[KMAX + 4]>(lds);
+    double* vred = reinterpret_cast<double*>(lds + KMAX * (KMAX + 4));
+    float* Wsb = lds + KMAX * (KMAX + 4) + 8;
+#define WS(wv_, r_, c_) Wsb[((wv_) * 64 + (r_)) * wstride + (c_)]
     const int k = sd.k, off = sd.off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < KMAX * KMAX; e += 256) {
@@ -74,6 +85,18 @@ __device__ __forceinline__ void sweep_body(
     for (int ch = 0; ch < chunks_per_block; ++ch) {
         const int row = (blockIdx.x * chunks_per_block + ch) * 256 + tid;
         const bool live = row < L;
+        // stream-K pass A: was this (row tile, component group) cut between two workgroups?
+        // A slot spans at most two component groups and a wave's 64 rows lie in one row tile,
+        // so two wave-uniform flags cover every element.
+        bool cut0 = false, cut1 = false;
+        int mg_edge = 1 << 30;
+        if (sp.plane1) {
+            const int rt = __builtin_amdgcn_readfirstlane(min(row, L - 1) / sp.tile_rows);
+            const int g0 = off / sp.tile_cols, g1 = (off + k - 1) / sp.tile_cols;
+            mg_edge = (g0 + 1) * sp.tile_cols;
+            cut0 = sp.split[rt * sp.mgroups + g0] != 0;
+            cut1 = sp.split[rt * sp.mgroups + g1] != 0;
+        }
         float w[KP], p[KP];
 #pragma unroll
         for (int c = 0; c < KP; ++c) {
@@ -82,10 +105,7 @@ __device__ __forceinline__ void sweep_body(
                 const size_t idx = (size_t)(off + c) * ldv + row;
                 w[c] = V[idx];
                 float pv = P[idx];
-                if (sp.plane1) {       // stream-K pass A: tiles cut between two workgroups
-                    const int tile = (row / sp.tile_rows) * sp.mgroups + (off + c) / sp.tile_cols;
-                    if (sp.split[tile]) pv += sp.plane1[idx];
-                }
+                if (((off + c) < mg_edge) ? cut0 : cut1) pv += sp.plane1[idx];   // wave-uniform
                 p[c] = pv - l1_reg;
             }
         }
@@ -110,20 +130,20 @@ __device__ __forceinline__ void sweep_body(
             // Gram of the updated rows on the (otherwise idle) matrix pipe: acc += Wrows^T . Wrows
             constexpr int WC = SMALL ? 16 : KMAX;
 #pragma unroll
-            for (int c = 0; c < WC; ++c) Ws[wave][lane][c] = (c < KP) ? w[c < KP ? c : 0] : 0.f;
+            for (int c = 0; c < WC; ++c) WS(wave, lane, c) = (c < KP) ? w[c < KP ? c : 0] : 0.f;
             __builtin_amdgcn_wave_barrier();       // wave-private tile: LDS ops of one wave are in order
             if (SMALL) {
                 const int li = lane & 15, q = lane >> 4;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    const float a = Ws[wave][4 * s + q][li];
+                    const float a = WS(wave, 4 * s + q, li);
                     gacc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, gacc4, 0, 0, 0);
                 }
             } else {
                 const int li = lane & 31, h = lane >> 5;
 #pragma unroll 8
                 for (int s = 0; s < 32; ++s) {
-                    const float a = Ws[wave][2 * s + h][li];
+                    const float a = WS(wave, 2 * s + h, li);
                     gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, gacc, 0, 0, 0);
                 }
             }
@@ -139,18 +159,19 @@ __device__ __forceinline__ void sweep_body(
 
     // ---- gram: sum the 4 waves' accumulators through LDS, write the block partial
     __syncthreads();
-    float* gred = &Ws[0][0][0];          // reused as [4][32][33]  (4*32*33 <= 4*64*33 floats)
+    float* gred = Wsb;                   // reused as [4][GR][GR+1], GR = 16 or 32
+    constexpr int GR = SMALL ? 16 : 32;
     if (want_gram) {
         if (SMALL) {
             const int li = lane & 15, q = lane >> 4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gred[(wave * 32 + 4 * q + r) * 33 + li] = gacc4[r];
+            for (int r = 0; r < 4; ++r) gred[(wave * GR + 4 * q + r) * (GR + 1) + li] = gacc4[r];
         } else {
             const int li = lane & 31, h = lane >> 5;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-                gred[(wave * 32 + rr) * 33 + li] = gacc[r];
+                gred[(wave * GR + rr) * (GR + 1) + li] = gacc[r];
             }
         }
     }
@@ -160,13 +181,14 @@ __device__ __forceinline__ void sweep_body(
             const int r = e / 32, c = e % 32;
             float s = 0.f;
             if (r < k && c < k)
-                s = gred[(0 * 32 + r) * 33 + c] + gred[(1 * 32 + r) * 33 + c] +
-                    gred[(2 * 32 + r) * 33 + c] + gred[(3 * 32 + r) * 33 + c];
+                s = gred[(0 * GR + r) * (GR + 1) + c] + gred[(1 * GR + r) * (GR + 1) + c] +
+                    gred[(2 * GR + r) * (GR + 1) + c] + gred[(3 * GR + r) * (GR + 1) + c];
             gram_part[((size_t)slot * gridDim.x + blockIdx.x) * GRAM_SZ + e] = s;
         }
     }
     if (tid == 0)
         viol_part[(size_t)slot * gridDim.x + blockIdx.x] = vred[0] + vred[1] + vred[2] + vred[3];
+#undef WS
 }
 
 // One launch sweeps every slot in flight: grid = (row blocks, slots); the workgroup
@@ -180,18 +202,16 @@ __global__ __launch_bounds__(256) void sweep_kernel(
     float l1_reg,
     float* __restrict__ gram_part,           // [nslots][gridDim.x][32][32]
     double* __restrict__ viol_part,          // [nslots][gridDim.x]
-    int chunks_per_block, int want_gram)
+    int chunks_per_block, int want_gram, int wstride)
 {
     const int slot = blockIdx.y;
     const SlotDesc sd = slots[slot];
     if (!sd.active) return;
-    __shared__ __attribute__((aligned(16))) float Gs[KMAX][KMAX + 4];
-    __shared__ __attribute__((aligned(16))) float Ws[4][64][KMAX + 1];
-    __shared__ double vred[4];
+    extern __shared__ __attribute__((aligned(16))) float sweep_lds[];
 #define CNMF_SW(KP_)                                                                              \
     case KP_ / 4:                                                                                 \
         sweep_body<KP_>(V, ldv, L, P, sp, gram, sd, slot, l1_reg, gram_part, viol_part,           \
-                        chunks_per_block, want_gram, Gs, Ws, vred);                               \
+                        chunks_per_block, want_gram, sweep_lds, wstride);                         \
         break;
     switch ((sd.k + 3) / 4) {
         CNMF_SW(4) CNMF_SW(8) CNMF_SW(12) CNMF_SW(16) CNMF_SW(20) CNMF_SW(24) CNMF_SW(28) CNMF_SW(32)

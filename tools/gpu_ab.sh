@@ -1,10 +1,9 @@
 #!/bin/bash
-# A/B: bench with stream-K pass A vs classic T vs classic S (same box, same data)
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_nmf.py tests/test_gpu_pipeline.py -m gpu -x -q 2>&1 | tail -3
-for cfg in "streamk:" "T:CNMF_NO_STREAMK=1" "S:CNMF_GEMM_A=1"; do
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for cfg in "default:" ; do
   tag=${cfg%%:*}; envs=${cfg#*:}
-  env $envs python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+  env $envs python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tee gpurun_out/bench_ab_$tag.json | python -c "
 import sys, json
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('$tag', 'restarts/s %.2f' % d['value'], 'riter/s %.0f' % d['config']['restart_iterations_per_s'], 'passA %.3f ms passB %.3f ms' % (r['avg_launch_ms']['passA'], r['avg_launch_ms']['passB']), 'TF A %.1f B %.1f' % (r['achieved_passA'], r['achieved_passB']), 'gemm share %.3f util %.3f' % (r['gemm_share_of_gpu_time'], d['config']['column_utilisation']))
