@@ -86,7 +86,7 @@ static inline int round_up(int64_t v, int m) { return (int)(((v + m - 1) / m) * 
 //           3 = 2x2 wave grid (64 j per workgroup)
 struct GemmPlan { int variant; int mw; int jw; };
 
-template <int MTW, int WM, int WN, bool NN>
+template <int MTW, int WM, int WN, bool NN, int TBK = BK>
 static hipError_t launch_gemm_t(hipStream_t st, const float* A, int lda, const float* B, int ldb,
                                 float* C, int ldc, long long cstride, int KC, int Ktot, int J,
                                 int nsplit)
@@ -95,14 +95,14 @@ static hipError_t launch_gemm_t(hipStream_t st, const float* A, int lda, const f
     const int Kper = round_up((Ktot + nsplit - 1) / nsplit, BK);
     dim3 grid((J + JW - 1) / JW, KC / MW, nsplit);
     static bool attr_set = false;
-    constexpr size_t lds = gemm_lds_bytes<MTW, WM, WN, NN>();
+    constexpr size_t lds = gemm_lds_bytes<MTW, WM, WN, NN, TBK>();
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<MTW, WM, WN, NN>,
+        hipFuncSetAttribute((const void*)gemm_kernel<MTW, WM, WN, NN, TBK>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    gemm_kernel<MTW, WM, WN, NN><<<grid, 256, lds, st>>>(A, lda, B, ldb, C, ldc, cstride, Kper,
-                                                        Ktot, J);
+    gemm_kernel<MTW, WM, WN, NN, TBK><<<grid, 256, lds, st>>>(A, lda, B, ldb, C, ldc, cstride, Kper,
+                                                             Ktot, J);
     return hipGetLastError();
 }
 
@@ -123,6 +123,10 @@ static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int l
         case 3:  // 2x2
             if (KC % 128 == 0) GO(2, 2, 2);
             GO(1, 2, 2);
+        case 4:   // T with 16-deep stages (half the LDS per workgroup -> 3-4 workgroups per CU)
+            if (KC % 128 == 0)
+                return launch_gemm_t<4, 1, 4, NN, 16>(st, A, lda, B, ldb, C, ldc, cstride, KC, Ktot, J, nsplit);
+            [[fallthrough]];
         default:  // T: every wave all comps of the M group, 128 j
             if (KC % 128 == 0) GO(4, 1, 4);
             if (KC % 64 == 0) GO(2, 1, 4);
@@ -156,7 +160,7 @@ static StreamK plan_streamk(int KC, int N_pad, int G_pad, int n_wg_slots)
     if (KC % 128 != 0 || getenv("CNMF_NO_STREAMK")) return sk;
     sk.MG = KC / 128;
     sk.T = sk.MG * (N_pad / 128);
-    sk.nk = G_pad / BK;
+    sk.nk = G_pad / (getenv("CNMF_BK16") ? 16 : BK);       // stages per tile, as the kernel counts them
     sk.P = n_wg_slots;
     if (sk.T <= sk.P) sk.P = n_wg_slots / 2;              // one workgroup per CU
     if (sk.T <= sk.P || sk.T % sk.P == 0) return sk;      // nothing to balance
@@ -170,19 +174,29 @@ static StreamK plan_streamk(int KC, int N_pad, int G_pad, int n_wg_slots)
     return sk;
 }
 
-static hipError_t launch_streamk_passA(hipStream_t st, const StreamK& sk, const float* A, int lda,
-                                       const float* B, int ldb, float* C0, float* C1, int ldc, int Jtot)
+template <int TBK>
+static hipError_t launch_streamk_t(hipStream_t st, const StreamK& sk, const float* A, int lda,
+                                   const float* B, int ldb, float* C0, float* C1, int ldc, int Jtot, int stagger)
 {
-    constexpr size_t lds = gemm_lds_bytes<4, 1, 4, false>();
+    constexpr size_t lds = gemm_lds_bytes<4, 1, 4, false, TBK>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_streamk_kernel<4, 1, 4, false>,
+        hipFuncSetAttribute((const void*)gemm_streamk_kernel<4, 1, 4, false, TBK>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    gemm_streamk_kernel<4, 1, 4, false><<<sk.P, 256, lds, st>>>(A, lda, B, ldb, C0, C1, ldc, sk.MG, sk.T,
-                                                               sk.nk, Jtot);
+    gemm_streamk_kernel<4, 1, 4, false, TBK><<<sk.P, 256, lds, st>>>(A, lda, B, ldb, C0, C1, ldc, sk.MG,
+                                                                    sk.T, sk.nk, Jtot, stagger);
     return hipGetLastError();
+}
+
+static hipError_t launch_streamk_passA(hipStream_t st, const StreamK& sk, const float* A, int lda,
+                                       const float* B, int ldb, float* C0, float* C1, int ldc, int Jtot)
+{
+    static const int bk16 = getenv("CNMF_BK16") ? 1 : 0;
+    static const int stagger = getenv("CNMF_STAGGER") ? 1 : 0;
+    if (bk16) return launch_streamk_t<16>(st, sk, A, lda, B, ldb, C0, C1, ldc, Jtot, stagger);
+    return launch_streamk_t<32>(st, sk, A, lda, B, ldb, C0, C1, ldc, Jtot, stagger);
 }
 
 static hipError_t launch_reduce_splits(hipStream_t st, float* P, int nsplit, long long split_stride,

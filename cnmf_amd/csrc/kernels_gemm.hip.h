@@ -34,12 +34,11 @@ namespace cnmf {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;        // k extent of one LDS stage
-constexpr int LDK = BK + 4;   // padded row length of a K-contiguous LDS tile
+constexpr int BK = 32;        // default k extent of one LDS stage (template parameter TBK)
 
 // MTW : 32-row component tiles per wave        WM x WN : wave grid (WM*WN == 4)
 // NN  : false -> B is [J][ldb] K-contiguous (pass A); true -> B is [K][ldb] J-contiguous (pass B)
-template <int MTW, int WM, int WN, bool NN>
+template <int MTW, int WM, int WN, bool NN, int TBK>
 __device__ __forceinline__ void gemm_segment(
     const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb,
@@ -47,10 +46,15 @@ __device__ __forceinline__ void gemm_segment(
     int m0, int j0, int kbeg, int nk, int Jtot, float* smem)
 {
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int BK = TBK;             // shadows the namespace default inside this function
+    constexpr int LDK = BK + 4;         // padded row of a K-contiguous LDS tile (ds_read_b128 conflict-free)
+    constexpr int QK = BK / 4;          // float4 per K-contiguous row
+    constexpr int RP = 256 / QK;        // rows staged per pass of the 256 threads
     constexpr int MW = WM * MTW * 32;   // component rows per workgroup
     constexpr int JW = WN * 32;         // j columns per workgroup
-    constexpr int A_F4 = MW / 32;       // float4 per thread per A stage
-    constexpr int B_F4 = JW / 32;       // float4 per thread per B stage
+    constexpr int A_F4 = MW / RP;       // float4 per thread per A stage
+    constexpr int B_F4 = NN ? (BK * JW) / 1024 : JW / RP;   // float4 per thread per B stage
+    static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for the staging map");
     constexpr int A_TILE = MW * LDK;
     constexpr int B_TILE = NN ? (BK * JW) : (JW * LDK);
 
@@ -64,7 +68,7 @@ __device__ __forceinline__ void gemm_segment(
     const int li = lane & 31, h = lane >> 5;
 
     // ---- global -> register staging addresses
-    const int a_row = tid >> 3, a_kq = tid & 7;            // A: 8 float4 per 32-k row
+    const int a_row = tid / QK, a_kq = tid % QK;           // QK float4 per K-contiguous row
     const float* a_src = A + (size_t)(m0 + a_row) * lda + kbeg + a_kq * 4;
     v4f a_reg[A_F4];
     v4f b_reg[B_F4];
@@ -84,10 +88,10 @@ __device__ __forceinline__ void gemm_segment(
 #define CNMF_LOAD_STAGE(kt_)                                                                         \
     {                                                                                                \
         _Pragma("unroll") for (int i = 0; i < A_F4; ++i)                                             \
-            a_reg[i] = *reinterpret_cast<const v4f*>(a_src + (size_t)(32 * i) * lda + (kt_) * BK); \
+            a_reg[i] = *reinterpret_cast<const v4f*>(a_src + (size_t)(RP * i) * lda + (kt_) * BK); \
         if (!NN) {                                                                                   \
             _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                         \
-                b_reg[i] = *reinterpret_cast<const v4f*>(b_src + (size_t)(32 * i) * ldb + (kt_) * BK); \
+                b_reg[i] = *reinterpret_cast<const v4f*>(b_src + (size_t)(RP * i) * ldb + (kt_) * BK); \
         } else {                                                                                     \
             _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                         \
                 b_reg[i] = *reinterpret_cast<const v4f*>(b_src + (size_t)((kt_) * BK + RPI * i) * ldb); \
@@ -98,10 +102,10 @@ __device__ __forceinline__ void gemm_segment(
         float* as_ = As + (buf_) * A_TILE;                                                           \
         float* bs_ = Bs + (buf_) * B_TILE;                                                           \
         _Pragma("unroll") for (int i = 0; i < A_F4; ++i)                                             \
-            *reinterpret_cast<v4f*>(as_ + (a_row + 32 * i) * LDK + a_kq * 4) = a_reg[i];          \
+            *reinterpret_cast<v4f*>(as_ + (a_row + RP * i) * LDK + a_kq * 4) = a_reg[i];          \
         if (!NN) {                                                                                   \
             _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                         \
-                *reinterpret_cast<v4f*>(bs_ + (a_row + 32 * i) * LDK + a_kq * 4) = b_reg[i];      \
+                *reinterpret_cast<v4f*>(bs_ + (a_row + RP * i) * LDK + a_kq * 4) = b_reg[i];      \
         } else {                                                                                     \
             _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                         \
                 *reinterpret_cast<v4f*>(bs_ + (b_kr + RPI * i) * JW + b_jq * 4) = b_reg[i];       \
@@ -184,7 +188,7 @@ __device__ __forceinline__ void gemm_segment(
 #undef CNMF_STORE_STAGE
 
 // grid-mapped launch: blockIdx = (j tile, component group, K split)
-template <int MTW, int WM, int WN, bool NN>
+template <int MTW, int WM, int WN, bool NN, int TBK = BK>
 __global__ __launch_bounds__(256) void gemm_kernel(
     const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb,
@@ -195,8 +199,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(
     constexpr int MW = WM * MTW * 32, JW = WN * 32;
     const int kbeg = blockIdx.z * Kper;
     const int kend = min(kbeg + Kper, Ktot);
-    gemm_segment<MTW, WM, WN, NN>(A, lda, B, ldb, C + (size_t)blockIdx.z * c_split_stride, ldc,
-                                  blockIdx.y * MW, blockIdx.x * JW, kbeg, (kend - kbeg) / BK, Jtot, smem);
+    gemm_segment<MTW, WM, WN, NN, TBK>(A, lda, B, ldb, C + (size_t)blockIdx.z * c_split_stride, ldc,
+                                       blockIdx.y * MW, blockIdx.x * JW, kbeg, (kend - kbeg) / TBK, Jtot, smem);
 }
 
 // stream-K launch (pass A): `gridDim.x` persistent workgroups share T tiles x nk stages evenly.
@@ -204,32 +208,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 // j tile sit in the same / neighbouring workgroup and share the X tile in L2).  With at least nk
 // units per workgroup a tile is cut at most once: the piece that starts at stage 0 goes to plane 0,
 // the piece that ends at stage nk to plane 1 (sweep_kernel adds plane 1 where `split[tile]`).
-template <int MTW, int WM, int WN, bool NN>
+template <int MTW, int WM, int WN, bool NN, int TBK = BK>
 __global__ __launch_bounds__(256) void gemm_streamk_kernel(
     const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb,
     float* __restrict__ C0, float* __restrict__ C1, int ldc,
-    int MG, int T, int nk, int Jtot)
+    int MG, int T, int nk, int Jtot, int stagger)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int MW = WM * MTW * 32, JW = WN * 32;
     const long long U = (long long)T * nk;
     long long u = U * blockIdx.x / gridDim.x;
     const long long u1 = U * (blockIdx.x + 1) / gridDim.x;
+    // de-phase the two workgroups that share a CU so that their barrier / staging phases do not
+    // coincide (the matrix pipe idles when both are outside their MFMA phase)
+    if (stagger && (blockIdx.x & 256)) __builtin_amdgcn_s_sleep(127);
     while (u < u1) {
         const int tile = (int)(u / nk), kb = (int)(u % nk);
         const int ke = (int)min((long long)nk, kb + (u1 - u));
         const int jt = tile / MG, mg = tile % MG;
-        gemm_segment<MTW, WM, WN, NN>(A, lda, B, ldb, (kb == 0) ? C0 : C1, ldc, mg * MW, jt * JW,
-                                      kb * BK, ke - kb, Jtot, smem);
+        gemm_segment<MTW, WM, WN, NN, TBK>(A, lda, B, ldb, (kb == 0) ? C0 : C1, ldc, mg * MW, jt * JW,
+                                           kb * TBK, ke - kb, Jtot, smem);
         u += ke - kb;
         __syncthreads();                 // LDS stages are reused by the next segment
     }
 }
 
-template <int MTW, int WM, int WN, bool NN>
+template <int MTW, int WM, int WN, bool NN, int TBK = BK>
 constexpr size_t gemm_lds_bytes() {
-    return sizeof(float) * 2 * (size_t)(WM * MTW * 32 * LDK + (NN ? BK * WN * 32 : WN * 32 * LDK));
+    return sizeof(float) * 2 * (size_t)(WM * MTW * 32 * (TBK + 4) + (NN ? TBK * WN * 32 : WN * 32 * (TBK + 4)));
 }
 
 }  // namespace cnmf

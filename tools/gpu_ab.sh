@@ -1,9 +1,10 @@
 #!/bin/bash
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for cfg in "default:" ; do
-  tag=${cfg%%:*}; envs=${cfg#*:}
-  env $envs python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tee gpurun_out/bench_ab_$tag.json | python -c "
+python -m pytest tests/test_gpu_nmf.py -m gpu -x -q 2>&1 | tail -2
+CNMF_BK16=1 python -m pytest tests/test_gpu_nmf.py -m gpu -x -q 2>&1 | tail -2
+for cfg in "base:" "bk16:CNMF_BK16=1" "stagger:CNMF_STAGGER=1" "bk16B:CNMF_GEMM_B=4" "bk16+stag:CNMF_BK16=1,CNMF_STAGGER=1,CNMF_GEMM_B=4"; do
+  tag=${cfg%%:*}; envs=$(echo ${cfg#*:} | tr ',' ' ')
+  env $envs python bench.py --steps 1 --warmup 0 --restarts-per-k 10 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('$tag', 'restarts/s %.2f' % d['value'], 'riter/s %.0f' % d['config']['restart_iterations_per_s'], 'passA %.3f ms passB %.3f ms' % (r['avg_launch_ms']['passA'], r['avg_launch_ms']['passB']), 'TF A %.1f B %.1f' % (r['achieved_passA'], r['achieved_passB']), 'gemm share %.3f util %.3f' % (r['gemm_share_of_gpu_time'], d['config']['column_utilisation']))
