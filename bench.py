@@ -80,6 +80,37 @@ def cpu_baseline(X32, mean_iters_per_restart, max_iter):
     }
 
 
+def consensus_wallclock(eng, with_cpu=True):
+    """BASELINE config 5 (consensus-only stress: 5000 stacked spectra x 2000 genes, k=20):
+    wall-clock of the consensus core on the GPU (host call incl. transfers) next to the
+    reference's sklearn/pandas calls on the host cores.  Reported beside the headline metric."""
+    from cnmf_amd import synth
+    S, _ = synth.consensus_stress(R=5000, G=2000, k=20, n_outliers=100, seed=0)
+    eng.consensus(S, 20, density_threshold=0.5)                     # warm-up (allocations, code objects)
+    t0 = time.perf_counter()
+    out = eng.consensus(S, 20, density_threshold=0.5)
+    gpu_s = time.perf_counter() - t0
+    res = {"workload": "C5: 5000 spectra x 2000 genes, k=20, density_threshold 0.5, n_neighbors 75",
+           "gpu_ms": 1e3 * gpu_s, "rows_kept": int(out["n_kept"]), "dtype": "f64"}
+    if with_cpu:
+        import pandas as pd
+        from sklearn.cluster import KMeans
+        from sklearn.metrics.pairwise import euclidean_distances
+        t0 = time.perf_counter()
+        l2 = (S.T / np.sqrt((S ** 2).sum(axis=1))).T
+        D = euclidean_distances(l2)
+        n = int(0.30 * S.shape[0] / 20)
+        po = np.argpartition(D, n + 1)[:, :n + 1]
+        dens = D[np.arange(D.shape[0])[:, None], po].sum(1) / n
+        l2k = l2[dens < 0.5]
+        km = KMeans(n_clusters=20, n_init=10, random_state=1).fit(l2k)
+        pd.DataFrame(l2k).groupby(pd.Series(km.labels_ + 1)).median()
+        res["cpu_reference_ms"] = 1e3 * (time.perf_counter() - t0)
+        res["cpu_cores"] = os.cpu_count()
+        res["labels_match_cpu"] = bool(np.array_equal(out["labels"][out["density_filter"]], km.labels_))
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -212,6 +243,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, mean_it, args.cpu_iters)
+            out["consensus"] = consensus_wallclock(eng)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

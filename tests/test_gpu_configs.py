@@ -1,0 +1,70 @@
+"""BASELINE.json configurations at (or near) full size on the GPU.
+
+C2  2700 x 2000 (PBMC3k stand-in), K=10, n_iter=100: the whole ledger through the slot
+    work-queue; a sample of restarts is compared with the float64 oracle.
+C4  200 000 x 2000 sparse (CSR, ~8 % dense), K=20: densify-on-device + size-independent
+    properties (checksum of the densified matrix, determinism, non-negativity, monotone
+    objective) -- the CPU oracle cannot finish this size in seconds.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from cnmf_amd import synth
+from oracle import nmf_cd, sklearn_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def test_C2_full_ledger_sampled_parity(engine):
+    X = synth.make_config("C2", dtype=np.float64)
+    assert X.shape[0] == 2700 and X.shape[1] <= 2000
+    engine.set_matrix(X)
+    led = sklearn_ref.ledger([10], 100, 14)
+    ks = [k for k, _, _ in led]
+    seeds = [s for _, _, s in led]
+    H, _, n_iter, viol = engine.nmf_batch(ks, seeds=seeds, warn=False)
+    assert len(H) == 100 and all(h.shape == (10, X.shape[1]) for h in H)
+    assert (n_iter >= 1).all() and (n_iter <= 1000).all()
+    conv = n_iter < 1000
+    assert (viol[conv] <= 1e-4).all()                       # sklearn's stopping rule held on the device
+    assert all(np.isfinite(h).all() and (h >= 0).all() for h in H)
+    st = engine.last_stats
+    assert st["restart_iterations"] == int(n_iter.sum())
+    # sample: the five fastest-converging restarts against the float64 oracle
+    for r in np.argsort(n_iter)[:5]:
+        _, H_ref, n_ref = nmf_cd.nmf(X, 10, seed=seeds[r])
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, H[r])
+        assert abs(int(n_iter[r]) - n_ref) <= max(3, n_ref // 100), (r, n_iter[r], n_ref)
+        assert maxabs <= (1e-4 if n_ref <= 500 else 5e-4) and relfro <= 1e-3, (r, maxabs, relfro)
+
+
+def test_C4_sparse_densify_on_device_properties(engine):
+    rs = np.random.RandomState(3)
+    N, G, k = 200_000, 2000, 20
+    X = sp.random(N, G, density=0.08, format="csr", dtype=np.float32, random_state=rs,
+                  data_rvs=lambda n: rs.gamma(1.0, 1.0, size=n).astype(np.float32))
+    X = X[np.asarray(X.sum(axis=1)).ravel() > 0]
+    engine.set_matrix(X)
+    N = X.shape[0]
+    # (1) checksum of the densified matrix: ||X - 0||^2 on the device == sum of squares of the CSR data
+    zW = np.zeros((N, 1)); zH = np.zeros((1, G))
+    ss = engine.prediction_error(zW, zH)
+    ref = float((X.data.astype(np.float64) ** 2).sum())
+    assert abs(ss - ref) <= 1e-6 * ref
+    # (2) two K=20 restarts, 25 outer iterations: deterministic, non-negative, finite
+    H1, W1, n1, _ = engine.nmf_batch([k, k], seeds=[11, 12], max_iter=25, return_W=True, warn=False)
+    H2, W2, n2, _ = engine.nmf_batch([k, k], seeds=[11, 12], max_iter=25, return_W=True, warn=False)
+    assert list(n1) == [25, 25] and list(n2) == [25, 25]
+    for a, b in zip(H1 + W1, H2 + W2):
+        assert np.array_equal(a, b)                          # no atomics / fixed reduction orders
+        assert np.isfinite(a).all() and (a >= 0).all()
+    # (3) the objective after 25 iterations is far below the objective after 2
+    H3, W3, _, _ = engine.nmf_batch([k], seeds=[11], max_iter=2, return_W=True, warn=False)
+    e25 = engine.prediction_error(W1[0], H1[0])
+    e2 = engine.prediction_error(W3[0], H3[0])
+    assert e25 < e2 < ss
+    # (4) NNLS refit at full size reproduces the usages of a converged W half-step:
+    #     refitting with H fixed can only lower the objective
+    Wr, _ = engine.nnls(H1[0], max_iter=200)
+    assert engine.prediction_error(Wr, H1[0]) <= e25 * (1 + 1e-6)
