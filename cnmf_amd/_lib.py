@@ -19,7 +19,7 @@ SYMBOLS = [
     "cnmf_device_count", "cnmf_create", "cnmf_destroy", "cnmf_last_error", "cnmf_version",
     "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_get_shape",
     "cnmf_nmf_cd_batch", "cnmf_nmf_cd_batch_resident", "cnmf_nnls",
-    "cnmf_consensus", "cnmf_prediction_error",
+    "cnmf_consensus", "cnmf_prediction_error", "cnmf_nmf_mu_batch",
     "cnmf_debug_gemm", "cnmf_debug_standard_normal",
 ]
 
@@ -115,6 +115,9 @@ def load():
     lib.cnmf_nmf_cd_batch_resident.argtypes = [vp, i32, i32p, i32, u32p, dblp, f32p, f32p,
                                                C.POINTER(CdParams), i32p, dblp,
                                                C.POINTER(BatchStats)]
+    lib.cnmf_nmf_mu_batch.restype = i32
+    lib.cnmf_nmf_mu_batch.argtypes = [vp, i32, i32p, i32, u32p, dblp, f32p, f32p, i32, i32,
+                                      C.POINTER(CdParams), f32p, f32p, i32p, dblp]
     lib.cnmf_nnls.restype = i32
     lib.cnmf_nnls.argtypes = [vp, i32, f32p, C.POINTER(CdParams), f32p, i32p, dblp]
     lib.cnmf_consensus.restype = i32

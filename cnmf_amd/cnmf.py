@@ -202,9 +202,15 @@ class cNMF:
 
     # ------------------------------------------------------------------ the NMF call-site
     def _check_kwargs(self, kw):
-        if kw.get("beta_loss", "frobenius") != "frobenius" or kw.get("solver", "cd") != "cd":
-            raise NotImplementedError("the device engine implements solver='cd' (beta_loss='frobenius'); "
-                                      "got solver=%r beta_loss=%r" % (kw.get("solver"), kw.get("beta_loss")))
+        """The two solver configurations the reference can produce (cnmf.py:618-631):
+        ('cd','frobenius') and ('mu', 'kullback-leibler' | 'itakura-saito')."""
+        solver, beta = kw.get("solver", "cd"), kw.get("beta_loss", "frobenius")
+        ok = (solver == "cd" and beta in ("frobenius", 2)) or \
+             (solver == "mu" and beta in ("kullback-leibler", "itakura-saito", 1, 0))
+        if not ok:
+            raise NotImplementedError("the device engine implements solver='cd'/beta_loss='frobenius' and "
+                                      "solver='mu'/beta_loss in ('kullback-leibler','itakura-saito'); "
+                                      "got solver=%r beta_loss=%r" % (solver, beta))
         if kw.get("init", "random") not in ("random", "custom", None) and "H" not in kw:
             raise NotImplementedError("init=%r is not implemented on the device (random / custom only)" % kw.get("init"))
 
@@ -215,15 +221,31 @@ class cNMF:
         self._check_kwargs(kw)
         Xv = X.values if isinstance(X, pd.DataFrame) else X
         eng = self._get_engine(Xv, ("obj", id(X), getattr(Xv, "shape", None)))
+        mu = kw.get("solver", "cd") == "mu"
         if kw.get("update_H", True) is False:
             H = np.asarray(kw["H"])
             xdt = Xv.dtype if Xv.dtype in (np.float32, np.float64) else np.dtype(np.float64)
             if H.dtype != xdt:
                 raise TypeError("H should have the same dtype as X. Got H.dtype = {}.".format(H.dtype))
-            W, _ = eng.nnls(H, tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 200),
-                            alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
+            if mu:
+                W, _ = eng.nnls_mu(H, beta_loss=kw["beta_loss"], tol=kw.get("tol", 1e-4),
+                                   max_iter=kw.get("max_iter", 200), alpha_W=kw.get("alpha_W", 0.0),
+                                   l1_ratio=kw.get("l1_ratio", 0.0))
+            else:
+                W, _ = eng.nnls(H, tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 200),
+                                alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
             return H, W.astype(xdt, copy=False)
         k = int(kw["n_components"])
+        if mu:
+            common = dict(beta_loss=kw["beta_loss"], tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 200),
+                          alpha_W=kw.get("alpha_W", 0.0), alpha_H=kw.get("alpha_H", 0.0),
+                          l1_ratio=kw.get("l1_ratio", 0.0), return_W=True)
+            if kw.get("init") == "custom":
+                Hl, Wl, _, _ = eng.nmf_mu_batch([k], W0=[kw["W"]], H0=[kw["H"]], **common)
+            else:
+                Hl, Wl, _, _ = eng.nmf_mu_batch([k], seeds=[int(kw["random_state"])], **common)
+            xdt = Xv.dtype if Xv.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+            return Hl[0].astype(xdt), Wl[0].astype(xdt)
         if kw.get("init") == "custom":
             Hl, Wl, _, _ = eng.nmf_batch([k], W0=[kw["W"]], H0=[kw["H"]], tol=kw.get("tol", 1e-4),
                                          max_iter=kw.get("max_iter", 200), alpha_W=kw.get("alpha_W", 0.0),
@@ -257,11 +279,15 @@ class cNMF:
         seeds = [int(run_params.iloc[idx]["nmf_seed"]) for idx in jobs]
         for idx in jobs:
             print("[Worker %d]. Starting task %d." % (worker_i, idx))
-        H_list, _, n_iter, _ = eng.nmf_batch(
-            ks, seeds=seeds, tol=_nmf_kwargs.get("tol", 1e-4), max_iter=_nmf_kwargs.get("max_iter", 1000),
-            alpha_W=_nmf_kwargs.get("alpha_W", 0.0), alpha_H=_nmf_kwargs.get("alpha_H", 0.0),
-            l1_ratio=_nmf_kwargs.get("l1_ratio", 0.0), kc_max=kc_max)
-        self.last_factorize_stats = dict(eng.last_stats, n_iter=n_iter)
+        common = dict(tol=_nmf_kwargs.get("tol", 1e-4), max_iter=_nmf_kwargs.get("max_iter", 1000),
+                      alpha_W=_nmf_kwargs.get("alpha_W", 0.0), alpha_H=_nmf_kwargs.get("alpha_H", 0.0),
+                      l1_ratio=_nmf_kwargs.get("l1_ratio", 0.0))
+        if _nmf_kwargs.get("solver", "cd") == "mu":
+            H_list, _, n_iter, _ = eng.nmf_mu_batch(ks, seeds=seeds, beta_loss=_nmf_kwargs["beta_loss"], **common)
+            self.last_factorize_stats = dict(n_iter=n_iter)
+        else:
+            H_list, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, kc_max=kc_max, **common)
+            self.last_factorize_stats = dict(eng.last_stats, n_iter=n_iter)
         xdt = norm_counts.values.dtype if norm_counts.values.dtype in (np.float32, np.float64) else np.float64
         for idx, H in zip(jobs, H_list):
             p = run_params.iloc[idx, :]

@@ -871,6 +871,9 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
 // ------------------------------------------------------------------ consensus step
 #include "consensus_host.hip.h"
 
+// ------------------------------------------------------------------ multiplicative-update solver
+#include "mu_host.hip.h"
+
 // ------------------------------------------------------------------ diagnostics
 extern "C" int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float* A, const float* B,
                                float* C, int KC, int K, int J, int nsplit, double* ms_out, int reps)

@@ -188,6 +188,80 @@ class Engine:
                           % max_iter, ConvergenceWarning)
         return H_list, W_list, n_iter, viol
 
+    # ------------------------------------------------------------------ multiplicative update
+    _BETA = {"kullback-leibler": 1, "itakura-saito": 0, 1: 1, 0: 0, 1.0: 1, 0.0: 0}
+
+    def nmf_mu_batch(self, ks, seeds=None, W0=None, H0=None, beta_loss="kullback-leibler", tol=1e-4,
+                     max_iter=1000, alpha_W=0.0, alpha_H=0.0, l1_ratio=0.0, return_W=False, warn=True):
+        """``solver='mu'`` restarts (the reference's path for beta_loss != 'frobenius',
+        cnmf.py:618-631).  Same arguments / returns as :meth:`nmf_batch`; the last element of the
+        returned tuple is sqrt(2*beta-divergence) at the final evaluation."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        if beta_loss not in self._BETA:
+            raise NotImplementedError("beta_loss=%r is not implemented on the device" % (beta_loss,))
+        N, G = self.shape
+        ks = np.ascontiguousarray(ks, dtype=np.int32).ravel()
+        n = int(ks.size)
+        prm = self._params(tol, max_iter, alpha_W, alpha_H, l1_ratio)
+        i32p, u32p, dblp = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+        avg = np.ascontiguousarray([self.init_scale(int(k)) for k in ks], dtype=np.float64)
+        if seeds is not None:
+            seeds_a = np.ascontiguousarray(np.asarray(seeds, dtype=np.int64).astype(np.uint32)).ravel()
+            mode, w0p, h0p, seedp = 1, None, None, seeds_a.ctypes.data_as(u32p)
+        else:
+            w0 = np.concatenate([np.ascontiguousarray(w, dtype=np.float32).ravel() for w in W0])
+            h0 = np.concatenate([np.ascontiguousarray(h, dtype=np.float32).ravel() for h in H0])
+            mode, w0p, h0p, seedp = 0, _fp(w0), _fp(h0), None
+        tot_k = int(ks.sum()) if n else 0
+        H_out = np.empty((max(tot_k, 1), G), dtype=np.float32)
+        W_out = np.empty(max(tot_k, 1) * N, dtype=np.float32) if return_W else None
+        n_iter = np.zeros(max(n, 1), dtype=np.int32)
+        err = np.zeros(max(n, 1), dtype=np.float64)
+        self._check(self._lib.cnmf_nmf_mu_batch(self._ctx, n, ks.ctypes.data_as(i32p), mode, seedp,
+                                                avg.ctypes.data_as(dblp), w0p, h0p, self._BETA[beta_loss], 1,
+                                                C.byref(prm), _fp(H_out), _fp(W_out) if return_W else None,
+                                                n_iter.ctypes.data_as(i32p), err.ctypes.data_as(dblp)))
+        offs = np.concatenate([[0], np.cumsum(ks)]).astype(np.int64)
+        H_list = [H_out[offs[r]:offs[r + 1]] for r in range(n)]
+        W_list = [W_out[offs[r] * N:offs[r + 1] * N].reshape(N, ks[r]) for r in range(n)] if return_W else None
+        n_iter, err = n_iter[:n], err[:n]
+        if warn and n and tol > 0 and (n_iter == max_iter).any():
+            warnings.warn("Maximum number of iterations %d reached. Increase it to improve convergence."
+                          % max_iter, ConvergenceWarning)
+        return H_list, W_list, n_iter, err
+
+    def nnls_mu(self, H, beta_loss="kullback-leibler", tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0,
+                warn=True):
+        """Refit with fixed H and ``solver='mu'``: W starts from avg everywhere (sklearn _nmf.py:1229-1231)."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        H = np.asarray(H)
+        if H.ndim != 2 or H.shape[1] != G:
+            raise ValueError("Array with wrong shape passed to NMF (input H).")
+        if H.min() < 0:
+            raise ValueError("Negative values in data passed to NMF (input H)")
+        if H.max() == 0:
+            raise ValueError("Array passed to NMF (input H) is full of zeros.")
+        k = int(H.shape[0])
+        ks = np.array([k], dtype=np.int32)
+        Hf = np.ascontiguousarray(H, dtype=np.float32)
+        avg = np.array([self.init_scale(k)], dtype=np.float64)
+        prm = self._params(tol, max_iter, alpha_W, 0.0, l1_ratio)
+        W = np.empty((N, k), dtype=np.float32)
+        n_iter = np.zeros(1, dtype=np.int32)
+        err = np.zeros(1, dtype=np.float64)
+        i32p, dblp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        self._check(self._lib.cnmf_nmf_mu_batch(self._ctx, 1, ks.ctypes.data_as(i32p), 0, None,
+                                                avg.ctypes.data_as(dblp), None, _fp(Hf), self._BETA[beta_loss], 0,
+                                                C.byref(prm), None, _fp(W), n_iter.ctypes.data_as(i32p),
+                                                err.ctypes.data_as(dblp)))
+        if warn and tol > 0 and n_iter[0] == max_iter:
+            warnings.warn("Maximum number of iterations %d reached. Increase it to improve convergence."
+                          % max_iter, ConvergenceWarning)
+        return W, int(n_iter[0])
+
     # ------------------------------------------------------------------ NNLS refit
     def nnls(self, H, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0, warn=True):
         """``non_negative_factorization(X, H=H, update_H=False, solver='cd')`` on the

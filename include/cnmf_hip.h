@@ -116,6 +116,20 @@ int cnmf_nmf_cd_batch_resident(cnmf_ctx* ctx, int n_restarts, const int32_t* k,
                                int32_t* n_iter_out, double* viol_out,
                                cnmf_batch_stats* stats);
 
+/* ---- multiplicative-update solver --------------------------------------------------------
+ * The reference keeps solver='mu' whenever beta_loss != 'frobenius' (cnmf.py:618-631):
+ *   non_negative_factorization(X, solver='mu', beta_loss='kullback-leibler'|'itakura-saito', ...)
+ *   = sklearn:decomposition/_nmf.py:731-893 (_fit_multiplicative_update), :526-728 (updates),
+ *     :84-194 (_beta_divergence, evaluated every 10 iterations for the stopping rule).
+ * beta: 1 = kullback-leibler, 0 = itakura-saito.  Same packing / init modes as cnmf_nmf_cd_batch.
+ * update_H = 0 is the refit (cnmf.py:776-802 with solver 'mu'): H0 holds the fixed spectra and W
+ * starts from avg[r] everywhere (sklearn:_nmf.py:1229-1231); H_out is then ignored.
+ * err_out[r] = sqrt(2 * beta-divergence) at the last evaluation.                               */
+int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n_restarts, const int32_t* k, int init_mode,
+                      const uint32_t* seeds, const double* avg, const float* W0, const float* H0,
+                      int beta, int update_H, const cnmf_cd_params* params,
+                      float* H_out, float* W_out, int32_t* n_iter_out, double* err_out);
+
 /* ---- NNLS refit ---------------------------------------------------------------------
  * Replaces cNMF.refit_usage (cnmf.py:776-802): non_negative_factorization(X, H=spectra,
  * update_H=False, n_components=k, solver='cd', ...) with W0 = 0 (sklearn:_nmf.py:1232-1233).

@@ -1,0 +1,76 @@
+"""GPU parity of the multiplicative-update solver (beta_loss = kullback-leibler / itakura-saito),
+the reference's path for beta_loss != 'frobenius' (cnmf.py:618-631), against the numpy
+restatement of sklearn's _fit_multiplicative_update (oracle/nmf_mu.py, pinned to sklearn).
+
+Tolerance: multiplicative updates are smooth, so the fp32 device trajectory tracks the float64
+oracle closely: normalised spectra max-abs <= 1e-4, rel-Frobenius <= 1e-3; n_iter (a multiple of
+10, the divergence is evaluated every 10 iterations) within one evaluation period."""
+import numpy as np
+import pytest
+
+from cnmf_amd import synth
+from oracle import nmf_cd, nmf_mu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def X():
+    return synth.make_config("C1", dtype=np.float64, n_cells=700)
+
+
+@pytest.mark.parametrize("beta_loss,k,seed", [("kullback-leibler", 7, 59886188), ("kullback-leibler", 12, 5),
+                                              ("itakura-saito", 5, 3), ("kullback-leibler", 20, 9)])
+def test_mu_restart_vs_oracle(engine, X, beta_loss, k, seed):
+    Xp = X + (1e-3 if beta_loss == "itakura-saito" else 0.0)
+    engine.set_matrix(Xp)
+    W_ref, H_ref, n_ref = nmf_mu.nmf_mu(Xp, k, seed=seed, beta_loss=beta_loss, max_iter=400)
+    H, W, n_iter, err = engine.nmf_mu_batch([k], seeds=[seed], beta_loss=beta_loss, max_iter=400,
+                                            return_W=True, warn=False)
+    assert abs(int(n_iter[0]) - n_ref) <= 10, (n_iter, n_ref)
+    if int(n_iter[0]) == n_ref:
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, H[0])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (maxabs, relfro)
+        assert np.abs(W[0] - W_ref).max() <= 2e-3 * np.abs(W_ref).max()
+    ref_err = nmf_mu.beta_divergence(Xp, W_ref, H_ref, nmf_mu.BETA[beta_loss], square_root=True)
+    assert abs(err[0] - ref_err) <= 2e-3 * ref_err
+
+
+def test_mu_custom_init_and_regularisation(engine, X):
+    engine.set_matrix(X)
+    W0, H0 = nmf_cd.random_init(X, 6, 11)
+    W_ref, H_ref, n_ref = nmf_mu.nmf_mu(X, 6, W0=W0, H0=H0, max_iter=200, alpha_W=0.001, alpha_H=0.002, l1_ratio=0.5)
+    H, _, n_iter, _ = engine.nmf_mu_batch([6], W0=[W0], H0=[H0], max_iter=200, alpha_W=0.001, alpha_H=0.002,
+                                          l1_ratio=0.5, warn=False)
+    assert abs(int(n_iter[0]) - n_ref) <= 10
+    if int(n_iter[0]) == n_ref:
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, H[0])
+        assert maxabs <= 1e-4 and relfro <= 1e-3
+
+
+def test_mu_refit(engine, X):
+    engine.set_matrix(X)
+    _, H, _ = nmf_mu.nmf_mu(X, 5, seed=1, max_iter=60)
+    Hn = H / H.sum(axis=1, keepdims=True)
+    W_ref, n_ref = nmf_mu.nnls_mu(X, Hn, max_iter=300)
+    W, n = engine.nnls_mu(Hn, max_iter=300, warn=False)
+    assert abs(n - n_ref) <= 10
+    if n == n_ref:
+        assert np.abs(W - W_ref).max() <= 2e-3 * np.abs(W_ref).max()
+
+
+def test_mu_through_cnmf_callsite(engine, X, tmp_path):
+    from cnmf_amd.cnmf import cNMF
+    obj = cNMF(output_dir=str(tmp_path), name="mu", engine=engine)
+    obj.prepare_from_matrix(X, components=[4], n_iter=3, seed=14, beta_loss="kullback-leibler", max_NMF_iter=120)
+    obj.factorize()
+    merged = obj.combine_nmf(4)
+    assert merged.shape == (12, X.shape[1]) and np.isfinite(merged.values).all() and (merged.values >= 0).all()
+    import yaml
+    kw = yaml.load(open(obj.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
+    assert kw["solver"] == "mu" and kw["beta_loss"] == "kullback-leibler"       # as the reference writes it
+    from oracle import sklearn_ref
+    led = sklearn_ref.ledger([4], 3, 14)
+    _, H_ref, _ = nmf_mu.nmf_mu(X, 4, seed=led[0][2], max_iter=120)
+    maxabs, relfro = nmf_cd.spectra_error(H_ref, merged.values[:4])
+    assert maxabs <= 1e-4 and relfro <= 1e-3
