@@ -19,7 +19,7 @@ SYMBOLS = [
     "cnmf_device_count", "cnmf_create", "cnmf_destroy", "cnmf_last_error", "cnmf_version",
     "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_get_shape",
     "cnmf_nmf_cd_batch", "cnmf_nmf_cd_batch_resident", "cnmf_nnls",
-    "cnmf_consensus", "cnmf_prediction_error", "cnmf_nmf_mu_batch",
+    "cnmf_consensus", "cnmf_prediction_error", "cnmf_nmf_mu_batch", "cnmf_x_matmul",
     "cnmf_debug_gemm", "cnmf_debug_standard_normal",
 ]
 
@@ -125,6 +125,8 @@ def load():
                                    dblp, i32p, i32p, dblp, dblp, dblp]
     lib.cnmf_prediction_error.restype = i32
     lib.cnmf_prediction_error.argtypes = [vp, i32, dblp, dblp, dblp]
+    lib.cnmf_x_matmul.restype = i32
+    lib.cnmf_x_matmul.argtypes = [vp, i32, f32p, i32, f32p]
     lib.cnmf_debug_gemm.restype = i32
     lib.cnmf_debug_gemm.argtypes = [vp, i32, i32, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
     lib.cnmf_debug_standard_normal.restype = i32

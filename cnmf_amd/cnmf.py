@@ -211,8 +211,8 @@ class cNMF:
             raise NotImplementedError("the device engine implements solver='cd'/beta_loss='frobenius' and "
                                       "solver='mu'/beta_loss in ('kullback-leibler','itakura-saito'); "
                                       "got solver=%r beta_loss=%r" % (solver, beta))
-        if kw.get("init", "random") not in ("random", "custom", None) and "H" not in kw:
-            raise NotImplementedError("init=%r is not implemented on the device (random / custom only)" % kw.get("init"))
+        if kw.get("init", "random") not in ("random", "custom", "nndsvd", None) and "H" not in kw:
+            raise NotImplementedError("init=%r is not implemented on the device (random / nndsvd / custom)" % kw.get("init"))
 
     def _nmf(self, X, nmf_kwargs):
         """Mirror of cNMF._nmf (cnmf.py:661-674): ``(spectra, usages)`` for one restart, or the
@@ -236,6 +236,9 @@ class cNMF:
                                 alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
             return H, W.astype(xdt, copy=False)
         k = int(kw["n_components"])
+        if kw.get("init") == "nndsvd":                       # `--init nndsvd` (cnmf.py:1252)
+            W0, H0 = eng.nndsvd_init(k, random_state=int(kw["random_state"]))
+            kw = dict(kw, init="custom", W=W0, H=H0)
         if mu:
             common = dict(beta_loss=kw["beta_loss"], tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 200),
                           alpha_W=kw.get("alpha_W", 0.0), alpha_H=kw.get("alpha_H", 0.0),
@@ -282,11 +285,15 @@ class cNMF:
         common = dict(tol=_nmf_kwargs.get("tol", 1e-4), max_iter=_nmf_kwargs.get("max_iter", 1000),
                       alpha_W=_nmf_kwargs.get("alpha_W", 0.0), alpha_H=_nmf_kwargs.get("alpha_H", 0.0),
                       l1_ratio=_nmf_kwargs.get("l1_ratio", 0.0))
+        init_kw = dict(seeds=seeds)
+        if _nmf_kwargs.get("init") == "nndsvd":
+            inits = [eng.nndsvd_init(k, random_state=s) for k, s in zip(ks, seeds)]
+            init_kw = dict(W0=[w for w, _ in inits], H0=[h for _, h in inits])
         if _nmf_kwargs.get("solver", "cd") == "mu":
-            H_list, _, n_iter, _ = eng.nmf_mu_batch(ks, seeds=seeds, beta_loss=_nmf_kwargs["beta_loss"], **common)
+            H_list, _, n_iter, _ = eng.nmf_mu_batch(ks, beta_loss=_nmf_kwargs["beta_loss"], **init_kw, **common)
             self.last_factorize_stats = dict(n_iter=n_iter)
         else:
-            H_list, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, kc_max=kc_max, **common)
+            H_list, _, n_iter, _ = eng.nmf_batch(ks, kc_max=kc_max, **init_kw, **common)
             self.last_factorize_stats = dict(eng.last_stats, n_iter=n_iter)
         xdt = norm_counts.values.dtype if norm_counts.values.dtype in (np.float32, np.float64) else np.float64
         for idx, H in zip(jobs, H_list):

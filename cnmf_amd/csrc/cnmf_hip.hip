@@ -874,6 +874,43 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
 // ------------------------------------------------------------------ multiplicative-update solver
 #include "mu_host.hip.h"
 
+// ------------------------------------------------------------------ X . Q / X^T . Q
+extern "C" int cnmf_x_matmul(cnmf_ctx* ctx, int trans, const float* Q, int ncols, float* out)
+{
+    if (!ctx || !Q || !out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (ncols < 1 || ncols > 256 || (trans != 0 && trans != 1)) { SET_ERR(ctx, "bad ncols/trans"); return CNMF_EINVAL; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    const int KC = ncols <= 32 ? 32 : (ncols <= 64 ? 64 : (ncols <= 128 ? 128 : 256));
+    const int Kin = trans ? N : G, Kp = trans ? ctx->N_pad : ctx->G_pad;     // contraction length
+    const int Jout = trans ? G : N, Jp = trans ? ctx->G_pad : ctx->N_pad;
+    DevPool pool;
+    float* dQ = pool.get<float>((size_t)Kin * ncols);
+    float* dA = pool.get<float>((size_t)KC * Kp, true, st);                   // Q^T, component-major, zero padded
+    const int nsplit = trans ? std::max(1, std::min(16, Kp / 2048)) : 1;
+    float* dC = pool.get<float>((size_t)nsplit * KC * Jp);
+    float* dO = pool.get<float>((size_t)Jout * ncols);
+    if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+    HIP_TRY(ctx, hipMemcpyAsync(dQ, Q, (size_t)Kin * ncols * sizeof(float), hipMemcpyHostToDevice, st));
+    dim3 gI((Kin + 255) / 256, ncols);
+    // install_kernel's W path transposes a row-major [L][k] block into component-major rows
+    install_kernel<<<gI, 256, 0, st>>>(nullptr, dQ, dA, Kp, 0, dA, Kp, Kin, 0, ncols);
+    if (!trans)
+        HIP_TRY(ctx, launch_gemm<false>(st, 0, dA, Kp, ctx->X, ctx->G_pad, dC, Jp, 0, KC, Kp, Jp, 1));
+    else {
+        HIP_TRY(ctx, launch_gemm<true>(st, 0, dA, Kp, ctx->X, ctx->G_pad, dC, Jp, (long long)KC * Jp, KC, Kp, Jp, nsplit));
+        HIP_TRY(ctx, launch_reduce_splits(st, dC, nsplit, (long long)KC * Jp, (long long)KC * Jp));
+    }
+    dim3 gO((Jout + 255) / 256, ncols);
+    extract_kernel<<<gO, 256, 0, st>>>(dC, Jp, Jout, 0, ncols, dO, 1);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, dO, (size_t)Jout * ncols * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return CNMF_OK;
+}
+
 // ------------------------------------------------------------------ diagnostics
 extern "C" int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float* A, const float* B,
                                float* C, int KC, int K, int J, int nsplit, double* ms_out, int reps)

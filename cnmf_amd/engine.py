@@ -292,6 +292,74 @@ class Engine:
                           % max_iter, ConvergenceWarning)
         return W, int(n_iter.value)
 
+    # ------------------------------------------------------------------ NNDSVD init
+    def x_matmul(self, Q, trans=False):
+        """``X @ Q`` (trans=False, Q is G x c) or ``X.T @ Q`` (trans=True, Q is N x c) on the device."""
+        N, G = self.shape
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        if Q.ndim != 2 or Q.shape[0] != (N if trans else G):
+            raise ValueError("shape mismatch in x_matmul")
+        out = np.empty(((G if trans else N), Q.shape[1]), dtype=np.float32)
+        self._check(self._lib.cnmf_x_matmul(self._ctx, int(bool(trans)), _fp(Q), Q.shape[1], _fp(out)))
+        return out
+
+    def nndsvd_init(self, n_components, random_state=None, eps=1e-6):
+        """sklearn's ``init='nndsvd'`` (decomposition/_nmf.py:316-354) with every product against X
+        on the device: ``_randomized_svd`` (utils/extmath.py:531-602: n_oversamples=10, n_iter 7|4,
+        LU-normalised power iterations, final QR, small SVD, svd_flip), then the positive/negative
+        split.  Returns (W0, H0) in float64 (cast to X's dtype by the caller, like sklearn)."""
+        from scipy import linalg
+        N, G = self.shape
+        k = int(n_components)
+        if k > min(N, G):
+            raise ValueError("init = 'nndsvd' can only be used when n_components <= min(n_samples, n_features)")
+        n_random = k + 10
+        n_iter = 7 if k < 0.1 * min(N, G) else 4
+        transpose = N < G                                     # M = X.T when n_samples < n_features
+        M_rows, M_cols = (G, N) if transpose else (N, G)
+        mm = lambda Q: self.x_matmul(Q, trans=transpose).astype(np.float64)        # M @ Q      # noqa: E731
+        mtm = lambda Q: self.x_matmul(Q, trans=not transpose).astype(np.float64)   # M.T @ Q    # noqa: E731
+        rng = np.random.RandomState(random_state) if not isinstance(random_state, np.random.RandomState) else random_state
+        Q = rng.normal(size=(M_cols, n_random))
+        for _ in range(n_iter):
+            Q, _ = linalg.lu(mm(Q), permute_l=True, check_finite=False)
+            Q, _ = linalg.lu(mtm(Q), permute_l=True, check_finite=False)
+        Q, _ = linalg.qr(mm(Q), mode="economic", check_finite=False)
+        B = mtm(Q).T                                          # Q.T @ M
+        Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver="gesdd")
+        U = Q @ Uhat
+        if not transpose:                                     # svd_flip(u_based_decision=True)
+            signs = np.sign(U[np.argmax(np.abs(U), axis=0), np.arange(U.shape[1])])
+        else:
+            signs = np.sign(Vt[np.arange(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])
+        U = U * signs[np.newaxis, :]
+        Vt = Vt * signs[:, np.newaxis]
+        if transpose:
+            U, S, V = Vt[:k, :].T, s[:k], U[:, :k].T
+        else:
+            U, S, V = U[:, :k], s[:k], Vt[:k, :]
+        W = np.zeros_like(U)
+        H = np.zeros_like(V)
+        W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0])
+        H[0, :] = np.sqrt(S[0]) * np.abs(V[0, :])
+        for j in range(1, k):
+            x, y = U[:, j], V[j, :]
+            x_p, y_p = np.maximum(x, 0), np.maximum(y, 0)
+            x_n, y_n = np.abs(np.minimum(x, 0)), np.abs(np.minimum(y, 0))
+            x_p_nrm, y_p_nrm = np.sqrt(x_p @ x_p), np.sqrt(y_p @ y_p)
+            x_n_nrm, y_n_nrm = np.sqrt(x_n @ x_n), np.sqrt(y_n @ y_n)
+            m_p, m_n = x_p_nrm * y_p_nrm, x_n_nrm * y_n_nrm
+            if m_p > m_n:
+                u, v, sigma = x_p / x_p_nrm, y_p / y_p_nrm, m_p
+            else:
+                u, v, sigma = x_n / x_n_nrm, y_n / y_n_nrm, m_n
+            lbd = np.sqrt(S[j] * sigma)
+            W[:, j] = lbd * u
+            H[j, :] = lbd * v
+        W[W < eps] = 0
+        H[H < eps] = 0
+        return W, H
+
     # ------------------------------------------------------------------ consensus core
     def consensus(self, spectra, k, density_threshold=0.5, local_neighborhood_size=0.30,
                   skip_density=False, want_silhouette=False, random_state=1, n_init=10,

@@ -171,6 +171,14 @@ int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G,
  * (W [N][k], H [k][G], float64). */
 int cnmf_prediction_error(cnmf_ctx* ctx, int k, const double* W, const double* H, double* err_out);
 
+/* ---- products with the resident matrix ----------------------------------------------------
+ * out = X . Q (trans = 0: Q [G][ncols] -> out [N][ncols]) or X^T . Q (trans = 1: Q [N][ncols] ->
+ * out [G][ncols]), ncols <= 256, through the engine's MFMA GEMM.  This is the only O(N.G) work in
+ * sklearn's NNDSVD initialisation (`--init nndsvd`, cnmf.py:1252 -> sklearn:_nmf.py:317 ->
+ * sklearn:utils/extmath.py:287-357 `_randomized_range_finder`: 2*n_iter+2 such products); the small
+ * LU / QR / SVD factorizations stay on the host (cnmf_amd/engine.py::Engine.nndsvd_init).        */
+int cnmf_x_matmul(cnmf_ctx* ctx, int trans, const float* Q, int ncols, float* out);
+
 /* ---- diagnostics used by the tests ---------------------------------------------------- */
 /* C[KC][J] = A[KC][K] . B  through the engine's MFMA GEMM; mode 0: B is [J][K] (pass A),
  * mode 1: B is [K][J] (pass B, split-K partials summed in split order).                  */

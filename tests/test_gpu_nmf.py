@@ -157,3 +157,34 @@ def test_rank_above_kmax_is_rejected(engine):
 def test_negative_input_raises(engine):
     with pytest.raises(ValueError):
         engine.set_matrix(np.array([[1.0, -1.0], [0.5, 2.0]]))
+
+
+def test_x_matmul_vs_numpy(engine):
+    X = synth.make_config("C1", dtype=np.float64, n_cells=777)
+    engine.set_matrix(X)
+    rs = np.random.RandomState(0)
+    for c in (1, 17, 33, 100):
+        Q = rs.standard_normal((X.shape[1], c))
+        ref = X @ Q
+        assert np.abs(engine.x_matmul(Q) - ref).max() <= 2e-6 * np.abs(ref).max() * np.sqrt(X.shape[1])
+        Q2 = rs.standard_normal((X.shape[0], c))
+        ref2 = X.T @ Q2
+        assert np.abs(engine.x_matmul(Q2, trans=True) - ref2).max() <= 2e-6 * np.abs(ref2).max() * np.sqrt(X.shape[0])
+
+
+@pytest.mark.parametrize("shape", ["tall", "wide"])
+def test_nndsvd_init_matches_sklearn(engine, shape):
+    """`--init nndsvd` (cnmf.py:1252): randomized-SVD products on the device, factorizations on the host."""
+    from sklearn.decomposition._nmf import _initialize_nmf
+    X = synth.make_config("C1", dtype=np.float64, n_cells=900 if shape == "tall" else 300)
+    engine.set_matrix(X)
+    W_ref, H_ref = _initialize_nmf(X, 6, init="nndsvd", random_state=42)
+    W0, H0 = engine.nndsvd_init(6, random_state=42)
+    assert np.abs(W0 - W_ref).max() <= 1e-3 * np.abs(W_ref).max()
+    assert np.abs(H0 - H_ref).max() <= 1e-3 * np.abs(H_ref).max()
+    # and a restart from it lands where sklearn's lands
+    from sklearn.decomposition import non_negative_factorization
+    Wr, Hr, nr = non_negative_factorization(X, n_components=6, init="nndsvd", solver="cd", tol=1e-4, max_iter=1000,
+                                            random_state=42)
+    H, _, n_iter, _ = engine.nmf_batch([6], W0=[W0], H0=[H0])
+    _check(Hr, nr, H[0], n_iter[0], slack=3)
