@@ -123,6 +123,10 @@ static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int l
         case 3:  // 2x2
             if (KC % 128 == 0) GO(2, 2, 2);
             GO(1, 2, 2);
+        case 5:   // T8: one workgroup owns all 256 components (X tile read once), 1 workgroup per CU
+            if (KC % 256 == 0)
+                return launch_gemm_t<8, 1, 4, NN>(st, A, lda, B, ldb, C, ldc, cstride, KC, Ktot, J, nsplit);
+            [[fallthrough]];
         case 4:   // T with 16-deep stages (half the LDS per workgroup -> 3-4 workgroups per CU)
             if (KC % 128 == 0)
                 return launch_gemm_t<4, 1, 4, NN, 16>(st, A, lda, B, ldb, C, ldc, cstride, KC, Ktot, J, nsplit);
@@ -150,7 +154,7 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
 // ---- stream-K pass A (T layout: 128 components x 128 cells per tile)
 struct StreamK {
     bool on = false;
-    int MG = 1, T = 0, nk = 0, P = 0;
+    int MG = 1, T = 0, nk = 0, P = 0, mw = 128;      // mw: component rows per workgroup tile
     std::vector<unsigned char> split;
 };
 
@@ -158,7 +162,8 @@ static StreamK plan_streamk(int KC, int N_pad, int G_pad, int n_wg_slots)
 {
     StreamK sk;
     if (KC % 128 != 0 || getenv("CNMF_NO_STREAMK")) return sk;
-    sk.MG = KC / 128;
+    if (KC % 256 == 0 && getenv("CNMF_T8")) { sk.mw = 256; n_wg_slots /= 2; }   // 110 KB LDS: 1 workgroup per CU
+    sk.MG = KC / sk.mw;
     sk.T = sk.MG * (N_pad / 128);
     sk.nk = G_pad / (getenv("CNMF_BK16") ? 16 : BK);       // stages per tile, as the kernel counts them
     sk.P = n_wg_slots;
@@ -174,19 +179,19 @@ static StreamK plan_streamk(int KC, int N_pad, int G_pad, int n_wg_slots)
     return sk;
 }
 
-template <int TBK>
+template <int TBK, int MTW = 4>
 static hipError_t launch_streamk_t(hipStream_t st, const StreamK& sk, const float* A, int lda,
                                    const float* B, int ldb, float* C0, float* C1, int ldc, int Jtot, int stagger)
 {
-    constexpr size_t lds = gemm_lds_bytes<4, 1, 4, false, TBK>();
+    constexpr size_t lds = gemm_lds_bytes<MTW, 1, 4, false, TBK>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_streamk_kernel<4, 1, 4, false, TBK>,
+        hipFuncSetAttribute((const void*)gemm_streamk_kernel<MTW, 1, 4, false, TBK>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    gemm_streamk_kernel<4, 1, 4, false, TBK><<<sk.P, 256, lds, st>>>(A, lda, B, ldb, C0, C1, ldc, sk.MG,
-                                                                    sk.T, sk.nk, Jtot, stagger);
+    gemm_streamk_kernel<MTW, 1, 4, false, TBK><<<sk.P, 256, lds, st>>>(A, lda, B, ldb, C0, C1, ldc, sk.MG,
+                                                                      sk.T, sk.nk, Jtot, stagger);
     return hipGetLastError();
 }
 
@@ -195,6 +200,7 @@ static hipError_t launch_streamk_passA(hipStream_t st, const StreamK& sk, const 
 {
     static const int bk16 = getenv("CNMF_BK16") ? 1 : 0;
     static const int stagger = getenv("CNMF_STAGGER") ? 1 : 0;
+    if (sk.mw == 256) return launch_streamk_t<32, 8>(st, sk, A, lda, B, ldb, C0, C1, ldc, Jtot, stagger);
     if (bk16) return launch_streamk_t<16>(st, sk, A, lda, B, ldb, C0, C1, ldc, Jtot, stagger);
     return launch_streamk_t<32>(st, sk, A, lda, B, ldb, C0, C1, ldc, Jtot, stagger);
 }
@@ -656,7 +662,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         // W half-step                                             (sklearn _nmf.py:500)
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
                                   ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k,
-                                  (sk.on && gvarA == 0) ? SplitInfo{ctx->XHt1, ctx->d_split, 128, 128, sk.MG}
+                                  (sk.on && gvarA == 0) ? SplitInfo{ctx->XHt1, ctx->d_split, 128, sk.mw, sk.MG}
                                                         : SplitInfo{nullptr, nullptr, 1, 1, 1}));
         finalize_kernel<<<dim3(nslots, 4), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
                                                 ctx->d_slots, 0, prm->tol, prm->max_iter, 1);

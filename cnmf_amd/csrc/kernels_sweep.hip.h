@@ -98,15 +98,34 @@ __device__ __forceinline__ void sweep_body(
             cut1 = sp.split[rt * sp.mgroups + g1] != 0;
         }
         float w[KP], p[KP];
+        {
+            // branch-free load phase: every lane issues all 2*KP (3*KP) loads back to back with
+            // clamped (always valid) addresses; the values of dead lanes / columns >= k are
+            // discarded by selects.  (Per-column branches serialise the memory latency.)
+            const int rowc = min(row, L - 1);
+            float vv[KP], pp[KP], qq[KP];
 #pragma unroll
-        for (int c = 0; c < KP; ++c) {
-            w[c] = 0.f; p[c] = 0.f;
-            if (live && c < k) {
-                const size_t idx = (size_t)(off + c) * ldv + row;
-                w[c] = V[idx];
-                float pv = P[idx];
-                if (((off + c) < mg_edge) ? cut0 : cut1) pv += sp.plane1[idx];   // wave-uniform
-                p[c] = pv - l1_reg;
+            for (int c = 0; c < KP; ++c) {
+                const size_t idx = (size_t)(off + min(c, k - 1)) * ldv + rowc;
+                vv[c] = V[idx];
+                pp[c] = P[idx];
+            }
+            if (cut0 | cut1) {                    // wave-uniform: one branch per chunk
+#pragma unroll
+                for (int c = 0; c < KP; ++c) {
+                    const size_t idx = (size_t)(off + min(c, k - 1)) * ldv + rowc;
+                    qq[c] = sp.plane1[idx];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < KP; ++c) qq[c] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < KP; ++c) {
+                const bool on = live && (c < k);
+                const bool cut = ((off + c) < mg_edge) ? cut0 : cut1;
+                w[c] = on ? vv[c] : 0.f;
+                p[c] = on ? (pp[c] + (cut ? qq[c] : 0.f) - l1_reg) : 0.f;
             }
         }
         if (live) {

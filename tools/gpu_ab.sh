@@ -1,8 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_nmf.py -m gpu -x -q 2>&1 | tail -2
-CNMF_BK16=1 python -m pytest tests/test_gpu_nmf.py -m gpu -x -q 2>&1 | tail -2
-for cfg in "base:" "bk16:CNMF_BK16=1" "stagger:CNMF_STAGGER=1" "bk16B:CNMF_GEMM_B=4" "bk16+stag:CNMF_BK16=1,CNMF_STAGGER=1,CNMF_GEMM_B=4"; do
+python -m pytest tests/test_gpu_nmf.py tests/test_gpu_pipeline.py -m gpu -x -q 2>&1 | tail -2
+for cfg in "base:" ; do
   tag=${cfg%%:*}; envs=$(echo ${cfg#*:} | tr ',' ' ')
   env $envs python bench.py --steps 1 --warmup 0 --restarts-per-k 10 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
