@@ -80,6 +80,19 @@ def cpu_baseline(X32, mean_iters_per_restart, max_iter):
     }
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE),
+    collected in separate rocprofv3 --pmc passes (tools/gpu_pmc_bench.sh) and committed under
+    profiles/ -- counters cannot be read from inside an un-profiled run.  None if absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        return {"hbm_bytes_per_launch": d[key]["hbm_bytes_per_launch"],
+                "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"][key],
+                "source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)"}
+    except Exception:
+        return None
+
+
 def consensus_wallclock(eng, with_cpu=True):
     """BASELINE config 5 (consensus-only stress: 5000 stacked spectra x 2000 genes, k=20):
     wall-clock of the consensus core on the GPU (host call incl. transfers) next to the
@@ -211,7 +224,7 @@ def main():
             "kernel": "gemm_kernel<NT> (pass A: X.Ht)" if dom == "A" else "gemm_kernel<NN> (pass B: Xt.W)",
             "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": pmc_traffic("passA" if dom == "A" else "passB"),
             "avg_launch_ms": {"passA": agg["passA_ms"] / max(agg["nA"], 1), "passB": agg["passB_ms"] / max(agg["nB"], 1)},
             "achieved_passA": tfA, "achieved_passB": tfB,
             "alg_flops_per_launch": alg_flops_A / max(agg["nA"], 1),

@@ -580,7 +580,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int64_t restart_iters = 0, column_iters = 0, restart_col_iters = 0;
     const bool dbg = getenv("CNMF_DEBUG") != nullptr;
     int64_t dbg_it[9] = {0}, dbg_live[9] = {0};
-    const int wg_slots = 2 * 256;                    // T-layout pass A: 2 workgroups per CU (73.7 KB LDS each)
+    const int wg_slots = getenv("CNMF_SK_WGS") ? atoi(getenv("CNMF_SK_WGS")) : 2 * 256;                    // T-layout pass A: 2 workgroups per CU (73.7 KB LDS each)
     StreamK sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
     if (sk.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
     int n_done = 0;

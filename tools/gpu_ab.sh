@@ -1,7 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_nmf.py tests/test_gpu_pipeline.py -m gpu -x -q 2>&1 | tail -2
-for cfg in "base:" ; do
+for cfg in "base:" "bk16x768:CNMF_BK16=1,CNMF_SK_WGS=768" "bk16x1024:CNMF_BK16=1,CNMF_SK_WGS=1024" "bk32x768:CNMF_SK_WGS=768"; do
   tag=${cfg%%:*}; envs=$(echo ${cfg#*:} | tr ',' ' ')
   env $envs python bench.py --steps 1 --warmup 0 --restarts-per-k 10 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
