@@ -1,0 +1,80 @@
+"""Edge cases of the restart engine through the C-ABI: tiny / ragged shapes (below every
+tile size), rank 1 and rank CNMF_KMAX, an empty restart list, all-zero rows, and
+regularisation strong enough to zero a factor (violation_init == 0 path)."""
+import numpy as np
+import pytest
+
+from oracle import nmf_cd
+
+pytestmark = pytest.mark.gpu
+
+
+def _x(n, g, seed=0):
+    rs = np.random.RandomState(seed)
+    return np.abs(rs.standard_normal((n, g))) * (rs.rand(n, g) < 0.6) + 0.01
+
+
+@pytest.mark.parametrize("n,g,k", [(7, 5, 2), (33, 31, 3), (129, 33, 5), (257, 65, 1), (200, 140, 32), (64, 128, 9)])
+def test_small_and_ragged_shapes(engine, n, g, k):
+    X = _x(n, g, seed=n + g)
+    engine.set_matrix(X)
+    W_ref, H_ref, n_ref = nmf_cd.nmf(X, k, seed=5, max_iter=300)
+    H, W, n_iter, _ = engine.nmf_batch([k], seeds=[5], max_iter=300, return_W=True, warn=False)
+    assert H[0].shape == (k, g) and W[0].shape == (n, k)
+    assert abs(int(n_iter[0]) - n_ref) <= max(3, n_ref // 50)
+    if int(n_iter[0]) == n_ref:
+        # same init, same component order: compare the reconstructions (robust to near-degenerate factors)
+        R, R_ref = W[0].astype(np.float64) @ H[0], W_ref @ H_ref
+        assert np.abs(R - R_ref).max() <= 2e-3 * max(1.0, np.abs(R_ref).max())
+
+
+def test_empty_restart_list(engine):
+    engine.set_matrix(_x(20, 10))
+    H, W, n_iter, viol = engine.nmf_batch([], seeds=[])
+    assert H == [] and len(n_iter) == 0 and len(viol) == 0
+
+
+def test_mixed_ranks_one_call(engine):
+    X = _x(150, 70, seed=3)
+    engine.set_matrix(X)
+    ks = [1, 32, 2, 17, 16, 5, 31, 8]
+    seeds = list(range(11, 11 + len(ks)))
+    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=60, warn=False)
+    for k, s, h, n in zip(ks, seeds, H, n_iter):
+        _, H_ref, n_ref = nmf_cd.nmf(X, k, seed=s, max_iter=60)
+        assert h.shape == (k, 70) and abs(int(n) - n_ref) <= 2
+        assert np.isfinite(h).all() and (h >= 0).all()
+
+
+def test_zero_rows_and_columns(engine):
+    X = _x(90, 40, seed=9)
+    X[10:15] = 0          # cells without counts
+    X[:, 7] = 0           # a gene without counts
+    engine.set_matrix(X)
+    W_ref, H_ref, n_ref = nmf_cd.nmf(X, 4, seed=2, max_iter=200)
+    H, W, n_iter, _ = engine.nmf_batch([4], seeds=[2], max_iter=200, return_W=True, warn=False)
+    assert abs(int(n_iter[0]) - n_ref) <= 3
+    assert np.abs(W[0][10:15]).max() <= 1e-6 and np.abs(H[0][:, 7]).max() <= 1e-6
+
+
+def test_heavy_l1_zeroes_usages(engine):
+    """l1 so strong that the first sweep zeroes W: then WtW = 0, the H sweep is skipped
+    (hess == 0, _cdnmf_fast.pyx:34) and sklearn stops on the violation ratio."""
+    X = _x(60, 30, seed=4)
+    engine.set_matrix(X)
+    W_ref, H_ref, n_ref = nmf_cd.nmf(X, 3, seed=8, alpha_W=50.0, alpha_H=50.0, l1_ratio=1.0, max_iter=50)
+    H, W, n_iter, _ = engine.nmf_batch([3], seeds=[8], alpha_W=50.0, alpha_H=50.0, l1_ratio=1.0, max_iter=50,
+                                       return_W=True, warn=False)
+    assert np.abs(W_ref).max() == 0 and np.abs(W[0]).max() == 0
+    assert np.abs(H[0] - H_ref).max() <= 1e-5 * np.abs(H_ref).max()
+    assert int(n_iter[0]) == n_ref
+
+
+def test_set_matrix_twice_and_shapes(engine):
+    engine.set_matrix(_x(50, 20))
+    engine.nmf_batch([3], seeds=[1], max_iter=5, warn=False)
+    engine.set_matrix(_x(31, 77))
+    H, _, _, _ = engine.nmf_batch([4], seeds=[1], max_iter=5, warn=False)
+    assert H[0].shape == (4, 77)
+    with pytest.raises(ValueError):
+        engine.nnls(np.ones((3, 20)))                       # H for the old gene count
