@@ -168,7 +168,7 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     CONS_TRY(hipMemcpyAsync(dkeep, keep_idx.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
     CONS_TRY(hipMemcpyAsync(du, uniforms, nu * sizeof(double), hipMemcpyHostToDevice, st));
     gather_rows_kernel<<<dim3((G + 255) / 256, Rk), 256, 0, st>>>(dL2, ld, dkeep, Rk, G, dX, ld);
-    col_stats_kernel<<<(G + 255) / 256, 256, 0, st>>>(dX, ld, Rk, G, dmean, dvar);
+    col_stats_kernel<<<(G + 63) / 64, 256, 0, st>>>(dX, ld, Rk, G, dmean, dvar);
     center_rows_kernel<<<Rk, 256, 0, st>>>(dX, ld, G, dmean, dxsq);
     std::vector<double> hvar(G);
     CONS_TRY(hipMemcpyAsync(hvar.data(), dvar, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -180,7 +180,7 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     const size_t acc_lds = (size_t)k * 256 * sizeof(double);
     CONS_TRY(hipFuncSetAttribute((const void*)accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
     auto dots = [&](const double* A) {     // ddots[64][Rkp] = A[64][ld] . X^T
-        dgemm_nt_kernel<<<dim3(Rkp / 64, 1), 256, 0, st>>>(A, ld, dX, ld, ddots, Rkp, ld);
+        dgemm_nt_small_kernel<<<dim3(Rkp / 16, 1), 256, 0, st>>>(A, ld, dX, ld, ddots, Rkp, ld);
     };
 
     std::vector<int> best_labels, labels(Rk);
@@ -258,7 +258,14 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     CONS_TRY(hipMemcpyAsync(dorder_rows, order_rows.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
     CONS_TRY(hipMemcpyAsync(dorder, order.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
     CONS_TRY(hipMemcpyAsync(dseg, seg.data(), (size_t)(k + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    cluster_median_kernel<<<dim3((G + 63) / 64, k), 64, 0, st>>>(dL2, ld, G, dorder_rows, dseg, dmed);
+    int max_m = 0;
+    for (int j = 0; j < k; ++j) max_m = std::max(max_m, seg[j + 1] - seg[j]);
+    if (max_m <= 512)
+        cluster_median_kernel<8><<<dim3((G + 3) / 4, k), 256, 0, st>>>(dL2, ld, G, dorder_rows, dseg, dmed);
+    else if (max_m <= 2048)
+        cluster_median_kernel<32><<<dim3((G + 3) / 4, k), 256, 0, st>>>(dL2, ld, G, dorder_rows, dseg, dmed);
+    else
+        cluster_median_big_kernel<<<dim3((G + 63) / 64, k), 64, 0, st>>>(dL2, ld, G, dorder_rows, dseg, dmed);
     normalise_rows_sum_kernel<<<k, 256, 0, st>>>(dmed, G);
     CONS_TRY(hipGetLastError());
     CONS_TRY(hipMemcpyAsync(median_out, dmed, (size_t)k * G * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -98,6 +98,52 @@ __global__ __launch_bounds__(256) void dgemm_nt_kernel(const double* __restrict_
             }
 }
 
+// Few-rows variant for the k-means products (M = 64 centre / candidate rows against all N rows):
+// workgroup tile 64 x 16 so that the launch has N/16 workgroups instead of N/64.
+__global__ __launch_bounds__(256) void dgemm_nt_small_kernel(const double* __restrict__ A, int lda,
+                                                             const double* __restrict__ B, int ldb,
+                                                             double* __restrict__ C, int ldc, int K)
+{
+    __shared__ __attribute__((aligned(16))) double As[2][64 * DLD];
+    __shared__ __attribute__((aligned(16))) double Bs[2][16 * DLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 16;
+    const int s_row = tid >> 3, s_k = (tid & 7) * 2;
+    const double* a_src = A + (size_t)(m0 + s_row) * lda + s_k;
+    const double* b_src = B + (size_t)(n0 + (s_row & 15)) * ldb + s_k;
+    const bool b_thr = tid < 128;
+    v2d ar[2], br = v2d{0.0, 0.0};
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int nk = K / DBK;
+    auto load = [&](int kt) {
+        ar[0] = *reinterpret_cast<const v2d*>(a_src + kt * DBK);
+        ar[1] = *reinterpret_cast<const v2d*>(a_src + (size_t)32 * lda + kt * DBK);
+        if (b_thr) br = *reinterpret_cast<const v2d*>(b_src + kt * DBK);
+    };
+    auto store = [&](int buf) {
+        *reinterpret_cast<v2d*>(&As[buf][s_row * DLD + s_k]) = ar[0];
+        *reinterpret_cast<v2d*>(&As[buf][(s_row + 32) * DLD + s_k]) = ar[1];
+        if (b_thr) *reinterpret_cast<v2d*>(&Bs[buf][s_row * DLD + s_k]) = br;
+    };
+    if (nk > 0) { load(0); store(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load(kt + 1);
+        const double* as = &As[buf][(wave * 16 + li) * DLD + lk];
+        const double* bs = &Bs[buf][li * DLD + lk];
+#pragma unroll
+        for (int q = 0; q < DBK / 4; ++q)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(as[q * 4], bs[q * 4], acc, 0, 0, 0);
+        if (kt + 1 < nk) store(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        C[(size_t)(m0 + wave * 16 + lk + 4 * r) * ldc + n0 + li] = acc[r];
+}
+
 // ---------------------------------------------------------------- small helpers
 __device__ __forceinline__ double block_sum(double v, double* red)
 {
@@ -190,19 +236,29 @@ __global__ void gather_rows_kernel(const double* __restrict__ in, int ld_in, con
     if (q < nrows && g < G) out[(size_t)q * ld_out + g] = in[(size_t)idx[q] * ld_in + g];
 }
 
-// column statistics of X [R][ld]: mean[g], var[g] (population), one thread per column, fixed order
-__global__ void col_stats_kernel(const double* __restrict__ X, int ld, int R, int G,
-                                 double* __restrict__ mean, double* __restrict__ var)
+// column statistics of X [R][ld]: mean[g], var[g] (population).  Block = 64 columns x 4 row groups;
+// fixed summation order (row group partials added in group order).
+__global__ __launch_bounds__(256) void col_stats_kernel(const double* __restrict__ X, int ld, int R, int G,
+                                                        double* __restrict__ mean, double* __restrict__ var)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
+    __shared__ double part[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int g = blockIdx.x * 64 + c;
+    const int per = (R + 3) / 4, rb = rg * per, re = min(R, rb + per);
     double s = 0.0;
-    for (int r = 0; r < R; ++r) s += X[(size_t)r * ld + g];
-    const double mu = s / R;
+    if (g < G) for (int r = rb; r < re; ++r) s += X[(size_t)r * ld + g];
+    part[rg][c] = s;
+    __syncthreads();
+    const double mu = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / R;
+    __syncthreads();
     double v = 0.0;
-    for (int r = 0; r < R; ++r) { const double d = X[(size_t)r * ld + g] - mu; v += d * d; }
-    mean[g] = mu;
-    var[g] = v / R;
+    if (g < G) for (int r = rb; r < re; ++r) { const double d = X[(size_t)r * ld + g] - mu; v += d * d; }
+    part[rg][c] = v;
+    __syncthreads();
+    if (rg == 0 && g < G) {
+        mean[g] = mu;
+        var[g] = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / R;
+    }
 }
 
 // X[r][g] -= mean[g];  sq[r] = |X[r]|^2
@@ -538,9 +594,50 @@ __device__ __forceinline__ double kth_smallest(const double* __restrict__ X, int
     return f64_unkey(lo);
 }
 
-__global__ void cluster_median_kernel(const double* __restrict__ X, int ld, int G,
-                                      const int* __restrict__ order, const int* __restrict__ seg,
-                                      double* __restrict__ med)
+// One WAVE per (cluster, gene): the lanes split the cluster's m rows, keep their values in
+// registers (VPL per lane) and count with a wave reduction -- 64 bisection steps on the key.
+template <int VPL>
+__device__ __forceinline__ double wave_kth(const unsigned long long (&key)[VPL], int kth)
+{
+    unsigned long long lo = 0ull, hi = ~0ull;
+    while (lo < hi) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) c += (key[v] <= mid) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (c >= kth) hi = mid; else lo = mid + 1;
+    }
+    return f64_unkey(lo);
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void cluster_median_kernel(const double* __restrict__ X, int ld, int G,
+                                                             const int* __restrict__ order,
+                                                             const int* __restrict__ seg,
+                                                             double* __restrict__ med)
+{
+    const int j = blockIdx.y, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const int b = seg[j], m = seg[j + 1] - b;
+    unsigned long long key[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int q = lane + 64 * v;
+        key[v] = (q < m) ? f64_key(X[(size_t)order[b + q] * ld + g]) : ~0ull;   // padding sorts last
+    }
+    double val;
+    if (m & 1) val = wave_kth<VPL>(key, m / 2 + 1);
+    else val = (wave_kth<VPL>(key, m / 2) + wave_kth<VPL>(key, m / 2 + 1)) / 2.0;
+    if (lane == 0) med[(size_t)j * G + g] = val;
+}
+
+// fallback for clusters with more than 2048 members: one thread per (cluster, gene), values re-read
+__global__ void cluster_median_big_kernel(const double* __restrict__ X, int ld, int G,
+                                          const int* __restrict__ order, const int* __restrict__ seg,
+                                          double* __restrict__ med)
 {
     const int j = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
@@ -548,11 +645,7 @@ __global__ void cluster_median_kernel(const double* __restrict__ X, int ld, int 
     const int* rows = order + b;
     double v;
     if (m & 1) v = kth_smallest(X, ld, g, rows, m, m / 2 + 1);
-    else {
-        const double a = kth_smallest(X, ld, g, rows, m, m / 2);
-        const double c = kth_smallest(X, ld, g, rows, m, m / 2 + 1);
-        v = (a + c) / 2.0;
-    }
+    else v = (kth_smallest(X, ld, g, rows, m, m / 2) + kth_smallest(X, ld, g, rows, m, m / 2 + 1)) / 2.0;
     med[(size_t)j * G + g] = v;
 }
 

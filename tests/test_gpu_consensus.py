@@ -106,3 +106,13 @@ def test_consensus_stress_C5_shape(engine):
     assert _same_partition(out["labels"][kept], truth[kept])             # the planted clusters come back
     assert np.allclose(out["median_spectra"].sum(axis=1), 1.0, atol=1e-12)
     assert (out["median_spectra"] >= 0).all()
+
+
+@pytest.mark.parametrize("R,k", [(2600, 1), (2600, 2), (900, 3)])
+def test_median_paths_large_clusters(engine, R, k):
+    """Cluster sizes above 512 / 2048 members take the wider / the re-reading median kernels."""
+    S, _ = synth.consensus_stress(R=R, G=96, k=k, n_outliers=0, seed=5)
+    ref = oc.consensus_core(S, np.abs(np.random.RandomState(0).standard_normal((20, 96))), k, density_threshold=2.0)
+    out = engine.consensus(S, k, density_threshold=2.0)
+    assert np.array_equal(out["labels"] + 1, ref["kmeans_labels"])
+    assert np.abs(out["median_spectra"] - ref["median_spectra"]).max() < 1e-12
