@@ -38,6 +38,13 @@ def save_df_to_npz(obj, filename):
     np.savez_compressed(filename, data=obj.values, index=obj.index.values, columns=obj.columns.values)
 
 
+def save_df_to_npz_fast(obj, filename):
+    """Same container as save_df_to_npz without zlib: used only for the (large) normalised
+    matrix, which the reference stores as uncompressed h5ad (cnmf.py:561); zlib over 400 MB
+    costs ~10 s and buys nothing on a scratch file."""
+    np.savez(filename, data=obj.values, index=obj.index.values, columns=obj.columns.values)
+
+
 def save_df_to_text(obj, filename):
     """cnmf.py:34-35"""
     obj.to_csv(filename, sep="\t")
@@ -187,7 +194,7 @@ class cNMF:
                             "and re-run or adjust the number of overdispersed genes. Quitting!"
                             % (zerocells.sum(), ", ".join(map(str, examples[:4]))))
         self._initialize_dirs()
-        save_df_to_npz(norm_counts, self.paths["normalized_counts"])
+        save_df_to_npz_fast(norm_counts, self.paths["normalized_counts"])
         with open(self.paths["nmf_genes_list"], "w") as F:
             F.write("\n".join(map(str, norm_counts.columns)))
         if tpm is not None:
