@@ -23,7 +23,7 @@ SYMBOLS = [
     "cnmf_debug_gemm", "cnmf_debug_standard_normal",
 ]
 
-CNMF_KMAX = 32
+CNMF_KMAX = 64
 
 
 class CdParams(C.Structure):

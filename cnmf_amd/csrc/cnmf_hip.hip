@@ -42,6 +42,7 @@ struct cnmf_ctx {
 
     // batch buffers (sized for kc_alloc columns)
     int kc_alloc = 0, nsplit_alloc = 0, parts_alloc = 0;
+    size_t gram_part_floats = 0;
     float *H = nullptr, *Wt = nullptr, *XHt = nullptr, *XHt1 = nullptr, *XtW = nullptr;
     unsigned char* d_split = nullptr;   // stream-K cut flags of the current plan
     float *gramH = nullptr, *gramW = nullptr, *gram_part = nullptr;
@@ -142,12 +143,23 @@ static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int l
 // ------------------------------------------------------------------ sweep dispatch
 static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, int L, const float* P,
                                const float* gram, const SlotDesc* slots, float l1, float* gram_part,
-                               double* viol_part, int chunks, int parts, int want_gram, int kmax,
+                               double* viol_part, int chunks, int parts, int want_gram, int kmax, int tiers,
                                SplitInfo sp = SplitInfo{nullptr, nullptr, 1, 1, 1})
 {
     dim3 grid(parts, nslots);
-    sweep_kernel<<<grid, 256, sweep_lds_bytes(kmax), st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part,
-                                                           viol_part, chunks, want_gram, sweep_wstride(kmax));
+    static bool attr_set = false;
+    if (!attr_set) {      // ranks above 32 need more than the default 64 KB of dynamic LDS
+        hipFuncSetAttribute((const void*)sweep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        hipFuncSetAttribute((const void*)sweep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        hipFuncSetAttribute((const void*)sweep_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        attr_set = true;
+    }
+    // one launch per rank tier present among the live slots; a launch skips the slots of other tiers at once
+    const size_t lds = sweep_lds_bytes(kmax);
+    const int kg = sweep_kg(kmax);
+    if (tiers & 1) sweep_kernel<0><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax);
+    if (tiers & 2) sweep_kernel<1><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax);
+    if (tiers & 4) sweep_kernel<2><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax);
     return hipGetLastError();
 }
 
@@ -267,7 +279,7 @@ static void free_batch(cnmf_ctx* c)
     c->H = c->Wt = c->XHt = c->XtW = c->gramH = c->gramW = c->gram_part = nullptr;
     c->viol_part = nullptr; c->d_slots = nullptr; c->d_slot_list = nullptr;
     c->h_slots = c->h_snap = nullptr; c->h_slot_list = nullptr;
-    c->kc_alloc = 0;
+    c->kc_alloc = 0; c->gram_part_floats = 0;
 }
 
 extern "C" void cnmf_destroy(cnmf_ctx* ctx)
@@ -375,11 +387,13 @@ static int pick_nsplit(const cnmf_ctx* ctx, int KC)
     return std::min(s, max_by_k);
 }
 
-static int ensure_batch(cnmf_ctx* ctx, int KC)
+static int ensure_batch(cnmf_ctx* ctx, int KC, int max_k = KMAX, int min_k = 1)
 {
     const int nsplit = pick_nsplit(ctx, KC);
     const int parts = std::max(sweep_parts((int)ctx->N), sweep_parts((int)ctx->G));
-    if (ctx->kc_alloc == KC && ctx->nsplit_alloc == nsplit && ctx->parts_alloc == parts) return CNMF_OK;
+    const size_t gp_need = (size_t)(KC / std::max(1, min_k) + 1) * parts * max_k * max_k;
+    if (ctx->kc_alloc == KC && ctx->nsplit_alloc == nsplit && ctx->parts_alloc == parts &&
+        ctx->gram_part_floats >= gp_need) return CNMF_OK;
     free_batch(ctx);
     const size_t hb = (size_t)KC * ctx->G_pad * sizeof(float);
     const size_t wb = (size_t)KC * ctx->N_pad * sizeof(float);
@@ -391,7 +405,8 @@ static int ensure_batch(cnmf_ctx* ctx, int KC)
     HIP_TRY(ctx, hipMalloc(&ctx->XtW, hb * nsplit));
     HIP_TRY(ctx, hipMalloc(&ctx->gramH, (size_t)KC * GRAM_SZ * sizeof(float)));
     HIP_TRY(ctx, hipMalloc(&ctx->gramW, (size_t)KC * GRAM_SZ * sizeof(float)));
-    HIP_TRY(ctx, hipMalloc(&ctx->gram_part, (size_t)KC * parts * GRAM_SZ * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(&ctx->gram_part, gp_need * sizeof(float)));
+    ctx->gram_part_floats = gp_need;
     HIP_TRY(ctx, hipMalloc(&ctx->viol_part, (size_t)KC * parts * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_slots, (size_t)KC * sizeof(SlotDesc)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_slot_list, (size_t)KC * RING * sizeof(int)));
@@ -492,22 +507,23 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     if (n == 0) return CNMF_OK;
 
     const int N = (int)ctx->N, G = (int)ctx->G;
-    int64_t total_k = 0; int max_k = 0;
+    int64_t total_k = 0; int max_k = 0, min_k = 1 << 30;
     std::vector<size_t> hoff(n + 1, 0), woff(n + 1, 0);
     for (int r = 0; r < n; ++r) {
         if (kk[r] < 1) { SET_ERR(ctx, "n_components must be >= 1 (restart %d)", r); return CNMF_EINVAL; }
         if (kk[r] > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d is not supported by the device sweep", kk[r], KMAX); return CNMF_EUNSUPPORTED; }
-        total_k += kk[r]; max_k = std::max(max_k, (int)kk[r]);
+        total_k += kk[r]; max_k = std::max(max_k, (int)kk[r]); min_k = std::min(min_k, (int)kk[r]);
         hoff[r + 1] = hoff[r] + (size_t)kk[r] * G;
         woff[r + 1] = woff[r] + (size_t)kk[r] * N;
     }
     int KC = pick_kc(total_k, max_k, prm->kc_max);
     const int KC0 = KC;
-    rc = ensure_batch(ctx, KC);
+    rc = ensure_batch(ctx, KC, max_k, min_k);
     if (rc) return rc;
     rc = ensure_stage(ctx, (size_t)N * KMAX, (size_t)G * KMAX);
     if (rc) return rc;
     int nsplit = ctx->nsplit_alloc;
+    const int fin_y = (max_k * max_k + 255) / 256;       // finalize blocks per slot
     const int lag = std::max(1, std::min(RING - 2, prm->lag > 0 ? prm->lag : 2));
     hipStream_t st = ctx->stream;
 
@@ -650,6 +666,9 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (n_active == 0 && n_pending == 0) break;
 
         // ---- one coordinate-descent outer iteration for every slot in flight
+        int tiers = 0;
+        for (int s2 = 0; s2 < nslots; ++s2)
+            if (hs[s2].state) tiers |= hs[s2].k <= 16 ? 1 : (hs[s2].k <= 32 ? 2 : 4);
         if (time_gemm) { gev.resize(gev.size() + 4); for (int i = 0; i < 4; ++i) hipEventCreate(&gev[gev.size() - 4 + i]); hipEventRecord(gev[gev.size() - 4], st); }
         // pass A : XHt[KC][N] = H_all . X^T                       (sklearn _nmf.py:387)
         if (sk.on && gvarA == 0)
@@ -661,11 +680,11 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (time_gemm) hipEventRecord(gev[gev.size() - 3], st);
         // W half-step                                             (sklearn _nmf.py:500)
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
-                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k,
+                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k, tiers,
                                   (sk.on && gvarA == 0) ? SplitInfo{ctx->XHt1, ctx->d_split, 128, sk.mw, sk.MG}
                                                         : SplitInfo{nullptr, nullptr, 1, 1, 1}));
-        finalize_kernel<<<dim3(nslots, 4), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
-                                                ctx->d_slots, 0, prm->tol, prm->max_iter, 1);
+        finalize_kernel<<<dim3(nslots, fin_y), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
+                                                ctx->d_slots, 0, prm->tol, prm->max_iter, 1, max_k);
         if (time_gemm) hipEventRecord(gev[gev.size() - 2], st);
         // pass B : XtW[S][KC][G] = Wt_all . X  (split over cells)  (sklearn _nmf.py:505-507)
         HIP_TRY(ctx, launch_gemm<true>(st, gvarB, ctx->Wt, ctx->N_pad, ctx->X, ctx->G_pad, ctx->XtW,
@@ -676,9 +695,9 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         HIP_TRY(ctx, launch_reduce_splits(st, ctx->XtW, nsplit, (long long)KC * ctx->G_pad,
                                           (long long)KC * ctx->G_pad));
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
-                                  ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k));
-        finalize_kernel<<<dim3(nslots, 4), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W,
-                                                ctx->d_slots, 1, prm->tol, prm->max_iter, 1);
+                                  ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers));
+        finalize_kernel<<<dim3(nslots, fin_y), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W,
+                                                ctx->d_slots, 1, prm->tol, prm->max_iter, 1, max_k);
         HIP_TRY(ctx, hipGetLastError());
         column_iters += KC;
         if (dbg) {
@@ -817,8 +836,8 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
     if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int N = (int)ctx->N, G = (int)ctx->G;
-    const int KC = 32;
-    rc = ensure_batch(ctx, KC);
+    const int KC = k <= 32 ? 32 : 64;
+    rc = ensure_batch(ctx, KC, k, k);
     if (rc) return rc;
     rc = ensure_stage(ctx, (size_t)N * KMAX, (size_t)G * KMAX);
     if (rc) return rc;
@@ -849,9 +868,9 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
         for (int b = 0; b < burst; ++b) {
             HIP_TRY(ctx, launch_sweep(st, 1, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
                                       ctx->d_slots, (float)prm->l1_reg_W, ctx->gram_part, ctx->viol_part,
-                                      chunksW, partsW, 0, k));
+                                      chunksW, partsW, 0, k, k <= 16 ? 1 : (k <= 32 ? 2 : 4)));
             finalize_kernel<<<dim3(1, 1), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, 0.f,
-                                               ctx->d_slots, 2, prm->tol, prm->max_iter, 0);
+                                               ctx->d_slots, 2, prm->tol, prm->max_iter, 0, k);
         }
         HIP_TRY(ctx, hipMemcpyAsync(snap, ctx->d_slots, sizeof(SlotDesc), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipEventRecord(ev, st));

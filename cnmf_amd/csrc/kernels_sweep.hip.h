@@ -20,15 +20,18 @@
 
 namespace cnmf {
 
-constexpr int KMAX = 32;            // largest rank handled by the register-resident sweep
-constexpr int GRAM_LD = KMAX;       // gram matrices are stored [slot][32][32]
+constexpr int KMAX = 64;            // largest rank handled by the register-resident sweep
+constexpr int GRAM_LD = KMAX;       // final gram matrices are stored [slot][64][64]
 constexpr int GRAM_SZ = KMAX * KMAX;
 
-// dynamic LDS of sweep_kernel for a batch whose largest rank is kmax
-static inline int sweep_wstride(int kmax) { return kmax <= 16 ? 17 : KMAX + 1; }
+// dynamic LDS of sweep_kernel for a batch whose largest rank is kmax:
+//   Gs [KG][KG+4] | vred [4] doubles | Ws [4][64][wstride]      (KG = 16 / 32 / 64)
+static inline int sweep_kg(int kmax) { return kmax <= 16 ? 16 : (kmax <= 32 ? 32 : 64); }
+static inline int sweep_wstride(int kmax) { return sweep_kg(kmax) + 1; }
 static inline size_t sweep_lds_bytes(int kmax)
 {
-    return sizeof(float) * (size_t)(KMAX * (KMAX + 4) + 8 + 4 * 64 * sweep_wstride(kmax));
+    const int kg = sweep_kg(kmax);
+    return sizeof(float) * (size_t)(kg * (kg + 4) + 8 + 4 * 64 * sweep_wstride(kmax));
 }
 
 struct SlotDesc {                   // one restart in flight (device + host mirror)
@@ -51,35 +54,41 @@ struct SplitInfo {                  // second partial plane of a stream-K produc
     int tile_rows, tile_cols, mgroups;
 };
 
-// Body of the sweep for one (row chunk, slot); KP = k rounded up to a multiple of 4
-// (compile-time register array size).  Gram of the updated rows:
+// Body of the sweep for one (row chunk, slot); KP = k rounded up (compile-time register array
+// size: multiples of 4 up to 32, then 48 and 64).  Gram of the updated rows on the matrix pipe:
 //   KP <= 16 : v_mfma_f32_16x16x4_f32  (16 MFMAs of 32 cycles per 64 rows)
-//   KP  > 16 : v_mfma_f32_32x32x2_f32  (32 MFMAs of 64 cycles per 64 rows)
+//   KP <= 32 : v_mfma_f32_32x32x2_f32  (32 MFMAs of 64 cycles per 64 rows)
+//   KP <= 64 : 2 x 2 tiles of 32x32x2
+// Partials are written compactly: entry (r,c) at r*gld + c, gld = largest rank of the batch.
 template <int KP>
 __device__ __forceinline__ void sweep_body(
     float* __restrict__ V, int ldv, int L, const float* __restrict__ P, const SplitInfo& sp,
     const float* __restrict__ gram, const SlotDesc& sd, int slot, float l1_reg,
     float* __restrict__ gram_part, double* __restrict__ viol_part,
-    int chunks_per_block, int want_gram, float* lds, int wstride)
+    int chunks_per_block, int want_gram, float* lds, int kg, int gld)
 {
-    constexpr bool SMALL = (KP <= 16);
-    // dynamic LDS: Gs [32][36] | vred [4] doubles | Ws [4][64][wstride]
-    float (*Gs)[KMAX + 4] = reinterpret_cast<float (*)[KMAX + 4]>(lds);
-    double* vred = reinterpret_cast<double*>(lds + KMAX * (KMAX + 4));
-    float* Wsb = lds + KMAX * (KMAX + 4) + 8;
+    constexpr int GMODE = (KP <= 16) ? 0 : ((KP <= 32) ? 1 : 2);
+    constexpr int GR = (GMODE == 0) ? 16 : ((GMODE == 1) ? 32 : 64);       // gram tile edge
+    const int gs = kg + 4, wstride = kg + 1;
+    float* Gsb = lds;                                                     // [kg][kg+4]
+    double* vred = reinterpret_cast<double*>(lds + kg * gs);
+    float* Wsb = lds + kg * gs + 8;
+#define GS(t_, r_) Gsb[(t_) * gs + (r_)]
 #define WS(wv_, r_, c_) Wsb[((wv_) * 64 + (r_)) * wstride + (c_)]
     const int k = sd.k, off = sd.off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < KMAX * KMAX; e += 256) {
-        const int r = e / KMAX, c = e % KMAX;
-        Gs[r][c] = (r < k && c < k) ? gram[(size_t)slot * GRAM_SZ + r * GRAM_LD + c] : 0.f;
+    for (int e = tid; e < KP * KP; e += 256) {
+        const int r = e / KP, c = e % KP;
+        GS(r, c) = (r < k && c < k) ? gram[(size_t)slot * GRAM_SZ + r * GRAM_LD + c] : 0.f;
     }
     __syncthreads();
 
-    f32x16 gacc;
+    f32x16 gacc[GMODE == 2 ? 4 : 1];
     f32x4 gacc4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+    for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gacc[a][r] = 0.f;
     float viol = 0.f;
 
     for (int ch = 0; ch < chunks_per_block; ++ch) {
@@ -103,29 +112,30 @@ __device__ __forceinline__ void sweep_body(
             // clamped (always valid) addresses; the values of dead lanes / columns >= k are
             // discarded by selects.  (Per-column branches serialise the memory latency.)
             const int rowc = min(row, L - 1);
-            float vv[KP], pp[KP], qq[KP];
 #pragma unroll
             for (int c = 0; c < KP; ++c) {
                 const size_t idx = (size_t)(off + min(c, k - 1)) * ldv + rowc;
-                vv[c] = V[idx];
-                pp[c] = P[idx];
+                w[c] = V[idx];
+                p[c] = P[idx];
             }
             if (cut0 | cut1) {                    // wave-uniform: one branch per chunk
+                float qq[KP];
 #pragma unroll
                 for (int c = 0; c < KP; ++c) {
                     const size_t idx = (size_t)(off + min(c, k - 1)) * ldv + rowc;
                     qq[c] = sp.plane1[idx];
                 }
-            } else {
 #pragma unroll
-                for (int c = 0; c < KP; ++c) qq[c] = 0.f;
+                for (int c = 0; c < KP; ++c) {
+                    const bool cut = ((off + c) < mg_edge) ? cut0 : cut1;
+                    p[c] += cut ? qq[c] : 0.f;
+                }
             }
 #pragma unroll
             for (int c = 0; c < KP; ++c) {
                 const bool on = live && (c < k);
-                const bool cut = ((off + c) < mg_edge) ? cut0 : cut1;
-                w[c] = on ? vv[c] : 0.f;
-                p[c] = on ? (pp[c] + (cut ? qq[c] : 0.f) - l1_reg) : 0.f;
+                w[c] = on ? w[c] : 0.f;
+                p[c] = on ? (p[c] - l1_reg) : 0.f;
             }
         }
         if (live) {
@@ -134,10 +144,10 @@ __device__ __forceinline__ void sweep_body(
                 if (t < k) {
                     float grad = -p[t];
 #pragma unroll
-                    for (int r = 0; r < KP; ++r) grad = fmaf(Gs[t][r], w[r], grad);
+                    for (int r = 0; r < KP; ++r) grad = fmaf(GS(t, r), w[r], grad);
                     const float pg = (w[t] == 0.f) ? fminf(0.f, grad) : grad;
                     viol += fabsf(pg);
-                    const float hess = Gs[t][t];
+                    const float hess = GS(t, t);
                     if (hess != 0.f) w[t] = fmaxf(w[t] - grad / hess, 0.f);
                 }
             }
@@ -147,23 +157,32 @@ __device__ __forceinline__ void sweep_body(
         }
         if (want_gram) {
             // Gram of the updated rows on the (otherwise idle) matrix pipe: acc += Wrows^T . Wrows
-            constexpr int WC = SMALL ? 16 : KMAX;
 #pragma unroll
-            for (int c = 0; c < WC; ++c) WS(wave, lane, c) = (c < KP) ? w[c < KP ? c : 0] : 0.f;
+            for (int c = 0; c < GR; ++c) WS(wave, lane, c) = (c < KP) ? w[c < KP ? c : 0] : 0.f;
             __builtin_amdgcn_wave_barrier();       // wave-private tile: LDS ops of one wave are in order
-            if (SMALL) {
+            if (GMODE == 0) {
                 const int li = lane & 15, q = lane >> 4;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const float a = WS(wave, 4 * s + q, li);
                     gacc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, gacc4, 0, 0, 0);
                 }
-            } else {
+            } else if (GMODE == 1) {
                 const int li = lane & 31, h = lane >> 5;
 #pragma unroll 8
                 for (int s = 0; s < 32; ++s) {
                     const float a = WS(wave, 2 * s + h, li);
-                    gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, gacc, 0, 0, 0);
+                    gacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, gacc[0], 0, 0, 0);
+                }
+            } else {
+                const int li = lane & 31, h = lane >> 5;
+#pragma unroll 4
+                for (int s = 0; s < 32; ++s) {
+                    const float a0 = WS(wave, 2 * s + h, li), a1 = WS(wave, 2 * s + h, 32 + li);
+                    gacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a0, gacc[0], 0, 0, 0);
+                    gacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a1, gacc[1], 0, 0, 0);
+                    gacc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a0, gacc[2], 0, 0, 0);
+                    gacc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a1, gacc[3], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -178,40 +197,44 @@ __device__ __forceinline__ void sweep_body(
 
     // ---- gram: sum the 4 waves' accumulators through LDS, write the block partial
     __syncthreads();
-    float* gred = Wsb;                   // reused as [4][GR][GR+1], GR = 16 or 32
-    constexpr int GR = SMALL ? 16 : 32;
+    float* gred = Wsb;                   // reused as [4][GR][GR+1]   (<= 4*64*(kg+1) floats)
     if (want_gram) {
-        if (SMALL) {
+        if (GMODE == 0) {
             const int li = lane & 15, q = lane >> 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) gred[(wave * GR + 4 * q + r) * (GR + 1) + li] = gacc4[r];
         } else {
             const int li = lane & 31, h = lane >> 5;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-                gred[(wave * GR + rr) * (GR + 1) + li] = gacc[r];
-            }
+            for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (a >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    gred[(wave * GR + rr) * (GR + 1) + (a & 1) * 32 + li] = gacc[a][r];
+                }
         }
     }
     __syncthreads();
     if (want_gram) {
-        for (int e = tid; e < GRAM_SZ; e += 256) {
-            const int r = e / 32, c = e % 32;
-            float s = 0.f;
-            if (r < k && c < k)
-                s = gred[(0 * GR + r) * (GR + 1) + c] + gred[(1 * GR + r) * (GR + 1) + c] +
-                    gred[(2 * GR + r) * (GR + 1) + c] + gred[(3 * GR + r) * (GR + 1) + c];
-            gram_part[((size_t)slot * gridDim.x + blockIdx.x) * GRAM_SZ + e] = s;
+        float* gp = gram_part + ((size_t)slot * gridDim.x + blockIdx.x) * (size_t)(gld * gld);
+        for (int e = tid; e < k * k; e += 256) {
+            const int r = e / k, c = e % k;
+            gp[r * gld + c] = gred[(0 * GR + r) * (GR + 1) + c] + gred[(1 * GR + r) * (GR + 1) + c] +
+                              gred[(2 * GR + r) * (GR + 1) + c] + gred[(3 * GR + r) * (GR + 1) + c];
         }
     }
     if (tid == 0)
         viol_part[(size_t)slot * gridDim.x + blockIdx.x] = vred[0] + vred[1] + vred[2] + vred[3];
 #undef WS
+#undef GS
 }
 
 // One launch sweeps every slot in flight: grid = (row blocks, slots); the workgroup
 // dispatches on its slot's rank to the right register-array size.
+// TIER 0 handles ranks <= 16, TIER 1 ranks 17..32, TIER 2 ranks 33..64: one kernel for all ranks would
+// give the common small-rank case the register allocation of the largest (232 VGPR + 64 AGPR = one
+// wave per SIMD).  The host launches only the tiers present in the batch.
+template <int TIER>
 __global__ __launch_bounds__(256) void sweep_kernel(
     float* __restrict__ V, int ldv, int L,
     const float* __restrict__ P,             // [KC][ldv] products (split-K already reduced)
@@ -221,20 +244,31 @@ __global__ __launch_bounds__(256) void sweep_kernel(
     float l1_reg,
     float* __restrict__ gram_part,           // [nslots][gridDim.x][32][32]
     double* __restrict__ viol_part,          // [nslots][gridDim.x]
-    int chunks_per_block, int want_gram, int wstride)
+    int chunks_per_block, int want_gram, int kg, int gld)
 {
     const int slot = blockIdx.y;
     const SlotDesc sd = slots[slot];
     if (!sd.active) return;
     extern __shared__ __attribute__((aligned(16))) float sweep_lds[];
 #define CNMF_SW(KP_)                                                                              \
-    case KP_ / 4:                                                                                 \
         sweep_body<KP_>(V, ldv, L, P, sp, gram, sd, slot, l1_reg, gram_part, viol_part,           \
-                        chunks_per_block, want_gram, sweep_lds, wstride);                         \
-        break;
-    switch ((sd.k + 3) / 4) {
-        CNMF_SW(4) CNMF_SW(8) CNMF_SW(12) CNMF_SW(16) CNMF_SW(20) CNMF_SW(24) CNMF_SW(28) CNMF_SW(32)
-        default: break;
+                        chunks_per_block, want_gram, sweep_lds, kg, gld);
+    const int k = sd.k;
+    if (TIER == 0) {
+        if (k > 16) return;
+        switch ((k + 3) / 4) {
+            case 1: CNMF_SW(4) break;   case 2: CNMF_SW(8) break;   case 3: CNMF_SW(12) break;
+            case 4: CNMF_SW(16) break;  default: break;
+        }
+    } else if (TIER == 1) {
+        if (k <= 16 || k > 32) return;
+        switch ((k + 3) / 4) {
+            case 5: CNMF_SW(20) break;  case 6: CNMF_SW(24) break;
+            case 7: CNMF_SW(28) break;  case 8: CNMF_SW(32) break;  default: break;
+        }
+    } else {
+        if (k <= 32) return;
+        if (k <= 48) { CNMF_SW(48) } else if (k <= 64) { CNMF_SW(64) }
     }
 #undef CNMF_SW
 }
@@ -260,7 +294,7 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(
     reinterpret_cast<v4f*>(out)[i] = acc;
 }
 
-// grid = (slots, 4): reduce the sweep's partials in a fixed order, add the l2 regulariser to
+// grid = (slots, ceil(kmax^2/256)): reduce the sweep's partials in a fixed order, add the l2 regulariser to
 // the diagonal (sklearn _nmf.py:389-392); block (slot,0) also runs the stopping rule of
 // _fit_coordinate_descent (sklearn _nmf.py:496-521) on the device.
 //   phase 0 : after the W half-step (update_H=True)  -> store violation, no decision
@@ -272,7 +306,7 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(
 __global__ __launch_bounds__(256) void finalize_kernel(
     const float* __restrict__ gram_part, const double* __restrict__ viol_part, int nparts,
     float* __restrict__ gram_out, float l2_reg,
-    SlotDesc* __restrict__ slots, int phase, double tol, int max_iter, int want_gram)
+    SlotDesc* __restrict__ slots, int phase, double tol, int max_iter, int want_gram, int gld)
 {
     const int slot = blockIdx.x;
     SlotDesc* sd = &slots[slot];
@@ -280,24 +314,24 @@ __global__ __launch_bounds__(256) void finalize_kernel(
     const int tid = threadIdx.x;
     const int k = sd->k;
     if (want_gram) {
-        const int e = blockIdx.y * 256 + tid;
-        const int r = e / 32, c = e % 32;
-        float s = 0.f;
-        if (r < k && c < k) {
-            const float* gp = gram_part + (size_t)slot * nparts * GRAM_SZ + e;
+        const int e = blockIdx.y * 256 + tid;          // grid.y covers kmax*kmax entries
+        if (e < k * k) {
+            const int r = e / k, c = e % k;
+            const size_t gsz = (size_t)gld * gld;
+            const float* gp = gram_part + (size_t)slot * nparts * gsz + r * gld + c;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
             int pI = 0;
             for (; pI + 4 <= nparts; pI += 4) {
-                s0 += gp[(size_t)pI * GRAM_SZ];
-                s1 += gp[(size_t)(pI + 1) * GRAM_SZ];
-                s2 += gp[(size_t)(pI + 2) * GRAM_SZ];
-                s3 += gp[(size_t)(pI + 3) * GRAM_SZ];
+                s0 += gp[(size_t)pI * gsz];
+                s1 += gp[(size_t)(pI + 1) * gsz];
+                s2 += gp[(size_t)(pI + 2) * gsz];
+                s3 += gp[(size_t)(pI + 3) * gsz];
             }
-            for (; pI < nparts; ++pI) s0 += gp[(size_t)pI * GRAM_SZ];
-            s = (s0 + s1) + (s2 + s3);
+            for (; pI < nparts; ++pI) s0 += gp[(size_t)pI * gsz];
+            float s = (s0 + s1) + (s2 + s3);
             if (r == c) s += l2_reg;
+            gram_out[(size_t)slot * GRAM_SZ + r * GRAM_LD + c] = s;
         }
-        gram_out[(size_t)slot * GRAM_SZ + e] = s;
     }
     if (blockIdx.y != 0) return;
     __shared__ double red[256];
@@ -341,31 +375,39 @@ __global__ __launch_bounds__(256) void gram_rows_kernel(
     const int slot = slot_list[blockIdx.x];
     const SlotDesc sd = slots[slot];
     const int k = sd.k, off = sd.off;
-    __shared__ float tile[KMAX][257];
+    __shared__ float tile[KMAX][129];
     const int tid = threadIdx.x;
-    // thread owns up to 4 (a,b) pairs: e = tid + 256*i
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int g0 = 0; g0 < L; g0 += 256) {
-        for (int c = 0; c < k; ++c)
-            tile[c][tid] = (g0 + tid < L) ? V[(size_t)(off + c) * ldv + g0 + tid] : 0.f;
+    // thread owns the (a,b) pairs e = tid + 256*i, e < k*k  (k <= 64 -> at most 16 pairs)
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    for (int g0 = 0; g0 < L; g0 += 128) {
+        for (int e = tid; e < k * 128; e += 256) {
+            const int c = e / 128, g = e % 128;
+            tile[c][g] = (g0 + g < L) ? V[(size_t)(off + c) * ldv + g0 + g] : 0.f;
+        }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + 256 * i, a = e / 32, b = e % 32;
-            if (a < k && b < k) {
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + 256 * i;
+            if (e < k * k) {
+                const int a = e / k, b = e % k;
                 float s = 0.f;
-                for (int g = 0; g < 256; ++g) s = fmaf(tile[a][g], tile[b][g], s);
+                for (int g = 0; g < 128; ++g) s = fmaf(tile[a][g], tile[b][g], s);
                 acc[i] += (double)s;
             }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + 256 * i, a = e / 32, b = e % 32;
-        float s = (a < k && b < k) ? (float)acc[i] : 0.f;
-        if (a == b && a < k) s += l2_reg;
-        gram_out[(size_t)slot * GRAM_SZ + e] = s;
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i;
+        if (e < k * k) {
+            const int a = e / k, b = e % k;
+            float s = (float)acc[i];
+            if (a == b) s += l2_reg;
+            gram_out[(size_t)slot * GRAM_SZ + a * GRAM_LD + b] = s;
+        }
     }
 }
 

@@ -94,7 +94,8 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
         const int k = kk[r];
         if (k < 1) { SET_ERR(ctx, "n_components must be >= 1"); return CNMF_EINVAL; }
         if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
-        const int KP = k <= 8 ? 8 : (k <= 16 ? 16 : 32);
+        if (k > 32 && beta != 1) { SET_ERR(ctx, "itakura-saito with n_components > 32 is not supported on the device"); return CNMF_EUNSUPPORTED; }
+        const int KP = k <= 8 ? 8 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
         const int nchunks = std::max(1, std::min(64, N / 256));
         const int rpc = (N + nchunks - 1) / nchunks;
         DevPool rp;                                   // per-restart scratch
@@ -134,7 +135,9 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
                                                  dpart, update_H, prm, &nit, &err)                              \
                          : mu_run_one<KP_, false>(ctx, st, N, G, k, dW, dHt, dHsum, dWsum, pnum, pden, nchunks, rpc, \
                                                   dpart, update_H, prm, &nit, &err)
-        if (KP == 8) { MU_GO(8); } else if (KP == 16) { MU_GO(16); } else { MU_GO(32); }
+        if (KP == 8) { MU_GO(8); } else if (KP == 16) { MU_GO(16); } else if (KP == 32) { MU_GO(32); }
+        else rc = mu_run_one<64, true>(ctx, st, N, G, k, dW, dHt, dHsum, dWsum, pnum, pden, nchunks, rpc, dpart,
+                                       update_H, prm, &nit, &err);
 #undef MU_GO
         if (rc) return rc;
         if (H_out && update_H) {

@@ -35,7 +35,7 @@ extern "C" {
 #define CNMF_EUNSUPPORTED -5   /* e.g. rank > CNMF_KMAX (NotImplementedError)    */
 #define CNMF_ECOMM        -6   /* RCCL failure                                   */
 
-#define CNMF_KMAX 32           /* largest rank handled by the device sweep       */
+#define CNMF_KMAX 64           /* largest rank handled by the device sweep       */
 
 typedef struct cnmf_ctx cnmf_ctx;
 

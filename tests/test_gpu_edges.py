@@ -14,7 +14,8 @@ def _x(n, g, seed=0):
     return np.abs(rs.standard_normal((n, g))) * (rs.rand(n, g) < 0.6) + 0.01
 
 
-@pytest.mark.parametrize("n,g,k", [(7, 5, 2), (33, 31, 3), (129, 33, 5), (257, 65, 1), (200, 140, 32), (64, 128, 9)])
+@pytest.mark.parametrize("n,g,k", [(7, 5, 2), (33, 31, 3), (129, 33, 5), (257, 65, 1), (200, 140, 32), (64, 128, 9),
+                                   (300, 150, 33), (260, 200, 48), (400, 180, 64)])
 def test_small_and_ragged_shapes(engine, n, g, k):
     X = _x(n, g, seed=n + g)
     engine.set_matrix(X)
@@ -37,7 +38,7 @@ def test_empty_restart_list(engine):
 def test_mixed_ranks_one_call(engine):
     X = _x(150, 70, seed=3)
     engine.set_matrix(X)
-    ks = [1, 32, 2, 17, 16, 5, 31, 8]
+    ks = [1, 32, 2, 17, 16, 5, 31, 8, 40, 64, 33]
     seeds = list(range(11, 11 + len(ks)))
     H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=60, warn=False)
     for k, s, h, n in zip(ks, seeds, H, n_iter):
@@ -78,3 +79,21 @@ def test_set_matrix_twice_and_shapes(engine):
     assert H[0].shape == (4, 77)
     with pytest.raises(ValueError):
         engine.nnls(np.ones((3, 20)))                       # H for the old gene count
+
+
+def test_large_rank_refit_and_mu(engine):
+    """Ranks above 32 through the NNLS refit and the KL multiplicative-update solver."""
+    from oracle import nmf_mu
+    X = _x(350, 160, seed=12)
+    engine.set_matrix(X)
+    _, H, _ = nmf_cd.nmf(X, 40, seed=3, max_iter=40)
+    W_ref, n_ref = nmf_cd.nnls(X, H, max_iter=100)
+    W, n = engine.nnls(H, max_iter=100, warn=False)
+    assert abs(n - n_ref) <= 2 and np.abs(W - W_ref).max() <= 2e-3 * np.abs(W_ref).max()
+    W_ref, H_ref, n_ref = nmf_mu.nmf_mu(X, 36, seed=4, max_iter=50)
+    Hm, Wm, nm, _ = engine.nmf_mu_batch([36], seeds=[4], max_iter=50, return_W=True, warn=False)
+    assert int(nm[0]) == n_ref
+    R, R_ref = Wm[0].astype(np.float64) @ Hm[0], W_ref @ H_ref
+    assert np.abs(R - R_ref).max() <= 2e-3 * np.abs(R_ref).max()
+    with pytest.raises(NotImplementedError):
+        engine.nmf_mu_batch([40], seeds=[1], beta_loss="itakura-saito", max_iter=5)

@@ -151,7 +151,7 @@ def test_rank_above_kmax_is_rejected(engine):
     X64 = synth.make_config("C1", dtype=np.float64, n_cells=300)
     engine.set_matrix(X64)
     with pytest.raises(NotImplementedError):
-        engine.nmf_batch([40], seeds=[1])
+        engine.nmf_batch([65], seeds=[1])
 
 
 def test_negative_input_raises(engine):
