@@ -124,14 +124,6 @@ static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int l
         case 3:  // 2x2
             if (KC % 128 == 0) GO(2, 2, 2);
             GO(1, 2, 2);
-        case 5:   // T8: one workgroup owns all 256 components (X tile read once), 1 workgroup per CU
-            if (KC % 256 == 0)
-                return launch_gemm_t<8, 1, 4, NN>(st, A, lda, B, ldb, C, ldc, cstride, KC, Ktot, J, nsplit);
-            [[fallthrough]];
-        case 4:   // T with 16-deep stages (half the LDS per workgroup -> 3-4 workgroups per CU)
-            if (KC % 128 == 0)
-                return launch_gemm_t<4, 1, 4, NN, 16>(st, A, lda, B, ldb, C, ldc, cstride, KC, Ktot, J, nsplit);
-            [[fallthrough]];
         default:  // T: every wave all comps of the M group, 128 j
             if (KC % 128 == 0) GO(4, 1, 4);
             if (KC % 64 == 0) GO(2, 1, 4);
@@ -174,10 +166,9 @@ static StreamK plan_streamk(int KC, int N_pad, int G_pad, int n_wg_slots)
 {
     StreamK sk;
     if (KC % 128 != 0 || getenv("CNMF_NO_STREAMK")) return sk;
-    if (KC % 256 == 0 && getenv("CNMF_T8")) { sk.mw = 256; n_wg_slots /= 2; }   // 110 KB LDS: 1 workgroup per CU
     sk.MG = KC / sk.mw;
     sk.T = sk.MG * (N_pad / 128);
-    sk.nk = G_pad / (getenv("CNMF_BK16") ? 16 : BK);       // stages per tile, as the kernel counts them
+    sk.nk = G_pad / BK;                                    // stages per tile, as the kernel counts them
     sk.P = n_wg_slots;
     if (sk.T <= sk.P) sk.P = n_wg_slots / 2;              // one workgroup per CU
     if (sk.T <= sk.P || sk.T % sk.P == 0) return sk;      // nothing to balance
@@ -191,30 +182,19 @@ static StreamK plan_streamk(int KC, int N_pad, int G_pad, int n_wg_slots)
     return sk;
 }
 
-template <int TBK, int MTW = 4>
-static hipError_t launch_streamk_t(hipStream_t st, const StreamK& sk, const float* A, int lda,
-                                   const float* B, int ldb, float* C0, float* C1, int ldc, int Jtot, int stagger)
-{
-    constexpr size_t lds = gemm_lds_bytes<MTW, 1, 4, false, TBK>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_streamk_kernel<MTW, 1, 4, false, TBK>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    gemm_streamk_kernel<MTW, 1, 4, false, TBK><<<sk.P, 256, lds, st>>>(A, lda, B, ldb, C0, C1, ldc, sk.MG,
-                                                                      sk.T, sk.nk, Jtot, stagger);
-    return hipGetLastError();
-}
-
 static hipError_t launch_streamk_passA(hipStream_t st, const StreamK& sk, const float* A, int lda,
                                        const float* B, int ldb, float* C0, float* C1, int ldc, int Jtot)
 {
-    static const int bk16 = getenv("CNMF_BK16") ? 1 : 0;
-    static const int stagger = getenv("CNMF_STAGGER") ? 1 : 0;
-    if (sk.mw == 256) return launch_streamk_t<32, 8>(st, sk, A, lda, B, ldb, C0, C1, ldc, Jtot, stagger);
-    if (bk16) return launch_streamk_t<16>(st, sk, A, lda, B, ldb, C0, C1, ldc, Jtot, stagger);
-    return launch_streamk_t<32>(st, sk, A, lda, B, ldb, C0, C1, ldc, Jtot, stagger);
+    constexpr size_t lds = gemm_lds_bytes<4, 1, 4, false>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_streamk_kernel<4, 1, 4, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    gemm_streamk_kernel<4, 1, 4, false><<<sk.P, 256, lds, st>>>(A, lda, B, ldb, C0, C1, ldc, sk.MG, sk.T,
+                                                               sk.nk, Jtot);
+    return hipGetLastError();
 }
 
 static hipError_t launch_reduce_splits(hipStream_t st, float* P, int nsplit, long long split_stride,

@@ -213,16 +213,13 @@ __global__ __launch_bounds__(256) void gemm_streamk_kernel(
     const float* __restrict__ A, int lda,
     const float* __restrict__ B, int ldb,
     float* __restrict__ C0, float* __restrict__ C1, int ldc,
-    int MG, int T, int nk, int Jtot, int stagger)
+    int MG, int T, int nk, int Jtot)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int MW = WM * MTW * 32, JW = WN * 32;
     const long long U = (long long)T * nk;
     long long u = U * blockIdx.x / gridDim.x;
     const long long u1 = U * (blockIdx.x + 1) / gridDim.x;
-    // de-phase the two workgroups that share a CU so that their barrier / staging phases do not
-    // coincide (the matrix pipe idles when both are outside their MFMA phase)
-    if (stagger && (blockIdx.x & 256)) __builtin_amdgcn_s_sleep(127);
     while (u < u1) {
         const int tile = (int)(u / nk), kb = (int)(u % nk);
         const int ke = (int)min((long long)nk, kb + (u1 - u));

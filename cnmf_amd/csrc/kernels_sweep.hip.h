@@ -160,14 +160,14 @@ __device__ __forceinline__ void sweep_body(
 #pragma unroll
             for (int c = 0; c < GR; ++c) WS(wave, lane, c) = (c < KP) ? w[c < KP ? c : 0] : 0.f;
             __builtin_amdgcn_wave_barrier();       // wave-private tile: LDS ops of one wave are in order
-            if (GMODE == 0) {
+            if constexpr (GMODE == 0) {
                 const int li = lane & 15, q = lane >> 4;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const float a = WS(wave, 4 * s + q, li);
                     gacc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, gacc4, 0, 0, 0);
                 }
-            } else if (GMODE == 1) {
+            } else if constexpr (GMODE == 1) {
                 const int li = lane & 31, h = lane >> 5;
 #pragma unroll 8
                 for (int s = 0; s < 32; ++s) {
@@ -199,7 +199,7 @@ __device__ __forceinline__ void sweep_body(
     __syncthreads();
     float* gred = Wsb;                   // reused as [4][GR][GR+1]   (<= 4*64*(kg+1) floats)
     if (want_gram) {
-        if (GMODE == 0) {
+        if constexpr (GMODE == 0) {
             const int li = lane & 15, q = lane >> 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) gred[(wave * GR + 4 * q + r) * (GR + 1) + li] = gacc4[r];
