@@ -224,7 +224,8 @@ def main():
             "kernel": "gemm_kernel<NT> (pass A: X.Ht)" if dom == "A" else "gemm_kernel<NN> (pass B: Xt.W)",
             "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-            "traffic": pmc_traffic("passA" if dom == "A" else "passB"),
+            "traffic": (pmc_traffic("passA" if dom == "A" else "passB") or {}).get("hbm_bytes_per_launch"),
+            "traffic_detail": pmc_traffic("passA" if dom == "A" else "passB"),
             "avg_launch_ms": {"passA": agg["passA_ms"] / max(agg["nA"], 1), "passB": agg["passB_ms"] / max(agg["nB"], 1)},
             "achieved_passA": tfA, "achieved_passB": tfB,
             "alg_flops_per_launch": alg_flops_A / max(agg["nA"], 1),

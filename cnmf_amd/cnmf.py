@@ -272,8 +272,11 @@ class cNMF:
     # ------------------------------------------------------------------ factorize (cnmf.py:692-745)
     def factorize(self, worker_i=0, total_workers=1, skip_completed_runs=False, write_iter_files=True,
                   kc_max=0):
+        import time as _time
+        _t = [_time.perf_counter()]
         run_params = load_df_from_npz(self.paths["nmf_replicate_parameters"])
         norm_counts = self._load_norm_counts()
+        _t.append(_time.perf_counter())
         _nmf_kwargs = yaml.load(open(self.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
         self._check_kwargs(_nmf_kwargs)
         if not skip_completed_runs:
@@ -285,10 +288,12 @@ class cNMF:
             return
         eng = self._get_engine(norm_counts.values, ("norm_counts", self.paths["normalized_counts"],
                                                     os.path.getmtime(self.paths["normalized_counts"])))
-        ks = [int(run_params.iloc[idx]["n_components"]) for idx in jobs]
-        seeds = [int(run_params.iloc[idx]["nmf_seed"]) for idx in jobs]
-        for idx in jobs:
-            print("[Worker %d]. Starting task %d." % (worker_i, idx))
+        _t.append(_time.perf_counter())
+        sub = run_params.iloc[jobs]
+        ks = [int(v) for v in sub["n_components"].values]
+        seeds = [int(v) for v in sub["nmf_seed"].values]
+        its = [int(v) for v in sub["iter"].values]
+        print("\n".join("[Worker %d]. Starting task %d." % (worker_i, idx) for idx in jobs))
         common = dict(tol=_nmf_kwargs.get("tol", 1e-4), max_iter=_nmf_kwargs.get("max_iter", 1000),
                       alpha_W=_nmf_kwargs.get("alpha_W", 0.0), alpha_H=_nmf_kwargs.get("alpha_H", 0.0),
                       l1_ratio=_nmf_kwargs.get("l1_ratio", 0.0))
@@ -302,14 +307,16 @@ class cNMF:
         else:
             H_list, _, n_iter, _ = eng.nmf_batch(ks, kc_max=kc_max, **init_kw, **common)
             self.last_factorize_stats = dict(eng.last_stats, n_iter=n_iter)
+        _t.append(_time.perf_counter())
         xdt = norm_counts.values.dtype if norm_counts.values.dtype in (np.float32, np.float64) else np.float64
-        for idx, H in zip(jobs, H_list):
-            p = run_params.iloc[idx, :]
-            k, it = int(p["n_components"]), int(p["iter"])
+        for k, it, H in zip(ks, its, H_list):
             spectra = pd.DataFrame(H.astype(xdt), index=np.arange(1, k + 1), columns=norm_counts.columns)
             self.spectra_cache[(k, it)] = spectra
             if write_iter_files:
                 save_df_to_npz(spectra, self.paths["iter_spectra"] % (k, it))
+        _t.append(_time.perf_counter())
+        self.last_factorize_stats["host_seconds"] = dict(load_inputs=_t[1] - _t[0], upload=_t[2] - _t[1],
+                                                         device_call=_t[3] - _t[2], store_results=_t[4] - _t[3])
 
     # ------------------------------------------------------------------ combine (cnmf.py:462-483, 748-773)
     def combine(self, components=None, skip_missing_files=False):

@@ -29,39 +29,62 @@ __device__ __forceinline__ void mu_ratio(float x, float wh, float& r, float& d)
 
 // ---- W half-step: W[i][c] *= (num[i][c] / den)^gamma
 //   num[i][c] = sum_g R[i][g] Ht[g][c];  den = Hsum[c] (KL)  or  sum_g WH^-1 Ht[g][c] (IS)
-// block = 256 threads = 64 cells x 4 gene quarters; grid.x = ceil(N/64)
+// block = 256 threads = 64 cells x 4 gene quarters; grid.x = ceil(N/64).  X goes through an LDS
+// tile [64 cells][64 genes] (loaded coalesced, 256 B per row; read back one row per lane, stride 65
+// -> conflict-free) and the matching Ht tile [64 genes][KP] is read back as wave-wide broadcasts.
 template <int KP, bool BETA1>
 __global__ __launch_bounds__(256) void mu_w_kernel(const float* __restrict__ X, int ldx, int N, int G,
                                                    float* __restrict__ W, const float* __restrict__ Ht,
                                                    const float* __restrict__ Hsum, float l1, float l2)
 {
-    __shared__ float red[BETA1 ? 1 : 2][3][64][KP + 1];    // quarters 1..3 hand their sums to quarter 0
+    constexpr int XS = 64 * 65, HS = 64 * KP;
+    constexpr int RED = (BETA1 ? 1 : 2) * 3 * 64 * (KP + 1);
+    __shared__ __attribute__((aligned(16))) float lds[(XS + HS) > RED ? (XS + HS) : RED];
+    float* xs = lds;                 // [64][65]
+    float* hs = lds + XS;            // [64][KP]
     const int tid = threadIdx.x, ci = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave index: provably uniform
-    const int i = blockIdx.x * 64 + ci;
+    const int i0 = blockIdx.x * 64;
+    const int i = i0 + ci;
     const bool live = i < N;
     float w[KP], num[KP], den[KP];
 #pragma unroll
     for (int c = 0; c < KP; ++c) { w[c] = live ? W[(size_t)i * KP + c] : 0.f; num[c] = 0.f; den[c] = 0.f; }
-    // genes are split in four quarters (multiples of 4); X and Ht are zero padded to ldx columns,
-    // a padded gene contributes exactly 0 to num and den
-    const int gq = (((ldx + 3) / 4) + 3) / 4 * 4;
-    const int g_beg = q * gq, g_end = min(ldx, g_beg + gq);
-    const float* xrow = X + (size_t)(live ? i : 0) * ldx;
-    for (int g4 = g_beg; g4 < g_end; g4 += 4) {
-        const v4f xv = *reinterpret_cast<const v4f*>(xrow + g4);
+    const int lrow = tid >> 4, lc4 = (tid & 15) * 4;              // tile loader: 16 float4 per row
+    for (int g0 = 0; g0 < ldx; g0 += 64) {
+        // X and Ht are zero padded to ldx (a multiple of 32) columns / rows; a padded gene adds 0
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float* h = Ht + (size_t)(g4 + u) * KP;          // wave-uniform -> scalar loads
+        for (int j = 0; j < 4; ++j) {
+            const int r = lrow + 16 * j;
+            const int row = min(i0 + r, N - 1);
+            v4f v = v4f{0.f, 0.f, 0.f, 0.f};
+            if (g0 + lc4 < ldx) v = *reinterpret_cast<const v4f*>(X + (size_t)row * ldx + g0 + lc4);
+            float* d = xs + r * 65 + lc4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        for (int e = tid * 4; e < HS; e += 1024) {
+            const int g = g0 + e / KP;
+            v4f v = v4f{0.f, 0.f, 0.f, 0.f};
+            if (g < ldx) v = *reinterpret_cast<const v4f*>(Ht + (size_t)g0 * KP + e);
+            *reinterpret_cast<v4f*>(hs + e) = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int u = 0; u < 16; ++u) {
+            const int gl = q * 16 + u;
+            const float x = xs[ci * 65 + gl];
+            const float* h = hs + gl * KP;                        // same address for the whole wave
             float wh = 0.f;
 #pragma unroll
             for (int c = 0; c < KP; ++c) wh = fmaf(w[c], h[c], wh);
             float r, d;
-            mu_ratio<BETA1>(xv[u], wh, r, d);
+            mu_ratio<BETA1>(x, wh, r, d);
 #pragma unroll
             for (int c = 0; c < KP; ++c) { num[c] = fmaf(r, h[c], num[c]); if (!BETA1) den[c] = fmaf(d, h[c], den[c]); }
         }
+        __syncthreads();
     }
+    float (*red)[3][64][KP + 1] = reinterpret_cast<float (*)[3][64][KP + 1]>(lds);   // quarters 1..3 -> quarter 0
     if (q > 0) {
 #pragma unroll
         for (int c = 0; c < KP; ++c) { red[0][q - 1][ci][c] = num[c]; if (!BETA1) red[BETA1 ? 0 : 1][q - 1][ci][c] = den[c]; }
@@ -99,9 +122,27 @@ __global__ __launch_bounds__(256) void mu_h_partial_kernel(const float* __restri
 #pragma unroll
     for (int c = 0; c < KP; ++c) { h[c] = live ? Ht[(size_t)g * KP + c] : 0.f; num[c] = 0.f; den[c] = 0.f; }
     const int ib = blockIdx.y * rows_per_chunk, ie = min(N, ib + rows_per_chunk);
-    for (int i = ib; i < ie; ++i) {
+    const int gc = live ? g : 0;
+    int i = ib;
+    for (; i + 4 <= ie; i += 4) {                         // 4 cells per trip: loads issued before use
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = X[(size_t)(i + u) * ldx + gc];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* wr = W + (size_t)(i + u) * KP;   // wave-uniform -> scalar loads
+            float wh = 0.f;
+#pragma unroll
+            for (int c = 0; c < KP; ++c) wh = fmaf(wr[c], h[c], wh);
+            float r, d;
+            mu_ratio<BETA1>(live ? x[u] : 0.f, wh, r, d);
+#pragma unroll
+            for (int c = 0; c < KP; ++c) { num[c] = fmaf(r, wr[c], num[c]); if (!BETA1) den[c] = fmaf(d, wr[c], den[c]); }
+        }
+    }
+    for (; i < ie; ++i) {
         const float x = live ? X[(size_t)i * ldx + g] : 0.f;
-        const float* wr = W + (size_t)i * KP;             // wave-uniform
+        const float* wr = W + (size_t)i * KP;
         float wh = 0.f;
 #pragma unroll
         for (int c = 0; c < KP; ++c) wh = fmaf(wr[c], h[c], wh);
@@ -145,20 +186,34 @@ __global__ void mu_h_finish_kernel(float* __restrict__ Ht, int G, const float* _
     Ht[e] = v;
 }
 
-// column sums: out[c] = sum_r M[r][c] for M [R][KP]   (Hsum over genes, Wsum over cells), one block
+// column sums: out[c] = sum_r M[r][c] for M [R][KP]   (Hsum over genes, Wsum over cells).
+// Two levels, fixed order: `nb` blocks write partial sums [nb][KP], block 0 of the second launch adds them.
 template <int KP>
-__global__ __launch_bounds__(256) void mu_colsum_kernel(const float* __restrict__ M, int R, float* __restrict__ out)
+__global__ __launch_bounds__(256) void mu_colsum_part_kernel(const float* __restrict__ M, int R, double* __restrict__ part)
 {
-    __shared__ double red[256];
-    for (int c = 0; c < KP; ++c) {
-        double s = 0.0;
-        for (int r = threadIdx.x; r < R; r += 256) s += (double)M[(size_t)r * KP + c];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-        if (threadIdx.x == 0) out[c] = (float)red[0];
-        __syncthreads();
+    __shared__ double red[256 / KP > 0 ? 256 / KP : 1][KP];
+    constexpr int RG = 256 / KP;                  // row groups per block (KP = 8,16,32,64 -> 32,16,8,4)
+    const int c = threadIdx.x % KP, rg = threadIdx.x / KP;
+    const int per = (R + gridDim.x - 1) / gridDim.x;
+    const int rb = blockIdx.x * per, re = min(R, rb + per);
+    double s = 0.0;
+    for (int r = rb + rg; r < re; r += RG) s += (double)M[(size_t)r * KP + c];
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0) {
+        double t = 0.0;
+        for (int q = 0; q < RG; ++q) t += red[q][c];
+        part[(size_t)blockIdx.x * KP + c] = t;
     }
+}
+template <int KP>
+__global__ void mu_colsum_final_kernel(const double* __restrict__ part, int nb, float* __restrict__ out)
+{
+    const int c = threadIdx.x;
+    if (c >= KP) return;
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += part[(size_t)b * KP + c];
+    out[c] = (float)t;
 }
 
 // ---- beta divergence partials (sklearn _nmf.py:84-194), entries with X > EPSILON only:

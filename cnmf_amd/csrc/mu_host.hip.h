@@ -12,7 +12,8 @@ namespace cnmf {
 template <int KP, bool BETA1>
 static int mu_run_one(cnmf_ctx* ctx, hipStream_t st, int N, int G, int k, float* dW, float* dHt,
                       float* dHsum, float* dWsum, float* pnum, float* pden, int nchunks, int rpc,
-                      double* dpart, int update_H, const cnmf_cd_params* prm, int* n_iter_out, double* err_out)
+                      double* dpart, double* dcs, int update_H, const cnmf_cd_params* prm, int* n_iter_out,
+                      double* err_out)
 {
     const int ldx = ctx->G_pad;
     const dim3 gW((N + 63) / 64), gH((G + 255) / 256, nchunks);
@@ -20,9 +21,14 @@ static int mu_run_one(cnmf_ctx* ctx, hipStream_t st, int N, int G, int k, float*
     const int npart = (int)(gH.x * gH.y);
     std::vector<double> hpart(npart);
     float hs[2][KP];
+    auto colsum = [&](const float* M, int R, float* out) {
+        const int nb = std::max(1, std::min(256, R / 256));
+        mu_colsum_part_kernel<KP><<<nb, 256, 0, st>>>(M, R, dcs);
+        mu_colsum_final_kernel<KP><<<1, 64, 0, st>>>(dcs, nb, out);
+    };
     auto divergence = [&](double* err) -> int {
-        mu_colsum_kernel<KP><<<1, 256, 0, st>>>(dHt, G, dHsum);
-        mu_colsum_kernel<KP><<<1, 256, 0, st>>>(dW, N, dWsum);
+        colsum(dHt, G, dHsum);
+        colsum(dW, N, dWsum);
         mu_divergence_kernel<KP, BETA1><<<gH, 256, 0, st>>>(ctx->X, ldx, N, G, dW, dHt, rpc, dpart);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(hpart.data(), dpart, (size_t)npart * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -45,10 +51,10 @@ static int mu_run_one(cnmf_ctx* ctx, hipStream_t st, int N, int G, int k, float*
     int it = 0;
     bool hsum_valid = false;
     for (it = 1; it <= prm->max_iter; ++it) {
-        if (BETA1 && !hsum_valid) { mu_colsum_kernel<KP><<<1, 256, 0, st>>>(dHt, G, dHsum); hsum_valid = true; }
+        if (BETA1 && !hsum_valid) { colsum(dHt, G, dHsum); hsum_valid = true; }
         mu_w_kernel<KP, BETA1><<<gW, 256, 0, st>>>(ctx->X, ldx, N, G, dW, dHt, dHsum, l1W, l2W);
         if (update_H) {
-            if (BETA1) mu_colsum_kernel<KP><<<1, 256, 0, st>>>(dW, N, dWsum);
+            if (BETA1) colsum(dW, N, dWsum);
             mu_h_partial_kernel<KP, BETA1><<<gH, 256, 0, st>>>(ctx->X, ldx, N, G, dW, dHt, rpc, pnum, pden);
             mu_h_finish_kernel<KP, BETA1><<<nfin, 256, 0, st>>>(dHt, G, pnum, pden, nchunks, dWsum, l1H, l2H);
             hsum_valid = false;
@@ -106,6 +112,7 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
         float* pnum = rp.get<float>((size_t)nchunks * G * KP);
         float* pden = rp.get<float>(beta == 0 ? (size_t)nchunks * G * KP : 1);
         double* dpart = rp.get<double>((size_t)((G + 255) / 256) * nchunks);
+        double* dcs = rp.get<double>((size_t)256 * 64);
         float* cmH = rp.get<float>((size_t)k * G);
         float* cmW = rp.get<float>((size_t)k * N);
         if (rp.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
@@ -132,12 +139,12 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
         int nit = 0; double err = 0.0;
 #define MU_GO(KP_)                                                                                             \
         rc = (beta == 1) ? mu_run_one<KP_, true>(ctx, st, N, G, k, dW, dHt, dHsum, dWsum, pnum, pden, nchunks, rpc, \
-                                                 dpart, update_H, prm, &nit, &err)                              \
+                                                 dpart, dcs, update_H, prm, &nit, &err)                              \
                          : mu_run_one<KP_, false>(ctx, st, N, G, k, dW, dHt, dHsum, dWsum, pnum, pden, nchunks, rpc, \
-                                                  dpart, update_H, prm, &nit, &err)
+                                                  dpart, dcs, update_H, prm, &nit, &err)
         if (KP == 8) { MU_GO(8); } else if (KP == 16) { MU_GO(16); } else if (KP == 32) { MU_GO(32); }
         else rc = mu_run_one<64, true>(ctx, st, N, G, k, dW, dHt, dHsum, dWsum, pnum, pden, nchunks, rpc, dpart,
-                                       update_H, prm, &nit, &err);
+                                       dcs, update_H, prm, &nit, &err);
 #undef MU_GO
         if (rc) return rc;
         if (H_out && update_H) {

@@ -32,6 +32,7 @@ res = dict(config="C3 north star: 50000 x 2000, K=5..13, n_iter=%d (%d restarts)
            stages=t, total_prepare_to_consensus_s=sum(v for k, v in t.items() if k != "synthesize_input_s"),
            restarts=9 * n_iter, restarts_per_s=9 * n_iter / t["factorize_s"],
            mean_iterations_per_restart=float(np.mean(st["n_iter"])), gpu_ms=st.get("gpu_ms"),
+           factorize_host_seconds=st.get("host_seconds"),
            k_selection=stats.to_dict(orient="list"))
 print(json.dumps(res))
 os.makedirs("gpurun_out", exist_ok=True)
