@@ -8,6 +8,7 @@
 // by the caller so that seeds match scikit-learn exactly (SURVEY.md "hard parts").
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -80,10 +81,21 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     const int L = 2 + (int)std::log((double)k);
     if (!uniforms) { SET_ERR(ctx, "uniforms (n_init x (1+(k-1)*(2+int(log k)))) is NULL"); return CNMF_EINVAL; }
     if (L > 8) { SET_ERR(ctx, "too many local trials"); return CNMF_EUNSUPPORTED; }
+    if (n_init > 64) { SET_ERR(ctx, "n_init > 64 is not supported"); return CNMF_EUNSUPPORTED; }
     if (!prm->skip_density && prm->n_neighbors < 1) { SET_ERR(ctx, "n_neighbors must be >= 1"); return CNMF_EINVAL; }
     if (!prm->skip_density && prm->n_neighbors + 1 > R) { SET_ERR(ctx, "n_neighbors+1 > number of spectra"); return CNMF_EINVAL; }
     CONS_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    const bool dbg = getenv("CNMF_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        hipStreamSynchronize(st);
+        const double t = now();
+        fprintf(stderr, "[cnmf consensus] %-28s %8.2f ms\n", what, t - t_prev);
+        t_prev = t;
+    };
     DevPool pool;
     const int ld = round_up(G, 16);
     const int Rp = round_up(R, 64);
@@ -95,6 +107,7 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
     CONS_TRY(hipMemcpyAsync(dS, spectra, (size_t)R * G * sizeof(double), hipMemcpyHostToDevice, st));
     l2_rows_kernel<<<R, 256, 0, st>>>(dS, R, G, dL2, ld, dsq);
+    lap("alloc + upload + l2");
 
     // ---- all-pairs distances + KNN local density (cnmf.py:891-898)
     const bool need_dist = !prm->skip_density || prm->want_silhouette || dist_out;
@@ -111,6 +124,7 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
             CONS_TRY(hipMemcpy2DAsync(dist_out, (size_t)R * sizeof(double), dD, (size_t)Rp * sizeof(double),
                                       (size_t)R * sizeof(double), R, hipMemcpyDeviceToHost, st));
     }
+    lap("distance matrix");
     if (!prm->skip_density) {
         double* ddens = pool.get<double>(R);
         if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
@@ -133,37 +147,44 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     if (Rk == 0) { SET_ERR(ctx, "Zero components remain after density filtering. Consider increasing density threshold"); return CNMF_ESTATE; }
     if (Rk < k) { SET_ERR(ctx, "n_samples=%d should be >= n_clusters=%d.", Rk, k); return CNMF_EINVAL; }
 
-    // ---- KMeans on the kept rows (cnmf.py:908-909; sklearn _kmeans.py:1427-1555)
+    lap("knn density + filter");
+    // ---- KMeans on the kept rows (cnmf.py:908-909; sklearn _kmeans.py:1427-1555), all inits batched
     const int Rkp = round_up(Rk, 64);
+    const int I = n_init;
+    const int MT = round_up(I * k, 64), MC = round_up(I * L, 64), MD = std::max(MT, MC);
+    const size_t ustride = 1 + (size_t)(k - 1) * L;
+    const KmDims kd{Rk, Rkp, G, ld, k, L};
     int* dkeep = pool.get<int>(Rk);
     double* dX = pool.get<double>((size_t)Rkp * ld, true, st);
     double* dxsq = pool.get<double>(Rkp, true, st);
     double* dmean = pool.get<double>(ld, true, st);
     double* dvar = pool.get<double>(ld, true, st);
-    double* dcA = pool.get<double>((size_t)64 * ld, true, st);
-    double* dcB = pool.get<double>((size_t)64 * ld, true, st);
-    double* dcand = pool.get<double>((size_t)64 * ld, true, st);
-    double* ddots = pool.get<double>((size_t)64 * Rkp, true, st);
-    double* dclosest = pool.get<double>(Rkp);
-    double* dcum = pool.get<double>(Rkp);
-    double* ddmin = pool.get<double>((size_t)8 * Rkp);
-    double* dcpot = pool.get<double>(8);
-    double* dcsq = pool.get<double>(64);
-    int* dlabels = pool.get<int>(Rkp);
-    const int rows_per_chunk = std::max(32, (Rk + 31) / 32);
+    double* dcA = pool.get<double>((size_t)MT * ld, true, st);
+    double* dcB = pool.get<double>((size_t)MT * ld, true, st);
+    double* dcand = pool.get<double>((size_t)MC * ld, true, st);
+    double* ddots = pool.get<double>((size_t)MD * Rkp, true, st);
+    double* dclosest = pool.get<double>((size_t)I * Rkp);
+    double* dcum = pool.get<double>((size_t)I * Rkp);
+    double* ddmin = pool.get<double>((size_t)I * 8 * Rkp);
+    double* dcpot = pool.get<double>((size_t)I * 8);
+    double* dcsq = pool.get<double>(MT);
+    int* dlabels = pool.get<int>((size_t)I * Rkp);
+    const int rows_per_chunk = std::max(64, (Rk + 15) / 16);
     const int nchunks = (Rk + rows_per_chunk - 1) / rows_per_chunk;
-    double* dpartial = pool.get<double>((size_t)nchunks * k * ld);
-    int* dpcount = pool.get<int>((size_t)nchunks * k);
-    double* dsums = pool.get<double>((size_t)k * ld);
-    int* dcounts = pool.get<int>(k);
-    double* ddist = pool.get<double>(Rkp);
-    int* dcids = pool.get<int>(64);
-    KmState* dst = pool.get<KmState>(1, true, st);
-    const size_t nu = (size_t)n_init * (1 + (size_t)(k - 1) * L);
+    double* dpartial = pool.get<double>((size_t)I * nchunks * k * ld);
+    int* dpcount = pool.get<int>((size_t)I * nchunks * k);
+    double* dsums = pool.get<double>((size_t)I * k * ld);
+    int* dcounts = pool.get<int>((size_t)I * k);
+    double* ddist = pool.get<double>((size_t)I * Rkp);
+    int* dcids = pool.get<int>((size_t)I * 64);
+    int* dc0 = pool.get<int>(I);
+    int* dneed = pool.get<int>(I);
+    KmState* dst = pool.get<KmState>(I, true, st);
+    const size_t nu = (size_t)I * ustride;
     double* du = pool.get<double>(nu);
     KmState* hst = nullptr;
     if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
-    CONS_TRY(hipHostMalloc(&hst, sizeof(KmState)));
+    CONS_TRY(hipHostMalloc(&hst, sizeof(KmState) * I));
     struct HostFree { void* p; ~HostFree() { hipHostFree(p); } } hf{hst};
     CONS_TRY(hipMemcpyAsync(dkeep, keep_idx.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
     CONS_TRY(hipMemcpyAsync(du, uniforms, nu * sizeof(double), hipMemcpyHostToDevice, st));
@@ -179,67 +200,88 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
 
     const size_t acc_lds = (size_t)k * 256 * sizeof(double);
     CONS_TRY(hipFuncSetAttribute((const void*)accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
-    auto dots = [&](const double* A) {     // ddots[64][Rkp] = A[64][ld] . X^T
-        dgemm_nt_small_kernel<<<dim3(Rkp / 16, 1), 256, 0, st>>>(A, ld, dX, ld, ddots, Rkp, ld);
+    auto dots = [&](const double* A, int M) {     // ddots[M][Rkp] = A[M][ld] . X^T  (one product for every init)
+        dgemm_nt_small_kernel<<<dim3(Rkp / 16, M / 64), 256, 0, st>>>(A, ld, dX, ld, ddots, Rkp, ld);
     };
+    lap("kmeans setup (gather, stats)");
 
+    // -- k-means++ for all inits in lock step (sklearn _kmeans.py:174-272)
+    std::vector<int> c0(I);
+    for (int i = 0; i < I; ++i) c0[i] = std::min(first_center_index(Rk, uniforms[(size_t)i * ustride]), Rk - 1);
+    CONS_TRY(hipMemcpyAsync(dc0, c0.data(), (size_t)I * sizeof(int), hipMemcpyHostToDevice, st));
+    pp_seed_kernel<<<dim3((ld + 255) / 256, I), 256, 0, st>>>(dX, kd, dc0, dcA, dcids);
+    dots(dcA, MT);
+    pp_first_kernel<<<I, 256, 0, st>>>(ddots, kd, dxsq, dc0, dclosest, dst);
+    for (int c = 1; c < k; ++c) {
+        pp_candidates_kernel<<<I, 256, 0, st>>>(dclosest, kd, du, (int)ustride, 1 + (c - 1) * L, dcum, dst);
+        pp_gather_kernel<<<dim3((G + 255) / 256, L, I), 256, 0, st>>>(dX, kd, dst, dcand);
+        dots(dcand, MC);
+        pp_update_kernel<<<dim3(L, I), 256, 0, st>>>(ddots, kd, dxsq, dclosest, dst, ddmin, dcpot);
+        pp_pick_kernel<<<I, 256, 0, st>>>(dcpot, kd, ddmin, dclosest, dst, dX, dcA, c, dcids);
+    }
+    CONS_TRY(hipGetLastError());
+    lap("kmeans++ (all inits)");
+
+    // -- Lloyd for all inits in lock step; an init leaves the loop at its own iteration (sklearn _kmeans.py:624-752)
+    double* cur = dcA; double* nxt = dcB;
+    CONS_TRY(hipMemsetAsync(dlabels, 0xff, (size_t)I * Rkp * sizeof(int), st));          // labels = -1
+    std::vector<char> done(I, 0), strict(I, 0);
+    std::vector<int> iters(I, 0);
+    int n_done = 0;
+    for (int it = 0; it < max_iter && n_done < I; ++it) {
+        center_norms_kernel<<<I * k, 256, 0, st>>>(cur, ld, G, dcsq);
+        dots(cur, MT);
+        km_reset_kernel<<<1, 64, 0, st>>>(dst, I);
+        assign_kernel<<<dim3((Rk + 255) / 256, I), 256, 0, st>>>(ddots, kd, dcsq, dlabels, dst, 0, nullptr);
+        accumulate_kernel<<<dim3((G + 255) / 256, nchunks, I), 256, acc_lds, st>>>(dX, kd, dlabels, rows_per_chunk, nchunks, dpartial, dpcount, dst);
+        reduce_partial_kernel<<<dim3((G + 255) / 256, k, I), 256, 0, st>>>(dpartial, dpcount, nchunks, kd, dsums, dcounts, dst);
+        row_center_dist_kernel<<<dim3(Rk, I), 256, 0, st>>>(dX, kd, cur, dlabels, ddist, dst, 0);
+        relocate_empty_kernel<<<I, 256, 0, st>>>(dX, kd, dlabels, ddist, dsums, dcounts, dst);
+        finish_centers_kernel<<<I, 256, 0, st>>>(dsums, dcounts, kd, cur, nxt, dst);
+        CONS_TRY(hipGetLastError());
+        CONS_TRY(hipMemcpyAsync(hst, dst, sizeof(KmState) * I, hipMemcpyDeviceToHost, st));
+        CONS_TRY(hipStreamSynchronize(st));
+        std::swap(cur, nxt);
+        bool any_new = false;
+        for (int i = 0; i < I; ++i) {
+            if (done[i]) continue;
+            iters[i] = it + 1;
+            if (hst[i].changed == 0) { strict[i] = 1; done[i] = 1; }
+            else if (hst[i].shift_tot <= tol_) done[i] = 1;
+            if (done[i]) { hst[i].done = 1; ++n_done; any_new = true; }
+        }
+        if (any_new)      // publish the done flags (only that field changes; the device copy is otherwise current)
+            for (int i = 0; i < I; ++i)
+                if (done[i]) CONS_TRY(hipMemcpyAsync(&dst[i].done, &hst[i].done, sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    // inits that stopped on the tolerance (or max_iter) re-run the E step so labels match the final centres
+    std::vector<int> need(I, 0);
+    bool any_need = false;
+    for (int i = 0; i < I; ++i) { need[i] = strict[i] ? 0 : 1; any_need |= need[i] != 0; }
+    if (any_need) {
+        CONS_TRY(hipMemcpyAsync(dneed, need.data(), (size_t)I * sizeof(int), hipMemcpyHostToDevice, st));
+        center_norms_kernel<<<I * k, 256, 0, st>>>(cur, ld, G, dcsq);
+        dots(cur, MT);
+        assign_kernel<<<dim3((Rk + 255) / 256, I), 256, 0, st>>>(ddots, kd, dcsq, dlabels, dst, 1, dneed);
+    }
+    row_center_dist_kernel<<<dim3(Rk, I), 256, 0, st>>>(dX, kd, cur, dlabels, ddist, dst, 1);
+    inertia_kernel<<<I, 256, 0, st>>>(ddist, kd, dst);
+    CONS_TRY(hipGetLastError());
+    std::vector<int> all_labels((size_t)I * Rkp);
+    CONS_TRY(hipMemcpyAsync(hst, dst, sizeof(KmState) * I, hipMemcpyDeviceToHost, st));
+    CONS_TRY(hipMemcpyAsync(all_labels.data(), dlabels, all_labels.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    CONS_TRY(hipStreamSynchronize(st));
+    // best-of-n_init in init order (sklearn _kmeans.py:1525-1533)
     std::vector<int> best_labels, labels(Rk);
     double best_inertia = 0.0; int best_iter = 0; bool have_best = false;
-    for (int init = 0; init < n_init; ++init) {
-        const double* hu = uniforms + (size_t)init * (1 + (size_t)(k - 1) * L);
-        const double* dui = du + (size_t)init * (1 + (size_t)(k - 1) * L);
-        // -- k-means++ (sklearn _kmeans.py:174-272)
-        const int c0 = std::min(first_center_index(Rk, hu[0]), Rk - 1);
-        CONS_TRY(hipMemsetAsync(dcA, 0, (size_t)64 * ld * sizeof(double), st));
-        copy_row_kernel<<<(ld + 255) / 256, 256, 0, st>>>(dX, ld, G, c0, dcA, 0);
-        dots(dcA);
-        pp_first_kernel<<<1, 256, 0, st>>>(ddots, Rk, dxsq, c0, dclosest, dst);
-        for (int c = 1; c < k; ++c) {
-            pp_candidates_kernel<<<1, 256, 0, st>>>(dclosest, Rk, dui + 1 + (size_t)(c - 1) * L, L, dcum, dst);
-            gather_rows_kernel<<<dim3((G + 255) / 256, L), 256, 0, st>>>(dX, ld, &dst->cand[0], L, G, dcand, ld);
-            dots(dcand);
-            pp_update_kernel<<<L, 256, 0, st>>>(ddots, Rkp, Rk, dxsq, dclosest, dst, ddmin, dcpot);
-            pp_pick_kernel<<<1, 256, 0, st>>>(dcpot, L, Rk, ddmin, dclosest, dst, dX, ld, G, dcA, c, dcids);
-        }
-        CONS_TRY(hipGetLastError());
-        // -- Lloyd (sklearn _kmeans.py:624-752)
-        double* cur = dcA; double* nxt = dcB;
-        CONS_TRY(hipMemsetAsync(dlabels, 0xff, (size_t)Rkp * sizeof(int), st));     // labels = -1
-        bool strict = false; int it = 0;
-        for (it = 0; it < max_iter; ++it) {
-            center_norms_kernel<<<k, 256, 0, st>>>(cur, ld, G, dcsq);
-            dots(cur);
-            CONS_TRY(hipMemsetAsync(&dst->changed, 0, 2 * sizeof(int), st));         // changed, n_empty
-            assign_kernel<<<(Rk + 255) / 256, 256, 0, st>>>(ddots, Rkp, Rk, k, dcsq, dlabels, dst, 1);
-            accumulate_kernel<<<dim3((G + 255) / 256, nchunks), 256, acc_lds, st>>>(dX, ld, Rk, G, dlabels, k, rows_per_chunk, dpartial, dpcount);
-            reduce_partial_kernel<<<dim3((G + 255) / 256, k), 256, 0, st>>>(dpartial, dpcount, nchunks, k, ld, G, dsums, dcounts, dst);
-            row_center_dist_kernel<<<Rk, 256, 0, st>>>(dX, ld, G, cur, dlabels, ddist, dst);
-            relocate_empty_kernel<<<1, 256, 0, st>>>(dX, ld, G, Rk, k, dlabels, ddist, dsums, dcounts, dst);
-            finish_centers_kernel<<<1, 256, 0, st>>>(dsums, dcounts, k, ld, G, cur, nxt, dst);
-            CONS_TRY(hipGetLastError());
-            CONS_TRY(hipMemcpyAsync(hst, dst, sizeof(KmState), hipMemcpyDeviceToHost, st));
-            CONS_TRY(hipStreamSynchronize(st));
-            std::swap(cur, nxt);
-            if (hst->changed == 0) { strict = true; break; }
-            if (hst->shift_tot <= tol_) break;
-        }
-        const int n_it = std::min(it + 1, max_iter);
-        if (!strict) {      // re-run the E step so that labels match the final centres
-            center_norms_kernel<<<k, 256, 0, st>>>(cur, ld, G, dcsq);
-            dots(cur);
-            assign_kernel<<<(Rk + 255) / 256, 256, 0, st>>>(ddots, Rkp, Rk, k, dcsq, dlabels, dst, 0);
-        }
-        row_center_dist_kernel<<<Rk, 256, 0, st>>>(dX, ld, G, cur, dlabels, ddist, nullptr);
-        sum_kernel<<<1, 256, 0, st>>>(ddist, Rk, &dst->inertia);
-        CONS_TRY(hipGetLastError());
-        CONS_TRY(hipMemcpyAsync(hst, dst, sizeof(KmState), hipMemcpyDeviceToHost, st));
-        CONS_TRY(hipMemcpyAsync(labels.data(), dlabels, (size_t)Rk * sizeof(int), hipMemcpyDeviceToHost, st));
-        CONS_TRY(hipStreamSynchronize(st));
-        const double inertia = hst->inertia;
+    for (int i = 0; i < I; ++i) {
+        std::copy(all_labels.begin() + (size_t)i * Rkp, all_labels.begin() + (size_t)i * Rkp + Rk, labels.begin());
+        const double inertia = hst[i].inertia;
         if (!have_best || (inertia < best_inertia && !same_clustering(labels, best_labels, k))) {
-            best_labels = labels; best_inertia = inertia; best_iter = n_it; have_best = true;
+            best_labels = labels; best_inertia = inertia; best_iter = std::min(iters[i], max_iter); have_best = true;
         }
     }
+    lap("kmeans (all inits)");
     for (int q = 0; q < Rk; ++q) labels_out[keep_idx[q]] = best_labels[q];
 
     // ---- per-cluster per-gene median, rows normalised to sum 1 (cnmf.py:913-916)
@@ -270,6 +312,7 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     CONS_TRY(hipGetLastError());
     CONS_TRY(hipMemcpyAsync(median_out, dmed, (size_t)k * G * sizeof(double), hipMemcpyDeviceToHost, st));
 
+    lap("medians");
     // ---- silhouette (cnmf.py:923)
     double sil = 0.0;
     if (prm->want_silhouette) {

@@ -278,7 +278,11 @@ __global__ __launch_bounds__(256) void center_rows_kernel(double* __restrict__ X
     if (threadIdx.x == 0) sq[r] = s;
 }
 
-// ---------------------------------------------------------------- k-means++
+// ---------------------------------------------------------------- k-means (all inits batched)
+// The n_init runs of KMeans are independent given their random draws (whose count is data
+// independent), so every kernel below processes ALL inits at once: blockIdx.z (or .y / .x where
+// noted) is the init index.  Per-init arrays are laid out [init][...]; centre rows of init i are
+// rows [i*k, (i+1)*k) of one tall matrix so that ONE f64 MFMA product serves every init.
 struct KmState {          // device-resident scalars of one k-means run
     double pot;           // current potential
     double shift_tot;     // sum_j |new_j - old_j|^2 of the last Lloyd step
@@ -287,110 +291,134 @@ struct KmState {          // device-resident scalars of one k-means run
     int n_empty;
     int cand[8];          // candidate row ids of the current k-means++ step
     int best;
-    int pad_;
+    int done;             // Lloyd loop finished for this init (host sets it)
 };
 
-// closest[r] = max(0, sq_c + sq_r - 2 dot[0][r]) for the first centre; pot = sum closest
-__global__ __launch_bounds__(256) void pp_first_kernel(const double* __restrict__ dots, int R,
-                                                       const double* __restrict__ sq, int c0,
+struct KmDims { int R, Rp, G, ld, k, L; };   // kept rows, padded rows, genes, padded genes, clusters, local trials
+
+// first centre: centers[init*k] = X[c0[init]]
+__global__ void pp_seed_kernel(const double* __restrict__ X, KmDims d, const int* __restrict__ c0,
+                               double* __restrict__ centers, int* __restrict__ center_ids)
+{
+    const int init = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < d.ld) centers[(size_t)(init * d.k) * d.ld + g] = (g < d.G) ? X[(size_t)c0[init] * d.ld + g] : 0.0;
+    if (g == 0) center_ids[init * 64] = c0[init];
+}
+
+// closest[r] = max(0, sq_c + sq_r - 2 dot[centre 0][r]); pot = sum closest          grid = n_init
+__global__ __launch_bounds__(256) void pp_first_kernel(const double* __restrict__ dots, KmDims d,
+                                                       const double* __restrict__ sq, const int* __restrict__ c0,
                                                        double* __restrict__ closest, KmState* st)
 {
     __shared__ double red[4];
+    const int init = blockIdx.x;
+    const double* drow = dots + (size_t)(init * d.k) * d.Rp;
+    double* cl = closest + (size_t)init * d.Rp;
+    const double sc = sq[c0[init]];
     double s = 0.0;
-    for (int r = threadIdx.x; r < R; r += 256) {
-        double d = -2.0 * dots[r];
-        d += sq[c0]; d += sq[r];
-        d = fmax(d, 0.0);
-        closest[r] = d;
-        s += d;
+    for (int r = threadIdx.x; r < d.R; r += 256) {
+        double v = -2.0 * drow[r];
+        v += sc; v += sq[r];
+        v = fmax(v, 0.0);
+        cl[r] = v;
+        s += v;
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) st->pot = s;
+    if (threadIdx.x == 0) st[init].pot = s;
 }
 
-// cumulative sum of closest[] (sequential order like np.cumsum) + searchsorted of L random
-// values u[j]*pot (side='left'), clipped to R-1.  Single workgroup; chunked serial scan.
-__global__ __launch_bounds__(256) void pp_candidates_kernel(const double* __restrict__ closest, int R,
-                                                            const double* __restrict__ u, int L,
+// cumulative sum of closest[] (chunked serial scan, like np.cumsum up to rounding) + searchsorted of
+// the L random values u*pot (side='left'), clipped to R-1.                             grid = n_init
+__global__ __launch_bounds__(256) void pp_candidates_kernel(const double* __restrict__ closest, KmDims d,
+                                                            const double* __restrict__ u, int ustride, int uoff,
                                                             double* __restrict__ cum, KmState* st)
 {
     __shared__ double part[256];
-    const int tid = threadIdx.x;
+    const int init = blockIdx.x, tid = threadIdx.x, R = d.R;
+    const double* cl = closest + (size_t)init * d.Rp;
+    double* cm = cum + (size_t)init * d.Rp;
     const int per = (R + 255) / 256;
     const int b = tid * per, e = min(b + per, R);
     double s = 0.0;
-    for (int r = b; r < e; ++r) s += closest[r];
+    for (int r = b; r < e; ++r) s += cl[r];
     part[tid] = s;
     __syncthreads();
     if (tid == 0) { double run = 0.0; for (int t = 0; t < 256; ++t) { const double v = part[t]; part[t] = run; run += v; } }
     __syncthreads();
     double run = part[tid];
-    for (int r = b; r < e; ++r) { run += closest[r]; cum[r] = run; }
+    for (int r = b; r < e; ++r) { run += cl[r]; cm[r] = run; }
     __syncthreads();
-    __threadfence_block();
-    if (tid < L) {
-        const double v = u[tid] * st->pot;
+    if (tid < d.L) {
+        const double v = u[(size_t)init * ustride + uoff + tid] * st[init].pot;
         int lo = 0, hi = R;                       // first index with cum[idx] >= v
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cum[mid] < v) lo = mid + 1; else hi = mid; }
-        st->cand[tid] = min(lo, R - 1);
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cm[mid] < v) lo = mid + 1; else hi = mid; }
+        st[init].cand[tid] = min(lo, R - 1);
     }
 }
 
-// dmin[j][r] = min(closest[r], max(0, sq_cand_j + sq_r - 2 dots[j][r]));  cpot[j] = sum_r dmin[j][r]
-__global__ __launch_bounds__(256) void pp_update_kernel(const double* __restrict__ dots, int ldd, int R,
+// candidate rows of every init into one tall matrix: cand[init*L + j] = X[st[init].cand[j]]   grid (G/256, L, n_init)
+__global__ void pp_gather_kernel(const double* __restrict__ X, KmDims d, const KmState* __restrict__ st,
+                                 double* __restrict__ cand)
+{
+    const int init = blockIdx.z, j = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < d.G) cand[(size_t)(init * d.L + j) * d.ld + g] = X[(size_t)st[init].cand[j] * d.ld + g];
+}
+
+// dmin[init][j][r] = min(closest[r], max(0, sq_cand + sq_r - 2 dots[init*L+j][r])); cpot = sum   grid (L, n_init)
+__global__ __launch_bounds__(256) void pp_update_kernel(const double* __restrict__ dots, KmDims d,
                                                         const double* __restrict__ sq,
                                                         const double* __restrict__ closest,
-                                                        const KmState* st, double* __restrict__ dmin,
+                                                        const KmState* __restrict__ st, double* __restrict__ dmin,
                                                         double* __restrict__ cpot)
 {
     __shared__ double red[4];
-    const int j = blockIdx.x;
-    const int c = st->cand[j];
+    const int j = blockIdx.x, init = blockIdx.y;
+    const int c = st[init].cand[j];
+    const double* drow = dots + (size_t)(init * d.L + j) * d.Rp;
+    const double* cl = closest + (size_t)init * d.Rp;
+    double* dm = dmin + ((size_t)init * 8 + j) * d.Rp;
     double s = 0.0;
-    for (int r = threadIdx.x; r < R; r += 256) {
-        double d = -2.0 * dots[(size_t)j * ldd + r];
-        d += sq[c]; d += sq[r];
-        d = fmax(d, 0.0);
-        d = fmin(closest[r], d);
-        dmin[(size_t)j * R + r] = d;
-        s += d;
+    for (int r = threadIdx.x; r < d.R; r += 256) {
+        double v = -2.0 * drow[r];
+        v += sq[c]; v += sq[r];
+        v = fmax(v, 0.0);
+        v = fmin(cl[r], v);
+        dm[r] = v;
+        s += v;
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) cpot[j] = s;
+    if (threadIdx.x == 0) cpot[init * 8 + j] = s;
 }
 
-// choose the candidate with the smallest potential (first min), make it centre `c`
-__global__ __launch_bounds__(256) void pp_pick_kernel(const double* __restrict__ cpot, int L, int R,
+// choose the candidate with the smallest potential (first min), make it centre `c`      grid = n_init
+__global__ __launch_bounds__(256) void pp_pick_kernel(const double* __restrict__ cpot, KmDims d,
                                                       const double* __restrict__ dmin,
                                                       double* __restrict__ closest, KmState* st,
-                                                      const double* __restrict__ X, int ld, int G,
+                                                      const double* __restrict__ X,
                                                       double* __restrict__ centers, int c,
                                                       int* __restrict__ center_ids)
 {
     __shared__ int best_s;
+    const int init = blockIdx.x;
     if (threadIdx.x == 0) {
         int best = 0;
-        for (int j = 1; j < L; ++j) if (cpot[j] < cpot[best]) best = j;
+        for (int j = 1; j < d.L; ++j) if (cpot[init * 8 + j] < cpot[init * 8 + best]) best = j;
         best_s = best;
-        st->pot = cpot[best];
-        st->best = st->cand[best];
-        center_ids[c] = st->cand[best];
+        st[init].pot = cpot[init * 8 + best];
+        st[init].best = st[init].cand[best];
+        center_ids[init * 64 + c] = st[init].cand[best];
     }
     __syncthreads();
-    const int best = best_s, row = st->cand[best];
-    for (int r = threadIdx.x; r < R; r += 256) closest[r] = dmin[(size_t)best * R + r];
-    for (int g = threadIdx.x; g < ld; g += 256) centers[(size_t)c * ld + g] = (g < G) ? X[(size_t)row * ld + g] : 0.0;
-}
-
-__global__ void copy_row_kernel(const double* __restrict__ X, int ld, int G, int row,
-                                double* __restrict__ centers, int c)
-{
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < ld) centers[(size_t)c * ld + g] = (g < G) ? X[(size_t)row * ld + g] : 0.0;
+    const int best = best_s, row = st[init].cand[best];
+    const double* dm = dmin + ((size_t)init * 8 + best) * d.Rp;
+    double* cl = closest + (size_t)init * d.Rp;
+    for (int r = threadIdx.x; r < d.R; r += 256) cl[r] = dm[r];
+    double* cdst = centers + (size_t)(init * d.k + c) * d.ld;
+    for (int g = threadIdx.x; g < d.ld; g += 256) cdst[g] = (g < d.G) ? X[(size_t)row * d.ld + g] : 0.0;
 }
 
 // ---------------------------------------------------------------- Lloyd
-// csq[j] = |centers[j]|^2
+// csq[row] = |centers[row]|^2 for all n_init*k centre rows                             grid = n_init*k
 __global__ __launch_bounds__(256) void center_norms_kernel(const double* __restrict__ centers, int ld,
                                                            int G, double* __restrict__ csq)
 {
@@ -402,103 +430,129 @@ __global__ __launch_bounds__(256) void center_norms_kernel(const double* __restr
     if (threadIdx.x == 0) csq[j] = s;
 }
 
-// labels[r] = first argmin_j (csq[j] - 2 dots[j][r]); counts the labels that changed
-__global__ __launch_bounds__(256) void assign_kernel(const double* __restrict__ dots, int ldd, int R, int k,
-                                                     const double* __restrict__ csq,
-                                                     int* __restrict__ labels, KmState* st, int track)
+__global__ void km_reset_kernel(KmState* st, int n_init)
 {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_init) { st[i].changed = 0; st[i].n_empty = 0; }
+}
+
+// labels[r] = first argmin_j (csq[j] - 2 dots[j][r]); counts changed labels      grid (R/256, n_init)
+// mode 0: Lloyd E step of the inits that are not done; mode 1: final E step of the inits flagged in `need`
+__global__ __launch_bounds__(256) void assign_kernel(const double* __restrict__ dots, KmDims d,
+                                                     const double* __restrict__ csq,
+                                                     int* __restrict__ labels, KmState* st, int mode,
+                                                     const int* __restrict__ need)
+{
+    const int init = blockIdx.y;
+    if (mode == 0 ? st[init].done : !need[init]) return;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const double* dr = dots + (size_t)(init * d.k) * d.Rp;
+    const double* cs = csq + init * d.k;
+    int* lab = labels + (size_t)init * d.Rp;
     int ch = 0;
-    if (r < R) {
-        int best = 0; double bv = csq[0] - 2.0 * dots[r];
-        for (int j = 1; j < k; ++j) {
-            const double v = csq[j] - 2.0 * dots[(size_t)j * ldd + r];
+    if (r < d.R) {
+        int best = 0; double bv = cs[0] - 2.0 * dr[r];
+        for (int j = 1; j < d.k; ++j) {
+            const double v = cs[j] - 2.0 * dr[(size_t)j * d.Rp + r];
             if (v < bv) { bv = v; best = j; }
         }
-        ch = (labels[r] != best) ? 1 : 0;
-        labels[r] = best;
+        ch = (lab[r] != best) ? 1 : 0;
+        lab[r] = best;
     }
-    if (track) {
+    if (mode == 0) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ch += __shfl_xor(ch, o, 64);
-        if ((threadIdx.x & 63) == 0 && ch) atomicAdd(&st->changed, ch);
+        if ((threadIdx.x & 63) == 0 && ch) atomicAdd(&st[init].changed, ch);
     }
 }
 
-// partial[chunk][j][g] = sum over the chunk's rows with label j of X[r][g];  pcount[chunk][j]
-__global__ __launch_bounds__(256) void accumulate_kernel(const double* __restrict__ X, int ld, int R, int G,
-                                                         const int* __restrict__ labels, int k,
-                                                         int rows_per_chunk, double* __restrict__ partial,
-                                                         int* __restrict__ pcount)
+// partial[init][chunk][j][g] = sum over the chunk's rows with label j of X[r][g]   grid (G/256, nchunks, n_init)
+__global__ __launch_bounds__(256) void accumulate_kernel(const double* __restrict__ X, KmDims d,
+                                                         const int* __restrict__ labels,
+                                                         int rows_per_chunk, int nchunks,
+                                                         double* __restrict__ partial,
+                                                         int* __restrict__ pcount, const KmState* __restrict__ st)
 {
     extern __shared__ __attribute__((aligned(16))) double accs[];     // [k][256]
-    const int g = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
+    const int init = blockIdx.z;
+    if (st[init].done) return;
+    const int g = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y, k = d.k;
+    const int* lab = labels + (size_t)init * d.Rp;
     for (int j = 0; j < k; ++j) accs[j * 256 + threadIdx.x] = 0.0;
-    const int rb = chunk * rows_per_chunk, re = min(rb + rows_per_chunk, R);
-    if (g < G)
-        for (int r = rb; r < re; ++r) accs[labels[r] * 256 + threadIdx.x] += X[(size_t)r * ld + g];
-    if (g < G)
-        for (int j = 0; j < k; ++j) partial[((size_t)chunk * k + j) * ld + g] = accs[j * 256 + threadIdx.x];
-    if (blockIdx.x == 0 && threadIdx.x < k) {
+    const int rb = chunk * rows_per_chunk, re = min(rb + rows_per_chunk, d.R);
+    if (g < d.G)
+        for (int r = rb; r < re; ++r) accs[lab[r] * 256 + threadIdx.x] += X[(size_t)r * d.ld + g];
+    double* pp = partial + (((size_t)init * nchunks + chunk) * k) * d.ld;
+    if (g < d.G)
+        for (int j = 0; j < k; ++j) pp[(size_t)j * d.ld + g] = accs[j * 256 + threadIdx.x];
+    if (blockIdx.x == 0 && (int)threadIdx.x < k) {
         int c = 0;
-        for (int r = rb; r < re; ++r) c += (labels[r] == (int)threadIdx.x) ? 1 : 0;
-        pcount[chunk * k + threadIdx.x] = c;
+        for (int r = rb; r < re; ++r) c += (lab[r] == (int)threadIdx.x) ? 1 : 0;
+        pcount[(init * nchunks + chunk) * k + threadIdx.x] = c;
     }
 }
 
-// sums[j][g] = sum_chunks partial; counts[j] = sum_chunks pcount        (fixed chunk order)
+// sums[init][j][g] = sum_chunks partial; counts[init][j] = sum_chunks pcount     grid (G/256, k, n_init)
 __global__ void reduce_partial_kernel(const double* __restrict__ partial, const int* __restrict__ pcount,
-                                      int nchunks, int k, int ld, int G, double* __restrict__ sums,
+                                      int nchunks, KmDims d, double* __restrict__ sums,
                                       int* __restrict__ counts, KmState* st)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
-    if (g < G) {
+    const int init = blockIdx.z;
+    if (st[init].done) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = d.k;
+    if (g < d.G) {
         double s = 0.0;
-        for (int c = 0; c < nchunks; ++c) s += partial[((size_t)c * k + j) * ld + g];
-        sums[(size_t)j * ld + g] = s;
+        for (int c = 0; c < nchunks; ++c) s += partial[(((size_t)init * nchunks + c) * k + j) * d.ld + g];
+        sums[((size_t)init * k + j) * d.ld + g] = s;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int c = 0;
-        for (int q = 0; q < nchunks; ++q) c += pcount[q * k + j];
-        counts[j] = c;
-        if (c == 0) atomicAdd(&st->n_empty, 1);
+        for (int q = 0; q < nchunks; ++q) c += pcount[(init * nchunks + q) * k + j];
+        counts[init * k + j] = c;
+        if (c == 0) atomicAdd(&st[init].n_empty, 1);
     }
 }
 
-// squared distance of every row to its assigned (old) centre: used by the empty-cluster
-// relocation and by the inertia
-__global__ __launch_bounds__(256) void row_center_dist_kernel(const double* __restrict__ X, int ld, int G,
+// squared distance of every row to its assigned centre                          grid (R, n_init)
+// mode 0: only for inits with an empty cluster (relocation); mode 1: all inits (inertia)
+__global__ __launch_bounds__(256) void row_center_dist_kernel(const double* __restrict__ X, KmDims d,
                                                               const double* __restrict__ centers,
                                                               const int* __restrict__ labels,
                                                               double* __restrict__ dist,
-                                                              const KmState* only_if_empty)
+                                                              const KmState* __restrict__ st, int mode)
 {
     __shared__ double red[4];
-    if (only_if_empty && only_if_empty->n_empty == 0) return;
+    const int init = blockIdx.y;
+    if (mode == 0 && (st[init].done || st[init].n_empty == 0)) return;
     const int r = blockIdx.x;
-    const double* c = centers + (size_t)labels[r] * ld;
+    const double* c = centers + (size_t)(init * d.k + labels[(size_t)init * d.Rp + r]) * d.ld;
     double s = 0.0;
-    for (int g = threadIdx.x; g < G; g += 256) { const double d = X[(size_t)r * ld + g] - c[g]; s += d * d; }
+    for (int g = threadIdx.x; g < d.G; g += 256) { const double v = X[(size_t)r * d.ld + g] - c[g]; s += v * v; }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) dist[r] = s;
+    if (threadIdx.x == 0) dist[(size_t)init * d.Rp + r] = s;
 }
 
-// relocate empty clusters to the farthest points (sklearn _k_means_common.pyx:167-211), single
-// workgroup: clusters in ascending id, points in descending distance.
-__global__ __launch_bounds__(256) void relocate_empty_kernel(const double* __restrict__ X, int ld, int G,
-                                                             int R, int k, int* __restrict__ labels_ro,
+// relocate empty clusters to the farthest points (sklearn _k_means_common.pyx:167-211): clusters in
+// ascending id, points in descending distance.                                         grid = n_init
+__global__ __launch_bounds__(256) void relocate_empty_kernel(const double* __restrict__ X, KmDims d,
+                                                             const int* __restrict__ labels,
                                                              double* __restrict__ dist,
                                                              double* __restrict__ sums, int* __restrict__ counts,
-                                                             const KmState* st)
+                                                             const KmState* __restrict__ st)
 {
-    if (st->n_empty == 0) return;
+    const int init = blockIdx.x;
+    if (st[init].done || st[init].n_empty == 0) return;
     __shared__ double bv[256];
     __shared__ int bi[256];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, k = d.k;
+    const int* lab = labels + (size_t)init * d.Rp;
+    double* di = dist + (size_t)init * d.Rp;
+    double* sm = sums + (size_t)init * k * d.ld;
+    int* cn = counts + init * k;
     for (int e = 0; e < k; ++e) {
-        if (counts[e] != 0) continue;               // uniform
+        if (cn[e] != 0) continue;               // uniform
         double v = -1.0; int idx = -1;
-        for (int r = tid; r < R; r += 256) if (dist[r] > v) { v = dist[r]; idx = r; }
+        for (int r = tid; r < d.R; r += 256) if (di[r] > v) { v = di[r]; idx = r; }
         bv[tid] = v; bi[tid] = idx;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
@@ -511,51 +565,73 @@ __global__ __launch_bounds__(256) void relocate_empty_kernel(const double* __res
         const double fv = bv[0];
         __syncthreads();
         if (far < 0 || fv <= 0.0) return;           // all points coincide with their centres
-        const int old = labels_ro[far];
-        for (int g = tid; g < G; g += 256) {
-            const double x = X[(size_t)far * ld + g];
-            sums[(size_t)old * ld + g] -= x;
-            sums[(size_t)e * ld + g] = x;
+        const int old = lab[far];
+        for (int g = tid; g < d.G; g += 256) {
+            const double x = X[(size_t)far * d.ld + g];
+            sm[(size_t)old * d.ld + g] -= x;
+            sm[(size_t)e * d.ld + g] = x;
         }
-        if (tid == 0) { counts[e] = 1; counts[old] -= 1; dist[far] = -1.0; }
+        __syncthreads();
+        if (tid == 0) { cn[e] = 1; cn[old] -= 1; di[far] = -1.0; }
         __syncthreads();
     }
 }
 
-// new centres = sums * (1/count) (empty -> copy of the heaviest cluster); shift_tot = sum |new-old|^2
+// new centres = sums * (1/count) (empty -> copy of the heaviest cluster); shift_tot = sum |new-old|^2.
+// A finished init just carries its centres over so both buffers stay valid.             grid = n_init
 __global__ __launch_bounds__(256) void finish_centers_kernel(const double* __restrict__ sums,
-                                                             const int* __restrict__ counts, int k, int ld,
-                                                             int G, const double* __restrict__ old_c,
+                                                             const int* __restrict__ counts, KmDims d,
+                                                             const double* __restrict__ old_c,
                                                              double* __restrict__ new_c, KmState* st)
 {
     __shared__ double red[4];
     __shared__ int amax_s;
+    const int init = blockIdx.x, k = d.k;
+    const double* oc = old_c + (size_t)init * k * d.ld;
+    double* nc = new_c + (size_t)init * k * d.ld;
+    if (st[init].done) {
+        for (int e = threadIdx.x; e < k * d.ld; e += 256) nc[e] = oc[e];
+        return;
+    }
+    const double* sm = sums + (size_t)init * k * d.ld;
+    const int* cn = counts + init * k;
     if (threadIdx.x == 0) {
         int am = 0;
-        for (int j = 1; j < k; ++j) if (counts[j] > counts[am]) am = j;
+        for (int j = 1; j < k; ++j) if (cn[j] > cn[am]) am = j;
         amax_s = am;
     }
     __syncthreads();
     const int am = amax_s;
     double tot = 0.0;
     for (int j = 0; j < k; ++j) {
-        const int src = (counts[j] > 0) ? j : am;
-        const double alpha = 1.0 / (double)counts[src];
+        const int src = (cn[j] > 0) ? j : am;
+        const double alpha = 1.0 / (double)cn[src];
         double s = 0.0;
-        for (int g = threadIdx.x; g < ld; g += 256) {
+        for (int g = threadIdx.x; g < d.ld; g += 256) {
             double v = 0.0;
-            if (g < G) {
-                v = sums[(size_t)src * ld + g] * alpha;
-                const double d = v - old_c[(size_t)j * ld + g];
-                s += d * d;
+            if (g < d.G) {
+                v = sm[(size_t)src * d.ld + g] * alpha;
+                const double df = v - oc[(size_t)j * d.ld + g];
+                s += df * df;
             }
-            new_c[(size_t)j * ld + g] = v;
+            nc[(size_t)j * d.ld + g] = v;
         }
         s = block_sum(s, red);
         const double sh = sqrt(s);
         tot += sh * sh;
     }
-    if (threadIdx.x == 0) st->shift_tot = tot;
+    if (threadIdx.x == 0) st[init].shift_tot = tot;
+}
+
+// inertia[init] = sum_r dist[init][r]                                                   grid = n_init
+__global__ __launch_bounds__(256) void inertia_kernel(const double* __restrict__ dist, KmDims d, KmState* st)
+{
+    __shared__ double red[4];
+    const int init = blockIdx.x;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < d.R; r += 256) s += dist[(size_t)init * d.Rp + r];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) st[init].inertia = s;
 }
 
 __global__ __launch_bounds__(256) void sum_kernel(const double* __restrict__ v, int n, double* out)
