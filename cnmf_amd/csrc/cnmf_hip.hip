@@ -41,7 +41,7 @@ struct cnmf_ctx {
     float* X = nullptr;
 
     // batch buffers (sized for kc_alloc columns)
-    int kc_alloc = 0, nsplit_alloc = 0, parts_alloc = 0;
+    int kc_alloc = 0, nsplit_alloc = 0, nsplitA_alloc = 0, parts_alloc = 0;
     size_t gram_part_floats = 0;
     float *H = nullptr, *Wt = nullptr, *XHt = nullptr, *XHt1 = nullptr, *XtW = nullptr;
     unsigned char* d_split = nullptr;   // stream-K cut flags of the current plan
@@ -353,7 +353,12 @@ extern "C" int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* N, int64_t* G)
 }
 
 // ------------------------------------------------------------------ batch buffers
-static int sweep_chunks(int L) { return std::max(1, (int)(((int64_t)L + 256 * 64 - 1) / (256 * 64))); }
+static int sweep_max_parts()
+{
+    static const int v = getenv("CNMF_SWEEP_PARTS") ? atoi(getenv("CNMF_SWEEP_PARTS")) : 64;
+    return std::max(1, v);
+}
+static int sweep_chunks(int L) { const int64_t m = 256ll * sweep_max_parts(); return std::max(1, (int)(((int64_t)L + m - 1) / m)); }
 static int sweep_parts(int L) { int c = sweep_chunks(L); return (L + 256 * c - 1) / (256 * c); }
 
 static int pick_nsplit(const cnmf_ctx* ctx, int KC)
@@ -367,19 +372,39 @@ static int pick_nsplit(const cnmf_ctx* ctx, int KC)
     return std::min(s, max_by_k);
 }
 
+// splits that actually receive work once the per-split K range is rounded up to whole stages
+static int effective_splits(int Ktot, int nsplit)
+{
+    const int Kper = round_up((Ktot + nsplit - 1) / nsplit, BK);
+    return (Ktot + Kper - 1) / Kper;
+}
+
+// pass A on few cells: fewer than one 128-cell tile per CU -> split the gene (K) range too, so
+// that ~2 workgroups per CU are in flight; the planes are summed by reduce_splits_kernel.
+static int pick_nsplit_A(const cnmf_ctx* ctx, int KC)
+{
+    if (const char* s = getenv("CNMF_NSPLIT_A")) { int v = atoi(s); if (v > 0) return effective_splits(ctx->G_pad, v); }
+    const int T = (ctx->N_pad / 128) * std::max(1, KC / 128);
+    if (T > 256) return 1;                                  // stream-K territory
+    int s = std::max(1, 512 / T);
+    s = std::min(s, std::max(1, ctx->G_pad / (4 * BK)));    // at least 4 stages per split
+    return effective_splits(ctx->G_pad, std::min(s, 16));
+}
+
 static int ensure_batch(cnmf_ctx* ctx, int KC, int max_k = KMAX, int min_k = 1)
 {
     const int nsplit = pick_nsplit(ctx, KC);
+    const int nsplitA = pick_nsplit_A(ctx, KC);
     const int parts = std::max(sweep_parts((int)ctx->N), sweep_parts((int)ctx->G));
     const size_t gp_need = (size_t)(KC / std::max(1, min_k) + 1) * parts * max_k * max_k;
-    if (ctx->kc_alloc == KC && ctx->nsplit_alloc == nsplit && ctx->parts_alloc == parts &&
-        ctx->gram_part_floats >= gp_need) return CNMF_OK;
+    if (ctx->kc_alloc == KC && ctx->nsplit_alloc == nsplit && ctx->nsplitA_alloc == nsplitA &&
+        ctx->parts_alloc == parts && ctx->gram_part_floats >= gp_need) return CNMF_OK;
     free_batch(ctx);
     const size_t hb = (size_t)KC * ctx->G_pad * sizeof(float);
     const size_t wb = (size_t)KC * ctx->N_pad * sizeof(float);
     HIP_TRY(ctx, hipMalloc(&ctx->H, hb));
     HIP_TRY(ctx, hipMalloc(&ctx->Wt, wb));
-    HIP_TRY(ctx, hipMalloc(&ctx->XHt, wb));
+    HIP_TRY(ctx, hipMalloc(&ctx->XHt, wb * nsplitA));
     HIP_TRY(ctx, hipMalloc(&ctx->XHt1, wb));
     HIP_TRY(ctx, hipMalloc(&ctx->d_split, (size_t)(KC / 32 + 1) * (ctx->N_pad / 128 + 1)));
     HIP_TRY(ctx, hipMalloc(&ctx->XtW, hb * nsplit));
@@ -395,10 +420,10 @@ static int ensure_batch(cnmf_ctx* ctx, int KC, int max_k = KMAX, int min_k = 1)
     HIP_TRY(ctx, hipHostMalloc(&ctx->h_slot_list, (size_t)KC * RING * sizeof(int)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, hb, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->Wt, 0, wb, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->XHt, 0, wb, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->XHt, 0, wb * nsplitA, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->XtW, 0, hb * nsplit, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_slots, 0, (size_t)KC * sizeof(SlotDesc), ctx->stream));
-    ctx->kc_alloc = KC; ctx->nsplit_alloc = nsplit; ctx->parts_alloc = parts;
+    ctx->kc_alloc = KC; ctx->nsplit_alloc = nsplit; ctx->nsplitA_alloc = nsplitA; ctx->parts_alloc = parts;
     return CNMF_OK;
 }
 
@@ -579,6 +604,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     const int wg_slots = getenv("CNMF_SK_WGS") ? atoi(getenv("CNMF_SK_WGS")) : 2 * 256;                    // T-layout pass A: 2 workgroups per CU (73.7 KB LDS each)
     StreamK sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
     if (sk.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
+    int nsplitA = (sk.on && gvarA == 0) ? 1 : ctx->nsplitA_alloc;
     int n_done = 0;
 
     auto retire = [&](int s, const SlotDesc& snap) -> int {
@@ -656,8 +682,11 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                                               ctx->XHt1, ctx->N_pad, ctx->N_pad));
         else
             HIP_TRY(ctx, launch_gemm<false>(st, gvarA, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt,
-                                            ctx->N_pad, 0, KC, ctx->G_pad, ctx->N_pad, 1));
+                                            ctx->N_pad, (long long)KC * ctx->N_pad, KC, ctx->G_pad, ctx->N_pad, nsplitA));
         if (time_gemm) hipEventRecord(gev[gev.size() - 3], st);
+        if (!(sk.on && gvarA == 0))
+            HIP_TRY(ctx, launch_reduce_splits(st, ctx->XHt, nsplitA, (long long)KC * ctx->N_pad,
+                                              (long long)KC * ctx->N_pad));
         // W half-step                                             (sklearn _nmf.py:500)
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
                                   ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k, tiers,
@@ -741,6 +770,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                 const int cap = (ctx->nsplit_alloc * KC0) / KC;
                 nsplit = std::max(1, std::min(pick_nsplit(ctx, KC), cap));
                 sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
+                nsplitA = (sk.on && gvarA == 0) ? 1
+                        : std::max(1, std::min(pick_nsplit_A(ctx, KC), (ctx->nsplitA_alloc * KC0) / KC));
                 if (sk.on) {
                     // the flags of the old plan may still be read by an in-flight sweep: same stream -> ordered
                     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
