@@ -126,6 +126,11 @@ def consensus_wallclock(eng, with_cpu=True):
 
 def main():
     args = parse()
+    # stdout must carry exactly ONE JSON line, but RCCL prints a version banner to the C-level
+    # stdout (flushed at exit): keep the real stdout aside and point fd 1 at stderr meanwhile
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,6 +150,12 @@ def main():
     N, G = X.shape
     eng = Engine(local_rank)
     eng.set_matrix(X)
+    # transport of the gather: "torch" = torch.distributed all_gather (backend nccl = RCCL);
+    # "rccl" = ncclAllGather inside the C-ABI library, spectra taken from the device-resident store
+    gather_mode = os.environ.get("CNMF_GATHER", "torch") if dist is not None else "none"
+    if gather_mode == "rccl":
+        from cnmf_amd import dist as cd
+        cd.comm_bootstrap_torch(eng)            # only the 128-byte id travels through torch
 
     ks_all = list(range(args.kmin, args.kmax + 1))
     n_steps_total = args.warmup + args.steps
@@ -172,24 +183,36 @@ def main():
             return
         import torch
         from cnmf_amd import dist as cd
+        if gather_mode == "rccl":
+            hdr = np.array([(i, int(k), step) for i, k in enumerate(ks)], dtype=np.int32).reshape(-1, 3)
+            cd.allgather_spectra_rccl(eng, hdr, None, G)
+            return
         rows = [(i, int(H.shape[0]), step) for i, H in enumerate(H_list)]
         hdr, blk = cd.pack_local(rows, H_list, G)
         cd.allgather_spectra(hdr, blk, G, device="cuda:%d" % local_rank)
         torch.cuda.synchronize()
 
+    def run_step(step, profile):
+        ks, seeds = step_jobs(step)
+        if gather_mode == "rccl":
+            eng.spectra_reset()
+            _, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=profile, resident=True)
+            st = dict(eng.last_stats)
+            gather(None, ks, step)
+        else:
+            H, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=profile)
+            st = dict(eng.last_stats)
+            gather(H, ks, step)
+        return ks, st
+
     agg = dict(restarts=0, restart_iters=0, rc_iters=0, outer=0, col_iters=0, passA_ms=0.0,
                passB_ms=0.0, nA=0, nB=0, gpu_ms=0.0, kc=0, nsplit=0)
     for step in range(args.warmup):
-        ks, seeds = step_jobs(step)
-        H, _, _, _ = eng.nmf_batch(ks, seeds=seeds, warn=False)
-        gather(H)
+        run_step(step, False)
     barrier()
     t0 = time.perf_counter()
     for step in range(args.warmup, n_steps_total):
-        ks, seeds = step_jobs(step)
-        H, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=True)
-        gather(H)
-        st = eng.last_stats
+        ks, st = run_step(step, True)
         agg["restarts"] += len(ks)
         agg["restart_iters"] += int(st["restart_iterations"])
         agg["rc_iters"] += int(st["restart_column_iterations"])
@@ -252,13 +275,14 @@ def main():
                        "mean_iterations_per_restart": mean_it,
                        "restart_iterations_per_s": total_riters / elapsed,
                        "column_utilisation": agg["rc_iters"] / max(agg["col_iters"], 1),
-                       "parallelism": "restart-sharded x%d" % world},
+                       "parallelism": "restart-sharded x%d" % world, "gather": gather_mode},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(X, mean_it, args.cpu_iters)
             out["consensus"] = consensus_wallclock(eng)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

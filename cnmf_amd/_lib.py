@@ -20,8 +20,13 @@ SYMBOLS = [
     "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_get_shape",
     "cnmf_nmf_cd_batch", "cnmf_nmf_cd_batch_resident", "cnmf_nnls",
     "cnmf_consensus", "cnmf_prediction_error", "cnmf_nmf_mu_batch", "cnmf_x_matmul",
+    "cnmf_comm_unique_id", "cnmf_comm_init", "cnmf_comm_finalize", "cnmf_comm_rank", "cnmf_comm_world",
+    "cnmf_allgather_bytes", "cnmf_allgather_spectra",
+    "cnmf_spectra_rows", "cnmf_spectra_reset", "cnmf_spectra_fetch",
     "cnmf_debug_gemm", "cnmf_debug_standard_normal",
 ]
+
+COMM_ID_BYTES = 128
 
 CNMF_KMAX = 64
 
@@ -127,6 +132,27 @@ def load():
     lib.cnmf_prediction_error.argtypes = [vp, i32, dblp, dblp, dblp]
     lib.cnmf_x_matmul.restype = i32
     lib.cnmf_x_matmul.argtypes = [vp, i32, f32p, i32, f32p]
+    u8p = C.POINTER(C.c_ubyte)
+    lib.cnmf_comm_unique_id.restype = i32
+    lib.cnmf_comm_unique_id.argtypes = [u8p]
+    lib.cnmf_comm_init.restype = i32
+    lib.cnmf_comm_init.argtypes = [vp, u8p, i32, i32]
+    lib.cnmf_comm_finalize.restype = i32
+    lib.cnmf_comm_finalize.argtypes = [vp]
+    lib.cnmf_comm_rank.restype = i32
+    lib.cnmf_comm_rank.argtypes = [vp]
+    lib.cnmf_comm_world.restype = i32
+    lib.cnmf_comm_world.argtypes = [vp]
+    lib.cnmf_allgather_bytes.restype = i32
+    lib.cnmf_allgather_bytes.argtypes = [vp, vp, i64, vp]
+    lib.cnmf_allgather_spectra.restype = i32
+    lib.cnmf_allgather_spectra.argtypes = [vp, f32p, i64, i64, i64, f32p]
+    lib.cnmf_spectra_rows.restype = i64
+    lib.cnmf_spectra_rows.argtypes = [vp]
+    lib.cnmf_spectra_reset.restype = i32
+    lib.cnmf_spectra_reset.argtypes = [vp]
+    lib.cnmf_spectra_fetch.restype = i32
+    lib.cnmf_spectra_fetch.argtypes = [vp, f32p]
     lib.cnmf_debug_gemm.restype = i32
     lib.cnmf_debug_gemm.argtypes = [vp, i32, i32, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
     lib.cnmf_debug_standard_normal.restype = i32

@@ -123,6 +123,13 @@ class cNMF:
             }
 
     # ------------------------------------------------------------------ engine plumbing
+    @property
+    def engine(self):
+        """The per-process device context (one process per GPU)."""
+        if self._engine is None:
+            self._engine = Engine(self.device)
+        return self._engine
+
     def _get_engine(self, X, key):
         """One resident upload per distinct matrix (X is NOT re-read per restart/worker)."""
         if self._engine is None:

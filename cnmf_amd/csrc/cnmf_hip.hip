@@ -30,6 +30,8 @@ using namespace cnmf;
 
 static thread_local std::string g_last_error;
 
+struct cnmf_comm;
+
 struct cnmf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -58,6 +60,8 @@ struct cnmf_ctx {
     // resident spectra store (device) for the gather / consensus
     float* spectra = nullptr;
     size_t spectra_cap = 0, spectra_rows = 0;
+
+    cnmf_comm* comm = nullptr;        // RCCL communicator (comm_host.hip.h); NULL = single GPU
 };
 
 static constexpr int RING = 8;
@@ -268,6 +272,7 @@ extern "C" void cnmf_destroy(cnmf_ctx* ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     free_batch(ctx);
+    cnmf_comm_finalize(ctx);
     hipFree(ctx->X); hipFree(ctx->stageW); hipFree(ctx->stageH); hipFree(ctx->spectra);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -283,6 +288,7 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     free_batch(ctx);
     hipFree(ctx->X); ctx->X = nullptr;
+    ctx->spectra_rows = 0;            // spectra of another matrix are not comparable
     ctx->N = N; ctx->G = G;
     ctx->N_pad = round_up(N, 128);
     ctx->G_pad = round_up(G, 32);
@@ -909,6 +915,7 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
 
 // ------------------------------------------------------------------ multiplicative-update solver
 #include "mu_host.hip.h"
+#include "comm_host.hip.h"
 
 // ------------------------------------------------------------------ X . Q / X^T . Q
 extern "C" int cnmf_x_matmul(cnmf_ctx* ctx, int trans, const float* Q, int ncols, float* out)

@@ -6,11 +6,15 @@ The restart hot loop shards with no data-path collective: ledger row ``idx`` goe
 50k x 2000, 1.6 GB at 200k x 2000, versus 288 GB of HBM).  The reference's "gather" is the
 filesystem (``combine`` re-reads one npz per restart, cnmf.py:755-770); here it is ONE
 ``all_gather`` of the packed float32 spectra (<= 130 MB in total for the largest BASELINE
-config, i.e. latency- not bandwidth-bound on xGMI) through ``torch.distributed`` --
-backend "nccl" is RCCL on ROCm (GPU tensors), backend "gloo" is used by the CPU tests.
-After the gather every k's consensus is independent again.
+config, i.e. latency- not bandwidth-bound on xGMI).  Two transports, same packing:
 
-torch is plumbing here (process group + collective); nothing numeric runs through it.
+* ``allgather_spectra_rccl`` -- ``ncclAllGather`` inside the C-ABI library
+  (``cnmf_allgather_spectra``, include/cnmf_hip.h): no torch anywhere; the 128-byte RCCL id
+  travels through a file (``comm_bootstrap_file``) or any launcher's own store.
+* ``allgather_spectra`` -- ``torch.distributed`` (backend "nccl" IS RCCL on ROCm; "gloo" for
+  the CPU tests); torch is plumbing there (process group + collective), nothing numeric.
+
+After the gather every k's consensus is independent again.
 """
 import numpy as np
 
@@ -65,6 +69,57 @@ def allgather_spectra(hdr, blk, n_genes, device=None):
     return unpack([hs[r, :sizes[r][0]] for r in range(world)], [bs[r, :sizes[r][1]] for r in range(world)])
 
 
+def comm_bootstrap_file(engine, rank, world, path, timeout=300.0):
+    """Torch-free rendezvous for the library's RCCL communicator: rank 0 writes the id to
+    ``path`` (atomically), the others wait for it; then the collective ``comm_init``."""
+    import os
+    import time
+    if world == 1:
+        return engine.comm_init(engine.comm_unique_id(), 0, 1)
+    if rank == 0:
+        uid = engine.comm_unique_id()
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+    else:
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout:
+                raise TimeoutError("no RCCL id at %s after %.0f s" % (path, timeout))
+            time.sleep(0.05)
+        with open(path, "rb") as f:
+            uid = f.read()
+    engine.comm_init(uid, rank, world)
+
+
+def comm_bootstrap_torch(engine):
+    """Same, when a torch.distributed process group already exists (bench.py's launcher):
+    the id is broadcast through it; the data path stays inside the library."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    engine.comm_init(box[0], rank, world)
+
+
+def allgather_spectra_rccl(engine, hdr, blk, n_genes):
+    """The gather through the C-ABI library: one small ``cnmf_allgather_bytes`` for the sizes,
+    one for the headers, then ONE ``cnmf_allgather_spectra`` (ncclAllGather) for the payload.
+    ``blk=None`` sends the context's resident spectra store (rows in ``hdr`` order)."""
+    world = engine.comm_world
+    rows_local = engine.spectra_rows if blk is None else int(blk.shape[0])
+    sizes = engine.allgather_array(np.array([hdr.shape[0], rows_local], dtype=np.int64))
+    max_n = max(1, int(sizes[:, 0].max()))
+    max_rows = max(1, int(sizes[:, 1].max()))
+    h = np.zeros((max_n, 3), dtype=np.int32)
+    h[:hdr.shape[0]] = hdr
+    hs = engine.allgather_array(h)
+    bs = engine.allgather_spectra(blk, max_rows, n_genes)
+    return unpack([hs[r, :int(sizes[r, 0])] for r in range(world)],
+                  [bs[r, :int(sizes[r, 1])] for r in range(world)])
+
+
 def unpack(headers, blocks):
     out = {}
     for hdr, blk in zip(headers, blocks):
@@ -75,9 +130,11 @@ def unpack(headers, blocks):
     return out
 
 
-def factorize_distributed(obj, rank, world, device=None, **factorize_kwargs):
+def factorize_distributed(obj, rank, world, device=None, gather="torch", **factorize_kwargs):
     """``cNMF.factorize`` on this rank's shard, then the gather: afterwards every rank's
-    ``obj.spectra_cache`` holds every restart, so ``obj.combine()`` needs no files."""
+    ``obj.spectra_cache`` holds every restart, so ``obj.combine()`` needs no files.
+    ``gather="rccl"`` uses the library's own communicator (``obj.engine`` must have had
+    ``comm_init``, e.g. via ``comm_bootstrap_file``); ``"torch"`` uses torch.distributed."""
     import pandas as pd
     from .cnmf import load_df_from_npz
     run_params = load_df_from_npz(obj.paths["nmf_replicate_parameters"])
@@ -95,7 +152,10 @@ def factorize_distributed(obj, rank, world, device=None, **factorize_kwargs):
     if genes is None:
         genes = load_df_from_npz(obj.paths["normalized_counts"]).columns
     hdr, blk = pack_local(rows, spectra, len(genes))
-    merged = allgather_spectra(hdr, blk, len(genes), device=device)
+    if gather == "rccl":
+        merged = allgather_spectra_rccl(obj.engine, hdr, blk, len(genes))
+    else:
+        merged = allgather_spectra(hdr, blk, len(genes), device=device)
     for (k, it), H in merged.items():
         obj.spectra_cache[(k, it)] = pd.DataFrame(H.astype(np.float64), index=np.arange(1, k + 1), columns=genes)
     return merged

@@ -423,6 +423,73 @@ class Engine:
         return float(err.value)
 
     # ------------------------------------------------------------------ diagnostics
+    # ------------------------------------------------------------------ multi-GPU exchange (RCCL)
+    def comm_unique_id(self):
+        """128-byte RCCL id (rank 0 creates it; ship it to the other ranks out of band)."""
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+        self._check(self._lib.cnmf_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        """Collective: every rank calls it with the same id (ncclCommInitRank)."""
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % _lib.COMM_ID_BYTES)
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._lib.cnmf_comm_init(self._ctx, buf, int(rank), int(world)))
+
+    def comm_finalize(self):
+        self._check(self._lib.cnmf_comm_finalize(self._ctx))
+
+    @property
+    def comm_rank(self):
+        return int(self._lib.cnmf_comm_rank(self._ctx))
+
+    @property
+    def comm_world(self):
+        return int(self._lib.cnmf_comm_world(self._ctx))
+
+    def allgather_array(self, a):
+        """All-gather equally-shaped host arrays: returns ``[world, *a.shape]``."""
+        a = np.ascontiguousarray(a)
+        out = np.empty((self.comm_world,) + a.shape, dtype=a.dtype)
+        self._check(self._lib.cnmf_allgather_bytes(self._ctx, a.ctypes.data_as(C.c_void_p), a.nbytes,
+                                                   out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def allgather_spectra(self, local, rows_max, n_genes=None):
+        """THE data-path collective: one all-gather of this rank's packed float32 spectra
+        (``local`` [rows, G], or ``None`` for the context's resident store) zero-padded to
+        ``rows_max`` rows.  Returns ``[world, rows_max, G]`` float32."""
+        if local is None:
+            rows, G = self.spectra_rows, self.shape[1]
+            lp = None
+        else:
+            local = np.ascontiguousarray(local, dtype=np.float32)
+            rows, G = (int(local.shape[0]), int(local.shape[1] if local.ndim == 2 else n_genes))
+            lp = _fp(local) if rows else None
+            if not rows:
+                lp = _fp(np.zeros(1, np.float32))
+        if n_genes is not None and int(n_genes) != G:
+            raise ValueError("n_genes does not match the block")
+        out = np.empty((self.comm_world, int(rows_max), G), dtype=np.float32)
+        if rows_max:
+            self._check(self._lib.cnmf_allgather_spectra(self._ctx, lp, rows, int(rows_max), G, _fp(out)))
+        return out
+
+    @property
+    def spectra_rows(self):
+        """Rows in the resident spectra store (``nmf_batch(..., resident=True)`` appends to it)."""
+        return int(self._lib.cnmf_spectra_rows(self._ctx))
+
+    def spectra_reset(self):
+        self._check(self._lib.cnmf_spectra_reset(self._ctx))
+
+    def spectra_fetch(self):
+        out = np.empty((self.spectra_rows, self.shape[1]), dtype=np.float32)
+        if out.size:
+            self._check(self._lib.cnmf_spectra_fetch(self._ctx, _fp(out)))
+        return out
+
     def debug_gemm(self, mode, A, B, variant=0, nsplit=1, reps=0):
         A = np.ascontiguousarray(A, dtype=np.float32)
         B = np.ascontiguousarray(B, dtype=np.float32)

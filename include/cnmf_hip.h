@@ -179,6 +179,38 @@ int cnmf_prediction_error(cnmf_ctx* ctx, int k, const double* W, const double* H
  * LU / QR / SVD factorizations stay on the host (cnmf_amd/engine.py::Engine.nndsvd_init).        */
 int cnmf_x_matmul(cnmf_ctx* ctx, int trans, const float* Q, int ncols, float* out);
 
+/* ---- multi-GPU exchange (RCCL over xGMI) ---------------------------------------------------
+ * The restarts shard with no collective: ledger row idx runs on rank idx % world, the
+ * reference's worker_filter (cnmf.py:52-53).  The reference's "gather" is the filesystem:
+ * combine_nmf re-reads one npz per restart (cnmf.py:755-770).  Here it is ONE ncclAllGather of
+ * the packed float32 spectra.  One process per GPU, one context per process.  RCCL is bound
+ * lazily (dlopen) on the first cnmf_comm_* call; single-GPU use never touches it, and without
+ * a communicator the gathers below degenerate to copies (world = 1).
+ *
+ *   rank 0:     cnmf_comm_unique_id(id)  -> ship the 128 bytes to the other ranks out of band
+ *               (a file, an environment variable, MPI, a torch.distributed store ...)
+ *   every rank: cnmf_comm_init(ctx, id, rank, world)             (collective: ncclCommInitRank)
+ *               cnmf_allgather_bytes(ctx, mine, n, all)          headers / row counts, host buffers
+ *               cnmf_allgather_spectra(ctx, local, rows_local, rows_max, G, out)
+ *                   local [rows_local][G] host floats, or NULL = the context's resident store
+ *                   (cnmf_nmf_cd_batch_resident) -> then the spectra never visit the host before
+ *                   the exchange;  out [world][rows_max][G] host floats, shards zero-padded to
+ *                   rows_max (= max over ranks, from the header gather).
+ *               cnmf_comm_finalize(ctx)                          (also done by cnmf_destroy)      */
+#define CNMF_COMM_ID_BYTES 128
+int cnmf_comm_unique_id(unsigned char* id_out /* [CNMF_COMM_ID_BYTES] */);
+int cnmf_comm_init(cnmf_ctx* ctx, const unsigned char* id /* [CNMF_COMM_ID_BYTES] */, int rank, int world);
+int cnmf_comm_finalize(cnmf_ctx* ctx);
+int cnmf_comm_rank(const cnmf_ctx* ctx);
+int cnmf_comm_world(const cnmf_ctx* ctx);
+int cnmf_allgather_bytes(cnmf_ctx* ctx, const void* send, int64_t nbytes, void* recv /* [world][nbytes] */);
+int cnmf_allgather_spectra(cnmf_ctx* ctx, const float* local, int64_t rows_local, int64_t rows_max,
+                           int64_t n_genes, float* out);
+/* the resident spectra store filled by cnmf_nmf_cd_batch_resident (rows in restart order) */
+int64_t cnmf_spectra_rows(const cnmf_ctx* ctx);
+int cnmf_spectra_reset(cnmf_ctx* ctx);
+int cnmf_spectra_fetch(cnmf_ctx* ctx, float* out /* [rows][G] */);
+
 /* ---- diagnostics used by the tests ---------------------------------------------------- */
 /* C[KC][J] = A[KC][K] . B  through the engine's MFMA GEMM; mode 0: B is [J][K] (pass A),
  * mode 1: B is [K][J] (pass B, split-K partials summed in split order).                  */

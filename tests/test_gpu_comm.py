@@ -1,0 +1,58 @@
+"""The library's own exchange (include/cnmf_hip.h "multi-GPU exchange"): RCCL bound lazily with
+dlopen, a real communicator (world = 1 is all a 1-GPU box offers; the N > 1 packing logic is
+covered on CPU by tests/test_dist_gloo.py), the resident spectra store, ragged zero-padding."""
+import numpy as np
+import pytest
+
+from cnmf_amd import dist, synth
+from cnmf_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gather_without_communicator_is_a_copy(engine):
+    X = synth.make_config("C1", dtype=np.float32, n_cells=300)
+    engine.set_matrix(X)
+    assert engine.comm_world == 1 and engine.comm_rank == 0
+    blk = np.random.RandomState(0).rand(17, X.shape[1]).astype(np.float32)
+    out = engine.allgather_spectra(blk, rows_max=20)
+    assert out.shape == (1, 20, X.shape[1])
+    assert np.array_equal(out[0, :17], blk) and not out[0, 17:].any()      # ragged shard zero-padded
+    a = np.arange(12, dtype=np.int64).reshape(3, 4)
+    assert np.array_equal(engine.allgather_array(a)[0], a)
+
+
+def test_rccl_communicator_world1_and_resident_store(tmp_path):
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllGather through the C-ABI, spectra taken
+    straight from the device-resident store (they never visit the host before the exchange)."""
+    X = synth.make_config("C1", dtype=np.float32, n_cells=400)
+    with Engine(0) as eng:
+        eng.set_matrix(X)
+        dist.comm_bootstrap_file(eng, 0, 1, str(tmp_path / "rccl_id"))
+        assert eng.comm_world == 1
+        with pytest.raises(RuntimeError):
+            eng.comm_init(eng.comm_unique_id(), 0, 1)                      # already initialised
+        ks, seeds = [5, 7, 6], [11, 12, 13]
+        H, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds)
+        eng.spectra_reset()
+        eng.nmf_batch(ks[:2], seeds=seeds[:2], resident=True)
+        eng.nmf_batch(ks[2:], seeds=seeds[2:], resident=True)              # appends
+        assert eng.spectra_rows == sum(ks)
+        ref = np.concatenate(H, axis=0)
+        assert np.array_equal(eng.spectra_fetch(), ref)                    # same kernels, same bits
+        hdr = np.array([(i, k, i) for i, k in enumerate(ks)], dtype=np.int32)
+        merged = dist.allgather_spectra_rccl(eng, hdr, None, X.shape[1])   # blk=None -> resident store
+        assert set(merged) == {(k, i) for i, k in enumerate(ks)}
+        for i, k in enumerate(ks):
+            assert np.array_equal(merged[(k, i)], H[i])
+        # host-block route gives the same answer
+        merged2 = dist.allgather_spectra_rccl(eng, hdr, ref, X.shape[1])
+        for key in merged:
+            assert np.array_equal(merged[key], merged2[key])
+        with pytest.raises(ValueError):
+            eng.allgather_spectra(None, rows_max=3)                        # rows_max < rows held
+        eng.comm_finalize()
+        assert eng.comm_world == 1
+        # a new matrix invalidates the store
+        eng.set_matrix(X[:100])
+        assert eng.spectra_rows == 0
