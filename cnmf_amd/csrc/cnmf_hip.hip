@@ -83,6 +83,43 @@ static constexpr int RING = 8;
         }                                                                   \
     } while (0)
 
+// Scope-bound device allocations / events: released when the entry point returns, on EVERY path
+// (the HIP_TRY early returns included; hipFree waits for work that still uses the buffer).
+struct DevPool {
+    std::vector<void*> ptrs;
+    hipError_t err = hipSuccess;
+    template <typename T> T* get(size_t n, bool zero = false, hipStream_t st = nullptr) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) { err = e; return nullptr; }
+        ptrs.push_back(p);
+        if (zero) hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(T), st);
+        return (T*)p;
+    }
+    ~DevPool() { for (void* p : ptrs) hipFree(p); }
+};
+
+struct EventPool {
+    std::vector<hipEvent_t> evs;
+    hipError_t err = hipSuccess;
+    hipEvent_t get(unsigned flags = hipEventDefault) {
+        hipEvent_t e = nullptr;
+        hipError_t r = hipEventCreateWithFlags(&e, flags);
+        if (r != hipSuccess) { err = r; return nullptr; }
+        evs.push_back(e);
+        return e;
+    }
+    ~EventPool() { for (hipEvent_t e : evs) hipEventDestroy(e); }
+};
+
+#define POOL_TRY(ctx, pool)                                                                   \
+    do {                                                                                      \
+        if ((pool).err != hipSuccess) {                                                       \
+            SET_ERR(ctx, "device allocation failed: %s (%s:%d)", hipGetErrorString((pool).err), __FILE__, __LINE__); \
+            return ((pool).err == hipErrorOutOfMemory) ? CNMF_ENOMEM : CNMF_EHIP;             \
+        }                                                                                     \
+    } while (0)
+
 static inline int round_up(int64_t v, int m) { return (int)(((v + m - 1) / m) * m); }
 
 // ------------------------------------------------------------------ GEMM dispatch
@@ -333,11 +370,11 @@ extern "C" int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const i
     int rc = alloc_matrix(ctx, N, G);
     if (rc) return rc;
     const int64_t nnz = indptr[N];
-    int *d_ptr = nullptr, *d_idx = nullptr;
-    float* d_val = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_ptr, (size_t)(N + 1) * sizeof(int)));
-    HIP_TRY(ctx, hipMalloc(&d_idx, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int)));
-    HIP_TRY(ctx, hipMalloc(&d_val, (size_t)std::max<int64_t>(nnz, 1) * sizeof(float)));
+    DevPool pool;
+    int* d_ptr = pool.get<int>((size_t)(N + 1));
+    int* d_idx = pool.get<int>((size_t)nnz);
+    float* d_val = pool.get<float>((size_t)nnz);
+    POOL_TRY(ctx, pool);
     HIP_TRY(ctx, hipMemcpyAsync(d_ptr, indptr, (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     if (nnz > 0) {
         HIP_TRY(ctx, hipMemcpyAsync(d_idx, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -346,7 +383,6 @@ extern "C" int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const i
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d_ptr); hipFree(d_idx); hipFree(d_val);
     return CNMF_OK;
 }
 
@@ -539,6 +575,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     hipStream_t st = ctx->stream;
 
     // device result buffers
+    DevPool pool;
+    EventPool events;
     float* d_Hres = nullptr; float* d_Wres = nullptr;
     if (resident) {
         const size_t need = (ctx->spectra_rows + (size_t)total_k) * G;
@@ -546,26 +584,30 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             float* nb = nullptr;
             const size_t cap = std::max(need, ctx->spectra_cap * 2);
             HIP_TRY(ctx, hipMalloc(&nb, cap * sizeof(float)));
+            hipError_t ce = hipSuccess;
             if (ctx->spectra_rows)
-                HIP_TRY(ctx, hipMemcpyAsync(nb, ctx->spectra, ctx->spectra_rows * G * sizeof(float), hipMemcpyDeviceToDevice, st));
-            HIP_TRY(ctx, hipStreamSynchronize(st));
+                ce = hipMemcpyAsync(nb, ctx->spectra, ctx->spectra_rows * G * sizeof(float), hipMemcpyDeviceToDevice, st);
+            if (ce == hipSuccess) ce = hipStreamSynchronize(st);
+            if (ce != hipSuccess) { hipFree(nb); HIP_TRY(ctx, ce); }
             hipFree(ctx->spectra);
             ctx->spectra = nb; ctx->spectra_cap = cap;
         }
         d_Hres = ctx->spectra + ctx->spectra_rows * G;
     } else {
-        HIP_TRY(ctx, hipMalloc(&d_Hres, hoff[n] * sizeof(float)));
+        d_Hres = pool.get<float>(hoff[n]);
     }
-    if (W_out) HIP_TRY(ctx, hipMalloc(&d_Wres, woff[n] * sizeof(float)));
+    if (W_out) d_Wres = pool.get<float>(woff[n]);
+    POOL_TRY(ctx, pool);
 
     // init_mode 1: sklearn's init='random' for EVERY restart of the call, generated up front on the
     // device (one workgroup per restart) into a component-major store; install = row copy.
     float *d_H0 = nullptr, *d_Wt0 = nullptr;
     RngJob* d_jobs = nullptr;
     if (init_mode == 1) {
-        HIP_TRY(ctx, hipMalloc(&d_H0, hoff[n] * sizeof(float)));
-        HIP_TRY(ctx, hipMalloc(&d_Wt0, woff[n] * sizeof(float)));
-        HIP_TRY(ctx, hipMalloc(&d_jobs, (size_t)n * sizeof(RngJob)));
+        d_H0 = pool.get<float>(hoff[n]);
+        d_Wt0 = pool.get<float>(woff[n]);
+        d_jobs = pool.get<RngJob>((size_t)n);
+        POOL_TRY(ctx, pool);
         std::vector<RngJob> jobs(n);
         int rowoff = 0;
         for (int r = 0; r < n; ++r) {
@@ -590,10 +632,9 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int n_active = 0;
     int64_t it = 0;          // batch iterations enqueued so far
     std::vector<hipEvent_t> ev(RING);
-    for (auto& e : ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    hipEvent_t ev_begin, ev_end;
-    HIP_TRY(ctx, hipEventCreate(&ev_begin));
-    HIP_TRY(ctx, hipEventCreate(&ev_end));
+    for (auto& e : ev) e = events.get(hipEventDisableTiming);
+    hipEvent_t ev_begin = events.get(), ev_end = events.get();
+    POOL_TRY(ctx, events);
     HIP_TRY(ctx, hipEventRecord(ev_begin, st));
     const bool time_gemm = stats && (prm->profile || getenv("CNMF_TIME_GEMM"));
     std::vector<hipEvent_t> gev;   // (a0,a1,b0,b1) per iteration when timing is requested
@@ -681,7 +722,11 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         int tiers = 0;
         for (int s2 = 0; s2 < nslots; ++s2)
             if (hs[s2].state) tiers |= hs[s2].k <= 16 ? 1 : (hs[s2].k <= 32 ? 2 : 4);
-        if (time_gemm) { gev.resize(gev.size() + 4); for (int i = 0; i < 4; ++i) hipEventCreate(&gev[gev.size() - 4 + i]); hipEventRecord(gev[gev.size() - 4], st); }
+        if (time_gemm) {
+            for (int i = 0; i < 4; ++i) gev.push_back(events.get());
+            POOL_TRY(ctx, events);
+            hipEventRecord(gev[gev.size() - 4], st);
+        }
         // pass A : XHt[KC][N] = H_all . X^T                       (sklearn _nmf.py:387)
         if (sk.on && gvarA == 0)
             HIP_TRY(ctx, launch_streamk_passA(st, sk, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt,
@@ -797,9 +842,6 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         HIP_TRY(ctx, hipMemcpyAsync(W_out, d_Wres, woff[n] * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (resident) ctx->spectra_rows += (size_t)total_k;
-    else hipFree(d_Hres);
-    hipFree(d_Wres);
-    hipFree(d_H0); hipFree(d_Wt0); hipFree(d_jobs);
     if (stats) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, ev_begin, ev_end);
@@ -817,9 +859,6 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             stats->passA_launches++; stats->passB_launches++;
         }
     }
-    for (auto& e : gev) hipEventDestroy(e);
-    for (auto& e : ev) hipEventDestroy(e);
-    hipEventDestroy(ev_begin); hipEventDestroy(ev_end);
     return CNMF_OK;
 }
 
@@ -876,8 +915,12 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
     gram_rows_kernel<<<1, 256, 0, st>>>(ctx->H, ctx->G_pad, G, ctx->d_slots, ctx->d_slot_list, ctx->gramH, (float)prm->l2_reg_W);
     HIP_TRY(ctx, launch_gemm<false>(st, 0, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt, ctx->N_pad, 0, KC, ctx->G_pad, ctx->N_pad, 1));
     const int chunksW = sweep_chunks(N), partsW = sweep_parts(N);
-    hipEvent_t ev;
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    DevPool pool;
+    EventPool events;
+    hipEvent_t ev = events.get(hipEventDisableTiming);
+    float* d_W = pool.get<float>((size_t)N * k);
+    POOL_TRY(ctx, events);
+    POOL_TRY(ctx, pool);
     const int burst = 8;        // sweeps enqueued between two looks at the slot state
     int done = 0;
     SlotDesc* snap = ctx->h_snap;
@@ -894,9 +937,6 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
         HIP_TRY(ctx, hipEventSynchronize(ev));
         done = (snap->active == 0);
     }
-    hipEventDestroy(ev);
-    float* d_W = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_W, (size_t)N * k * sizeof(float)));
     dim3 gW((N + 255) / 256, k);
     extract_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, 0, k, d_W, 1);
     HIP_TRY(ctx, hipMemcpyAsync(W_out, d_W, (size_t)N * k * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -904,7 +944,6 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
     clear_rows_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, 0, k);
     clear_rows_kernel<<<gWc, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, 0, k);
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    hipFree(d_W);
     if (n_iter_out) *n_iter_out = snap->iter;
     if (viol_out) *viol_out = snap->viol_last;
     return CNMF_OK;
@@ -966,16 +1005,20 @@ extern "C" int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float
     hipStream_t st = ctx->stream;
     const int Jp = round_up(J, 128);           // J padded like N_pad so any tile shape is addressable
     const int Kp = K;
-    float *dA, *dB, *dC;
+    DevPool pool;
+    EventPool events;
     const size_t bA = (size_t)KC * Kp * sizeof(float);
     const size_t bB = (mode == 0 ? (size_t)Jp * Kp : ((size_t)Kp + 1) * J + 128) * sizeof(float);
     const size_t bC = (size_t)nsplit * KC * Jp * sizeof(float);
-    HIP_TRY(ctx, hipMalloc(&dA, bA)); HIP_TRY(ctx, hipMalloc(&dB, bB)); HIP_TRY(ctx, hipMalloc(&dC, bC));
+    float* dA = pool.get<float>(bA / sizeof(float));
+    float* dB = pool.get<float>(bB / sizeof(float));
+    float* dC = pool.get<float>(bC / sizeof(float));
+    POOL_TRY(ctx, pool);
     HIP_TRY(ctx, hipMemsetAsync(dB, 0, bB, st));
     HIP_TRY(ctx, hipMemcpyAsync(dA, A, bA, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dB, B, (size_t)(mode == 0 ? J : Kp) * (mode == 0 ? Kp : J) * sizeof(float), hipMemcpyHostToDevice, st));
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEvent_t e0 = events.get(), e1 = events.get();
+    POOL_TRY(ctx, events);
     reps = std::max(1, reps);
     for (int i = 0; i < reps + 1; ++i) {
         if (i == 1) hipEventRecord(e0, st);
@@ -998,8 +1041,6 @@ extern "C" int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float
                 for (int z = 1; z < nsplit; ++z) s += hc[((size_t)z * KC + c) * Jp + j];
             C[(size_t)c * J + j] = s;
         }
-    hipFree(dA); hipFree(dB); hipFree(dC);
-    hipEventDestroy(e0); hipEventDestroy(e1);
     return CNMF_OK;
 }
 
@@ -1007,12 +1048,12 @@ extern "C" int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t 
 {
     if (!ctx || !out || n < 0) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    double* d = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d, (size_t)std::max<int64_t>(n, 1) * sizeof(double)));
+    DevPool pool;
+    double* d = pool.get<double>((size_t)n);
+    POOL_TRY(ctx, pool);
     launch_standard_normal(ctx->stream, seed, n, d);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(d);
     return CNMF_OK;
 }

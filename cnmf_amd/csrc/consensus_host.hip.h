@@ -17,19 +17,7 @@
 
 namespace cnmf {
 
-struct DevPool {               // frees everything it handed out when it goes out of scope
-    std::vector<void*> ptrs;
-    hipError_t err = hipSuccess;
-    template <typename T> T* get(size_t n, bool zero = false, hipStream_t st = nullptr) {
-        void* p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
-        if (e != hipSuccess) { err = e; return nullptr; }
-        ptrs.push_back(p);
-        if (zero) hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(T), st);
-        return (T*)p;
-    }
-    ~DevPool() { for (void* p : ptrs) hipFree(p); }
-};
+// (DevPool, the scope-bound device allocator, is defined in cnmf_hip.hip)
 
 static inline bool same_clustering(const std::vector<int>& a, const std::vector<int>& b, int k)
 {   // sklearn _k_means_common.pyx:314-330

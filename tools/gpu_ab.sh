@@ -1,7 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_comm.py -m gpu -x -q > gpurun_out/comm_test.log 2>&1
-export MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 CNMF_BENCH_FORCE_DIST=1
-for g in torch rccl; do
-  CNMF_GATHER=$g timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --restarts-per-k 10 2>gpurun_out/err_$g.log >gpurun_out/out_$g.log
-done
+python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1
+tail -3 gpurun_out/gpu_tests.log
+python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+wc -l gpurun_out/bench_default.json
