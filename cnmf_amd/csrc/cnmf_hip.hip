@@ -23,6 +23,7 @@
 
 #include "../../include/cnmf_hip.h"
 #include "kernels_gemm.hip.h"
+#include "kernels_gemm3.hip.h"
 #include "kernels_rng.hip.h"
 #include "kernels_sweep.hip.h"
 
@@ -41,11 +42,13 @@ struct cnmf_ctx {
     int64_t N = 0, G = 0;
     int N_pad = 0, G_pad = 0;
     float* X = nullptr;
+    unsigned char *X3 = nullptr, *Xt3 = nullptr;   // bf16 planes of X and X^T (split-operand GEMM), built on first use
 
     // batch buffers (sized for kc_alloc columns)
     int kc_alloc = 0, nsplit_alloc = 0, nsplitA_alloc = 0, parts_alloc = 0;
     size_t gram_part_floats = 0;
-    float *H = nullptr, *Wt = nullptr, *XHt = nullptr, *XHt1 = nullptr, *XtW = nullptr;
+    float *H = nullptr, *Wt = nullptr, *XHt = nullptr, *XHt1 = nullptr, *XHt2 = nullptr, *XtW = nullptr;
+    unsigned char *H3 = nullptr, *Wt3 = nullptr;   // planes of the packed factors, refreshed every iteration
     unsigned char* d_split = nullptr;   // stream-K cut flags of the current plan
     float *gramH = nullptr, *gramW = nullptr, *gram_part = nullptr;
     double* viol_part = nullptr;
@@ -65,6 +68,9 @@ struct cnmf_ctx {
 };
 
 static constexpr int RING = 8;
+#ifndef CNMF_GEMM3_DEFAULT
+#define CNMF_GEMM3_DEFAULT 2
+#endif
 
 #define SET_ERR(ctx, ...)                                                   \
     do {                                                                    \
@@ -290,8 +296,9 @@ extern "C" cnmf_ctx* cnmf_create(int device)
 
 static void free_batch(cnmf_ctx* c)
 {
-    hipFree(c->H); hipFree(c->Wt); hipFree(c->XHt); hipFree(c->XHt1); hipFree(c->XtW); hipFree(c->d_split);
-    c->XHt1 = nullptr; c->d_split = nullptr;
+    hipFree(c->H); hipFree(c->Wt); hipFree(c->XHt); hipFree(c->XHt1); hipFree(c->XHt2); hipFree(c->XtW); hipFree(c->d_split);
+    hipFree(c->H3); hipFree(c->Wt3);
+    c->XHt1 = c->XHt2 = nullptr; c->d_split = nullptr; c->H3 = c->Wt3 = nullptr;
     hipFree(c->gramH); hipFree(c->gramW); hipFree(c->gram_part); hipFree(c->viol_part);
     hipFree(c->d_slots); hipFree(c->d_slot_list);
     if (c->h_slots) hipHostFree(c->h_slots);
@@ -310,7 +317,8 @@ extern "C" void cnmf_destroy(cnmf_ctx* ctx)
     hipStreamSynchronize(ctx->stream);
     free_batch(ctx);
     cnmf_comm_finalize(ctx);
-    hipFree(ctx->X); hipFree(ctx->stageW); hipFree(ctx->stageH); hipFree(ctx->spectra);
+    hipFree(ctx->X); hipFree(ctx->X3); hipFree(ctx->Xt3);
+    hipFree(ctx->stageW); hipFree(ctx->stageH); hipFree(ctx->spectra);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -325,10 +333,11 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     free_batch(ctx);
     hipFree(ctx->X); ctx->X = nullptr;
+    hipFree(ctx->X3); hipFree(ctx->Xt3); ctx->X3 = ctx->Xt3 = nullptr;
     ctx->spectra_rows = 0;            // spectra of another matrix are not comparable
     ctx->N = N; ctx->G = G;
     ctx->N_pad = round_up(N, 128);
-    ctx->G_pad = round_up(G, 32);
+    ctx->G_pad = round_up(G, G >= 512 ? 128 : 32);   // whole 128-gene tiles for the split-operand GEMM
     // one extra row of slack: pass B's last 128-gene tile runs past G_pad into the next row
     // (values that only feed never-stored output columns), so the last row needs a successor
     const size_t bytes = ((size_t)ctx->N_pad + 1) * ctx->G_pad * sizeof(float);
@@ -394,6 +403,120 @@ extern "C" int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* N, int64_t* G)
     return ctx->X ? CNMF_OK : CNMF_ESTATE;
 }
 
+// ------------------------------------------------------------------ split-operand GEMM launchers
+static hipError_t launch_split3(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst)
+{
+    const long long total = (long long)rows * (K / 8);
+    split3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(src, ld, rows, K, (unsigned short*)dst);
+    return hipGetLastError();
+}
+
+// CNMF_GEMM3: 0 = exact-f32 matrix pipe only, 1 = split-operand bf16 path, two register-staged 4-wave
+// workgroups per CU (the simple reference variant), 2 = split-operand bf16 path, one 8-wave LDS-DMA
+// ping-pong workgroup per CU (default).  Read on every call so that tests can switch it.
+static int gemm3_mode()
+{
+    const char* e = getenv("CNMF_GEMM3");
+    const int mode = e ? atoi(e) : CNMF_GEMM3_DEFAULT;
+    return (mode < 0 || mode > 2) ? CNMF_GEMM3_DEFAULT : mode;
+}
+static int gemm3_wg_slots() { return gemm3_mode() == 2 ? 256 : 512; }
+
+static hipError_t launch_gemm3(hipStream_t st, const unsigned char* A3, const unsigned char* B3, int Kb,
+                               float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm3g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3G_LDS_BYTES);
+        attr_set = true;
+    }
+    const int kb_per = (Kb + nsplit - 1) / nsplit;
+    dim3 grid(Jpad / G3_JW, KC / G3_MW, (Kb + kb_per - 1) / kb_per);
+    if (gemm3_mode() == 2)
+        gemm3g_kernel<<<grid, 512, G3G_LDS_BYTES, st>>>(A3, B3, Kb, C, ldc, cstride, kb_per);
+    else
+        gemm3_kernel<<<grid, 256, G3_LDS_BYTES, st>>>(A3, B3, Kb, C, ldc, cstride, kb_per);
+    return hipGetLastError();
+}
+
+
+// ---- stream-K plan for the split-operand pass A (tile = 256 components x 128 cells, up to 2 cuts per tile)
+struct StreamK3 {
+    bool on = false;
+    int T = 0, Kb = 0, P = 0, MG = 1;
+    std::vector<unsigned char> flags;     // bit 0: >= 1 cut (plane 1 holds the tail), bit 1: 2 cuts (plane 2 the middle)
+};
+
+static StreamK3 plan_streamk3(int KC, int N_pad, int G_pad, int n_wg_slots)
+{
+    StreamK3 sk;
+    sk.MG = KC / G3_MW;
+    sk.T = sk.MG * (N_pad / G3_JW);
+    sk.Kb = G_pad / G3_BK;
+    sk.P = n_wg_slots;
+    if (sk.T < 256 || sk.P > 2 * sk.T || getenv("CNMF_NO_STREAMK")) return sk;   // few tiles: K split + reduce instead
+    sk.on = true;
+    sk.flags.assign(sk.T, 0);
+    const long long U = (long long)sk.T * sk.Kb;
+    for (int p = 1; p < sk.P; ++p) {
+        const long long b = U * p / sk.P;
+        if (b % sk.Kb) {
+            unsigned char& f = sk.flags[b / sk.Kb];
+            f = f ? 3 : 1;
+        }
+    }
+    return sk;
+}
+
+static hipError_t launch_gemm3_streamk(hipStream_t st, const StreamK3& sk, const unsigned char* A3,
+                                       const unsigned char* B3, float* C0, float* C1, float* C2, int ldc)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm3_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm3g_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3G_LDS_BYTES);
+        attr_set = true;
+    }
+    if (gemm3_mode() == 2)
+        gemm3g_streamk_kernel<<<sk.P, 512, G3G_LDS_BYTES, st>>>(A3, B3, sk.Kb, C0, C1, C2, ldc, sk.MG, sk.T);
+    else
+        gemm3_streamk_kernel<<<sk.P, 256, G3_LDS_BYTES, st>>>(A3, B3, sk.Kb, C0, C1, C2, ldc, sk.MG, sk.T);
+    return hipGetLastError();
+}
+
+// planes of X (pass A) and of X^T (pass B), built once per matrix on first use
+static int ensure_planes(cnmf_ctx* ctx)
+{
+    if (ctx->X3 && ctx->Xt3) return CNMF_OK;
+    const size_t bA = (size_t)ctx->N_pad * (ctx->G_pad / 16) * G3_ROWB;
+    const size_t bB = (size_t)ctx->G_pad * (ctx->N_pad / 16) * G3_ROWB;
+    HIP_TRY(ctx, hipMalloc(&ctx->X3, bA));
+    HIP_TRY(ctx, hipMalloc(&ctx->Xt3, bB));
+    HIP_TRY(ctx, launch_split3(ctx->stream, ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->X3));
+    dim3 grid((ctx->G_pad + 255) / 256, ctx->N_pad / 8);
+    split3_transpose_kernel<<<grid, 256, 0, ctx->stream>>>(ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->N_pad,
+                                                            (unsigned short*)ctx->Xt3);
+    HIP_TRY(ctx, hipGetLastError());
+    return CNMF_OK;
+}
+
+// the split-operand path needs whole 256 x 128 tiles
+static bool gemm3_enabled(const cnmf_ctx* ctx, int KC)
+{
+    return gemm3_mode() != 0 && KC % G3_MW == 0 && ctx->G_pad % G3_JW == 0 && ctx->N_pad % G3_JW == 0;
+}
+
+static int pick_nsplit3(const cnmf_ctx* ctx, int KC)
+{
+    // pass B grid = (G_pad/128) x (KC/256) x nsplit; aim at 2 workgroups per CU, >= 16 blocks per split
+    const int tiles = (ctx->G_pad / G3_JW) * std::max(1, KC / G3_MW);
+    const int Kb = ctx->N_pad / G3_BK;
+    int s = std::max(1, std::min(gemm3_wg_slots() / std::max(1, tiles), Kb / 16));
+    const int kb_per = (Kb + s - 1) / s;
+    return (Kb + kb_per - 1) / kb_per;
+}
+
 // ------------------------------------------------------------------ batch buffers
 static int sweep_max_parts()
 {
@@ -435,12 +558,13 @@ static int pick_nsplit_A(const cnmf_ctx* ctx, int KC)
 
 static int ensure_batch(cnmf_ctx* ctx, int KC, int max_k = KMAX, int min_k = 1)
 {
-    const int nsplit = pick_nsplit(ctx, KC);
+    const bool use3 = gemm3_enabled(ctx, KC);
+    const int nsplit = use3 ? std::max(pick_nsplit(ctx, KC), pick_nsplit3(ctx, KC)) : pick_nsplit(ctx, KC);
     const int nsplitA = pick_nsplit_A(ctx, KC);
     const int parts = std::max(sweep_parts((int)ctx->N), sweep_parts((int)ctx->G));
     const size_t gp_need = (size_t)(KC / std::max(1, min_k) + 1) * parts * max_k * max_k;
     if (ctx->kc_alloc == KC && ctx->nsplit_alloc == nsplit && ctx->nsplitA_alloc == nsplitA &&
-        ctx->parts_alloc == parts && ctx->gram_part_floats >= gp_need) return CNMF_OK;
+        ctx->parts_alloc == parts && ctx->gram_part_floats >= gp_need && (!use3 || ctx->H3)) return CNMF_OK;
     free_batch(ctx);
     const size_t hb = (size_t)KC * ctx->G_pad * sizeof(float);
     const size_t wb = (size_t)KC * ctx->N_pad * sizeof(float);
@@ -448,6 +572,11 @@ static int ensure_batch(cnmf_ctx* ctx, int KC, int max_k = KMAX, int min_k = 1)
     HIP_TRY(ctx, hipMalloc(&ctx->Wt, wb));
     HIP_TRY(ctx, hipMalloc(&ctx->XHt, wb * nsplitA));
     HIP_TRY(ctx, hipMalloc(&ctx->XHt1, wb));
+    if (use3) {
+        HIP_TRY(ctx, hipMalloc(&ctx->XHt2, wb));
+        HIP_TRY(ctx, hipMalloc(&ctx->H3, (size_t)KC * (ctx->G_pad / 16) * G3_ROWB));
+        HIP_TRY(ctx, hipMalloc(&ctx->Wt3, (size_t)KC * (ctx->N_pad / 16) * G3_ROWB));
+    }
     HIP_TRY(ctx, hipMalloc(&ctx->d_split, (size_t)(KC / 32 + 1) * (ctx->N_pad / 128 + 1)));
     HIP_TRY(ctx, hipMalloc(&ctx->XtW, hb * nsplit));
     HIP_TRY(ctx, hipMalloc(&ctx->gramH, (size_t)KC * GRAM_SZ * sizeof(float)));
@@ -569,7 +698,10 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     if (rc) return rc;
     rc = ensure_stage(ctx, (size_t)N * KMAX, (size_t)G * KMAX);
     if (rc) return rc;
-    int nsplit = ctx->nsplit_alloc;
+    int nsplit = std::min(pick_nsplit(ctx, KC), ctx->nsplit_alloc);
+    bool use3 = gemm3_enabled(ctx, KC);            // split-operand bf16 MFMA path (whole 256-column tiles only)
+    if (use3) { rc = ensure_planes(ctx); if (rc) return rc; }
+    const int nsplit3 = use3 ? pick_nsplit3(ctx, KC) : 1;
     const int fin_y = (max_k * max_k + 255) / 256;       // finalize blocks per slot
     const int lag = std::max(1, std::min(RING - 2, prm->lag > 0 ? prm->lag : 2));
     hipStream_t st = ctx->stream;
@@ -652,6 +784,12 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     StreamK sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
     if (sk.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
     int nsplitA = (sk.on && gvarA == 0) ? 1 : ctx->nsplitA_alloc;
+    StreamK3 sk3;
+    if (use3) {
+        sk3 = plan_streamk3(KC, ctx->N_pad, ctx->G_pad, gemm3_wg_slots());
+        if (sk3.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk3.flags.data(), sk3.flags.size(), hipMemcpyHostToDevice, st));
+        else if (sk.on) use3 = false;              // (cannot happen: both plans switch on the same tile count)
+    }
     int n_done = 0;
 
     auto retire = [&](int s, const SlotDesc& snap) -> int {
@@ -728,31 +866,47 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             hipEventRecord(gev[gev.size() - 4], st);
         }
         // pass A : XHt[KC][N] = H_all . X^T                       (sklearn _nmf.py:387)
-        if (sk.on && gvarA == 0)
+        SplitInfo spA{nullptr, nullptr, 1, 1, 1};
+        if (use3) {
+            HIP_TRY(ctx, launch_split3(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3));
+            if (time_gemm) hipEventRecord(gev[gev.size() - 4], st);
+            if (sk3.on) {
+                HIP_TRY(ctx, launch_gemm3_streamk(st, sk3, ctx->H3, ctx->X3, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
+                spA = SplitInfo{ctx->XHt1, ctx->d_split, G3_JW, G3_MW, sk3.MG, ctx->XHt2};
+            } else {
+                HIP_TRY(ctx, launch_gemm3(st, ctx->H3, ctx->X3, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
+                                          (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
+            }
+        } else if (sk.on && gvarA == 0) {
             HIP_TRY(ctx, launch_streamk_passA(st, sk, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt,
                                               ctx->XHt1, ctx->N_pad, ctx->N_pad));
-        else
+            spA = SplitInfo{ctx->XHt1, ctx->d_split, 128, sk.mw, sk.MG};
+        } else
             HIP_TRY(ctx, launch_gemm<false>(st, gvarA, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt,
                                             ctx->N_pad, (long long)KC * ctx->N_pad, KC, ctx->G_pad, ctx->N_pad, nsplitA));
         if (time_gemm) hipEventRecord(gev[gev.size() - 3], st);
-        if (!(sk.on && gvarA == 0))
+        if (!spA.plane1)
             HIP_TRY(ctx, launch_reduce_splits(st, ctx->XHt, nsplitA, (long long)KC * ctx->N_pad,
                                               (long long)KC * ctx->N_pad));
         // W half-step                                             (sklearn _nmf.py:500)
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
-                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k, tiers,
-                                  (sk.on && gvarA == 0) ? SplitInfo{ctx->XHt1, ctx->d_split, 128, sk.mw, sk.MG}
-                                                        : SplitInfo{nullptr, nullptr, 1, 1, 1}));
+                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k, tiers, spA));
         finalize_kernel<<<dim3(nslots, fin_y), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
                                                 ctx->d_slots, 0, prm->tol, prm->max_iter, 1, max_k);
+        if (use3) HIP_TRY(ctx, launch_split3(st, ctx->Wt, ctx->N_pad, KC, ctx->N_pad, ctx->Wt3));
         if (time_gemm) hipEventRecord(gev[gev.size() - 2], st);
         // pass B : XtW[S][KC][G] = Wt_all . X  (split over cells)  (sklearn _nmf.py:505-507)
-        HIP_TRY(ctx, launch_gemm<true>(st, gvarB, ctx->Wt, ctx->N_pad, ctx->X, ctx->G_pad, ctx->XtW,
-                                       ctx->G_pad, (long long)KC * ctx->G_pad, KC, ctx->N_pad,
-                                       ctx->G_pad, nsplit));
+        const int nsB = use3 ? nsplit3 : nsplit;
+        if (use3)
+            HIP_TRY(ctx, launch_gemm3(st, ctx->Wt3, ctx->Xt3, ctx->N_pad / 16, ctx->XtW, ctx->G_pad,
+                                      (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3));
+        else
+            HIP_TRY(ctx, launch_gemm<true>(st, gvarB, ctx->Wt, ctx->N_pad, ctx->X, ctx->G_pad, ctx->XtW,
+                                           ctx->G_pad, (long long)KC * ctx->G_pad, KC, ctx->N_pad,
+                                           ctx->G_pad, nsplit));
         if (time_gemm) hipEventRecord(gev[gev.size() - 1], st);
         // H half-step
-        HIP_TRY(ctx, launch_reduce_splits(st, ctx->XtW, nsplit, (long long)KC * ctx->G_pad,
+        HIP_TRY(ctx, launch_reduce_splits(st, ctx->XtW, nsB, (long long)KC * ctx->G_pad,
                                           (long long)KC * ctx->G_pad));
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
                                   ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers));
@@ -820,6 +974,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                 for (int s : idx) cols.alloc(hs[s].k);
                 const int cap = (ctx->nsplit_alloc * KC0) / KC;
                 nsplit = std::max(1, std::min(pick_nsplit(ctx, KC), cap));
+                use3 = false;                       // fewer than 256 packed columns: the f32 pipe takes over
                 sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
                 nsplitA = (sk.on && gvarA == 0) ? 1
                         : std::max(1, std::min(pick_nsplit_A(ctx, KC), (ctx->nsplitA_alloc * KC0) / KC));
@@ -1040,6 +1195,52 @@ extern "C" int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float
             if (mode == 1)
                 for (int z = 1; z < nsplit; ++z) s += hc[((size_t)z * KC + c) * Jp + j];
             C[(size_t)c * J + j] = s;
+        }
+    return CNMF_OK;
+}
+
+// C[KC][J] = A[KC][K] . B[J][K]^T through the split-operand bf16 MFMA path (KC % 256 == 0, K % 16 == 0)
+extern "C" int cnmf_debug_gemm3(cnmf_ctx* ctx, const float* A, const float* B, float* C, int KC, int K, int J,
+                                int nsplit, double* ms_out, int reps)
+{
+    if (!ctx || !A || !B || !C) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    if (KC % 256 || K % 16 || J < 1 || nsplit < 1) { SET_ERR(ctx, "debug_gemm3 needs KC %% 256 == 0, K %% 16 == 0"); return CNMF_EINVAL; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int Jp = round_up(J, G3_JW), Kb = K / 16;
+    DevPool pool;
+    EventPool events;
+    float* dA = pool.get<float>((size_t)KC * K);
+    float* dB = pool.get<float>((size_t)Jp * K, true, st);
+    unsigned char* dA3 = pool.get<unsigned char>((size_t)KC * Kb * G3_ROWB);
+    unsigned char* dB3 = pool.get<unsigned char>((size_t)Jp * Kb * G3_ROWB);
+    float* dC = pool.get<float>((size_t)nsplit * KC * Jp);
+    hipEvent_t e0 = events.get(), e1 = events.get();
+    POOL_TRY(ctx, pool);
+    POOL_TRY(ctx, events);
+    HIP_TRY(ctx, hipMemcpyAsync(dA, A, (size_t)KC * K * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dB, B, (size_t)J * K * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, launch_split3(st, dA, K, KC, K, dA3));
+    HIP_TRY(ctx, launch_split3(st, dB, K, Jp, K, dB3));
+    reps = std::max(1, reps);
+    int zs = 1;
+    for (int i = 0; i < reps + 1; ++i) {
+        if (i == 1) hipEventRecord(e0, st);
+        HIP_TRY(ctx, launch_gemm3(st, dA3, dB3, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit));
+    }
+    hipEventRecord(e1, st);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    { const int kb_per = (Kb + nsplit - 1) / nsplit; zs = (Kb + kb_per - 1) / kb_per; }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) *ms_out = ms / reps;
+    std::vector<float> hc((size_t)zs * KC * Jp);
+    HIP_TRY(ctx, hipMemcpy(hc.data(), dC, hc.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int c = 0; c < KC; ++c)
+        for (int j = 0; j < J; ++j) {
+            float v = hc[(size_t)c * Jp + j];
+            for (int z = 1; z < zs; ++z) v += hc[((size_t)z * KC + c) * Jp + j];
+            C[(size_t)c * J + j] = v;
         }
     return CNMF_OK;
 }

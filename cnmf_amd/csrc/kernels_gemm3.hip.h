@@ -1,0 +1,449 @@
+// Split-operand MFMA GEMM: f32-accurate products on the bf16 matrix pipe (gfx950 only).
+//
+// The exact-f32 MFMA (kernels_gemm.hip.h) runs at 1/16 of the bf16 MFMA rate.  Here every f32
+// operand x is held as THREE bf16 planes  x = h + m + l  (h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m); 3 x 8 significand bits >= the 24 of f32, the subtractions are exact), and a
+// product a*b is accumulated in f32 from the six partial products whose weight is >= 2^-18:
+//
+//      a*b  ~=  ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh)
+//
+// The three dropped ones (am*bl, al*bm, al*bl) are below 2^-25 |a*b|, i.e. below the rounding of
+// the f32 product itself, so the result carries f32-class error (tests/test_gpu_nmf.py holds it to
+// the same 2e-6 bound as the f32 pipe).  6 bf16 MFMAs per 16 k at 16x the f32 rate = 2.67x the
+// f32 matrix peak.
+//
+// Both passes are "NT" products  C[c][j] = sum_k A[c][k] * B[j][k]  with K contiguous in both
+// operands: pass A uses planes of X (cells x genes), pass B planes of X^T (genes x cells) -- the
+// data matrix is resident twice (288 GB of HBM; 1.2 GB at 50k x 2000).
+//
+// Plane layout in memory (A and B alike), "k-blocked interleave":
+//      row r, 16-k block kb :  [h: 16 bf16][m: 16 bf16][l: 16 bf16]   = 96 contiguous bytes
+// so one LDS stage (BK = 16) of a row is ONE 96-byte segment.  In LDS a row is padded to 112 B
+// (28 dwords: ds_read_b128 of 16 consecutive rows hits 16 disjoint 4-bank groups).
+//
+// v_mfma_f32_32x32x16_bf16: lane l supplies row/col (l & 31) and the 8 k's of half (l >> 5) of the
+// block; A and B use the same assignment, so the order of k inside a block is immaterial.
+// Workgroup = 4 waves, tile 256 components x 128 j; wave (wm, wn) owns 128 x 64 = 4 x 2 MFMA tiles
+// (128 accumulator registers).  X is read ONCE per pass for all 256 packed columns.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cnmf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef float f32x16_3 __attribute__((ext_vector_type(16)));
+
+constexpr int G3_MW = 256;            // component rows per workgroup tile
+constexpr int G3_JW = 128;            // j columns per workgroup tile
+constexpr int G3_BK = 16;             // k per stage = one MFMA block
+constexpr int G3_ROWB = 96;           // bytes of one row-block in memory
+constexpr int G3_LDSROW = 112;        // bytes of one row in LDS
+constexpr int G3_ROWS = G3_MW + G3_JW;
+constexpr int G3_LDS_BYTES = G3_ROWS * G3_LDSROW;       // 43 008 B -> 2 workgroups per CU
+constexpr int G3_CHUNKS = G3_ROWS * 6 / 256;            // 16-byte chunks staged per thread (9)
+
+__device__ __forceinline__ unsigned short bf16_rne(float x)
+{
+    unsigned int u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+
+// x -> (h, m, l)
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l)
+{
+    h = bf16_rne(x);
+    const float r1 = x - bf16_to_f32(h);
+    m = bf16_rne(r1);
+    const float r2 = r1 - bf16_to_f32(m);
+    l = bf16_rne(r2);
+}
+
+// src [rows][ld] f32 (K-contiguous)  ->  dst planes [rows][K/16][3][16] bf16.  One thread per 8 k.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, int ld, int rows, int K,
+                                                     unsigned short* __restrict__ dst)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = K / 8;
+    const long long total = (long long)rows * per_row;
+    if (t >= total) return;
+    const int row = (int)(t / per_row), o = (int)(t % per_row);
+    const int kb = o >> 1, half = o & 1;
+    const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)row * ld + kb * 16 + half * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)row * ld + kb * 16 + half * 8 + 4);
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned short p[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) split3(x[i], p[0][i], p[1][i], p[2][i]);
+    unsigned short* d = dst + ((size_t)row * (K / 16) + kb) * 48 + half * 8;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        u32x4 w;
+        w.x = p[q][0] | ((unsigned)p[q][1] << 16); w.y = p[q][2] | ((unsigned)p[q][3] << 16);
+        w.z = p[q][4] | ((unsigned)p[q][5] << 16); w.w = p[q][6] | ((unsigned)p[q][7] << 16);
+        *reinterpret_cast<u32x4*>(d + q * 16) = w;
+    }
+}
+
+// planes of the TRANSPOSE: src [K rows][ld] f32 (J-contiguous, J = dst rows) -> dst [J_rows][K/16][3][16].
+// One thread per (dst row j, 8 k); lanes run along j so the reads coalesce.  One-off per matrix.
+__global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ src, int ld, int src_rows,
+                                                               int J, int K, unsigned short* __restrict__ dst)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int o = blockIdx.y;                 // 8-k group
+    if (j >= J) return;
+    const int kb = o >> 1, half = o & 1;
+    unsigned short p[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = o * 8 + i;
+        const float x = (k < src_rows) ? src[(size_t)k * ld + j] : 0.f;
+        split3(x, p[0][i], p[1][i], p[2][i]);
+    }
+    unsigned short* d = dst + ((size_t)j * (K / 16) + kb) * 48 + half * 8;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        u32x4 w;
+        w.x = p[q][0] | ((unsigned)p[q][1] << 16); w.y = p[q][2] | ((unsigned)p[q][3] << 16);
+        w.z = p[q][4] | ((unsigned)p[q][5] << 16); w.w = p[q][6] | ((unsigned)p[q][7] << 16);
+        *reinterpret_cast<u32x4*>(d + q * 16) = w;
+    }
+}
+
+// One K segment [kb0, kb0 + nkb) (in 16-k blocks) of one 256 x 128 tile, stored to C.
+//   A3 : planes of the component-major factor, rows m0.. (KC rows in total), Kb blocks per row
+//   B3 : planes of X (or X^T), rows j0..
+// Rows of B beyond the allocation are never touched: the caller pads the plane buffers to whole tiles.
+__device__ __forceinline__ void gemm3_segment(const unsigned char* __restrict__ A3, const unsigned char* __restrict__ B3,
+                                              int Kb, float* __restrict__ C, int ldc, int m0, int j0, int kb0,
+                                              int nkb, unsigned char* smem)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+
+    // ---- staging map: chunk c = tid + 256*i ; row = c / 6 ; part = c % 6 ; rows 0..255 = A, 256..383 = B
+    // (two 64-bit bases + 32-bit per-chunk offsets: a tile's rows span < 2^31 bytes)
+    const size_t rowbytes = (size_t)Kb * G3_ROWB;
+    const unsigned char* abase = A3 + (size_t)m0 * rowbytes + (size_t)kb0 * G3_ROWB;
+    const unsigned char* bbase = B3 + (size_t)j0 * rowbytes + (size_t)kb0 * G3_ROWB;
+    unsigned int goff[G3_CHUNKS];
+    int lds_off[G3_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < G3_CHUNKS; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / 6, part = c - row * 6;
+        lds_off[i] = row * G3_LDSROW + part * 16;
+        goff[i] = (unsigned int)((i < 6 ? row : row - G3_MW) * rowbytes + part * 16);
+    }
+#define G3_SRC(i_) ((i_) < 6 ? abase + goff[i_] : bbase + goff[i_])
+    u32x4 stage[G3_CHUNKS];
+
+    f32x16_3 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const unsigned char* a_lds = smem + (wm * 128 + li) * G3_LDSROW + h * 16;
+    const unsigned char* b_lds = smem + (G3_MW + wn * 64 + li) * G3_LDSROW + h * 16;
+
+#pragma unroll
+    for (int i = 0; i < G3_CHUNKS; ++i) stage[i] = *reinterpret_cast<const u32x4*>(G3_SRC(i));
+#pragma unroll
+    for (int i = 0; i < G3_CHUNKS; ++i) *reinterpret_cast<u32x4*>(smem + lds_off[i]) = stage[i];
+    __syncthreads();
+
+    for (int s = 0; s < nkb; ++s) {
+        // prefetch the next block into registers (clamped on the last stage: a harmless re-read)
+        const int sn = (s + 1 < nkb) ? s + 1 : s;
+#pragma unroll
+        for (int i = 0; i < G3_CHUNKS; ++i)
+            stage[i] = *reinterpret_cast<const u32x4*>(G3_SRC(i) + (size_t)sn * G3_ROWB);
+        __builtin_amdgcn_sched_barrier(0);
+
+        bf16x8 bq[2][3];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                bq[n][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b_lds + n * 32 * G3_LDSROW + p * 32));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            bf16x8 aq[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                aq[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a_lds + m * 32 * G3_LDSROW + p * 32));
+            // smallest terms first, alternating accumulators so that dependent MFMAs are two apart
+#define G3_MFMA(pa, pb)                                                                                   \
+            acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[pa], bq[0][pb], acc[m][0], 0, 0, 0);   \
+            acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[pa], bq[1][pb], acc[m][1], 0, 0, 0);
+            G3_MFMA(0, 2) G3_MFMA(1, 1) G3_MFMA(2, 0)
+            G3_MFMA(0, 1) G3_MFMA(1, 0)
+            G3_MFMA(0, 0)
+#undef G3_MFMA
+        }
+        __syncthreads();                                   // every wave is done reading this block
+#pragma unroll
+        for (int i = 0; i < G3_CHUNKS; ++i) *reinterpret_cast<u32x4*>(smem + lds_off[i]) = stage[i];
+        __syncthreads();
+    }
+
+#undef G3_SRC
+    const int j = j0 + wn * 64 + li;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int cbase = m0 + wm * 128 + m * 32 + 4 * h;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = cbase + (r & 3) + 8 * (r >> 2);
+                C[(size_t)row * ldc + j + n * 32] = acc[m][n][r];
+            }
+    }
+}
+
+// grid-mapped launch: blockIdx = (j tile, component group of 256, K split)
+__global__ __launch_bounds__(256, 2) void gemm3_kernel(const unsigned char* __restrict__ A3,
+                                                       const unsigned char* __restrict__ B3, int Kb,
+                                                       float* __restrict__ C, int ldc, long long c_split_stride,
+                                                       int kb_per)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const int kb0 = blockIdx.z * kb_per;
+    const int nkb = min(kb_per, Kb - kb0);
+    gemm3_segment(A3, B3, Kb, C + (size_t)blockIdx.z * c_split_stride, ldc, blockIdx.y * G3_MW,
+                  blockIdx.x * G3_JW, kb0, nkb, smem3);
+}
+
+// stream-K launch: gridDim.x persistent workgroups share T tiles x Kb blocks evenly.  With
+// gridDim.x <= 2 T a tile is cut at most twice: the piece that starts at block 0 goes to plane C0, the
+// piece that ends at Kb to C1, a piece in the middle to C2 (sweep_kernel adds the planes the tile's
+// flags name).  Fixed piece -> plane mapping and fixed summation order: bit-reproducible.
+__global__ __launch_bounds__(256, 2) void gemm3_streamk_kernel(const unsigned char* __restrict__ A3,
+                                                               const unsigned char* __restrict__ B3, int Kb,
+                                                               float* __restrict__ C0, float* __restrict__ C1,
+                                                               float* __restrict__ C2, int ldc, int MG, int T)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const long long U = (long long)T * Kb;
+    long long u = U * blockIdx.x / gridDim.x;
+    const long long u1 = U * (blockIdx.x + 1) / gridDim.x;
+    while (u < u1) {
+        const int tile = (int)(u / Kb), kb = (int)(u % Kb);
+        const int ke = (int)min((long long)Kb, kb + (u1 - u));
+        const int jt = tile / MG, mg = tile % MG;
+        gemm3_segment(A3, B3, Kb, (kb == 0) ? C0 : (ke == Kb ? C1 : C2), ldc, mg * G3_MW, jt * G3_JW, kb,
+                      ke - kb, smem3);
+        u += ke - kb;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA ping-pong variant (the production kernel).  ONE workgroup of 8 waves per CU, as two groups
+// of 4 waves that own the SAME 256 x 128 tile and alternate k blocks (group 0 even, group 1 odd): the
+// matrix pipe never sees two equal bursts at once (two independent workgroups per CU fall into
+// lockstep: both in the MFMA burst, then both in the memory phase).  Blocks go global -> LDS directly
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass) into FOUR dense 36 KB images (two
+// per group), so a block is requested three phases (~5000 cycles) before it is multiplied.  At the
+// end group 1 hands its partial accumulators to group 0 through LDS (thread t of either group owns
+// the same tile elements): a fixed two-term sum.  One raw s_barrier per phase, placed in the middle
+// of the computing group's 48 MFMAs: the other group's fragment reads overlap that tail, so the
+// matrix pipe goes from one group's burst straight into the other's.
+//   * LDS image of a block: chunk c = row*6 + part at byte 16 c (lane-linear, as the DMA writes it);
+//     dense 96-byte rows make ds_read_b128 2-way bank conflicted -- irrelevant at < 40 % LDS load.
+//   * vmcnt is counted by hand (9 DMA instructions per block and wave): "my next block has landed"
+//     = vmcnt(9) while the block after it is still in flight.  __syncthreads() would drain it.
+constexpr int G3G_BLK = G3_ROWS * G3_ROWB;              // 36 864 B
+constexpr int G3G_LDS_BYTES = 4 * G3G_BLK;              // 147 456 B (the 128 KB exchange area overlays it)
+
+#define G3_AS1(p_) ((const __attribute__((address_space(1))) void*)(p_))
+#define G3_AS3(p_) ((__attribute__((address_space(3))) void*)(p_))
+#define G3_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+#define G3_RAW_BARRIER()                                   \
+    {                                                      \
+        asm volatile("" ::: "memory");                     \
+        __builtin_amdgcn_s_barrier();                      \
+        asm volatile("" ::: "memory");                     \
+    }
+
+__device__ __forceinline__ void gemm3g_segment(const unsigned char* __restrict__ A3, const unsigned char* __restrict__ B3,
+                                               int Kb, float* __restrict__ C, int ldc, int m0, int j0, int kb0,
+                                               int nkb, unsigned char* smem)
+{
+    const int grp = threadIdx.x >> 8;
+    const int tid = threadIdx.x & 255;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    unsigned char* gbuf = smem + grp * 2 * G3G_BLK;
+
+    const size_t rowbytes = (size_t)Kb * G3_ROWB;
+    const unsigned char* abase = A3 + (size_t)m0 * rowbytes + (size_t)(kb0 + grp) * G3_ROWB;
+    const unsigned char* bbase = B3 + (size_t)j0 * rowbytes + (size_t)(kb0 + grp) * G3_ROWB;
+    unsigned int goff[G3_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < G3_CHUNKS; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / 6, part = c - row * 6;
+        goff[i] = (unsigned int)((i < 6 ? row : row - G3_MW) * rowbytes + part * 16);
+    }
+    f32x16_3 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int a_off = (wm * 128 + li) * G3_ROWB + h * 16;
+    const int b_off = (G3_MW + wn * 64 + li) * G3_ROWB + h * 16;
+    const int n_own = (nkb - grp + 1) >> 1;                 // this group's blocks: grp, grp + 2, ...
+
+#define G3_SRC(i_) ((i_) < 6 ? abase + goff[i_] : bbase + goff[i_])
+#define G3G_ISSUE(own_)                                                                            \
+    {                                                                                              \
+        const size_t o_ = (size_t)(own_) * (2 * G3_ROWB);                                          \
+        unsigned char* d_ = gbuf + ((own_) & 1) * G3G_BLK + wave * 1024;                           \
+        _Pragma("unroll") for (int i = 0; i < G3_CHUNKS; ++i)                                      \
+            __builtin_amdgcn_global_load_lds(G3_AS1(G3_SRC(i) + o_), G3_AS3(d_ + i * 4096), 16, 0, 0); \
+    }
+#define G3_FRAG(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ptr_))
+#define G3_MFMA(m_, aq_, pa, pb)                                                                   \
+    acc[m_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq_[pa], bq[0][pb], acc[m_][0], 0, 0, 0); \
+    acc[m_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq_[pa], bq[1][pb], acc[m_][1], 0, 0, 0);
+#define G3_MFMA6(m_, aq_)                                                                          \
+    G3_MFMA(m_, aq_, 0, 2) G3_MFMA(m_, aq_, 1, 1) G3_MFMA(m_, aq_, 2, 0)                           \
+    G3_MFMA(m_, aq_, 0, 1) G3_MFMA(m_, aq_, 1, 0) G3_MFMA(m_, aq_, 0, 0)
+
+// two component tiles at a time: consecutive MFMAs cycle through FOUR accumulators, so an accumulator
+// is touched again only after three other 8-pass MFMAs
+#define G3_MFMA2(ma_, mb_, pa, pb)                                                                 \
+    G3_MFMA(ma_, aq[ma_], pa, pb) G3_MFMA(mb_, aq[mb_], pa, pb)
+#define G3_MFMA12(ma_, mb_)                                                                        \
+    G3_MFMA2(ma_, mb_, 0, 2) G3_MFMA2(ma_, mb_, 1, 1) G3_MFMA2(ma_, mb_, 2, 0)                     \
+    G3_MFMA2(ma_, mb_, 0, 1) G3_MFMA2(ma_, mb_, 1, 0) G3_MFMA2(ma_, mb_, 0, 0)
+    G3_WAIT_VM(0);                                          // stores of a previous segment
+    if (n_own > 0) G3G_ISSUE(0)
+    if (n_own > 1) G3G_ISSUE(1)
+    if (grp == 0) { if (n_own > 1) G3_WAIT_VM(9); else G3_WAIT_VM(0); }
+    G3_RAW_BARRIER()
+
+    bf16x8 bq[2][3], aq[4][3];
+    for (int p = 0; p < nkb; ++p) {
+        const bool mine = ((p & 1) == grp);
+        const int own = p >> 1;
+        if (mine) {
+            // all 18 fragment reads first (they return in order: the B and m = 0 fragments feed the first
+            // MFMAs while the rest land), pinned so that the scheduler cannot sink them between MFMAs
+            const unsigned char* bb = gbuf + (own & 1) * G3G_BLK;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bq[n][q] = G3_FRAG(bb + b_off + n * 32 * G3_ROWB + q * 32);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) aq[m][q] = G3_FRAG(bb + a_off + m * 32 * G3_ROWB + q * 32);
+            __builtin_amdgcn_sched_barrier(0);
+            G3_MFMA12(0, 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of this image has returned
+        } else if (p + 1 < nkb) {
+            const int j = (p + 1) >> 1;                     // my next block must have landed before the barrier
+            if (j + 1 < n_own) G3_WAIT_VM(9); else G3_WAIT_VM(0);
+        }
+        G3_RAW_BARRIER()
+        if (mine) {
+            G3_MFMA12(2, 3)                                 // the second half of the burst overlaps the
+                                                            // other group's fragment reads
+            if (own + 2 < n_own) G3G_ISSUE(own + 2)         // refill the image just consumed
+        }
+    }
+#undef G3_MFMA12
+#undef G3_MFMA2
+#undef G3_MFMA6
+#undef G3_MFMA
+#undef G3_FRAG
+#undef G3G_ISSUE
+#undef G3_SRC
+
+    // ---- group 1 hands its partial sums to group 0 (nothing is in flight any more)
+    __syncthreads();
+    float* xch = reinterpret_cast<float*>(smem);
+    if (grp == 1) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[((m * 2 + n) * 16 + r) * 256 + tid] = acc[m][n][r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+        const int j = j0 + wn * 64 + li;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int cbase = m0 + wm * 128 + m * 32 + 4 * h;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = cbase + (r & 3) + 8 * (r >> 2);
+                    C[(size_t)row * ldc + j + n * 32] = acc[m][n][r] + xch[((m * 2 + n) * 16 + r) * 256 + tid];
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm3g_kernel(const unsigned char* __restrict__ A3,
+                                                     const unsigned char* __restrict__ B3, int Kb,
+                                                     float* __restrict__ C, int ldc, long long c_split_stride,
+                                                     int kb_per)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round robin, and every j tile of one K
+    // split re-reads the same slice of A3.  Give each XCD whole K splits (all their j tiles), so a
+    // slice is fetched into ONE L2 instead of eight.  Needs gridDim.y == 1 and gridDim.z % 8 == 0.
+    int jt = blockIdx.x, z = blockIdx.z;
+    if (gridDim.y == 1 && (gridDim.z & 7) == 0) {
+        const int L = blockIdx.x + gridDim.x * blockIdx.z;
+        const int xcd = L & 7, idx = L >> 3;
+        z = xcd + 8 * (idx / (int)gridDim.x);
+        jt = idx % (int)gridDim.x;
+    }
+    const int kb0 = z * kb_per;
+    const int nkb = min(kb_per, Kb - kb0);
+    gemm3g_segment(A3, B3, Kb, C + (size_t)z * c_split_stride, ldc, blockIdx.y * G3_MW, jt * G3_JW, kb0, nkb,
+                   smem3);
+}
+
+__global__ __launch_bounds__(512) void gemm3g_streamk_kernel(const unsigned char* __restrict__ A3,
+                                                             const unsigned char* __restrict__ B3, int Kb,
+                                                             float* __restrict__ C0, float* __restrict__ C1,
+                                                             float* __restrict__ C2, int ldc, int MG, int T)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const long long U = (long long)T * Kb;
+    long long u = U * blockIdx.x / gridDim.x;
+    const long long u1 = U * (blockIdx.x + 1) / gridDim.x;
+    while (u < u1) {
+        const int tile = (int)(u / Kb), kb = (int)(u % Kb);
+        const int ke = (int)min((long long)Kb, kb + (u1 - u));
+        const int jt = tile / MG, mg = tile % MG;
+        gemm3g_segment(A3, B3, Kb, (kb == 0) ? C0 : (ke == Kb ? C1 : C2), ldc, mg * G3_MW, jt * G3_JW, kb,
+                       ke - kb, smem3);
+        u += ke - kb;
+        __syncthreads();                 // the exchange area is overwritten by the next segment's DMA
+    }
+}
+
+}  // namespace cnmf

@@ -48,10 +48,11 @@ struct SlotDesc {                   // one restart in flight (device + host mirr
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct SplitInfo {                  // second partial plane of a stream-K product (or plane1 == nullptr)
+struct SplitInfo {                  // further partial planes of a stream-K product (or plane1 == nullptr)
     const float* plane1;
-    const unsigned char* split;     // [tiles] 1 = the tile was cut, add plane 1
+    const unsigned char* split;     // [tiles] bit 0 = the tile was cut: add plane 1; bit 1 = cut twice: add plane 2 too
     int tile_rows, tile_cols, mgroups;
+    const float* plane2 = nullptr;
 };
 
 // Body of the sweep for one (row chunk, slot); KP = k rounded up (compile-time register array
@@ -97,14 +98,14 @@ __device__ __forceinline__ void sweep_body(
         // stream-K pass A: was this (row tile, component group) cut between two workgroups?
         // A slot spans at most two component groups and a wave's 64 rows lie in one row tile,
         // so two wave-uniform flags cover every element.
-        bool cut0 = false, cut1 = false;
+        int cut0 = 0, cut1 = 0;
         int mg_edge = 1 << 30;
         if (sp.plane1) {
             const int rt = __builtin_amdgcn_readfirstlane(min(row, L - 1) / sp.tile_rows);
             const int g0 = off / sp.tile_cols, g1 = (off + k - 1) / sp.tile_cols;
             mg_edge = (g0 + 1) * sp.tile_cols;
-            cut0 = sp.split[rt * sp.mgroups + g0] != 0;
-            cut1 = sp.split[rt * sp.mgroups + g1] != 0;
+            cut0 = sp.split[rt * sp.mgroups + g0];
+            cut1 = sp.split[rt * sp.mgroups + g1];
         }
         float w[KP], p[KP];
         {
@@ -118,7 +119,7 @@ __device__ __forceinline__ void sweep_body(
                 w[c] = V[idx];
                 p[c] = P[idx];
             }
-            if (cut0 | cut1) {                    // wave-uniform: one branch per chunk
+            if ((cut0 | cut1) & 1) {              // wave-uniform: one branch per chunk
                 float qq[KP];
 #pragma unroll
                 for (int c = 0; c < KP; ++c) {
@@ -127,8 +128,21 @@ __device__ __forceinline__ void sweep_body(
                 }
 #pragma unroll
                 for (int c = 0; c < KP; ++c) {
-                    const bool cut = ((off + c) < mg_edge) ? cut0 : cut1;
-                    p[c] += cut ? qq[c] : 0.f;
+                    const int cut = ((off + c) < mg_edge) ? cut0 : cut1;
+                    p[c] += (cut & 1) ? qq[c] : 0.f;
+                }
+            }
+            if ((cut0 | cut1) & 2) {
+                float qq[KP];
+#pragma unroll
+                for (int c = 0; c < KP; ++c) {
+                    const size_t idx = (size_t)(off + min(c, k - 1)) * ldv + rowc;
+                    qq[c] = sp.plane2[idx];
+                }
+#pragma unroll
+                for (int c = 0; c < KP; ++c) {
+                    const int cut = ((off + c) < mg_edge) ? cut0 : cut1;
+                    p[c] += (cut & 2) ? qq[c] : 0.f;
                 }
             }
 #pragma unroll

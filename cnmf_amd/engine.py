@@ -501,6 +501,18 @@ class Engine:
                                               KC, K, J, nsplit, C.byref(ms), reps))
         return Cout, ms.value
 
+    def debug_gemm3(self, A, B, nsplit=1, reps=0):
+        """A [KC, K] . B [J, K]^T through the split-operand bf16 MFMA path; returns (C, ms)."""
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        B = np.ascontiguousarray(B, dtype=np.float32)
+        KC, K = A.shape
+        J = B.shape[0]
+        Cout = np.empty((KC, J), dtype=np.float32)
+        ms = C.c_double(0.0)
+        self._check(self._lib.cnmf_debug_gemm3(self._ctx, _fp(A), _fp(B), _fp(Cout), KC, K, J, int(nsplit),
+                                               C.byref(ms), int(reps)))
+        return Cout, ms.value
+
     def debug_standard_normal(self, seed, n):
         out = np.empty(max(n, 1), dtype=np.float64)
         self._check(self._lib.cnmf_debug_standard_normal(self._ctx, C.c_uint32(seed), n,

@@ -216,6 +216,10 @@ int cnmf_spectra_fetch(cnmf_ctx* ctx, float* out /* [rows][G] */);
  * mode 1: B is [K][J] (pass B, split-K partials summed in split order).                  */
 int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float* A, const float* B,
                     float* C, int KC, int K, int J, int nsplit, double* ms_out, int reps);
+/* C[KC][J] = A[KC][K] . B[J][K]^T through the split-operand (3 x bf16 planes, f32-accurate) MFMA
+ * path; KC % 256 == 0, K % 16 == 0.                                                        */
+int cnmf_debug_gemm3(cnmf_ctx* ctx, const float* A, const float* B, float* C, int KC, int K, int J,
+                     int nsplit, double* ms_out, int reps);
 /* numpy RandomState(seed).standard_normal(n) reproduced on the device. */
 int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t n, double* out);
 

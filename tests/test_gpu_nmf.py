@@ -47,6 +47,54 @@ def test_gemm_vs_numpy(engine, variant, mode):
         assert err < 2e-6, (KC, K, J, ns, err)
 
 
+@pytest.mark.parametrize("g3mode", ["1", "2"])
+def test_split_operand_gemm_is_f32_accurate(engine, monkeypatch, g3mode):
+    """The 3 x bf16 split-operand MFMA product (kernels_gemm3.hip.h) is held to the SAME bound as the
+    exact-f32 matrix pipe above, on wide-dynamic-range and on non-negative sparse operands, for
+    both kernel variants, with and without a K split."""
+    monkeypatch.setenv("CNMF_GEMM3", g3mode)
+    rs = np.random.RandomState(7)
+    for K, J, ns in [(16, 40, 1), (64, 192, 1), (2016, 992, 1), (4096, 320, 4), (2048, 130, 7)]:
+        A = (rs.standard_normal((256, K)) * np.exp(rs.standard_normal((256, K)))).astype(np.float32)
+        B = (rs.standard_normal((J, K)) * np.exp(rs.standard_normal((J, K)))).astype(np.float32)
+        ref = A.astype(np.float64) @ B.astype(np.float64).T
+        out, _ = engine.debug_gemm3(A, B, nsplit=ns)
+        assert np.abs(out - ref).max() / np.abs(ref).max() < 2e-6, (K, J, ns)
+        # error relative to sum |a||b| (the natural scale of an inner product): f32-class
+        scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T
+        assert (np.abs(out - ref) / scale).max() < 3e-6, (K, J, ns)
+    A = np.abs(rs.standard_normal((256, 2016))).astype(np.float32)
+    B = (np.abs(rs.standard_normal((640, 2016))) * (rs.rand(640, 2016) < 0.1)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    out, _ = engine.debug_gemm3(A, B)
+    assert (np.abs(out - ref) / np.maximum(ref, 1e-30)).max() < 5e-6
+    # bit-reproducible
+    out2, _ = engine.debug_gemm3(A, B)
+    assert np.array_equal(out, out2)
+
+
+@pytest.mark.parametrize("g3mode", ["0", "1", "2"])
+def test_full_width_batch_matches_oracle_in_every_gemm_mode(engine, monkeypatch, g3mode):
+    """256 packed columns (the width at which the split-operand GEMM takes over): every restart
+    against its independent float64 oracle run, for the exact-f32 pipe (0) and both split-operand
+    variants (1, 2).  Same tolerance in all three."""
+    monkeypatch.setenv("CNMF_GEMM3", g3mode)
+    X64 = synth.make_config("C1", dtype=np.float64)
+    engine.set_matrix(X64)
+    rs = np.random.RandomState(11)
+    ks = [int(k) for k in rs.randint(5, 10, size=44)]
+    seeds = [int(s) for s in rs.randint(1, 2**31 - 1, size=44)]
+    assert sum(ks) > 256
+    H, _, n_iter, viol = engine.nmf_batch(ks, seeds=seeds)
+    assert engine.last_stats["kc"] == 256
+    for k, seed, h, n in list(zip(ks, seeds, H, n_iter))[::3]:
+        _, H_ref, n_ref = nmf_cd.nmf(X64, k, seed=seed)
+        _check(H_ref, n_ref, h, n, slack=3)
+    assert (viol[n_iter < 1000] <= 1e-4).all()
+    H2, _, n2, _ = engine.nmf_batch(ks, seeds=seeds)
+    assert list(n2) == list(n_iter) and all(np.array_equal(a, b) for a, b in zip(H, H2))
+
+
 def test_device_standard_normal_matches_numpy(engine):
     """numpy RandomState(seed).standard_normal reproduced on the device (MT19937 +
     legacy polar gauss); known-answer vector from SURVEY.md 8c first."""
