@@ -404,10 +404,16 @@ extern "C" int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* N, int64_t* G)
 }
 
 // ------------------------------------------------------------------ split-operand GEMM launchers
-static hipError_t launch_split3(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst)
+// planes of a K-contiguous f32 matrix, block-major with row tiles of TR rows (rows % TR == 0)
+static hipError_t launch_split3(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst, int TR)
 {
-    const long long total = (long long)rows * (K / 8);
-    split3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(src, ld, rows, K, (unsigned short*)dst);
+    if (rows % 64 == 0 && K % 64 == 0 && TR % 64 == 0) {        // tiled through LDS: both sides coalesced
+        dim3 grid(K / 64, rows / 64);
+        split3_tiled_kernel<<<grid, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst);
+        return hipGetLastError();
+    }
+    const long long total = (long long)rows * (K / 16);
+    split3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(src, ld, rows, K, TR, (unsigned short*)dst);
     return hipGetLastError();
 }
 
@@ -493,10 +499,10 @@ static int ensure_planes(cnmf_ctx* ctx)
     const size_t bB = (size_t)ctx->G_pad * (ctx->N_pad / 16) * G3_ROWB;
     HIP_TRY(ctx, hipMalloc(&ctx->X3, bA));
     HIP_TRY(ctx, hipMalloc(&ctx->Xt3, bB));
-    HIP_TRY(ctx, launch_split3(ctx->stream, ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->X3));
-    dim3 grid((ctx->G_pad + 255) / 256, ctx->N_pad / 8);
+    HIP_TRY(ctx, launch_split3(ctx->stream, ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->X3, G3_JW));
+    dim3 grid((ctx->G_pad + 255) / 256, ctx->N_pad / 16);
     split3_transpose_kernel<<<grid, 256, 0, ctx->stream>>>(ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->N_pad,
-                                                            (unsigned short*)ctx->Xt3);
+                                                            G3_JW, (unsigned short*)ctx->Xt3);
     HIP_TRY(ctx, hipGetLastError());
     return CNMF_OK;
 }
@@ -576,6 +582,7 @@ static int ensure_batch(cnmf_ctx* ctx, int KC, int max_k = KMAX, int min_k = 1)
         HIP_TRY(ctx, hipMalloc(&ctx->XHt2, wb));
         HIP_TRY(ctx, hipMalloc(&ctx->H3, (size_t)KC * (ctx->G_pad / 16) * G3_ROWB));
         HIP_TRY(ctx, hipMalloc(&ctx->Wt3, (size_t)KC * (ctx->N_pad / 16) * G3_ROWB));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->Wt3, 0, (size_t)KC * (ctx->N_pad / 16) * G3_ROWB, ctx->stream));
     }
     HIP_TRY(ctx, hipMalloc(&ctx->d_split, (size_t)(KC / 32 + 1) * (ctx->N_pad / 128 + 1)));
     HIP_TRY(ctx, hipMalloc(&ctx->XtW, hb * nsplit));
@@ -868,7 +875,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         // pass A : XHt[KC][N] = H_all . X^T                       (sklearn _nmf.py:387)
         SplitInfo spA{nullptr, nullptr, 1, 1, 1};
         if (use3) {
-            HIP_TRY(ctx, launch_split3(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3));
+            HIP_TRY(ctx, launch_split3(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW));
             if (time_gemm) hipEventRecord(gev[gev.size() - 4], st);
             if (sk3.on) {
                 HIP_TRY(ctx, launch_gemm3_streamk(st, sk3, ctx->H3, ctx->X3, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
@@ -893,7 +900,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                                   ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k, tiers, spA));
         finalize_kernel<<<dim3(nslots, fin_y), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
                                                 ctx->d_slots, 0, prm->tol, prm->max_iter, 1, max_k);
-        if (use3) HIP_TRY(ctx, launch_split3(st, ctx->Wt, ctx->N_pad, KC, ctx->N_pad, ctx->Wt3));
+        // (writing the planes from inside the sweep was measured slower: 2-byte stores, lower occupancy)
+        if (use3) HIP_TRY(ctx, launch_split3(st, ctx->Wt, ctx->N_pad, KC, ctx->N_pad, ctx->Wt3, G3_MW));
         if (time_gemm) hipEventRecord(gev[gev.size() - 2], st);
         // pass B : XtW[S][KC][G] = Wt_all . X  (split over cells)  (sklearn _nmf.py:505-507)
         const int nsB = use3 ? nsplit3 : nsplit;
@@ -1220,8 +1228,8 @@ extern "C" int cnmf_debug_gemm3(cnmf_ctx* ctx, const float* A, const float* B, f
     POOL_TRY(ctx, events);
     HIP_TRY(ctx, hipMemcpyAsync(dA, A, (size_t)KC * K * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dB, B, (size_t)J * K * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, launch_split3(st, dA, K, KC, K, dA3));
-    HIP_TRY(ctx, launch_split3(st, dB, K, Jp, K, dB3));
+    HIP_TRY(ctx, launch_split3(st, dA, K, KC, K, dA3, G3_MW));
+    HIP_TRY(ctx, launch_split3(st, dB, K, Jp, K, dB3, G3_JW));
     reps = std::max(1, reps);
     int zs = 1;
     for (int i = 0; i < reps + 1; ++i) {

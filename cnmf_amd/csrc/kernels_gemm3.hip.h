@@ -16,10 +16,14 @@
 // operands: pass A uses planes of X (cells x genes), pass B planes of X^T (genes x cells) -- the
 // data matrix is resident twice (288 GB of HBM; 1.2 GB at 50k x 2000).
 //
-// Plane layout in memory (A and B alike), "k-blocked interleave":
-//      row r, 16-k block kb :  [h: 16 bf16][m: 16 bf16][l: 16 bf16]   = 96 contiguous bytes
-// so one LDS stage (BK = 16) of a row is ONE 96-byte segment.  In LDS a row is padded to 112 B
-// (28 dwords: ds_read_b128 of 16 consecutive rows hits 16 disjoint 4-bank groups).
+// Plane layout in memory (A and B alike), "block-major":
+//      [row tile of TR rows][16-k block kb][row in tile][h: 16 bf16 | m: 16 bf16 | l: 16 bf16]
+// i.e. one row of one block is 96 contiguous bytes and ONE (tile, block) is ONE contiguous run of
+// TR * 96 bytes (TR = 256 for the packed factor, 128 for X / X^T) in exactly the order the kernel wants
+// it in LDS.  A stage is therefore fetched as whole 128-byte lines, 1 KB per wave instruction (rows
+// of a row-major layout would be 96-byte segments 12 KB apart: twice the L1/TA line requests).
+// The register-staged variant pads LDS rows to 112 B (28 dwords: ds_read_b128 of 16 consecutive
+// rows hits 16 disjoint 4-bank groups); the LDS-DMA variant keeps the dense image.
 //
 // v_mfma_f32_32x32x16_bf16: lane l supplies row/col (l & 31) and the 8 k's of half (l >> 5) of the
 // block; A and B use the same assignment, so the order of k inside a block is immaterial.
@@ -62,55 +66,98 @@ __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned shor
     l = bf16_rne(r2);
 }
 
-// src [rows][ld] f32 (K-contiguous)  ->  dst planes [rows][K/16][3][16] bf16.  One thread per 8 k.
-__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, int ld, int rows, int K,
+// src [rows][ld] f32 (K-contiguous)  ->  block-major planes with row tiles of TR rows.
+// One thread per (row, 16-k block): reads 64 contiguous bytes, writes the row's 96 bytes of that block.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, int ld, int rows, int K, int TR,
                                                      unsigned short* __restrict__ dst)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int per_row = K / 8;
-    const long long total = (long long)rows * per_row;
-    if (t >= total) return;
-    const int row = (int)(t / per_row), o = (int)(t % per_row);
-    const int kb = o >> 1, half = o & 1;
-    const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)row * ld + kb * 16 + half * 8);
-    const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)row * ld + kb * 16 + half * 8 + 4);
-    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    unsigned short p[3][8];
+    const int Kb = K / 16;
+    if (t >= (long long)rows * Kb) return;
+    const int row = (int)(t / Kb), kb = (int)(t % Kb);
+    const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)row * ld + kb * 16);
+    float x[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) split3(x[i], p[0][i], p[1][i], p[2][i]);
-    unsigned short* d = dst + ((size_t)row * (K / 16) + kb) * 48 + half * 8;
+    for (int q = 0; q < 4; ++q) { const float4 v = s4[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
+    unsigned short p[3][16];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        u32x4 w;
-        w.x = p[q][0] | ((unsigned)p[q][1] << 16); w.y = p[q][2] | ((unsigned)p[q][3] << 16);
-        w.z = p[q][4] | ((unsigned)p[q][5] << 16); w.w = p[q][6] | ((unsigned)p[q][7] << 16);
-        *reinterpret_cast<u32x4*>(d + q * 16) = w;
-    }
+    for (int i = 0; i < 16; ++i) split3(x[i], p[0][i], p[1][i], p[2][i]);
+    unsigned short* d = dst + (((size_t)(row / TR) * Kb + kb) * TR + (row % TR)) * 48;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            u32x4 w;
+            w.x = p[q][8 * hf + 0] | ((unsigned)p[q][8 * hf + 1] << 16); w.y = p[q][8 * hf + 2] | ((unsigned)p[q][8 * hf + 3] << 16);
+            w.z = p[q][8 * hf + 4] | ((unsigned)p[q][8 * hf + 5] << 16); w.w = p[q][8 * hf + 6] | ((unsigned)p[q][8 * hf + 7] << 16);
+            *reinterpret_cast<u32x4*>(d + q * 16 + hf * 8) = w;
+        }
 }
 
-// planes of the TRANSPOSE: src [K rows][ld] f32 (J-contiguous, J = dst rows) -> dst [J_rows][K/16][3][16].
-// One thread per (dst row j, 8 k); lanes run along j so the reads coalesce.  One-off per matrix.
+// planes of the TRANSPOSE: src [K rows][ld] f32 (J-contiguous, J = dst rows) -> block-major planes of the
+// J x K matrix.  One thread per (dst row j, 16-k block); lanes run along j so the reads coalesce.  One-off.
 __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ src, int ld, int src_rows,
-                                                               int J, int K, unsigned short* __restrict__ dst)
+                                                               int J, int K, int TR, unsigned short* __restrict__ dst)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    const int o = blockIdx.y;                 // 8-k group
+    const int kb = blockIdx.y;
     if (j >= J) return;
-    const int kb = o >> 1, half = o & 1;
-    unsigned short p[3][8];
+    const int Kb = K / 16;
+    unsigned short p[3][16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k = o * 8 + i;
+    for (int i = 0; i < 16; ++i) {
+        const int k = kb * 16 + i;
         const float x = (k < src_rows) ? src[(size_t)k * ld + j] : 0.f;
         split3(x, p[0][i], p[1][i], p[2][i]);
     }
-    unsigned short* d = dst + ((size_t)j * (K / 16) + kb) * 48 + half * 8;
+    unsigned short* d = dst + (((size_t)(j / TR) * Kb + kb) * TR + (j % TR)) * 48;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        u32x4 w;
-        w.x = p[q][0] | ((unsigned)p[q][1] << 16); w.y = p[q][2] | ((unsigned)p[q][3] << 16);
-        w.z = p[q][4] | ((unsigned)p[q][5] << 16); w.w = p[q][6] | ((unsigned)p[q][7] << 16);
-        *reinterpret_cast<u32x4*>(d + q * 16) = w;
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            u32x4 w;
+            w.x = p[q][8 * hf + 0] | ((unsigned)p[q][8 * hf + 1] << 16); w.y = p[q][8 * hf + 2] | ((unsigned)p[q][8 * hf + 3] << 16);
+            w.z = p[q][8 * hf + 4] | ((unsigned)p[q][8 * hf + 5] << 16); w.w = p[q][8 * hf + 6] | ((unsigned)p[q][8 * hf + 7] << 16);
+            *reinterpret_cast<u32x4*>(d + q * 16 + hf * 8) = w;
+        }
+}
+
+// The same through LDS for the per-iteration split of the packed factors: a workgroup converts 64 rows
+// x 64 k (four blocks).  Reads: 16 lanes cover 256 contiguous bytes of a row; writes: the 64 rows of
+// one block are 6 KB contiguous in the block-major layout.  (rows, K, TR multiples of 64.)
+__global__ __launch_bounds__(256) void split3_tiled_kernel(const float* __restrict__ src, int ld, int K, int TR,
+                                                           unsigned short* __restrict__ dst)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short tile[4][64][48];      // [block][row][h16|m16|l16]
+    const int t = threadIdx.x;
+    const int k0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int kq = t & 15, rr = t >> 4;                  // float4 index along k, row within a pass of 16
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = rr + 16 * i;
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * ld + k0 + kq * 4);
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        unsigned short p[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(x[e], p[0][e], p[1][e], p[2][e]);
+        unsigned short* d = &tile[kq >> 2][row][(kq & 3) * 4];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            uint2 w;
+            w.x = p[q][0] | ((unsigned)p[q][1] << 16); w.y = p[q][2] | ((unsigned)p[q][3] << 16);
+            *reinterpret_cast<uint2*>(d + q * 16) = w;
+        }
+    }
+    __syncthreads();
+    const int Kb = K / 16;
+    const int tr = r0 / TR, rin = r0 % TR;               // the 64 rows lie in one row tile (TR % 64 == 0)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        unsigned short* g = dst + (((size_t)tr * Kb + (k0 / 16 + b)) * TR + rin) * 48;
+        const u32x4* s4 = reinterpret_cast<const u32x4*>(&tile[b][0][0]);          // 64 rows x 96 B = 384 chunks
+        u32x4* g4 = reinterpret_cast<u32x4*>(g);
+        g4[t] = s4[t];
+        if (t < 128) g4[256 + t] = s4[256 + t];
     }
 }
 
@@ -129,19 +176,18 @@ __device__ __forceinline__ void gemm3_segment(const unsigned char* __restrict__ 
 
     // ---- staging map: chunk c = tid + 256*i ; row = c / 6 ; part = c % 6 ; rows 0..255 = A, 256..383 = B
     // (two 64-bit bases + 32-bit per-chunk offsets: a tile's rows span < 2^31 bytes)
-    const size_t rowbytes = (size_t)Kb * G3_ROWB;
-    const unsigned char* abase = A3 + (size_t)m0 * rowbytes + (size_t)kb0 * G3_ROWB;
-    const unsigned char* bbase = B3 + (size_t)j0 * rowbytes + (size_t)kb0 * G3_ROWB;
-    unsigned int goff[G3_CHUNKS];
+    // block-major planes: block (tile, kb) is one contiguous run, chunk c of it at byte 16 c
+    const unsigned char* abase = A3 + ((size_t)(m0 / G3_MW) * Kb + kb0) * (G3_MW * G3_ROWB) + tid * 16;
+    const unsigned char* bbase = B3 + ((size_t)(j0 / G3_JW) * Kb + kb0) * (G3_JW * G3_ROWB) + tid * 16;
     int lds_off[G3_CHUNKS];
 #pragma unroll
     for (int i = 0; i < G3_CHUNKS; ++i) {
         const int c = tid + 256 * i;
         const int row = c / 6, part = c - row * 6;
         lds_off[i] = row * G3_LDSROW + part * 16;
-        goff[i] = (unsigned int)((i < 6 ? row : row - G3_MW) * rowbytes + part * 16);
     }
-#define G3_SRC(i_) ((i_) < 6 ? abase + goff[i_] : bbase + goff[i_])
+#define G3_SRC(i_) ((i_) < 6 ? abase + (i_) * 4096 : bbase + ((i_) - 6) * 4096)
+#define G3_BLK(i_) ((i_) < 6 ? G3_MW * G3_ROWB : G3_JW * G3_ROWB)
     u32x4 stage[G3_CHUNKS];
 
     f32x16_3 acc[4][2];
@@ -166,7 +212,7 @@ __device__ __forceinline__ void gemm3_segment(const unsigned char* __restrict__ 
         const int sn = (s + 1 < nkb) ? s + 1 : s;
 #pragma unroll
         for (int i = 0; i < G3_CHUNKS; ++i)
-            stage[i] = *reinterpret_cast<const u32x4*>(G3_SRC(i) + (size_t)sn * G3_ROWB);
+            stage[i] = *reinterpret_cast<const u32x4*>(G3_SRC(i) + (size_t)sn * G3_BLK(i));
         __builtin_amdgcn_sched_barrier(0);
 
         bf16x8 bq[2][3];
@@ -197,6 +243,7 @@ __device__ __forceinline__ void gemm3_segment(const unsigned char* __restrict__ 
     }
 
 #undef G3_SRC
+#undef G3_BLK
     const int j = j0 + wn * 64 + li;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -287,16 +334,9 @@ __device__ __forceinline__ void gemm3g_segment(const unsigned char* __restrict__
     const int li = lane & 31, h = lane >> 5;
     unsigned char* gbuf = smem + grp * 2 * G3G_BLK;
 
-    const size_t rowbytes = (size_t)Kb * G3_ROWB;
-    const unsigned char* abase = A3 + (size_t)m0 * rowbytes + (size_t)(kb0 + grp) * G3_ROWB;
-    const unsigned char* bbase = B3 + (size_t)j0 * rowbytes + (size_t)(kb0 + grp) * G3_ROWB;
-    unsigned int goff[G3_CHUNKS];
-#pragma unroll
-    for (int i = 0; i < G3_CHUNKS; ++i) {
-        const int c = tid + 256 * i;
-        const int row = c / 6, part = c - row * 6;
-        goff[i] = (unsigned int)((i < 6 ? row : row - G3_MW) * rowbytes + part * 16);
-    }
+    // block-major planes: block (tile, kb) is one contiguous run and IS the LDS image (chunk c at byte 16 c)
+    const unsigned char* abase = A3 + ((size_t)(m0 / G3_MW) * Kb + kb0 + grp) * (G3_MW * G3_ROWB) + tid * 16;
+    const unsigned char* bbase = B3 + ((size_t)(j0 / G3_JW) * Kb + kb0 + grp) * (G3_JW * G3_ROWB) + tid * 16;
     f32x16_3 acc[4][2];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -309,13 +349,13 @@ __device__ __forceinline__ void gemm3g_segment(const unsigned char* __restrict__
     const int b_off = (G3_MW + wn * 64 + li) * G3_ROWB + h * 16;
     const int n_own = (nkb - grp + 1) >> 1;                 // this group's blocks: grp, grp + 2, ...
 
-#define G3_SRC(i_) ((i_) < 6 ? abase + goff[i_] : bbase + goff[i_])
+#define G3_SRC(i_) ((i_) < 6 ? abase + (i_) * 4096 + oa_ : bbase + ((i_) - 6) * 4096 + ob_)
 #define G3G_ISSUE(own_)                                                                            \
     {                                                                                              \
-        const size_t o_ = (size_t)(own_) * (2 * G3_ROWB);                                          \
+        const size_t oa_ = (size_t)(own_) * (2 * G3_MW * G3_ROWB), ob_ = (size_t)(own_) * (2 * G3_JW * G3_ROWB); \
         unsigned char* d_ = gbuf + ((own_) & 1) * G3G_BLK + wave * 1024;                           \
         _Pragma("unroll") for (int i = 0; i < G3_CHUNKS; ++i)                                      \
-            __builtin_amdgcn_global_load_lds(G3_AS1(G3_SRC(i) + o_), G3_AS3(d_ + i * 4096), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds(G3_AS1(G3_SRC(i)), G3_AS3(d_ + i * 4096), 16, 0, 0);  \
     }
 #define G3_FRAG(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ptr_))
 #define G3_MFMA(m_, aq_, pa, pb)                                                                   \
