@@ -32,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+SPLIT_MFMAS_PER_PRODUCT = 6        # kernels_gemm3.hip.h: ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -80,15 +82,16 @@ def cpu_baseline(X32, mean_iters_per_restart, max_iter):
     }
 
 
-def pmc_traffic(key):
+def pmc_traffic(key, split_operand):
     """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE),
     collected in separate rocprofv3 --pmc passes (tools/gpu_pmc_bench.sh) and committed under
     profiles/ -- counters cannot be read from inside an un-profiled run.  None if absent."""
+    name = "r1_pmc_traffic_split.json" if split_operand else "r1_pmc_traffic.json"
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
         return {"hbm_bytes_per_launch": d[key]["hbm_bytes_per_launch"],
                 "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"][key],
-                "source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)"}
+                "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)" % name}
     except Exception:
         return None
 
@@ -206,7 +209,7 @@ def main():
         return ks, st
 
     agg = dict(restarts=0, restart_iters=0, rc_iters=0, outer=0, col_iters=0, passA_ms=0.0,
-               passB_ms=0.0, nA=0, nB=0, gpu_ms=0.0, kc=0, nsplit=0)
+               passB_ms=0.0, nA=0, nB=0, gpu_ms=0.0, kc=0, nsplit=0, gemm_mode=0)
     for step in range(args.warmup):
         run_step(step, False)
     barrier()
@@ -221,6 +224,7 @@ def main():
         agg["passA_ms"] += st["passA_ms"]; agg["passB_ms"] += st["passB_ms"]
         agg["nA"] += int(st["passA_launches"]); agg["nB"] += int(st["passB_launches"])
         agg["gpu_ms"] += st["gpu_ms"]; agg["kc"] = int(st["kc"]); agg["nsplit"] = int(st["nsplit"])
+        agg["gemm_mode"] = int(st["gemm_mode"])
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -242,22 +246,42 @@ def main():
         tfB = alg_flops_A / max(agg["passB_ms"], 1e-9) / 1e9
         dom = "A" if agg["passA_ms"] >= agg["passB_ms"] else "B"
         ach = tfA if dom == "A" else tfB
+        split = agg["gemm_mode"] > 0
+        if split:
+            # f32-accurate products on the bf16 matrix pipe: 6 bf16 MFMAs per product, so the roofline of
+            # the scheme in f32-equivalent flops is the dense bf16 peak / 6 (2.65x the f32 matrix pipe)
+            peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_MFMAS_PER_PRODUCT
+            kern = ("gemm3g_streamk_kernel (pass A: X.Ht, 3 x bf16 planes)" if dom == "A"
+                    else "gemm3g_kernel (pass B: Xt.W, 3 x bf16 planes)")
+        else:
+            peak = FP32_MFMA_PEAK_TFLOPS
+            kern = "gemm_streamk_kernel<NT> (pass A: X.Ht)" if dom == "A" else "gemm_kernel<NN> (pass B: Xt.W)"
         roof = {
             "bound": "mfma",
-            "kernel": "gemm_kernel<NT> (pass A: X.Ht)" if dom == "A" else "gemm_kernel<NN> (pass B: Xt.W)",
-            "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-            "traffic": (pmc_traffic("passA" if dom == "A" else "passB") or {}).get("hbm_bytes_per_launch"),
-            "traffic_detail": pmc_traffic("passA" if dom == "A" else "passB"),
+            "kernel": kern,
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "flop_basis": ("f32-equivalent flops (2.N.G per column and pass); peak = bf16 dense MFMA peak / 6"
+                           if split else "f32 flops; peak = f32 MFMA peak"),
+            "frac": ach / peak,
+            "traffic": (pmc_traffic("passA" if dom == "A" else "passB", split) or {}).get("hbm_bytes_per_launch"),
+            "traffic_detail": pmc_traffic("passA" if dom == "A" else "passB", split),
             "avg_launch_ms": {"passA": agg["passA_ms"] / max(agg["nA"], 1), "passB": agg["passB_ms"] / max(agg["nB"], 1)},
             "achieved_passA": tfA, "achieved_passB": tfB,
             "alg_flops_per_launch": alg_flops_A / max(agg["nA"], 1),
             "issued_flops_per_launch": flops_per_col_iter * agg["kc"],
-            "x_stream_GBs": {"passA": N * G * 4 / (agg["passA_ms"] / max(agg["nA"], 1)) / 1e6,
-                             "passB": N * G * 4 / (agg["passB_ms"] / max(agg["nB"], 1)) / 1e6,
+            "x_stream_GBs": {"passA": N * G * (6 if split else 4) / (agg["passA_ms"] / max(agg["nA"], 1)) / 1e6,
+                             "passB": N * G * (6 if split else 4) / (agg["passB_ms"] / max(agg["nB"], 1)) / 1e6,
                              "peak": HBM_PEAK_GBS},
             "gemm_share_of_gpu_time": (agg["passA_ms"] + agg["passB_ms"]) / max(agg["gpu_ms"], 1e-9),
         }
+        if split:
+            roof["matrix_pipe"] = {
+                "scheme": "x = h + m + l (3 bf16 planes); a*b from the 6 partial products of weight >= 2^-18; f32 accumulate",
+                "bf16_tflops_issued": ach * SPLIT_MFMAS_PER_PRODUCT * agg["col_iters"] / max(agg["rc_iters"], 1),
+                "bf16_dense_peak": BF16_MFMA_PEAK_TFLOPS,
+                "vs_f32_matrix_peak": ach / FP32_MFMA_PEAK_TFLOPS,
+                "note": "launch averages include the tail launches (< 256 packed columns) that run on the exact-f32 pipe",
+            }
         mean_it = total_riters / max(total_restarts, 1.0)
         out = {
             "metric": "NMF restarts/sec (%dx%dxK%d..%d)" % (N, G, args.kmin, args.kmax),
@@ -266,7 +290,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": ("f32 (operands split into 3 bf16 planes, 6 bf16 MFMAs per product, f32 accumulate)"
+                      if agg["gemm_mode"] > 0 else "f32"),
+            "data": "synthetic",
             "config": {"workload": "%s: %d cells x %d HVGs synthetic dense, K=%d..%d, %d restarts per K per step "
                                    "per GPU, sklearn CD solver tol=1e-4 max_iter=1000, init=random from ledger seeds"
                                    % (args.workload, N, G, args.kmin, args.kmax, args.restarts_per_k),

@@ -43,6 +43,7 @@ struct cnmf_ctx {
     int N_pad = 0, G_pad = 0;
     float* X = nullptr;
     unsigned char *X3 = nullptr, *Xt3 = nullptr;   // bf16 planes of X and X^T (split-operand GEMM), built on first use
+    int planes_tr = 0;                             // row-tile height they were built with
 
     // batch buffers (sized for kc_alloc columns)
     int kc_alloc = 0, nsplit_alloc = 0, nsplitA_alloc = 0, parts_alloc = 0;
@@ -420,13 +421,16 @@ static hipError_t launch_split3(hipStream_t st, const float* src, int ld, int ro
 // CNMF_GEMM3: 0 = exact-f32 matrix pipe only, 1 = split-operand bf16 path, two register-staged 4-wave
 // workgroups per CU (the simple reference variant), 2 = split-operand bf16 path, one 8-wave LDS-DMA
 // ping-pong workgroup per CU (default).  Read on every call so that tests can switch it.
+// (Tried and dropped, all within 3 % of variant 2 at the 50k x 2000 shape: the same ping-pong with register
+//  staging; 256 x 256 tiles with the two wave groups half a block apart (2/3 of the DMA bytes per flop).)
 static int gemm3_mode()
 {
     const char* e = getenv("CNMF_GEMM3");
     const int mode = e ? atoi(e) : CNMF_GEMM3_DEFAULT;
     return (mode < 0 || mode > 2) ? CNMF_GEMM3_DEFAULT : mode;
 }
-static int gemm3_wg_slots() { return gemm3_mode() == 2 ? 256 : 512; }
+static int gemm3_wg_slots() { return gemm3_mode() >= 2 ? 256 : 512; }
+static int gemm3_jw() { return G3_JW; }     // j extent of a tile = row tile of the B planes
 
 static hipError_t launch_gemm3(hipStream_t st, const unsigned char* A3, const unsigned char* B3, int Kb,
                                float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
@@ -438,7 +442,7 @@ static hipError_t launch_gemm3(hipStream_t st, const unsigned char* A3, const un
         attr_set = true;
     }
     const int kb_per = (Kb + nsplit - 1) / nsplit;
-    dim3 grid(Jpad / G3_JW, KC / G3_MW, (Kb + kb_per - 1) / kb_per);
+    dim3 grid(Jpad / gemm3_jw(), KC / G3_MW, (Kb + kb_per - 1) / kb_per);
     if (gemm3_mode() == 2)
         gemm3g_kernel<<<grid, 512, G3G_LDS_BYTES, st>>>(A3, B3, Kb, C, ldc, cstride, kb_per);
     else
@@ -458,10 +462,10 @@ static StreamK3 plan_streamk3(int KC, int N_pad, int G_pad, int n_wg_slots)
 {
     StreamK3 sk;
     sk.MG = KC / G3_MW;
-    sk.T = sk.MG * (N_pad / G3_JW);
+    sk.T = sk.MG * (N_pad / gemm3_jw());
     sk.Kb = G_pad / G3_BK;
     sk.P = n_wg_slots;
-    if (sk.T < 256 || sk.P > 2 * sk.T || getenv("CNMF_NO_STREAMK")) return sk;   // few tiles: K split + reduce instead
+    if (sk.T < sk.P / 2 + sk.P / 4 || sk.P > 2 * sk.T || getenv("CNMF_NO_STREAMK")) return sk;   // few tiles: K split + reduce instead
     sk.on = true;
     sk.flags.assign(sk.T, 0);
     const long long U = (long long)sk.T * sk.Kb;
@@ -494,15 +498,18 @@ static hipError_t launch_gemm3_streamk(hipStream_t st, const StreamK3& sk, const
 // planes of X (pass A) and of X^T (pass B), built once per matrix on first use
 static int ensure_planes(cnmf_ctx* ctx)
 {
-    if (ctx->X3 && ctx->Xt3) return CNMF_OK;
+    const int TR = gemm3_jw();
+    if (ctx->X3 && ctx->Xt3 && ctx->planes_tr == TR) return CNMF_OK;
+    hipFree(ctx->X3); hipFree(ctx->Xt3); ctx->X3 = ctx->Xt3 = nullptr;
+    ctx->planes_tr = TR;
     const size_t bA = (size_t)ctx->N_pad * (ctx->G_pad / 16) * G3_ROWB;
     const size_t bB = (size_t)ctx->G_pad * (ctx->N_pad / 16) * G3_ROWB;
     HIP_TRY(ctx, hipMalloc(&ctx->X3, bA));
     HIP_TRY(ctx, hipMalloc(&ctx->Xt3, bB));
-    HIP_TRY(ctx, launch_split3(ctx->stream, ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->X3, G3_JW));
+    HIP_TRY(ctx, launch_split3(ctx->stream, ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->X3, TR));
     dim3 grid((ctx->G_pad + 255) / 256, ctx->N_pad / 16);
     split3_transpose_kernel<<<grid, 256, 0, ctx->stream>>>(ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->N_pad,
-                                                            G3_JW, (unsigned short*)ctx->Xt3);
+                                                            TR, (unsigned short*)ctx->Xt3);
     HIP_TRY(ctx, hipGetLastError());
     return CNMF_OK;
 }
@@ -510,13 +517,13 @@ static int ensure_planes(cnmf_ctx* ctx)
 // the split-operand path needs whole 256 x 128 tiles
 static bool gemm3_enabled(const cnmf_ctx* ctx, int KC)
 {
-    return gemm3_mode() != 0 && KC % G3_MW == 0 && ctx->G_pad % G3_JW == 0 && ctx->N_pad % G3_JW == 0;
+    return gemm3_mode() != 0 && KC % G3_MW == 0 && ctx->G_pad % gemm3_jw() == 0 && ctx->N_pad % gemm3_jw() == 0;
 }
 
 static int pick_nsplit3(const cnmf_ctx* ctx, int KC)
 {
     // pass B grid = (G_pad/128) x (KC/256) x nsplit; aim at 2 workgroups per CU, >= 16 blocks per split
-    const int tiles = (ctx->G_pad / G3_JW) * std::max(1, KC / G3_MW);
+    const int tiles = (ctx->G_pad / gemm3_jw()) * std::max(1, KC / G3_MW);
     const int Kb = ctx->N_pad / G3_BK;
     int s = std::max(1, std::min(gemm3_wg_slots() / std::max(1, tiles), Kb / 16));
     const int kb_per = (Kb + s - 1) / s;
@@ -707,6 +714,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     if (rc) return rc;
     int nsplit = std::min(pick_nsplit(ctx, KC), ctx->nsplit_alloc);
     bool use3 = gemm3_enabled(ctx, KC);            // split-operand bf16 MFMA path (whole 256-column tiles only)
+    const int gemm_mode_used = use3 ? gemm3_mode() : 0;
     if (use3) { rc = ensure_planes(ctx); if (rc) return rc; }
     const int nsplit3 = use3 ? pick_nsplit3(ctx, KC) : 1;
     const int fin_y = (max_k * max_k + 255) / 256;       // finalize blocks per slot
@@ -879,7 +887,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             if (time_gemm) hipEventRecord(gev[gev.size() - 4], st);
             if (sk3.on) {
                 HIP_TRY(ctx, launch_gemm3_streamk(st, sk3, ctx->H3, ctx->X3, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
-                spA = SplitInfo{ctx->XHt1, ctx->d_split, G3_JW, G3_MW, sk3.MG, ctx->XHt2};
+                spA = SplitInfo{ctx->XHt1, ctx->d_split, gemm3_jw(), G3_MW, sk3.MG, ctx->XHt2};
             } else {
                 HIP_TRY(ctx, launch_gemm3(st, ctx->H3, ctx->X3, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
                                           (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
@@ -1013,7 +1021,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         stats->restart_iterations = restart_iters;
         stats->column_iterations = column_iters;
         stats->restart_column_iterations = restart_col_iters;
-        stats->kc = KC0; stats->nsplit = ctx->nsplit_alloc;
+        stats->kc = KC0; stats->nsplit = gemm_mode_used ? nsplit3 : ctx->nsplit_alloc;
+        stats->gemm_mode = gemm_mode_used;
         for (size_t i = 0; i + 3 < gev.size(); i += 4) {
             float a = 0.f, b = 0.f;
             hipEventElapsedTime(&a, gev[i], gev[i + 1]);
@@ -1215,7 +1224,7 @@ extern "C" int cnmf_debug_gemm3(cnmf_ctx* ctx, const float* A, const float* B, f
     if (KC % 256 || K % 16 || J < 1 || nsplit < 1) { SET_ERR(ctx, "debug_gemm3 needs KC %% 256 == 0, K %% 16 == 0"); return CNMF_EINVAL; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const int Jp = round_up(J, G3_JW), Kb = K / 16;
+    const int Jp = round_up(J, gemm3_jw()), Kb = K / 16;
     DevPool pool;
     EventPool events;
     float* dA = pool.get<float>((size_t)KC * K);
@@ -1229,7 +1238,7 @@ extern "C" int cnmf_debug_gemm3(cnmf_ctx* ctx, const float* A, const float* B, f
     HIP_TRY(ctx, hipMemcpyAsync(dA, A, (size_t)KC * K * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dB, B, (size_t)J * K * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, launch_split3(st, dA, K, KC, K, dA3, G3_MW));
-    HIP_TRY(ctx, launch_split3(st, dB, K, Jp, K, dB3, G3_JW));
+    HIP_TRY(ctx, launch_split3(st, dB, K, Jp, K, dB3, gemm3_jw()));
     reps = std::max(1, reps);
     int zs = 1;
     for (int i = 0; i < reps + 1; ++i) {

@@ -63,6 +63,9 @@ typedef struct cnmf_batch_stats {
     int64_t passA_launches, passB_launches;
     int32_t kc;                    /* packed column count used                                  */
     int32_t nsplit;                /* split-K factor of pass B                                  */
+    int32_t gemm_mode;             /* 0 = exact-f32 MFMA, 1/2 = split-operand bf16 MFMA (CNMF_GEMM3) in
+                                      the 256-column phase of this call                          */
+    int32_t reserved_;
 } cnmf_batch_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------- */
