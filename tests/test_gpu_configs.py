@@ -68,6 +68,22 @@ def test_C4_sparse_densify_on_device_properties(engine):
     #     refitting with H fixed can only lower the objective
     Wr, _ = engine.nnls(H1[0], max_iter=200)
     assert engine.prediction_error(Wr, H1[0]) <= e25 * (1 + 1e-6)
+    # (5) 256 packed columns at this size (1563 cell tiles: ~6 per persistent workgroup of the stream-K
+    #     launch): the split-operand path against the exact-f32 matrix pipe, and bit-reproducible
+    ks12, seeds12 = [k] * 12, list(range(101, 113))
+    Ha, _, na, _ = engine.nmf_batch(ks12, seeds=seeds12, max_iter=12, warn=False)
+    assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] == 2
+    Hb, _, nb, _ = engine.nmf_batch(ks12, seeds=seeds12, max_iter=12, warn=False)
+    assert all(np.array_equal(a, b) for a, b in zip(Ha, Hb))
+    import os
+    os.environ["CNMF_GEMM3"] = "0"
+    try:
+        Hc, _, _, _ = engine.nmf_batch(ks12, seeds=seeds12, max_iter=12, warn=False)
+        assert engine.last_stats["gemm_mode"] == 0
+    finally:
+        del os.environ["CNMF_GEMM3"]
+    for a, c in zip(Ha, Hc):
+        assert np.isfinite(a).all() and np.abs(a - c).max() <= 1e-4 * max(1.0, np.abs(c).max())
 
 
 def test_C3_full_size_restarts_vs_sklearn(engine):
@@ -90,3 +106,33 @@ def test_C3_full_size_restarts_vs_sklearn(engine):
     # size-independent property at full size: re-running is bit-identical (fixed reduction orders)
     H2, _, n2, _ = engine.nmf_batch(ks, seeds=seeds, warn=False)
     assert list(n2) == list(n_iter) and all(np.array_equal(a, b) for a, b in zip(H, H2))
+
+
+def test_streamk_split_operand_path_at_scale(engine, monkeypatch):
+    """26 000 cells x 2000 genes with 256 packed columns: pass A runs as the stream-K launch of the
+    split-operand GEMM (tiles cut once or twice between persistent workgroups, partial planes added by
+    the sweep), pass B as its split-K launch.  25 outer iterations of 29 rank-9 restarts: three of them
+    against scikit-learn (float64) stopped at the same iteration, all of them against the exact-f32
+    matrix pipe, and twice for bit-reproducibility."""
+    X = synth.make_config("C3", dtype=np.float32, n_cells=26000)
+    engine.set_matrix(X)
+    ks = [9] * 29
+    seeds = [int(s) for s in np.random.RandomState(5).randint(1, 2**31 - 1, size=29)]
+    monkeypatch.setenv("CNMF_GEMM3", "2")
+    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
+    st = engine.last_stats
+    assert st["kc"] == 256 and st["gemm_mode"] == 2
+    assert list(n_iter) == [25] * 29
+    H2, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
+    assert all(np.array_equal(a, b) for a, b in zip(H, H2))
+    X64 = X.astype(np.float64)
+    for r in (0, 14, 28):
+        H_ref, _, n_ref = sklearn_ref.nmf(X64, 9, seeds[r], max_iter=25)
+        assert n_ref == 25
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, H[r])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (r, maxabs, relfro)
+    monkeypatch.setenv("CNMF_GEMM3", "0")
+    H0, _, n0, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
+    assert engine.last_stats["gemm_mode"] == 0
+    for a, b in zip(H, H0):
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
