@@ -22,8 +22,11 @@
 // TR * 96 bytes (TR = 256 for the packed factor, 128 for X / X^T) in exactly the order the kernel wants
 // it in LDS.  A stage is therefore fetched as whole 128-byte lines, 1 KB per wave instruction (rows
 // of a row-major layout would be 96-byte segments 12 KB apart: twice the L1/TA line requests).
-// The register-staged variant pads LDS rows to 112 B (28 dwords: ds_read_b128 of 16 consecutive
-// rows hits 16 disjoint 4-bank groups); the LDS-DMA variant keeps the dense image.
+// Inside a row the two 8-k halves of every plane are SWAPPED for rows with bit 3 set (G3_SWZ): a
+// ds_read_b128 lane group holds 16 rows of one half; with dense 96-byte rows their bank groups are
+// 24 r mod 64 = only 8 distinct values (2-way conflicts), and moving half of the rows by 16 bytes makes
+// all 16 distinct -- conflict-free fragment reads straight from the lane-linear DMA image, no padding.
+// The register-staged variant un-swaps while writing its padded (112 B = 28 dword) LDS rows.
 //
 // v_mfma_f32_32x32x16_bf16: lane l supplies row/col (l & 31) and the 8 k's of half (l >> 5) of the
 // block; A and B use the same assignment, so the order of k inside a block is immaterial.
@@ -47,6 +50,9 @@ constexpr int G3_LDSROW = 112;        // bytes of one row in LDS
 constexpr int G3_ROWS = G3_MW + G3_JW;
 constexpr int G3_LDS_BYTES = G3_ROWS * G3_LDSROW;       // 43 008 B -> 2 workgroups per CU
 constexpr int G3_CHUNKS = G3_ROWS * 6 / 256;            // 16-byte chunks staged per thread (9)
+
+// 1 if the 8-k halves of row r (index within its row tile) are stored swapped
+#define G3_SWZ(r_) (((r_) >> 3) & 1)
 
 __device__ __forceinline__ unsigned short bf16_rne(float x)
 {
@@ -83,6 +89,7 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s
 #pragma unroll
     for (int i = 0; i < 16; ++i) split3(x[i], p[0][i], p[1][i], p[2][i]);
     unsigned short* d = dst + (((size_t)(row / TR) * Kb + kb) * TR + (row % TR)) * 48;
+    const int swz = G3_SWZ(row % TR);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s
             u32x4 w;
             w.x = p[q][8 * hf + 0] | ((unsigned)p[q][8 * hf + 1] << 16); w.y = p[q][8 * hf + 2] | ((unsigned)p[q][8 * hf + 3] << 16);
             w.z = p[q][8 * hf + 4] | ((unsigned)p[q][8 * hf + 5] << 16); w.w = p[q][8 * hf + 6] | ((unsigned)p[q][8 * hf + 7] << 16);
-            *reinterpret_cast<u32x4*>(d + q * 16 + hf * 8) = w;
+            *reinterpret_cast<u32x4*>(d + q * 16 + (hf ^ swz) * 8) = w;
         }
 }
 
@@ -111,6 +118,7 @@ __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __re
         split3(x, p[0][i], p[1][i], p[2][i]);
     }
     unsigned short* d = dst + (((size_t)(j / TR) * Kb + kb) * TR + (j % TR)) * 48;
+    const int swz = G3_SWZ(j % TR);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __re
             u32x4 w;
             w.x = p[q][8 * hf + 0] | ((unsigned)p[q][8 * hf + 1] << 16); w.y = p[q][8 * hf + 2] | ((unsigned)p[q][8 * hf + 3] << 16);
             w.z = p[q][8 * hf + 4] | ((unsigned)p[q][8 * hf + 5] << 16); w.w = p[q][8 * hf + 6] | ((unsigned)p[q][8 * hf + 7] << 16);
-            *reinterpret_cast<u32x4*>(d + q * 16 + hf * 8) = w;
+            *reinterpret_cast<u32x4*>(d + q * 16 + (hf ^ swz) * 8) = w;
         }
 }
 
@@ -140,7 +148,8 @@ __global__ __launch_bounds__(256) void split3_tiled_kernel(const float* __restri
         unsigned short p[3][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) split3(x[e], p[0][e], p[1][e], p[2][e]);
-        unsigned short* d = &tile[kq >> 2][row][(kq & 3) * 4];
+        // (r0 and TR are multiples of 64: bit 3 of the in-tile row is bit 3 of the local row)
+        unsigned short* d = &tile[kq >> 2][row][((((kq & 3) >> 1) ^ G3_SWZ(row)) * 8) + (kq & 1) * 4];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             uint2 w;
@@ -184,7 +193,8 @@ __device__ __forceinline__ void gemm3_segment(const unsigned char* __restrict__ 
     for (int i = 0; i < G3_CHUNKS; ++i) {
         const int c = tid + 256 * i;
         const int row = c / 6, part = c - row * 6;
-        lds_off[i] = row * G3_LDSROW + part * 16;
+        // rows of the A region start at 0, of the B region at 256: bit 3 of the in-tile row = bit 3 of `row`
+        lds_off[i] = row * G3_LDSROW + (part ^ G3_SWZ(row)) * 16;
     }
 #define G3_SRC(i_) ((i_) < 6 ? abase + (i_) * 4096 : bbase + ((i_) - 6) * 4096)
 #define G3_BLK(i_) ((i_) < 6 ? G3_MW * G3_ROWB : G3_JW * G3_ROWB)
@@ -345,8 +355,9 @@ __device__ __forceinline__ void gemm3g_segment(const unsigned char* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const int a_off = (wm * 128 + li) * G3_ROWB + h * 16;
-    const int b_off = (G3_MW + wn * 64 + li) * G3_ROWB + h * 16;
+    const int hs = h ^ G3_SWZ(li);                       // every row offset below is a multiple of 32
+    const int a_off = (wm * 128 + li) * G3_ROWB + hs * 16;
+    const int b_off = (G3_MW + wn * 64 + li) * G3_ROWB + hs * 16;
     const int n_own = (nkb - grp + 1) >> 1;                 // this group's blocks: grp, grp + 2, ...
 
 #define G3_SRC(i_) ((i_) < 6 ? abase + (i_) * 4096 + oa_ : bbase + ((i_) - 6) * 4096 + ob_)
@@ -354,8 +365,11 @@ __device__ __forceinline__ void gemm3g_segment(const unsigned char* __restrict__
     {                                                                                              \
         const size_t oa_ = (size_t)(own_) * (2 * G3_MW * G3_ROWB), ob_ = (size_t)(own_) * (2 * G3_JW * G3_ROWB); \
         unsigned char* d_ = gbuf + ((own_) & 1) * G3G_BLK + wave * 1024;                           \
-        _Pragma("unroll") for (int i = 0; i < G3_CHUNKS; ++i)                                      \
-            __builtin_amdgcn_global_load_lds(G3_AS1(G3_SRC(i)), G3_AS3(d_ + i * 4096), 16, 0, 0);  \
+        _Pragma("unroll") for (int i = 0; i < G3_CHUNKS; ++i) {                                    \
+            /* the X planes are read once: non-temporal, so that they do not evict the factor planes */ \
+            if (i >= 6) __builtin_amdgcn_global_load_lds(G3_AS1(G3_SRC(i)), G3_AS3(d_ + i * 4096), 16, 0, 2); \
+            else        __builtin_amdgcn_global_load_lds(G3_AS1(G3_SRC(i)), G3_AS3(d_ + i * 4096), 16, 0, 0); \
+        }                                                                                          \
     }
 #define G3_FRAG(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ptr_))
 #define G3_MFMA(m_, aq_, pa, pb)                                                                   \
