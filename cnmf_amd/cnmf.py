@@ -214,6 +214,39 @@ class cNMF:
             alpha_usage=alpha_usage, alpha_spectra=alpha_spectra, init=init, max_iter=max_NMF_iter)
         self.save_nmf_iter_params(replicate_params, run_params)
 
+    def prepare_from_counts(self, counts, components, n_iter=100, seed=None, beta_loss="frobenius",
+                            alpha_usage=0.0, alpha_spectra=0.0, init="random", max_NMF_iter=1000, tpm=None):
+        """``get_norm_counts`` + the tail of ``prepare`` (cnmf.py:540-556, 452-459) with the
+        normalisation on the device: ``counts`` holds the RAW counts of the chosen high-variance genes
+        (cells x HVGs, DataFrame or ndarray; HVG selection itself stays with the reference / the
+        caller).  The matrix is uploaded once, scaled to unit variance per gene (ddof=1, float64
+        statistics), checked for zero cells, and STAYS resident for ``factorize``; the normalised
+        matrix is written to the reference's ``normalized_counts`` file for the other workers."""
+        if not isinstance(counts, pd.DataFrame):
+            counts = pd.DataFrame(np.asarray(counts),
+                                  index=["cell%d" % i for i in range(np.shape(counts)[0])],
+                                  columns=["gene%d" % j for j in range(np.shape(counts)[1])])
+        eng = self.engine
+        eng.set_matrix(np.ascontiguousarray(counts.values, dtype=np.float32))
+        self._engine_key = None
+        _, row_sums = eng.scale_genes_unit_variance()
+        zerocells = row_sums == 0
+        if zerocells.sum() > 0:
+            examples = counts.index[np.ravel(zerocells)]
+            raise Exception("Error: %d cells have zero counts of overdispersed genes. E.g. %s. Filter those cells "
+                            "and re-run or adjust the number of overdispersed genes. Quitting!"
+                            % (zerocells.sum(), ", ".join(map(str, examples[:4]))))
+        norm_counts = pd.DataFrame(eng.get_matrix().astype(np.float64), index=counts.index, columns=counts.columns)
+        x_mean, x_dtype = eng.x_mean, eng.x_dtype
+        self.prepare_from_matrix(norm_counts, components, n_iter=n_iter, seed=seed, beta_loss=beta_loss,
+                                 alpha_usage=alpha_usage, alpha_spectra=alpha_spectra, init=init,
+                                 max_NMF_iter=max_NMF_iter, tpm=tpm)
+        # the matrix just written is the one already resident: factorize() in this process skips the upload
+        self._engine_key = ("norm_counts", self.paths["normalized_counts"],
+                            os.path.getmtime(self.paths["normalized_counts"]))
+        eng.x_mean, eng.x_dtype = x_mean, x_dtype
+        return norm_counts
+
     # ------------------------------------------------------------------ the NMF call-site
     def _check_kwargs(self, kw):
         """The two solver configurations the reference can produce (cnmf.py:618-631):

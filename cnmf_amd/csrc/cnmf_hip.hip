@@ -1127,6 +1127,7 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
 // ------------------------------------------------------------------ multiplicative-update solver
 #include "mu_host.hip.h"
 #include "comm_host.hip.h"
+#include "normalize_host.hip.h"
 
 // ------------------------------------------------------------------ X . Q / X^T . Q
 extern "C" int cnmf_x_matmul(cnmf_ctx* ctx, int trans, const float* Q, int ncols, float* out)

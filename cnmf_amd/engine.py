@@ -113,6 +113,35 @@ class Engine:
         self.shape = (int(X.shape[0]), int(X.shape[1]))
         return self
 
+    def get_matrix(self):
+        """The resident matrix back on the host (float32 [n_cells, n_genes])."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        out = np.empty(self.shape, dtype=np.float32)
+        self._check(self._lib.cnmf_get_matrix(self._ctx, _fp(out)))
+        return out
+
+    def scale_genes_unit_variance(self):
+        """``X /= X.std(axis=0, ddof=1)`` on the resident matrix -- the dense branch of the reference's
+        ``get_norm_counts`` (cnmf.py:540-548), statistics in float64.  Returns ``(std, row_sums)``;
+        ``row_sums == 0`` marks the reference's "zero cells" (cnmf.py:550-554).  Afterwards the matrix
+        counts as float64 input, like ``norm_counts.X`` in the reference (cnmf.py:534)."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        if N < 2:
+            raise ValueError("need at least two cells for a variance")
+        dblp = C.POINTER(C.c_double)
+        mean, ssd = np.empty(G), np.empty(G)
+        self._check(self._lib.cnmf_col_moments(self._ctx, mean.ctypes.data_as(dblp), ssd.ctypes.data_as(dblp)))
+        std = np.sqrt(ssd / (N - 1))
+        self._check(self._lib.cnmf_scale_columns(self._ctx, std.ctypes.data_as(dblp)))
+        rs = np.empty(N)
+        self._check(self._lib.cnmf_row_sums(self._ctx, rs.ctypes.data_as(dblp)))
+        self.x_dtype = np.dtype(np.float64)
+        self.x_mean = np.float64(rs.sum() / (float(N) * float(G)))
+        return std, rs
+
     def init_scale(self, k):
         """``avg = sqrt(X.mean() / n_components)`` exactly as sklearn computes it
         (numpy scalar arithmetic in X's dtype; decomposition/_nmf.py:303)."""

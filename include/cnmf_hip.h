@@ -84,6 +84,20 @@ int cnmf_set_matrix(cnmf_ctx* ctx, const float* X, int64_t n_cells, int64_t n_ge
 int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const int32_t* indices,
                         const float* data, int64_t n_cells, int64_t n_genes);
 int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* n_cells, int64_t* n_genes);
+/* the resident matrix back on the host ([n_cells][n_genes] float32) */
+int cnmf_get_matrix(cnmf_ctx* ctx, float* out);
+
+/* ---- gene-wise scaling of the resident matrix ------------------------------------------
+ * The dense branch of the reference's get_norm_counts (cnmf.py:540-554): upload the raw counts of
+ * the high-variance genes with cnmf_set_matrix, then
+ *     cnmf_col_moments   -> mean[g] and ssd[g] = sum_i (x_ig - mean_g)^2   (float64, two passes)
+ *                           std(ddof=1) = sqrt(ssd / (n_cells - 1)) is formed by the caller
+ *     cnmf_scale_columns -> x_ig = float32(float64(x_ig) / divisor[g])     (divisors must be > 0)
+ *     cnmf_row_sums      -> float64 sum over the genes of every cell: the "zero cells" check
+ *                           (cnmf.py:550-554) and X.mean() for the random init are derived from it */
+int cnmf_col_moments(cnmf_ctx* ctx, double* mean_out /* [G] */, double* ssd_out /* [G] */);
+int cnmf_scale_columns(cnmf_ctx* ctx, const double* divisor /* [G] */);
+int cnmf_row_sums(cnmf_ctx* ctx, double* out /* [N] */);
 
 /* ---- the restart hot loop ---------------------------------------------------------
  * Replaces the loop body of cNMF.factorize (cnmf.py:735-741): for every restart r,

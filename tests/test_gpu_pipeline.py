@@ -114,3 +114,46 @@ def test_nmf_callsite_dtype_contract(run, gold):
                          beta_loss="frobenius", tol=1e-4, max_iter=50))
     with pytest.raises(NotImplementedError):
         run._nmf(X, dict(n_components=4, random_state=5, solver="mu", beta_loss=0.5))     # generic beta: not built
+
+
+def test_device_normalisation_matches_get_norm_counts(engine, tmp_path):
+    """`norm_counts.X /= norm_counts.X.std(axis=0, ddof=1)` (cnmf.py:546) on the device: float64
+    statistics, one rounding to float32; the zero-cell error of cnmf.py:550-554; and a factorize that
+    reuses the resident matrix gives what the host-normalised pipeline gives."""
+    from cnmf_amd import synth
+    from cnmf_amd.cnmf import cNMF
+    C, _ = synth.topic_counts(700, 300, 5, 1.0, 0.6, 3)
+    C = C[:, C.sum(axis=0) > 0]
+    C = C[C.sum(axis=1) > 0].astype(np.float64)
+    ref64 = C / C.std(axis=0, ddof=1)
+    engine.set_matrix(C.astype(np.float32))
+    std, rs = engine.scale_genes_unit_variance()
+    assert np.allclose(std, C.std(axis=0, ddof=1), rtol=1e-13, atol=0)
+    got = engine.get_matrix()
+    ref32 = ref64.astype(np.float32)
+    assert np.mean(got == ref32) > 0.99999                                   # the odd element may round the other way
+    assert np.abs(got.astype(np.float64) - ref64).max() <= np.abs(ref64).max() * 2.0 ** -23
+    assert np.allclose(rs, ref32.astype(np.float64).sum(axis=1), rtol=1e-12)
+    assert engine.x_dtype == np.float64 and abs(engine.x_mean - ref64.mean()) <= 1e-8 * ref64.mean()
+    # a gene without variance cannot be scaled
+    Cz = C.copy(); Cz[:, 7] = 3.0
+    engine.set_matrix(Cz.astype(np.float32))
+    with pytest.raises(ValueError):
+        engine.scale_genes_unit_variance()
+    # the mirror class: zero cells raise the reference's message; otherwise factorize reuses the upload
+    Cbad = C.copy(); Cbad[5, :] = 0
+    obj = cNMF(output_dir=str(tmp_path), name="dn")
+    with pytest.raises(Exception, match="cells have zero counts of overdispersed genes"):
+        obj.prepare_from_counts(Cbad, components=[4], n_iter=2, seed=3)
+    obj = cNMF(output_dir=str(tmp_path), name="dn2")
+    nc = obj.prepare_from_counts(C, components=[4, 5], n_iter=3, seed=14)
+    assert np.array_equal(nc.values, got.astype(np.float64))
+    key_before = obj._engine_key
+    obj.factorize(write_iter_files=False)
+    assert obj._engine_key == key_before                                      # no second upload
+    obj2 = cNMF(output_dir=str(tmp_path), name="dn3")
+    obj2.prepare_from_matrix(ref64, components=[4, 5], n_iter=3, seed=14)
+    obj2.factorize(write_iter_files=False)
+    for key in obj2.spectra_cache:
+        a, b = obj.spectra_cache[key].values, obj2.spectra_cache[key].values
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
