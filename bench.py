@@ -199,11 +199,11 @@ def main():
         ks, seeds = step_jobs(step)
         if gather_mode == "rccl":
             eng.spectra_reset()
-            _, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=profile, resident=True)
+            _, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=8 if profile else 0, resident=True)
             st = dict(eng.last_stats)
             gather(None, ks, step)
         else:
-            H, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=profile)
+            H, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=8 if profile else 0)
             st = dict(eng.last_stats)
             gather(H, ks, step)
         return ks, st
@@ -242,9 +242,14 @@ def main():
         # roofline of the dominant kernel (rank 0's launches): the MFMA GEMM pass
         flops_per_col_iter = 2.0 * N * G                        # one pass, one component column
         alg_flops_A = flops_per_col_iter * agg["rc_iters"]      # algorithmic (converged columns excluded)
-        tfA = alg_flops_A / max(agg["passA_ms"], 1e-9) / 1e9
-        tfB = alg_flops_A / max(agg["passB_ms"], 1e-9) / 1e9
-        dom = "A" if agg["passA_ms"] >= agg["passB_ms"] else "B"
+        # the passes of every 8th iteration are bracketed by HIP events (an event record costs ~6 us of
+        # queue time): average duration of the sampled launches x all launches = time in the pass
+        launches = max(agg["outer"], 1)
+        avgA = agg["passA_ms"] / max(agg["nA"], 1)
+        avgB = agg["passB_ms"] / max(agg["nB"], 1)
+        tfA = alg_flops_A / max(avgA * launches, 1e-9) / 1e9
+        tfB = alg_flops_A / max(avgB * launches, 1e-9) / 1e9
+        dom = "A" if avgA >= avgB else "B"
         ach = tfA if dom == "A" else tfB
         split = agg["gemm_mode"] > 0
         if split:
@@ -265,14 +270,15 @@ def main():
             "frac": ach / peak,
             "traffic": (pmc_traffic("passA" if dom == "A" else "passB", split) or {}).get("hbm_bytes_per_launch"),
             "traffic_detail": pmc_traffic("passA" if dom == "A" else "passB", split),
-            "avg_launch_ms": {"passA": agg["passA_ms"] / max(agg["nA"], 1), "passB": agg["passB_ms"] / max(agg["nB"], 1)},
+            "avg_launch_ms": {"passA": avgA, "passB": avgB},
+            "launches": {"per_pass": agg["outer"], "timed_with_hip_events": agg["nA"]},
             "achieved_passA": tfA, "achieved_passB": tfB,
-            "alg_flops_per_launch": alg_flops_A / max(agg["nA"], 1),
+            "alg_flops_per_launch": alg_flops_A / launches,
             "issued_flops_per_launch": flops_per_col_iter * agg["kc"],
-            "x_stream_GBs": {"passA": N * G * (6 if split else 4) / (agg["passA_ms"] / max(agg["nA"], 1)) / 1e6,
-                             "passB": N * G * (6 if split else 4) / (agg["passB_ms"] / max(agg["nB"], 1)) / 1e6,
+            "x_stream_GBs": {"passA": N * G * (6 if split else 4) / max(avgA, 1e-9) / 1e6,
+                             "passB": N * G * (6 if split else 4) / max(avgB, 1e-9) / 1e6,
                              "peak": HBM_PEAK_GBS},
-            "gemm_share_of_gpu_time": (agg["passA_ms"] + agg["passB_ms"]) / max(agg["gpu_ms"], 1e-9),
+            "gemm_share_of_gpu_time": (avgA + avgB) * launches / max(agg["gpu_ms"], 1e-9),
         }
         if split:
             roof["matrix_pipe"] = {

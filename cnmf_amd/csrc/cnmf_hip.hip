@@ -601,7 +601,10 @@ static int ensure_batch(cnmf_ctx* ctx, int KC, int max_k = KMAX, int min_k = 1)
     HIP_TRY(ctx, hipMalloc(&ctx->d_slots, (size_t)KC * sizeof(SlotDesc)));
     HIP_TRY(ctx, hipMalloc(&ctx->d_slot_list, (size_t)KC * RING * sizeof(int)));
     HIP_TRY(ctx, hipHostMalloc(&ctx->h_slots, (size_t)KC * sizeof(SlotDesc)));
-    HIP_TRY(ctx, hipHostMalloc(&ctx->h_snap, (size_t)KC * RING * sizeof(SlotDesc)));
+    // device-written, host-polled: coherent mapped pinned memory (zero-copy snapshots of the slot table)
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_snap, (size_t)KC * RING * sizeof(SlotDesc),
+                               hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ctx->h_snap, 0, (size_t)KC * RING * sizeof(SlotDesc));
     HIP_TRY(ctx, hipHostMalloc(&ctx->h_slot_list, (size_t)KC * RING * sizeof(int)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, hb, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->Wt, 0, wb, ctx->stream));
@@ -654,6 +657,32 @@ struct ColAlloc {
 };
 
 struct HostSlot { int state = 0; int restart = -1; int off = 0; int k = 0; int64_t installed_at = 0; };
+
+// Poll the stamps of one zero-copy snapshot (finalize_kernel -> publish_slot) until all `n` slots carry
+// `stamp`.  The snapshot is `lag` iterations old when it is needed, so this normally returns at once.
+static int wait_snapshot(cnmf_ctx* ctx, const SlotDesc* sp, int n, int stamp)
+{
+    for (int s = 0; s < n; ++s) {
+        const volatile int* flag = &sp[s].pad_;
+        long spins = 0;
+        while (*flag != stamp) {
+            if (++spins % 4096 == 0) {
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q == hipSuccess) {                       // stream drained: the stamp must be there
+                    if (*flag == stamp) break;
+                    SET_ERR(ctx, "slot snapshot %d was never published (slot %d)", stamp, s);
+                    return CNMF_EHIP;
+                }
+                if (q != hipErrorNotReady) {
+                    SET_ERR(ctx, "stream failed while waiting for a slot snapshot: %s", hipGetErrorString(q));
+                    return CNMF_EHIP;
+                }
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return CNMF_OK;
+}
 
 static int pick_kc(int64_t total_k, int max_k, int kc_max)
 {
@@ -778,12 +807,15 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int nslots = 0;          // highest used slot index + 1
     int n_active = 0;
     int64_t it = 0;          // batch iterations enqueued so far
-    std::vector<hipEvent_t> ev(RING);
-    for (auto& e : ev) e = events.get(hipEventDisableTiming);
+    int snap_nslots[RING] = {0};
+    // stamps restart at 1 in every call: forget the ones a previous call left in the ring (nothing is in flight here)
+    memset(ctx->h_snap, 0, (size_t)ctx->kc_alloc * RING * sizeof(SlotDesc));
     hipEvent_t ev_begin = events.get(), ev_end = events.get();
     POOL_TRY(ctx, events);
     HIP_TRY(ctx, hipEventRecord(ev_begin, st));
-    const bool time_gemm = stats && (prm->profile || getenv("CNMF_TIME_GEMM"));
+    // HIP events around the two GEMM passes of every `time_stride`-th iteration (an event record costs
+    // ~6 us of queue time: bracketing every launch would take 4 % off the throughput it measures)
+    const int time_stride = !stats ? 0 : (prm->profile > 0 ? prm->profile : (getenv("CNMF_TIME_GEMM") ? 1 : 0));
     std::vector<hipEvent_t> gev;   // (a0,a1,b0,b1) per iteration when timing is requested
 
     const int chunksW = sweep_chunks(N), partsW = sweep_parts(N);
@@ -875,6 +907,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         int tiers = 0;
         for (int s2 = 0; s2 < nslots; ++s2)
             if (hs[s2].state) tiers |= hs[s2].k <= 16 ? 1 : (hs[s2].k <= 32 ? 2 : 4);
+        const bool time_gemm = time_stride > 0 && it % time_stride == 0;
         if (time_gemm) {
             for (int i = 0; i < 4; ++i) gev.push_back(events.get());
             POOL_TRY(ctx, events);
@@ -926,28 +959,31 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                                           (long long)KC * ctx->G_pad));
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
                                   ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers));
+        // the H finalize also publishes every slot's state into the host-mapped ring entry of this
+        // iteration (stamp it + 1): no copy kernel and no event per iteration
+        SlotDesc* snap = ctx->h_snap + (size_t)(it % RING) * KC0;
+        SlotDesc* snap_dev = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&snap_dev, snap, 0));
         finalize_kernel<<<dim3(nslots, fin_y), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W,
-                                                ctx->d_slots, 1, prm->tol, prm->max_iter, 1, max_k);
+                                                ctx->d_slots, 1, prm->tol, prm->max_iter, 1, max_k,
+                                                snap_dev, (int)(it + 1));
         HIP_TRY(ctx, hipGetLastError());
+        snap_nslots[it % RING] = nslots;
         column_iters += KC;
         if (dbg) {
             int live = 0;
             for (int s2 = 0; s2 < nslots; ++s2) if (hs[s2].state) live += hs[s2].k;
             dbg_it[KC / 32] += 1; dbg_live[KC / 32] += live;
         }
-
-        // ---- snapshot of the slot table, examined `lag` iterations later
-        SlotDesc* snap = ctx->h_snap + (size_t)(it % RING) * KC0;
-        HIP_TRY(ctx, hipMemcpyAsync(snap, ctx->d_slots, (size_t)nslots * sizeof(SlotDesc), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipEventRecord(ev[it % RING], st));
         ++it;
         // catch up: everything older than `lag` must be inspected; drain fully when idle
         {
             const int64_t si = it - 1 - lag;   // snapshot index to inspect now
             if (si >= 0) {
-                HIP_TRY(ctx, hipEventSynchronize(ev[si % RING]));
                 const SlotDesc* sp = ctx->h_snap + (size_t)(si % RING) * KC0;
-                for (int s = 0; s < nslots; ++s)
+                rc = wait_snapshot(ctx, sp, snap_nslots[si % RING], (int)(si + 1));
+                if (rc) return rc;
+                for (int s = 0; s < snap_nslots[si % RING]; ++s)
                     if (hs[s].state == 1 && hs[s].installed_at <= si && sp[s].active == 0 && sp[s].restart == hs[s].restart) {
                         rc = retire(s, sp[s]);
                         if (rc) return rc;

@@ -315,17 +315,35 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(
 //   phase 1 : after the H half-step                  -> total violation, decide
 //   phase 2 : after the W half-step (update_H=False) -> decide on the W violation alone
 // NB the `active` flag is read by all four blocks of a slot and cleared by block 0 of the
+// Zero-copy snapshot: the slot state goes straight into a host-mapped (coherent, pinned) ring entry --
+// no copy kernel, no event per iteration.  The payload is written first, then (after a system-scope
+// fence) the stamp `pad_` = iteration number + 1; the host polls the stamp and reads the payload
+// only once it matches.
+__device__ __forceinline__ void publish_slot(SlotDesc* dst, const SlotDesc& s, int stamp)
+{
+    volatile SlotDesc* d = dst;
+    d->off = s.off; d->k = s.k; d->active = s.active; d->iter = s.iter; d->restart = s.restart;
+    d->viol = s.viol; d->viol_init = s.viol_init; d->viol_last = s.viol_last;
+    __threadfence_system();
+    d->pad_ = stamp;
+}
+
 // same launch; the flag copy `was_active` taken at entry keeps the other three consistent
 // enough: a block that sees the cleared flag skips a gram nobody will read again.
 __global__ __launch_bounds__(256) void finalize_kernel(
     const float* __restrict__ gram_part, const double* __restrict__ viol_part, int nparts,
     float* __restrict__ gram_out, float l2_reg,
-    SlotDesc* __restrict__ slots, int phase, double tol, int max_iter, int want_gram, int gld)
+    SlotDesc* __restrict__ slots, int phase, double tol, int max_iter, int want_gram, int gld,
+    SlotDesc* snap_out = nullptr, int stamp = 0)
 {
     const int slot = blockIdx.x;
     SlotDesc* sd = &slots[slot];
-    if (!sd->active) return;
     const int tid = threadIdx.x;
+    if (!sd->active) {
+        // the host's view of this iteration (zero-copy snapshot, see publish_slot): unchanged state
+        if (snap_out && blockIdx.y == 0 && tid == 0) publish_slot(snap_out + slot, *sd, stamp);
+        return;
+    }
     const int k = sd->k;
     if (want_gram) {
         const int e = blockIdx.y * 256 + tid;          // grid.y covers kmax*kmax entries
@@ -376,6 +394,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(
             sd->viol = 0.0;
             if (done) sd->active = 0;
         }
+        if (snap_out) publish_slot(snap_out + slot, *sd, stamp);
     }
 }
 

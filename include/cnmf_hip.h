@@ -49,7 +49,8 @@ typedef struct cnmf_cd_params {
     int    kc_max;       /* max packed component columns in flight: 32..256, 0 = auto */
     double l1_reg_W, l2_reg_W, l1_reg_H, l2_reg_H;
     int    lag;          /* host polls convergence `lag` iterations behind the GPU; 0 = default (2) */
-    int    profile;      /* 1: bracket the two GEMM passes with HIP events (fills passA_ms/passB_ms) */
+    int    profile;      /* n > 0: bracket the two GEMM passes of every n-th iteration with HIP events
+                            (fills passA_ms/passB_ms and the launch counts of the sampled iterations) */
 } cnmf_cd_params;
 
 /* Per-call statistics (optional, may be NULL). */
