@@ -4,8 +4,9 @@
 Workload (default, ``config.workload``): the north-star headline shape -- 50 000 cells x
 2000 high-variance genes (synthetic gamma-Poisson counts, reference `prepare` scaling,
 cnmf_amd/synth.py "C3"), K in {5..13}.  One STEP = one pass of the hot path over one
-batch of restarts: ``--restarts-per-k`` restarts for every K (default 20 -> 180 restarts
-streamed through 256 packed component columns by the slot work-queue), run to sklearn's stopping rule (tol 1e-4, max_iter 1000)
+batch of restarts: ``--restarts-per-k`` restarts for every K (default 100 = the north star's
+n_iter -> one step is one whole factorize() job of 900 restarts per GPU, streamed through 256
+packed component columns by the slot work-queue), run to sklearn's stopping rule (tol 1e-4, max_iter 1000)
 with sklearn's init='random' generated on the device from the cNMF ledger seeds
 (master seed 14).  X is resident in HBM before the timed region.
 
@@ -15,8 +16,9 @@ round-robin like the reference's worker_filter, cnmf.py:52-53); the only exchang
 all-gather of the per-restart spectra at the end of the step (RCCL over xGMI).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
-  roofline     -- the dominant kernel (MFMA GEMM passes): algorithmic flops / launch
-                  duration measured with HIP events inside the library, vs the fp32 MFMA peak
+  roofline     -- the dominant kernel (MFMA GEMM passes): algorithmic flops / launch duration measured
+                  with HIP events inside the library (every 8th iteration), vs the roofline of the
+                  f32-accurate split-operand scheme (bf16 dense MFMA peak / 6)
   cpu_baseline -- scikit-learn's non_negative_factorization (the call the reference makes,
                   cnmf.py:672) timed on this box's host cores on a bounded sample.
 """
@@ -44,7 +46,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C3", help="C1|C2|C3 (cnmf_amd/synth.py)")
     ap.add_argument("--n-cells", type=int, default=None, help="truncate the workload (debug only)")
-    ap.add_argument("--restarts-per-k", type=int, default=20)
+    ap.add_argument("--restarts-per-k", type=int, default=100)
     ap.add_argument("--kmin", type=int, default=5)
     ap.add_argument("--kmax", type=int, default=13)
     ap.add_argument("--no-cpu-baseline", action="store_true")
