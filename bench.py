@@ -35,7 +35,10 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
-SPLIT_MFMAS_PER_PRODUCT = 6        # kernels_gemm3.hip.h: ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh)
+# bf16 MFMAs per f32-accurate product (kernels_gemm3.hip.h), by cnmf_batch_stats.gemm_mode:
+#   1/2: both operands as three planes, ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh)
+#   3  : count-structured X = (integers <= 256) x per-gene scale -> ONE integer plane, (ah + am + al)*n, all exact
+SPLIT_MFMAS_PER_PRODUCT = {1: 6, 2: 6, 3: 3}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -88,7 +91,8 @@ def pmc_traffic(key, split_operand):
     """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE),
     collected in separate rocprofv3 --pmc passes (tools/gpu_pmc_bench.sh) and committed under
     profiles/ -- counters cannot be read from inside an un-profiled run.  None if absent."""
-    name = "r1_pmc_traffic_split.json" if split_operand else "r1_pmc_traffic.json"
+    name = {0: "r1_pmc_traffic.json", 1: "r1_pmc_traffic_split.json", 2: "r1_pmc_traffic_split.json",
+            3: "r1_pmc_traffic_counts.json"}[split_operand]
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         return {"hbm_bytes_per_launch": d[key]["hbm_bytes_per_launch"],
@@ -255,37 +259,47 @@ def main():
         ach = tfA if dom == "A" else tfB
         split = agg["gemm_mode"] > 0
         if split:
-            # f32-accurate products on the bf16 matrix pipe: 6 bf16 MFMAs per product, so the roofline of
-            # the scheme in f32-equivalent flops is the dense bf16 peak / 6 (2.65x the f32 matrix pipe)
-            peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_MFMAS_PER_PRODUCT
-            kern = ("gemm3g_streamk_kernel (pass A: X.Ht, 3 x bf16 planes)" if dom == "A"
-                    else "gemm3g_kernel (pass B: Xt.W, 3 x bf16 planes)")
+            # f32-accurate products on the bf16 matrix pipe: 6 (3 for count-structured X) bf16 MFMAs per product,
+            # so the roofline of the scheme in f32-equivalent flops is the dense bf16 peak / 6 (/ 3)
+            per_product = SPLIT_MFMAS_PER_PRODUCT[agg["gemm_mode"]]
+            peak = BF16_MFMA_PEAK_TFLOPS / per_product
+            if agg["gemm_mode"] == 3:
+                kern = ("gemm3c_streamk_kernel (pass A: X.Ht; X = one integer bf16 plane x per-gene scale, factor = 3 planes)"
+                        if dom == "A" else
+                        "gemm3c_kernel (pass B: Xt.W; X = one integer bf16 plane x per-gene scale, factor = 3 planes)")
+            else:
+                kern = ("gemm3g_streamk_kernel (pass A: X.Ht, 3 x bf16 planes)" if dom == "A"
+                        else "gemm3g_kernel (pass B: Xt.W, 3 x bf16 planes)")
         else:
             peak = FP32_MFMA_PEAK_TFLOPS
             kern = "gemm_streamk_kernel<NT> (pass A: X.Ht)" if dom == "A" else "gemm_kernel<NN> (pass B: Xt.W)"
+        xbytes = {0: 4, 1: 6, 2: 6, 3: 2}[agg["gemm_mode"]]     # bytes per element of X as the GEMM reads it
         roof = {
             "bound": "mfma",
             "kernel": kern,
             "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "flop_basis": ("f32-equivalent flops (2.N.G per column and pass); peak = bf16 dense MFMA peak / 6"
-                           if split else "f32 flops; peak = f32 MFMA peak"),
+            "flop_basis": ("f32-equivalent flops (2.N.G per column and pass); peak = bf16 dense MFMA peak / %d MFMAs per product"
+                           % SPLIT_MFMAS_PER_PRODUCT[agg["gemm_mode"]] if split else "f32 flops; peak = f32 MFMA peak"),
             "frac": ach / peak,
-            "traffic": (pmc_traffic("passA" if dom == "A" else "passB", split) or {}).get("hbm_bytes_per_launch"),
-            "traffic_detail": pmc_traffic("passA" if dom == "A" else "passB", split),
+            "traffic": (pmc_traffic("passA" if dom == "A" else "passB", agg["gemm_mode"]) or {}).get("hbm_bytes_per_launch"),
+            "traffic_detail": pmc_traffic("passA" if dom == "A" else "passB", agg["gemm_mode"]),
             "avg_launch_ms": {"passA": avgA, "passB": avgB},
             "launches": {"per_pass": agg["outer"], "timed_with_hip_events": agg["nA"]},
             "achieved_passA": tfA, "achieved_passB": tfB,
             "alg_flops_per_launch": alg_flops_A / launches,
             "issued_flops_per_launch": flops_per_col_iter * agg["kc"],
-            "x_stream_GBs": {"passA": N * G * (6 if split else 4) / max(avgA, 1e-9) / 1e6,
-                             "passB": N * G * (6 if split else 4) / max(avgB, 1e-9) / 1e6,
+            "x_stream_GBs": {"passA": N * G * xbytes / max(avgA, 1e-9) / 1e6,
+                             "passB": N * G * xbytes / max(avgB, 1e-9) / 1e6,
                              "peak": HBM_PEAK_GBS},
             "gemm_share_of_gpu_time": (avgA + avgB) * launches / max(agg["gpu_ms"], 1e-9),
         }
         if split:
             roof["matrix_pipe"] = {
-                "scheme": "x = h + m + l (3 bf16 planes); a*b from the 6 partial products of weight >= 2^-18; f32 accumulate",
-                "bf16_tflops_issued": ach * SPLIT_MFMAS_PER_PRODUCT * agg["col_iters"] / max(agg["rc_iters"], 1),
+                "scheme": ("X = n * d detected (n integer <= 256: one exact bf16 plane; d per gene, folded into the factor); "
+                           "factor = 3 bf16 planes; 3 exact partial products per product; f32 accumulate"
+                           if agg["gemm_mode"] == 3 else
+                           "x = h + m + l (3 bf16 planes); a*b from the 6 partial products of weight >= 2^-18; f32 accumulate"),
+                "bf16_tflops_issued": ach * per_product * agg["col_iters"] / max(agg["rc_iters"], 1),
                 "bf16_dense_peak": BF16_MFMA_PEAK_TFLOPS,
                 "vs_f32_matrix_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                 "note": "launch averages include the tail launches (< 256 packed columns) that run on the exact-f32 pipe",
@@ -298,8 +312,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (operands split into 3 bf16 planes, 6 bf16 MFMAs per product, f32 accumulate)"
-                      if agg["gemm_mode"] > 0 else "f32"),
+            "dtype": ({1: "f32 (operands split into 3 bf16 planes, 6 bf16 MFMAs per product, f32 accumulate)",
+                       2: "f32 (operands split into 3 bf16 planes, 6 bf16 MFMAs per product, f32 accumulate)",
+                       3: "f32 (X as one integer bf16 plane x per-gene scale, factors as 3 bf16 planes, 3 exact bf16 "
+                          "MFMAs per product, f32 accumulate)"}.get(agg["gemm_mode"], "f32")),
             "data": "synthetic",
             "config": {"workload": "%s: %d cells x %d HVGs synthetic dense, K=%d..%d, %d restarts per K per step "
                                    "per GPU, sklearn CD solver tol=1e-4 max_iter=1000, init=random from ledger seeds"

@@ -24,6 +24,7 @@
 #include "../../include/cnmf_hip.h"
 #include "kernels_gemm.hip.h"
 #include "kernels_gemm3.hip.h"
+#include "kernels_counts.hip.h"
 #include "kernels_rng.hip.h"
 #include "kernels_sweep.hip.h"
 
@@ -44,6 +45,10 @@ struct cnmf_ctx {
     float* X = nullptr;
     unsigned char *X3 = nullptr, *Xt3 = nullptr;   // bf16 planes of X and X^T (split-operand GEMM), built on first use
     int planes_tr = 0;                             // row-tile height they were built with
+    // count structure X = n * d (kernels_counts.hip.h): 0 = not examined, 1 = present, -1 = absent
+    int count_state = 0;
+    unsigned char *C1 = nullptr, *Ct1 = nullptr;   // integer planes of n and n^T (one bf16 plane, 256-row tiles)
+    double* d_scale = nullptr;                     // per-gene scale d [G_pad]
 
     // batch buffers (sized for kc_alloc columns)
     int kc_alloc = 0, nsplit_alloc = 0, nsplitA_alloc = 0, parts_alloc = 0;
@@ -70,7 +75,7 @@ struct cnmf_ctx {
 
 static constexpr int RING = 8;
 #ifndef CNMF_GEMM3_DEFAULT
-#define CNMF_GEMM3_DEFAULT 2
+#define CNMF_GEMM3_DEFAULT 3
 #endif
 
 #define SET_ERR(ctx, ...)                                                   \
@@ -246,11 +251,11 @@ static hipError_t launch_streamk_passA(hipStream_t st, const StreamK& sk, const 
 }
 
 static hipError_t launch_reduce_splits(hipStream_t st, float* P, int nsplit, long long split_stride,
-                                       long long n_floats)
+                                       long long n_floats, const double* colscale = nullptr, int ld = 1)
 {
-    if (nsplit <= 1) return hipSuccess;
+    if (nsplit <= 1 && !colscale) return hipSuccess;
     const long long nv = n_floats / 4;
-    reduce_splits_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, st>>>(P, nsplit, split_stride, P, nv);
+    reduce_splits_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, st>>>(P, nsplit, split_stride, P, nv, colscale, ld);
     return hipGetLastError();
 }
 
@@ -319,6 +324,7 @@ extern "C" void cnmf_destroy(cnmf_ctx* ctx)
     free_batch(ctx);
     cnmf_comm_finalize(ctx);
     hipFree(ctx->X); hipFree(ctx->X3); hipFree(ctx->Xt3);
+    hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->stageW); hipFree(ctx->stageH); hipFree(ctx->spectra);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -335,10 +341,12 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     free_batch(ctx);
     hipFree(ctx->X); ctx->X = nullptr;
     hipFree(ctx->X3); hipFree(ctx->Xt3); ctx->X3 = ctx->Xt3 = nullptr;
+    hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
+    ctx->C1 = ctx->Ct1 = nullptr; ctx->d_scale = nullptr; ctx->count_state = 0;
     ctx->spectra_rows = 0;            // spectra of another matrix are not comparable
     ctx->N = N; ctx->G = G;
-    ctx->N_pad = round_up(N, 128);
-    ctx->G_pad = round_up(G, G >= 512 ? 128 : 32);   // whole 128-gene tiles for the split-operand GEMM
+    ctx->N_pad = round_up(N, N >= 512 ? 256 : 128);  // whole 256-wide tiles for the split-operand GEMMs
+    ctx->G_pad = round_up(G, G >= 512 ? 256 : 32);
     // one extra row of slack: pass B's last 128-gene tile runs past G_pad into the next row
     // (values that only feed never-stored output columns), so the last row needs a successor
     const size_t bytes = ((size_t)ctx->N_pad + 1) * ctx->G_pad * sizeof(float);
@@ -406,28 +414,31 @@ extern "C" int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* N, int64_t* G)
 
 // ------------------------------------------------------------------ split-operand GEMM launchers
 // planes of a K-contiguous f32 matrix, block-major with row tiles of TR rows (rows % TR == 0)
-static hipError_t launch_split3(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst, int TR)
+static hipError_t launch_split3(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst, int TR,
+                                const double* kscale = nullptr)
 {
     if (rows % 64 == 0 && K % 64 == 0 && TR % 64 == 0) {        // tiled through LDS: both sides coalesced
         dim3 grid(K / 64, rows / 64);
-        split3_tiled_kernel<<<grid, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst);
+        split3_tiled_kernel<<<grid, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale);
         return hipGetLastError();
     }
     const long long total = (long long)rows * (K / 16);
-    split3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(src, ld, rows, K, TR, (unsigned short*)dst);
+    split3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(src, ld, rows, K, TR, (unsigned short*)dst, kscale);
     return hipGetLastError();
 }
 
 // CNMF_GEMM3: 0 = exact-f32 matrix pipe only, 1 = split-operand bf16 path, two register-staged 4-wave
 // workgroups per CU (the simple reference variant), 2 = split-operand bf16 path, one 8-wave LDS-DMA
-// ping-pong workgroup per CU (default).  Read on every call so that tests can switch it.
+// ping-pong workgroup per CU; 3 (default) = 2, plus the count-structured path (one integer plane for X, 3 MFMAs
+// per product on 256 x 256 tiles) whenever the resident matrix has that structure.  Read on every call so that
+// tests can switch it.
 // (Tried and dropped, all within 3 % of variant 2 at the 50k x 2000 shape: the same ping-pong with register
 //  staging; 256 x 256 tiles with the two wave groups half a block apart (2/3 of the DMA bytes per flop).)
 static int gemm3_mode()
 {
     const char* e = getenv("CNMF_GEMM3");
     const int mode = e ? atoi(e) : CNMF_GEMM3_DEFAULT;
-    return (mode < 0 || mode > 2) ? CNMF_GEMM3_DEFAULT : mode;
+    return (mode < 0 || mode > 3) ? CNMF_GEMM3_DEFAULT : mode;
 }
 static int gemm3_wg_slots() { return gemm3_mode() >= 2 ? 256 : 512; }
 static int gemm3_jw() { return G3_JW; }     // j extent of a tile = row tile of the B planes
@@ -443,7 +454,7 @@ static hipError_t launch_gemm3(hipStream_t st, const unsigned char* A3, const un
     }
     const int kb_per = (Kb + nsplit - 1) / nsplit;
     dim3 grid(Jpad / gemm3_jw(), KC / G3_MW, (Kb + kb_per - 1) / kb_per);
-    if (gemm3_mode() == 2)
+    if (gemm3_mode() >= 2)
         gemm3g_kernel<<<grid, 512, G3G_LDS_BYTES, st>>>(A3, B3, Kb, C, ldc, cstride, kb_per);
     else
         gemm3_kernel<<<grid, 256, G3_LDS_BYTES, st>>>(A3, B3, Kb, C, ldc, cstride, kb_per);
@@ -458,11 +469,11 @@ struct StreamK3 {
     std::vector<unsigned char> flags;     // bit 0: >= 1 cut (plane 1 holds the tail), bit 1: 2 cuts (plane 2 the middle)
 };
 
-static StreamK3 plan_streamk3(int KC, int N_pad, int G_pad, int n_wg_slots)
+static StreamK3 plan_streamk3(int KC, int N_pad, int G_pad, int n_wg_slots, int jw)
 {
     StreamK3 sk;
     sk.MG = KC / G3_MW;
-    sk.T = sk.MG * (N_pad / gemm3_jw());
+    sk.T = sk.MG * (N_pad / jw);
     sk.Kb = G_pad / G3_BK;
     sk.P = n_wg_slots;
     if (sk.T < sk.P / 2 + sk.P / 4 || sk.P > 2 * sk.T || getenv("CNMF_NO_STREAMK")) return sk;   // few tiles: K split + reduce instead
@@ -488,7 +499,7 @@ static hipError_t launch_gemm3_streamk(hipStream_t st, const StreamK3& sk, const
         hipFuncSetAttribute((const void*)gemm3g_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3G_LDS_BYTES);
         attr_set = true;
     }
-    if (gemm3_mode() == 2)
+    if (gemm3_mode() >= 2)
         gemm3g_streamk_kernel<<<sk.P, 512, G3G_LDS_BYTES, st>>>(A3, B3, sk.Kb, C0, C1, C2, ldc, sk.MG, sk.T);
     else
         gemm3_streamk_kernel<<<sk.P, 256, G3_LDS_BYTES, st>>>(A3, B3, sk.Kb, C0, C1, C2, ldc, sk.MG, sk.T);
@@ -514,16 +525,98 @@ static int ensure_planes(cnmf_ctx* ctx)
     return CNMF_OK;
 }
 
+// ---- count-structured data: launchers of the 256 x 256 integer-plane kernel
+static hipError_t launch_gemm3c(hipStream_t st, const unsigned char* A3, const unsigned char* B1, int Kb,
+                                float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm3c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3C_LDS_BYTES);
+        attr_set = true;
+    }
+    const int kb_per = (Kb + nsplit - 1) / nsplit;
+    dim3 grid(Jpad / G3C_JW, KC / G3_MW, (Kb + kb_per - 1) / kb_per);
+    gemm3c_kernel<<<grid, 512, G3C_LDS_BYTES, st>>>(A3, B1, Kb, C, ldc, cstride, kb_per);
+    return hipGetLastError();
+}
+
+static hipError_t launch_gemm3c_streamk(hipStream_t st, const StreamK3& sk, const unsigned char* A3,
+                                        const unsigned char* B1, float* C0, float* C1, float* C2, int ldc)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm3c_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3C_LDS_BYTES);
+        attr_set = true;
+    }
+    gemm3c_streamk_kernel<<<sk.P, 512, G3C_LDS_BYTES, st>>>(A3, B1, sk.Kb, C0, C1, C2, ldc, sk.MG, sk.T);
+    return hipGetLastError();
+}
+
+// Examine the resident matrix once: is every column (integers <= 256) x one constant?  If so build the
+// integer planes of X and X^T and the per-gene scale (kernels_counts.hip.h).
+static int ensure_counts(cnmf_ctx* ctx)
+{
+    if (ctx->count_state != 0) return CNMF_OK;
+    ctx->count_state = -1;
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    if (ctx->N_pad % G3C_JW || ctx->G_pad % G3C_JW || getenv("CNMF_NO_COUNTS")) return CNMF_OK;
+    hipStream_t st = ctx->stream;
+    const int chunks = (N + CNT_ROWS - 1) / CNT_ROWS;
+    DevPool pool;
+    float* part = pool.get<float>((size_t)chunks * G);
+    float* vmin = pool.get<float>(G);
+    unsigned* fail = pool.get<unsigned>(G, true, st);
+    float* unit = pool.get<float>(G);
+    double* psx = pool.get<double>((size_t)chunks * G);
+    double* psn = pool.get<double>((size_t)chunks * G);
+    POOL_TRY(ctx, pool);
+    dim3 grid((G + 255) / 256, chunks);
+    col_minpos_kernel<<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, part);
+    col_min_combine_kernel<<<(G + 255) / 256, 256, 0, st>>>(part, chunks, G, vmin);
+    count_check_kernel<<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, vmin, fail);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<float> h_v(G), h_unit(G);
+    std::vector<unsigned> h_fail(G);
+    HIP_TRY(ctx, hipMemcpyAsync(h_v.data(), vmin, (size_t)G * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(h_fail.data(), fail, (size_t)G * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int g = 0; g < G; ++g) {
+        int m = 0;
+        for (int c = 1; c <= CNT_MAXMULT && !m; ++c) if (!(h_fail[g] & (1u << (c - 1)))) m = c;
+        if (!m) return CNMF_OK;                            // this gene is not (small integers) x constant
+        h_unit[g] = h_v[g] > 0.f ? h_v[g] / (float)m : 0.f;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(unit, h_unit.data(), (size_t)G * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_scale, (size_t)ctx->G_pad * sizeof(double)));
+    count_sums_kernel<<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, unit, psx, psn);
+    count_scale_kernel<<<(ctx->G_pad + 255) / 256, 256, 0, st>>>(psx, psn, chunks, G, ctx->G_pad, ctx->d_scale);
+    const size_t bytes = (size_t)ctx->N_pad * ctx->G_pad * 2;
+    HIP_TRY(ctx, hipMalloc(&ctx->C1, bytes));
+    HIP_TRY(ctx, hipMalloc(&ctx->Ct1, bytes));
+    {
+        const long long total = (long long)ctx->N_pad * (ctx->G_pad / 16);
+        count_planes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+            ctx->X, ctx->G_pad, N, G, ctx->N_pad, ctx->G_pad, G3C_JW, unit, (unsigned short*)ctx->C1);
+        dim3 gt((ctx->G_pad + 255) / 256, ctx->N_pad / 16);
+        count_planes_transpose_kernel<<<gt, 256, 0, st>>>(
+            ctx->X, ctx->G_pad, N, G, ctx->G_pad, ctx->N_pad, G3C_JW, unit, (unsigned short*)ctx->Ct1);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));                // the pool's scratch is freed on return
+    ctx->count_state = 1;
+    return CNMF_OK;
+}
+
 // the split-operand path needs whole 256 x 128 tiles
 static bool gemm3_enabled(const cnmf_ctx* ctx, int KC)
 {
     return gemm3_mode() != 0 && KC % G3_MW == 0 && ctx->G_pad % gemm3_jw() == 0 && ctx->N_pad % gemm3_jw() == 0;
 }
 
-static int pick_nsplit3(const cnmf_ctx* ctx, int KC)
+static int pick_nsplit3(const cnmf_ctx* ctx, int KC, int jw)
 {
-    // pass B grid = (G_pad/128) x (KC/256) x nsplit; aim at 2 workgroups per CU, >= 16 blocks per split
-    const int tiles = (ctx->G_pad / gemm3_jw()) * std::max(1, KC / G3_MW);
+    // pass B grid = (G_pad/jw) x (KC/256) x nsplit; aim at one (two) workgroups per CU, >= 16 blocks per split
+    const int tiles = std::max(1, ctx->G_pad / jw) * std::max(1, KC / G3_MW);
     const int Kb = ctx->N_pad / G3_BK;
     int s = std::max(1, std::min(gemm3_wg_slots() / std::max(1, tiles), Kb / 16));
     const int kb_per = (Kb + s - 1) / s;
@@ -569,11 +662,24 @@ static int pick_nsplit_A(const cnmf_ctx* ctx, int KC)
     return effective_splits(ctx->G_pad, std::min(s, 16));
 }
 
+// pass A of the split-operand kernels on few cell tiles (no stream-K below 3/4 of the workgroup slots):
+// K splits so that about one workgroup per slot is in flight, >= 8 blocks each
+static int pick_nsplit_A3(const cnmf_ctx* ctx, int KC, int jw)
+{
+    const int T = std::max(1, ctx->N_pad / jw) * std::max(1, KC / G3_MW);
+    const int Kb = ctx->G_pad / G3_BK;
+    int s = std::max(1, std::min(gemm3_wg_slots() / T, Kb / 8));
+    const int kb_per = (Kb + s - 1) / s;
+    return (Kb + kb_per - 1) / kb_per;
+}
+
 static int ensure_batch(cnmf_ctx* ctx, int KC, int max_k = KMAX, int min_k = 1)
 {
     const bool use3 = gemm3_enabled(ctx, KC);
-    const int nsplit = use3 ? std::max(pick_nsplit(ctx, KC), pick_nsplit3(ctx, KC)) : pick_nsplit(ctx, KC);
-    const int nsplitA = pick_nsplit_A(ctx, KC);
+    const int nsplit = use3 ? std::max(pick_nsplit(ctx, KC), std::max(pick_nsplit3(ctx, KC, G3_JW), pick_nsplit3(ctx, KC, G3C_JW)))
+                            : pick_nsplit(ctx, KC);
+    const int nsplitA = use3 ? std::max(pick_nsplit_A(ctx, KC), std::max(pick_nsplit_A3(ctx, KC, G3_JW), pick_nsplit_A3(ctx, KC, G3C_JW)))
+                             : pick_nsplit_A(ctx, KC);
     const int parts = std::max(sweep_parts((int)ctx->N), sweep_parts((int)ctx->G));
     const size_t gp_need = (size_t)(KC / std::max(1, min_k) + 1) * parts * max_k * max_k;
     if (ctx->kc_alloc == KC && ctx->nsplit_alloc == nsplit && ctx->nsplitA_alloc == nsplitA &&
@@ -743,9 +849,16 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     if (rc) return rc;
     int nsplit = std::min(pick_nsplit(ctx, KC), ctx->nsplit_alloc);
     bool use3 = gemm3_enabled(ctx, KC);            // split-operand bf16 MFMA path (whole 256-column tiles only)
-    const int gemm_mode_used = use3 ? gemm3_mode() : 0;
-    if (use3) { rc = ensure_planes(ctx); if (rc) return rc; }
-    const int nsplit3 = use3 ? pick_nsplit3(ctx, KC) : 1;
+    bool usec = false;                             // ... with X as one integer plane (count-structured data)
+    if (use3 && gemm3_mode() == 3) {
+        rc = ensure_counts(ctx);
+        if (rc) return rc;
+        usec = ctx->count_state == 1;
+    }
+    const int gemm_mode_used = !use3 ? 0 : (usec ? 3 : std::min(gemm3_mode(), 2));
+    if (use3 && !usec) { rc = ensure_planes(ctx); if (rc) return rc; }
+    const int jwA = usec ? G3C_JW : G3_JW;         // width of a pass-A / pass-B tile
+    const int nsplit3 = use3 ? pick_nsplit3(ctx, KC, jwA) : 1;
     const int fin_y = (max_k * max_k + 255) / 256;       // finalize blocks per slot
     const int lag = std::max(1, std::min(RING - 2, prm->lag > 0 ? prm->lag : 2));
     hipStream_t st = ctx->stream;
@@ -830,12 +943,12 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     const int wg_slots = getenv("CNMF_SK_WGS") ? atoi(getenv("CNMF_SK_WGS")) : 2 * 256;                    // T-layout pass A: 2 workgroups per CU (73.7 KB LDS each)
     StreamK sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
     if (sk.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
-    int nsplitA = (sk.on && gvarA == 0) ? 1 : ctx->nsplitA_alloc;
+    int nsplitA = (sk.on && gvarA == 0) ? 1 : std::min(pick_nsplit_A(ctx, KC), ctx->nsplitA_alloc);
     StreamK3 sk3;
     if (use3) {
-        sk3 = plan_streamk3(KC, ctx->N_pad, ctx->G_pad, gemm3_wg_slots());
+        sk3 = plan_streamk3(KC, ctx->N_pad, ctx->G_pad, gemm3_wg_slots(), jwA);
         if (sk3.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk3.flags.data(), sk3.flags.size(), hipMemcpyHostToDevice, st));
-        else if (sk.on) use3 = false;              // (cannot happen: both plans switch on the same tile count)
+        else nsplitA = std::min(pick_nsplit_A3(ctx, KC, jwA), ctx->nsplitA_alloc);   // few tiles: K split + reduce
     }
     int n_done = 0;
 
@@ -916,11 +1029,18 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         // pass A : XHt[KC][N] = H_all . X^T                       (sklearn _nmf.py:387)
         SplitInfo spA{nullptr, nullptr, 1, 1, 1};
         if (use3) {
-            HIP_TRY(ctx, launch_split3(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW));
+            // count path: the per-gene scale rides on the factor, H' = H * d
+            HIP_TRY(ctx, launch_split3(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, usec ? ctx->d_scale : nullptr));
             if (time_gemm) hipEventRecord(gev[gev.size() - 4], st);
             if (sk3.on) {
-                HIP_TRY(ctx, launch_gemm3_streamk(st, sk3, ctx->H3, ctx->X3, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
-                spA = SplitInfo{ctx->XHt1, ctx->d_split, gemm3_jw(), G3_MW, sk3.MG, ctx->XHt2};
+                if (usec)
+                    HIP_TRY(ctx, launch_gemm3c_streamk(st, sk3, ctx->H3, ctx->C1, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
+                else
+                    HIP_TRY(ctx, launch_gemm3_streamk(st, sk3, ctx->H3, ctx->X3, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
+                spA = SplitInfo{ctx->XHt1, ctx->d_split, jwA, G3_MW, sk3.MG, ctx->XHt2};
+            } else if (usec) {
+                HIP_TRY(ctx, launch_gemm3c(st, ctx->H3, ctx->C1, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
+                                           (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
             } else {
                 HIP_TRY(ctx, launch_gemm3(st, ctx->H3, ctx->X3, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
                                           (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
@@ -946,7 +1066,10 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (time_gemm) hipEventRecord(gev[gev.size() - 2], st);
         // pass B : XtW[S][KC][G] = Wt_all . X  (split over cells)  (sklearn _nmf.py:505-507)
         const int nsB = use3 ? nsplit3 : nsplit;
-        if (use3)
+        if (usec)
+            HIP_TRY(ctx, launch_gemm3c(st, ctx->Wt3, ctx->Ct1, ctx->N_pad / 16, ctx->XtW, ctx->G_pad,
+                                       (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3));
+        else if (use3)
             HIP_TRY(ctx, launch_gemm3(st, ctx->Wt3, ctx->Xt3, ctx->N_pad / 16, ctx->XtW, ctx->G_pad,
                                       (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3));
         else
@@ -956,7 +1079,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (time_gemm) hipEventRecord(gev[gev.size() - 1], st);
         // H half-step
         HIP_TRY(ctx, launch_reduce_splits(st, ctx->XtW, nsB, (long long)KC * ctx->G_pad,
-                                          (long long)KC * ctx->G_pad));
+                                          (long long)KC * ctx->G_pad, usec ? ctx->d_scale : nullptr, ctx->G_pad));
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
                                   ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers));
         // the H finalize also publishes every slot's state into the host-mapped ring entry of this
@@ -1026,7 +1149,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                 for (int s : idx) cols.alloc(hs[s].k);
                 const int cap = (ctx->nsplit_alloc * KC0) / KC;
                 nsplit = std::max(1, std::min(pick_nsplit(ctx, KC), cap));
-                use3 = false;                       // fewer than 256 packed columns: the f32 pipe takes over
+                use3 = usec = false;                // fewer than 256 packed columns: the f32 pipe takes over
                 sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
                 nsplitA = (sk.on && gvarA == 0) ? 1
                         : std::max(1, std::min(pick_nsplit_A(ctx, KC), (ctx->nsplitA_alloc * KC0) / KC));
@@ -1285,6 +1408,60 @@ extern "C" int cnmf_debug_gemm3(cnmf_ctx* ctx, const float* A, const float* B, f
     hipEventRecord(e1, st);
     HIP_TRY(ctx, hipStreamSynchronize(st));
     { const int kb_per = (Kb + nsplit - 1) / nsplit; zs = (Kb + kb_per - 1) / kb_per; }
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) *ms_out = ms / reps;
+    std::vector<float> hc((size_t)zs * KC * Jp);
+    HIP_TRY(ctx, hipMemcpy(hc.data(), dC, hc.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int c = 0; c < KC; ++c)
+        for (int j = 0; j < J; ++j) {
+            float v = hc[(size_t)c * Jp + j];
+            for (int z = 1; z < zs; ++z) v += hc[((size_t)z * KC + c) * Jp + j];
+            C[(size_t)c * J + j] = v;
+        }
+    return CNMF_OK;
+}
+
+// C[KC][J] = A[KC][K] . Bn[J][K]^T through the count-path kernel: Bn holds non-negative integers <= 256
+// (one bf16 plane), A arbitrary float32 (three planes).  KC % 256 == 0, K % 16 == 0.
+extern "C" int cnmf_debug_gemm3c(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, int KC, int K, int J,
+                                 int nsplit, double* ms_out, int reps)
+{
+    if (!ctx || !A || !Bn || !C) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    if (KC % 256 || K % 16 || J < 1 || nsplit < 1) { SET_ERR(ctx, "debug_gemm3c needs KC %% 256 == 0, K %% 16 == 0"); return CNMF_EINVAL; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int Jp = round_up(J, G3C_JW), Kb = K / 16;
+    DevPool pool;
+    EventPool events;
+    float* dA = pool.get<float>((size_t)KC * K);
+    float* dB = pool.get<float>((size_t)J * K);
+    float* dUnit = pool.get<float>(K);
+    unsigned char* dA3 = pool.get<unsigned char>((size_t)KC * Kb * G3_ROWB);
+    unsigned char* dB1 = pool.get<unsigned char>((size_t)Jp * Kb * 32);
+    float* dC = pool.get<float>((size_t)nsplit * KC * Jp);
+    hipEvent_t e0 = events.get(), e1 = events.get();
+    POOL_TRY(ctx, pool);
+    POOL_TRY(ctx, events);
+    std::vector<float> ones(K, 1.0f);
+    HIP_TRY(ctx, hipMemcpyAsync(dA, A, (size_t)KC * K * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dB, Bn, (size_t)J * K * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dUnit, ones.data(), (size_t)K * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, launch_split3(st, dA, K, KC, K, dA3, G3_MW));
+    {
+        const long long total = (long long)Jp * Kb;
+        count_planes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dB, K, J, K, Jp, K, G3C_JW, dUnit,
+                                                                           (unsigned short*)dB1);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    reps = std::max(1, reps);
+    for (int i = 0; i < reps + 1; ++i) {
+        if (i == 1) hipEventRecord(e0, st);
+        HIP_TRY(ctx, launch_gemm3c(st, dA3, dB1, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit));
+    }
+    hipEventRecord(e1, st);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const int kb_per = (Kb + nsplit - 1) / nsplit, zs = (Kb + kb_per - 1) / kb_per;
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     if (ms_out) *ms_out = ms / reps;

@@ -75,7 +75,8 @@ __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned shor
 // src [rows][ld] f32 (K-contiguous)  ->  block-major planes with row tiles of TR rows.
 // One thread per (row, 16-k block): reads 64 contiguous bytes, writes the row's 96 bytes of that block.
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, int ld, int rows, int K, int TR,
-                                                     unsigned short* __restrict__ dst)
+                                                     unsigned short* __restrict__ dst,
+                                                     const double* __restrict__ kscale = nullptr)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int Kb = K / 16;
@@ -85,6 +86,10 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s
     float x[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const float4 v = s4[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
+    if (kscale) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = (float)((double)x[i] * kscale[kb * 16 + i]);
+    }
     unsigned short p[3][16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) split3(x[i], p[0][i], p[1][i], p[2][i]);
@@ -134,7 +139,8 @@ __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __re
 // x 64 k (four blocks).  Reads: 16 lanes cover 256 contiguous bytes of a row; writes: the 64 rows of
 // one block are 6 KB contiguous in the block-major layout.  (rows, K, TR multiples of 64.)
 __global__ __launch_bounds__(256) void split3_tiled_kernel(const float* __restrict__ src, int ld, int K, int TR,
-                                                           unsigned short* __restrict__ dst)
+                                                           unsigned short* __restrict__ dst,
+                                                           const double* __restrict__ kscale = nullptr)
 {
     __shared__ __attribute__((aligned(16))) unsigned short tile[4][64][48];      // [block][row][h16|m16|l16]
     const int t = threadIdx.x;
@@ -144,7 +150,11 @@ __global__ __launch_bounds__(256) void split3_tiled_kernel(const float* __restri
     for (int i = 0; i < 4; ++i) {
         const int row = rr + 16 * i;
         const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * ld + k0 + kq * 4);
-        const float x[4] = {v.x, v.y, v.z, v.w};
+        float x[4] = {v.x, v.y, v.z, v.w};
+        if (kscale) {                                     // count-structured data: the per-gene scale rides on the factor
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = (float)((double)x[e] * kscale[k0 + kq * 4 + e]);
+        }
         unsigned short p[3][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) split3(x[e], p[0][e], p[1][e], p[2][e]);
@@ -497,6 +507,158 @@ __global__ __launch_bounds__(512) void gemm3g_streamk_kernel(const unsigned char
                        ke - kb, smem3);
         u += ke - kb;
         __syncthreads();                 // the exchange area is overwritten by the next segment's DMA
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Count-structured data (kernels_counts.hip.h): B is ONE integer bf16 plane, A the factor's three planes.
+// 3 MFMAs per product, every partial product exact.  With half the MFMAs per block the operand feed would
+// be the limit on a 256 x 128 tile (the 24 KB of factor planes per block dominate), so this kernel works on
+// 256 components x 256 j: 8 waves, wave (g, wn) owns rows 128 g.., columns 64 wn.., EVERY wave multiplies
+// every k block -- 32 KB of operands per block for 2 x 12 MFMAs per SIMD lane-pair.  The two wave groups run
+// half a block apart: ONE instruction stream, group 1 enters it one barrier later, so its X_s barrier is
+// group 0's Y_s and its Y_s is group 0's X_{s+1} (s_barrier only counts arrivals):
+//     event 2s   : group 0 passes X_s      group 1 passes Y_{s-1}
+//     event 2s+1 : group 0 passes Y_s      group 1 passes X_s
+// Between X_s and Y_s a group reads its 14 fragments of block s and issues its first 12 MFMAs while the other
+// group issues its last 12 of the previous block.  Four 32 KB block images; block s+3 is requested after X_s
+// into the image whose last reader (group 1, block s-1) waited for its fragments before event 2s; block s+1
+// is awaited before Y_s (for group 1 that is event 2s+2, just before group 0 reads it).
+// Operand planes: block-major with 256-row tiles on both sides; B rows are 32 dense bytes.
+constexpr int G3C_JW = 256;
+constexpr int G3C_A = G3_MW * G3_ROWB;                  // 24 576 B of factor planes per block
+constexpr int G3C_B = G3C_JW * 32;                      //  8 192 B of integer plane per block
+constexpr int G3C_BLK = G3C_A + G3C_B;                  // 32 768 B
+constexpr int G3C_IMGS = 4;
+constexpr int G3C_LDS_BYTES = G3C_IMGS * G3C_BLK;       // 131 072 B
+constexpr int G3C_DMA = G3C_BLK / (512 * 16);           // DMA instructions per wave and block (4)
+
+__device__ __forceinline__ void gemm3c_segment(const unsigned char* __restrict__ A3, const unsigned char* __restrict__ B1,
+                                               int Kb, float* __restrict__ C, int ldc, int m0, int j0, int kb0,
+                                               int nkb, unsigned char* smem)
+{
+    const int tid = threadIdx.x;                         // 0..511
+    const int lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, h = lane >> 5;
+
+    // chunk c = tid + 512 i of a block image: i < 3 -> factor planes, i = 3 -> integer plane
+    const unsigned char* abase = A3 + ((size_t)(m0 / G3_MW) * Kb + kb0) * G3C_A + tid * 16;
+    const unsigned char* bbase = B1 + ((size_t)(j0 / G3C_JW) * Kb + kb0) * G3C_B + tid * 16;
+
+    f32x16_3 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int a_off = (grp * 128 + li) * G3_ROWB + (h ^ G3_SWZ(li)) * 16;
+    const int b_off = G3C_A + (wn * 64 + li) * 32 + h * 16;
+
+#define G3C_ISSUE(s_)                                                                              \
+    {                                                                                              \
+        unsigned char* d_ = smem + ((s_) % G3C_IMGS) * G3C_BLK + wave * 1024;                      \
+        const unsigned char* a_ = abase + (size_t)(s_) * G3C_A;                                    \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                              \
+            __builtin_amdgcn_global_load_lds(G3_AS1(a_ + i * 8192), G3_AS3(d_ + i * 8192), 16, 0, 0); \
+        /* the integer plane is read once per pass: non-temporal */                                \
+        __builtin_amdgcn_global_load_lds(G3_AS1(bbase + (size_t)(s_) * G3C_B), G3_AS3(d_ + 3 * 8192), 16, 0, 2); \
+    }
+#define G3_FRAG(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ptr_))
+#define G3C_READ(s_)                                                                               \
+    {                                                                                              \
+        const unsigned char* bb = smem + ((s_) % G3C_IMGS) * G3C_BLK;                              \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) bq[n] = G3_FRAG(bb + b_off + n * 32 * 32);   \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m)                                              \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) aq[m][q] = G3_FRAG(bb + a_off + m * 32 * G3_ROWB + q * 32); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+// two component tiles at a time, smallest plane first: consecutive MFMAs cycle through four accumulators
+#define G3C_MFMA(m_, q_)                                                                           \
+    acc[m_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[m_][q_], bq[0], acc[m_][0], 0, 0, 0);  \
+    acc[m_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[m_][q_], bq[1], acc[m_][1], 0, 0, 0);
+#define G3C_MFMA6(ma_, mb_)                                                                        \
+    G3C_MFMA(ma_, 2) G3C_MFMA(mb_, 2) G3C_MFMA(ma_, 1) G3C_MFMA(mb_, 1) G3C_MFMA(ma_, 0) G3C_MFMA(mb_, 0)
+
+    bf16x8 bq[2], aq[4][3];
+    G3_WAIT_VM(0);                                          // stores of a previous segment
+    G3C_ISSUE(0)
+    if (nkb > 1) G3C_ISSUE(1)
+    if (nkb > 2) G3C_ISSUE(2)
+    if (nkb > 2) G3_WAIT_VM(8); else if (nkb > 1) G3_WAIT_VM(4); else G3_WAIT_VM(0);      // block 0 landed
+    if (grp == 1) G3_RAW_BARRIER()
+    for (int s = 0; s < nkb; ++s) {
+        G3_RAW_BARRIER()                                        // X_s
+        if (s + 3 < nkb) G3C_ISSUE(s + 3)
+        G3C_READ(s)
+        G3C_MFMA6(0, 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this image is free once both groups pass here
+        // block s+1 must have landed before Y_s; s+2, s+3 may stay in flight
+        if (s + 1 < nkb) {
+            if (s + 3 < nkb) G3_WAIT_VM(8); else if (s + 2 < nkb) G3_WAIT_VM(4); else G3_WAIT_VM(0);
+        }
+        G3_RAW_BARRIER()                                        // Y_s
+        G3C_MFMA6(2, 3)
+    }
+    if (grp == 0) G3_RAW_BARRIER()
+#undef G3C_MFMA6
+#undef G3C_MFMA
+#undef G3C_READ
+#undef G3_FRAG
+#undef G3C_ISSUE
+
+    const int j = j0 + wn * 64 + li;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int cbase = m0 + grp * 128 + m * 32 + 4 * h;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = cbase + (r & 3) + 8 * (r >> 2);
+                C[(size_t)row * ldc + j + n * 32] = acc[m][n][r];
+            }
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm3c_kernel(const unsigned char* __restrict__ A3,
+                                                     const unsigned char* __restrict__ B1, int Kb,
+                                                     float* __restrict__ C, int ldc, long long c_split_stride,
+                                                     int kb_per)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    int jt = blockIdx.x, z = blockIdx.z;                 // XCD-aware order, as in gemm3g_kernel
+    if (gridDim.y == 1 && (gridDim.z & 7) == 0) {
+        const int L = blockIdx.x + gridDim.x * blockIdx.z;
+        const int xcd = L & 7, idx = L >> 3;
+        z = xcd + 8 * (idx / (int)gridDim.x);
+        jt = idx % (int)gridDim.x;
+    }
+    const int kb0 = z * kb_per;
+    const int nkb = min(kb_per, Kb - kb0);
+    gemm3c_segment(A3, B1, Kb, C + (size_t)z * c_split_stride, ldc, blockIdx.y * G3_MW, jt * G3C_JW, kb0, nkb, smem3);
+}
+
+__global__ __launch_bounds__(512) void gemm3c_streamk_kernel(const unsigned char* __restrict__ A3,
+                                                             const unsigned char* __restrict__ B1, int Kb,
+                                                             float* __restrict__ C0, float* __restrict__ C1,
+                                                             float* __restrict__ C2, int ldc, int MG, int T)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const long long U = (long long)T * Kb;
+    long long u = U * blockIdx.x / gridDim.x;
+    const long long u1 = U * (blockIdx.x + 1) / gridDim.x;
+    while (u < u1) {
+        const int tile = (int)(u / Kb), kb = (int)(u % Kb);
+        const int ke = (int)min((long long)Kb, kb + (u1 - u));
+        const int jt = tile / MG, mg = tile % MG;
+        gemm3c_segment(A3, B1, Kb, (kb == 0) ? C0 : (ke == Kb ? C1 : C2), ldc, mg * G3_MW, jt * G3C_JW, kb,
+                       ke - kb, smem3);
+        u += ke - kb;
+        G3_WAIT_VM(0);
+        __syncthreads();                 // the images are refilled by the next segment's DMA
     }
 }
 

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(
 // float4 grid-stride; rows of inactive / unused component columns are skipped via `rows`.
 __global__ __launch_bounds__(256) void reduce_splits_kernel(
     const float* __restrict__ P, int nsplit, long long split_stride, float* __restrict__ out,
-    long long n_vec4)
+    long long n_vec4, const double* __restrict__ colscale = nullptr, int ld = 1)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_vec4) return;
@@ -305,6 +305,11 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(
         acc += a; acc += b; acc += c; acc += d;
     }
     for (; s < nsplit; ++s) acc += p[(long long)s * sv];
+    if (colscale) {                                       // count-structured data: X^T.W = d * (n^T.W)
+        const int c0 = (int)((i * 4) % ld);               // ld is a multiple of 4: the four lanes share a row
+        acc.x = (float)((double)acc.x * colscale[c0]);     acc.y = (float)((double)acc.y * colscale[c0 + 1]);
+        acc.z = (float)((double)acc.z * colscale[c0 + 2]); acc.w = (float)((double)acc.w * colscale[c0 + 3]);
+    }
     reinterpret_cast<v4f*>(out)[i] = acc;
 }
 

@@ -542,6 +542,18 @@ class Engine:
                                                C.byref(ms), int(reps)))
         return Cout, ms.value
 
+    def debug_gemm3c(self, A, Bn, nsplit=1, reps=0):
+        """A [KC, K] . Bn [J, K]^T through the count-path kernel (Bn: integers <= 256); returns (C, ms)."""
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        Bn = np.ascontiguousarray(Bn, dtype=np.float32)
+        KC, K = A.shape
+        J = Bn.shape[0]
+        Cout = np.empty((KC, J), dtype=np.float32)
+        ms = C.c_double(0.0)
+        self._check(self._lib.cnmf_debug_gemm3c(self._ctx, _fp(A), _fp(Bn), _fp(Cout), KC, K, J, int(nsplit),
+                                                C.byref(ms), int(reps)))
+        return Cout, ms.value
+
     def debug_standard_normal(self, seed, n):
         out = np.empty(max(n, 1), dtype=np.float64)
         self._check(self._lib.cnmf_debug_standard_normal(self._ctx, C.c_uint32(seed), n,

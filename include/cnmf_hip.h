@@ -64,8 +64,9 @@ typedef struct cnmf_batch_stats {
     int64_t passA_launches, passB_launches;
     int32_t kc;                    /* packed column count used                                  */
     int32_t nsplit;                /* split-K factor of pass B                                  */
-    int32_t gemm_mode;             /* 0 = exact-f32 MFMA, 1/2 = split-operand bf16 MFMA (CNMF_GEMM3) in
-                                      the 256-column phase of this call                          */
+    int32_t gemm_mode;             /* GEMM path of the 256-column phase of this call: 0 = exact-f32 MFMA,
+                                      1/2 = split-operand bf16 MFMA (CNMF_GEMM3), 3 = the same with X as one
+                                      integer plane (count-structured data detected)               */
     int32_t reserved_;
 } cnmf_batch_stats;
 
@@ -238,6 +239,10 @@ int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float* A, const 
  * path; KC % 256 == 0, K % 16 == 0.                                                        */
 int cnmf_debug_gemm3(cnmf_ctx* ctx, const float* A, const float* B, float* C, int KC, int K, int J,
                      int nsplit, double* ms_out, int reps);
+/* the same for count-structured data: Bn [J][K] holds non-negative integers <= 256 (ONE bf16 plane),
+ * A arbitrary float32 (three planes); 3 exact bf16 MFMAs per product on 256 x 256 tiles.           */
+int cnmf_debug_gemm3c(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, int KC, int K, int J,
+                      int nsplit, double* ms_out, int reps);
 /* numpy RandomState(seed).standard_normal(n) reproduced on the device. */
 int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t n, double* out);
 

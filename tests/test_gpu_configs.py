@@ -136,3 +136,14 @@ def test_streamk_split_operand_path_at_scale(engine, monkeypatch):
     assert engine.last_stats["gemm_mode"] == 0
     for a, b in zip(H, H0):
         assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
+    # the default: count structure detected (the synthetic matrix is counts / std) -> integer-plane kernels,
+    # here with few 256-cell tiles (102 < 192: K split + reduce instead of stream-K)
+    monkeypatch.setenv("CNMF_GEMM3", "3")
+    Hc, _, nc, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
+    assert engine.last_stats["gemm_mode"] == 3
+    Hc2, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
+    assert all(np.array_equal(a, b) for a, b in zip(Hc, Hc2))
+    for r in (0, 14, 28):
+        H_ref, _, _ = sklearn_ref.nmf(X64, 9, seeds[r], max_iter=25)
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, Hc[r])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (r, maxabs, relfro)

@@ -73,11 +73,62 @@ def test_split_operand_gemm_is_f32_accurate(engine, monkeypatch, g3mode):
     assert np.array_equal(out, out2)
 
 
-@pytest.mark.parametrize("g3mode", ["0", "1", "2"])
+def test_count_path_gemm_is_exact_product_accurate(engine):
+    """Count-structured operand (kernels_counts.hip.h): B holds integers <= 256 as ONE bf16 plane, A three
+    planes -- every partial product is exact, so the only error is the f32 accumulation."""
+    rs = np.random.RandomState(3)
+    for K, J, ns in [(16, 40, 1), (64, 300, 1), (2048, 1000, 1), (4096, 520, 4), (2048, 130, 7)]:
+        A = (rs.standard_normal((256, K)) * np.exp(rs.standard_normal((256, K)))).astype(np.float32)
+        B = rs.poisson(3.0, size=(J, K)).astype(np.float32)
+        B[0, :3] = [256, 255, 0]
+        ref = A.astype(np.float64) @ B.astype(np.float64).T
+        out, _ = engine.debug_gemm3c(A, B, nsplit=ns)
+        assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-6, (K, J, ns)
+        scale = np.abs(A).astype(np.float64) @ B.astype(np.float64).T
+        assert (np.abs(out - ref) / np.maximum(scale, 1e-30)).max() < 1e-6, (K, J, ns)
+        out2, _ = engine.debug_gemm3c(A, B, nsplit=ns)
+        assert np.array_equal(out, out2)
+
+
+def test_count_structure_is_detected_only_where_it_exists(engine):
+    """X = counts / std (cnmf.py:546) has the structure (gemm_mode 3); the same matrix with one entry
+    nudged off the integer grid, or with a count above 256, does not (general three-plane path, 2)."""
+    C, _ = synth.topic_counts(1024, 520, 6, 5.0, 0.3, 2)
+    C = C[:, C.sum(axis=0) > 0]
+    C = C[C.sum(axis=1) > 0]
+    X = (C / C.std(axis=0, ddof=1)).astype(np.float64)
+    ks, seeds = [9] * 29, list(range(1, 30))
+    results = {}
+    for tag in ("counts", "nudged", "big"):
+        Xt = X.copy()
+        if tag == "nudged":
+            i, g = np.argwhere(C > 0)[0]
+            Xt[i, g] *= 1.37
+        if tag == "big":
+            Xt[3, 5] = X[:, 5][X[:, 5] > 0].min() * 300
+        engine.set_matrix(Xt)
+        H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=20, warn=False)
+        assert engine.last_stats["kc"] == 256
+        results[tag] = (engine.last_stats["gemm_mode"], H)
+    assert results["counts"][0] == 3 and results["nudged"][0] == 2 and results["big"][0] == 2
+    # and the count path computes the same factorisation as the exact-f32 pipe
+    import os
+    os.environ["CNMF_GEMM3"] = "0"
+    try:
+        engine.set_matrix(X)
+        H0, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=20, warn=False)
+        assert engine.last_stats["gemm_mode"] == 0
+    finally:
+        del os.environ["CNMF_GEMM3"]
+    for a, b in zip(results["counts"][1], H0):
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("g3mode", ["0", "1", "2", "3"])
 def test_full_width_batch_matches_oracle_in_every_gemm_mode(engine, monkeypatch, g3mode):
     """256 packed columns (the width at which the split-operand GEMM takes over): every restart
-    against its independent float64 oracle run, for the exact-f32 pipe (0) and both split-operand
-    variants (1, 2).  Same tolerance in all three."""
+    against its independent float64 oracle run, for the exact-f32 pipe (0), both general split-operand
+    variants (1, 2) and the count-structured path (3, the default).  Same tolerance in all four."""
     monkeypatch.setenv("CNMF_GEMM3", g3mode)
     X64 = synth.make_config("C1", dtype=np.float64)
     engine.set_matrix(X64)
