@@ -48,6 +48,8 @@ struct cnmf_ctx {
     // count structure X = n * d (kernels_counts.hip.h): 0 = not examined, 1 = present, -1 = absent
     int count_state = 0;
     unsigned char *C1 = nullptr, *Ct1 = nullptr;   // integer planes of n and n^T (one bf16 plane, 256-row tiles)
+    unsigned char *C1h = nullptr, *Ct1h = nullptr; // second planes (256 hi) when some count exceeds 256, else NULL
+    unsigned int *hiA = nullptr, *hiB = nullptr;   // their flags: one bit per (tile row, block)
     double* d_scale = nullptr;                     // per-gene scale d [G_pad]
 
     // batch buffers (sized for kc_alloc columns)
@@ -325,6 +327,7 @@ extern "C" void cnmf_destroy(cnmf_ctx* ctx)
     cnmf_comm_finalize(ctx);
     hipFree(ctx->X); hipFree(ctx->X3); hipFree(ctx->Xt3);
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
+    hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     hipFree(ctx->stageW); hipFree(ctx->stageH); hipFree(ctx->spectra);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -342,7 +345,9 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     hipFree(ctx->X); ctx->X = nullptr;
     hipFree(ctx->X3); hipFree(ctx->Xt3); ctx->X3 = ctx->Xt3 = nullptr;
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
-    ctx->C1 = ctx->Ct1 = nullptr; ctx->d_scale = nullptr; ctx->count_state = 0;
+    hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
+    ctx->C1 = ctx->Ct1 = ctx->C1h = ctx->Ct1h = nullptr; ctx->hiA = ctx->hiB = nullptr;
+    ctx->d_scale = nullptr; ctx->count_state = 0;
     ctx->spectra_rows = 0;            // spectra of another matrix are not comparable
     ctx->N = N; ctx->G = G;
     ctx->N_pad = round_up(N, N >= 512 ? 256 : 128);  // whole 256-wide tiles for the split-operand GEMMs
@@ -526,29 +531,33 @@ static int ensure_planes(cnmf_ctx* ctx)
 }
 
 // ---- count-structured data: launchers of the 256 x 256 integer-plane kernel
-static hipError_t launch_gemm3c(hipStream_t st, const unsigned char* A3, const unsigned char* B1, int Kb,
+// Bhi / hiflag: second integer plane and its block flags (nullptr when no count exceeds 256)
+static hipError_t launch_gemm3c(hipStream_t st, const unsigned char* A3, const unsigned char* B1,
+                                const unsigned char* Bhi, const unsigned int* hiflag, int Kb,
                                 float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm3c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3C_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm3c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, g3c_lds_bytes(true));
         attr_set = true;
     }
     const int kb_per = (Kb + nsplit - 1) / nsplit;
     dim3 grid(Jpad / G3C_JW, KC / G3_MW, (Kb + kb_per - 1) / kb_per);
-    gemm3c_kernel<<<grid, 512, G3C_LDS_BYTES, st>>>(A3, B1, Kb, C, ldc, cstride, kb_per);
+    gemm3c_kernel<<<grid, 512, g3c_lds_bytes(Bhi != nullptr), st>>>(A3, B1, Bhi, hiflag, Kb, C, ldc, cstride, kb_per);
     return hipGetLastError();
 }
 
 static hipError_t launch_gemm3c_streamk(hipStream_t st, const StreamK3& sk, const unsigned char* A3,
-                                        const unsigned char* B1, float* C0, float* C1, float* C2, int ldc)
+                                        const unsigned char* B1, const unsigned char* Bhi,
+                                        const unsigned int* hiflag, float* C0, float* C1, float* C2, int ldc)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm3c_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3C_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm3c_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, g3c_lds_bytes(true));
         attr_set = true;
     }
-    gemm3c_streamk_kernel<<<sk.P, 512, G3C_LDS_BYTES, st>>>(A3, B1, sk.Kb, C0, C1, C2, ldc, sk.MG, sk.T);
+    gemm3c_streamk_kernel<<<sk.P, 512, g3c_lds_bytes(Bhi != nullptr), st>>>(A3, B1, Bhi, hiflag, sk.Kb, C0, C1, C2, ldc,
+                                                                            sk.MG, sk.T);
     return hipGetLastError();
 }
 
@@ -590,16 +599,35 @@ static int ensure_counts(cnmf_ctx* ctx)
     HIP_TRY(ctx, hipMalloc(&ctx->d_scale, (size_t)ctx->G_pad * sizeof(double)));
     count_sums_kernel<<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, unit, psx, psn);
     count_scale_kernel<<<(ctx->G_pad + 255) / 256, 256, 0, st>>>(psx, psn, chunks, G, ctx->G_pad, ctx->d_scale);
+    // does any count exceed 256?  then a second plane (256 hi) with per-block flags rides along
+    unsigned* any_big = pool.get<unsigned>(1, true, st);
+    POOL_TRY(ctx, pool);
+    count_max_kernel<<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, unit, any_big);
+    unsigned h_big = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&h_big, any_big, sizeof h_big, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
     const size_t bytes = (size_t)ctx->N_pad * ctx->G_pad * 2;
     HIP_TRY(ctx, hipMalloc(&ctx->C1, bytes));
     HIP_TRY(ctx, hipMalloc(&ctx->Ct1, bytes));
+    if (h_big) {
+        const size_t nfA = (size_t)(ctx->N_pad / G3C_JW) * ((ctx->G_pad / 16 + 31) / 32) * sizeof(unsigned int);
+        const size_t nfB = (size_t)(ctx->G_pad / G3C_JW) * ((ctx->N_pad / 16 + 31) / 32) * sizeof(unsigned int);
+        HIP_TRY(ctx, hipMalloc(&ctx->C1h, bytes));
+        HIP_TRY(ctx, hipMalloc(&ctx->Ct1h, bytes));
+        HIP_TRY(ctx, hipMalloc(&ctx->hiA, nfA));
+        HIP_TRY(ctx, hipMalloc(&ctx->hiB, nfB));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->hiA, 0, nfA, st));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->hiB, 0, nfB, st));
+    }
     {
         const long long total = (long long)ctx->N_pad * (ctx->G_pad / 16);
         count_planes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
-            ctx->X, ctx->G_pad, N, G, ctx->N_pad, ctx->G_pad, G3C_JW, unit, (unsigned short*)ctx->C1);
+            ctx->X, ctx->G_pad, N, G, ctx->N_pad, ctx->G_pad, G3C_JW, unit, (unsigned short*)ctx->C1,
+            (unsigned short*)ctx->C1h, ctx->hiA);
         dim3 gt((ctx->G_pad + 255) / 256, ctx->N_pad / 16);
         count_planes_transpose_kernel<<<gt, 256, 0, st>>>(
-            ctx->X, ctx->G_pad, N, G, ctx->G_pad, ctx->N_pad, G3C_JW, unit, (unsigned short*)ctx->Ct1);
+            ctx->X, ctx->G_pad, N, G, ctx->G_pad, ctx->N_pad, G3C_JW, unit, (unsigned short*)ctx->Ct1,
+            (unsigned short*)ctx->Ct1h, ctx->hiB);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));                // the pool's scratch is freed on return
@@ -1034,12 +1062,13 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             if (time_gemm) hipEventRecord(gev[gev.size() - 4], st);
             if (sk3.on) {
                 if (usec)
-                    HIP_TRY(ctx, launch_gemm3c_streamk(st, sk3, ctx->H3, ctx->C1, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
+                    HIP_TRY(ctx, launch_gemm3c_streamk(st, sk3, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->XHt, ctx->XHt1,
+                                                       ctx->XHt2, ctx->N_pad));
                 else
                     HIP_TRY(ctx, launch_gemm3_streamk(st, sk3, ctx->H3, ctx->X3, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
                 spA = SplitInfo{ctx->XHt1, ctx->d_split, jwA, G3_MW, sk3.MG, ctx->XHt2};
             } else if (usec) {
-                HIP_TRY(ctx, launch_gemm3c(st, ctx->H3, ctx->C1, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
+                HIP_TRY(ctx, launch_gemm3c(st, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
                                            (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
             } else {
                 HIP_TRY(ctx, launch_gemm3(st, ctx->H3, ctx->X3, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
@@ -1067,7 +1096,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         // pass B : XtW[S][KC][G] = Wt_all . X  (split over cells)  (sklearn _nmf.py:505-507)
         const int nsB = use3 ? nsplit3 : nsplit;
         if (usec)
-            HIP_TRY(ctx, launch_gemm3c(st, ctx->Wt3, ctx->Ct1, ctx->N_pad / 16, ctx->XtW, ctx->G_pad,
+            HIP_TRY(ctx, launch_gemm3c(st, ctx->Wt3, ctx->Ct1, ctx->Ct1h, ctx->hiB, ctx->N_pad / 16, ctx->XtW, ctx->G_pad,
                                        (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3));
         else if (use3)
             HIP_TRY(ctx, launch_gemm3(st, ctx->Wt3, ctx->Xt3, ctx->N_pad / 16, ctx->XtW, ctx->G_pad,
@@ -1422,8 +1451,8 @@ extern "C" int cnmf_debug_gemm3(cnmf_ctx* ctx, const float* A, const float* B, f
     return CNMF_OK;
 }
 
-// C[KC][J] = A[KC][K] . Bn[J][K]^T through the count-path kernel: Bn holds non-negative integers <= 256
-// (one bf16 plane), A arbitrary float32 (three planes).  KC % 256 == 0, K % 16 == 0.
+// C[KC][J] = A[KC][K] . Bn[J][K]^T through the count-path kernel: Bn holds non-negative integers <= 65535
+// (lo plane + flagged hi plane), A arbitrary float32 (three planes).  KC % 256 == 0, K % 16 == 0.
 extern "C" int cnmf_debug_gemm3c(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, int KC, int K, int J,
                                  int nsplit, double* ms_out, int reps)
 {
@@ -1439,6 +1468,8 @@ extern "C" int cnmf_debug_gemm3c(cnmf_ctx* ctx, const float* A, const float* Bn,
     float* dUnit = pool.get<float>(K);
     unsigned char* dA3 = pool.get<unsigned char>((size_t)KC * Kb * G3_ROWB);
     unsigned char* dB1 = pool.get<unsigned char>((size_t)Jp * Kb * 32);
+    unsigned char* dBh = pool.get<unsigned char>((size_t)Jp * Kb * 32);
+    unsigned int* dFl = pool.get<unsigned int>((size_t)(Jp / G3C_JW) * ((Kb + 31) / 32), true, st);
     float* dC = pool.get<float>((size_t)nsplit * KC * Jp);
     hipEvent_t e0 = events.get(), e1 = events.get();
     POOL_TRY(ctx, pool);
@@ -1451,13 +1482,13 @@ extern "C" int cnmf_debug_gemm3c(cnmf_ctx* ctx, const float* A, const float* Bn,
     {
         const long long total = (long long)Jp * Kb;
         count_planes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dB, K, J, K, Jp, K, G3C_JW, dUnit,
-                                                                           (unsigned short*)dB1);
+                                                                           (unsigned short*)dB1, (unsigned short*)dBh, dFl);
         HIP_TRY(ctx, hipGetLastError());
     }
     reps = std::max(1, reps);
     for (int i = 0; i < reps + 1; ++i) {
         if (i == 1) hipEventRecord(e0, st);
-        HIP_TRY(ctx, launch_gemm3c(st, dA3, dB1, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit));
+        HIP_TRY(ctx, launch_gemm3c(st, dA3, dB1, dBh, dFl, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit));
     }
     hipEventRecord(e1, st);
     HIP_TRY(ctx, hipStreamSynchronize(st));

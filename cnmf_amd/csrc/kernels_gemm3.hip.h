@@ -527,13 +527,19 @@ __global__ __launch_bounds__(512) void gemm3g_streamk_kernel(const unsigned char
 // Operand planes: block-major with 256-row tiles on both sides; B rows are 32 dense bytes.
 constexpr int G3C_JW = 256;
 constexpr int G3C_A = G3_MW * G3_ROWB;                  // 24 576 B of factor planes per block
-constexpr int G3C_B = G3C_JW * 32;                      //  8 192 B of integer plane per block
-constexpr int G3C_BLK = G3C_A + G3C_B;                  // 32 768 B
+constexpr int G3C_B = G3C_JW * 32;                      //  8 192 B of one integer plane per block
 constexpr int G3C_IMGS = 4;
-constexpr int G3C_LDS_BYTES = G3C_IMGS * G3C_BLK;       // 131 072 B
-constexpr int G3C_DMA = G3C_BLK / (512 * 16);           // DMA instructions per wave and block (4)
+// LDS: four images of 32 KB (factor planes + integer plane), 40 KB when the matrix has a second integer plane
+constexpr int g3c_lds_bytes(bool with_hi) { return G3C_IMGS * (G3C_A + (with_hi ? 2 : 1) * G3C_B); }
 
+// Bhi / hiflag: second integer plane (256 hi) and its flags, one bit per (tile row, block), (Kb + 31) / 32 words
+// per tile row (nullptr: no second plane).  Only flagged blocks fetch it (a 5th DMA instruction) and spend 3 more
+// MFMAs per product.  The flag bits of the segment are fetched BEFORE the first DMA (a load inside the loop would
+// sit in the same vmcnt queue as the DMAs).  The counted vmcnt waits assume the minimum of four DMA instructions
+// per block: with extra ones in flight they only wait longer.
 __device__ __forceinline__ void gemm3c_segment(const unsigned char* __restrict__ A3, const unsigned char* __restrict__ B1,
+                                               const unsigned char* __restrict__ Bhi,
+                                               const unsigned int* __restrict__ hiflag,
                                                int Kb, float* __restrict__ C, int ldc, int m0, int j0, int kb0,
                                                int nkb, unsigned char* smem)
 {
@@ -541,10 +547,23 @@ __device__ __forceinline__ void gemm3c_segment(const unsigned char* __restrict__
     const int lane = tid & 63, wave = tid >> 6;
     const int grp = wave >> 2, wn = wave & 3;
     const int li = lane & 31, h = lane >> 5;
+    const int img_bytes = G3C_A + (Bhi ? 2 : 1) * G3C_B;
 
-    // chunk c = tid + 512 i of a block image: i < 3 -> factor planes, i = 3 -> integer plane
+    // chunk c = tid + 512 i of a block image: i < 3 -> factor planes, i = 3 -> integer plane, i = 4 -> its second plane
+    const size_t jblk = ((size_t)(j0 / G3C_JW) * Kb + kb0);
     const unsigned char* abase = A3 + ((size_t)(m0 / G3_MW) * Kb + kb0) * G3C_A + tid * 16;
-    const unsigned char* bbase = B1 + ((size_t)(j0 / G3C_JW) * Kb + kb0) * G3C_B + tid * 16;
+    const unsigned char* bbase = B1 + jblk * G3C_B + tid * 16;
+    const unsigned char* hbase = Bhi ? Bhi + jblk * G3C_B + tid * 16 : nullptr;
+    // flag bits of blocks kb0 .. kb0 + nkb - 1 (at most 5 words for up to 129 blocks; longer segments: all set)
+    unsigned int fw[5] = {0u, 0u, 0u, 0u, 0u};
+    if (Bhi) {
+        const int KW = (Kb + 31) >> 5, w0 = kb0 >> 5;
+        const unsigned int* fr = hiflag + (size_t)(j0 / G3C_JW) * KW;
+#pragma unroll
+        for (int w = 0; w < 5; ++w)
+            fw[w] = (nkb > 129) ? 0xFFFFFFFFu : ((w0 + w < KW) ? __builtin_amdgcn_readfirstlane(fr[w0 + w]) : 0u);
+    }
+    const int fbit0 = kb0 & 31;
 
     f32x16_3 acc[4][2];
 #pragma unroll
@@ -557,32 +576,36 @@ __device__ __forceinline__ void gemm3c_segment(const unsigned char* __restrict__
     const int a_off = (grp * 128 + li) * G3_ROWB + (h ^ G3_SWZ(li)) * 16;
     const int b_off = G3C_A + (wn * 64 + li) * 32 + h * 16;
 
+#define G3C_FLAG(s_) (Bhi && ((fw[(fbit0 + (s_)) >> 5 > 4 ? 4 : (fbit0 + (s_)) >> 5] >> ((fbit0 + (s_)) & 31)) & 1u))
 #define G3C_ISSUE(s_)                                                                              \
     {                                                                                              \
-        unsigned char* d_ = smem + ((s_) % G3C_IMGS) * G3C_BLK + wave * 1024;                      \
+        unsigned char* d_ = smem + ((s_) % G3C_IMGS) * img_bytes + wave * 1024;                    \
         const unsigned char* a_ = abase + (size_t)(s_) * G3C_A;                                    \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                              \
             __builtin_amdgcn_global_load_lds(G3_AS1(a_ + i * 8192), G3_AS3(d_ + i * 8192), 16, 0, 0); \
-        /* the integer plane is read once per pass: non-temporal */                                \
+        /* the integer planes are read once per pass: non-temporal */                              \
         __builtin_amdgcn_global_load_lds(G3_AS1(bbase + (size_t)(s_) * G3C_B), G3_AS3(d_ + 3 * 8192), 16, 0, 2); \
+        if (G3C_FLAG(s_))                                                                          \
+            __builtin_amdgcn_global_load_lds(G3_AS1(hbase + (size_t)(s_) * G3C_B), G3_AS3(d_ + 4 * 8192), 16, 0, 2); \
     }
 #define G3_FRAG(ptr_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ptr_))
 #define G3C_READ(s_)                                                                               \
     {                                                                                              \
-        const unsigned char* bb = smem + ((s_) % G3C_IMGS) * G3C_BLK;                              \
+        const unsigned char* bb = smem + ((s_) % G3C_IMGS) * img_bytes;                            \
         _Pragma("unroll") for (int n = 0; n < 2; ++n) bq[n] = G3_FRAG(bb + b_off + n * 32 * 32);   \
+        if (hi_blk) { _Pragma("unroll") for (int n = 0; n < 2; ++n) bh[n] = G3_FRAG(bb + b_off + G3C_B + n * 32 * 32); } \
         _Pragma("unroll") for (int m = 0; m < 4; ++m)                                              \
             _Pragma("unroll") for (int q = 0; q < 3; ++q) aq[m][q] = G3_FRAG(bb + a_off + m * 32 * G3_ROWB + q * 32); \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
 // two component tiles at a time, smallest plane first: consecutive MFMAs cycle through four accumulators
-#define G3C_MFMA(m_, q_)                                                                           \
-    acc[m_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[m_][q_], bq[0], acc[m_][0], 0, 0, 0);  \
-    acc[m_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[m_][q_], bq[1], acc[m_][1], 0, 0, 0);
-#define G3C_MFMA6(ma_, mb_)                                                                        \
-    G3C_MFMA(ma_, 2) G3C_MFMA(mb_, 2) G3C_MFMA(ma_, 1) G3C_MFMA(mb_, 1) G3C_MFMA(ma_, 0) G3C_MFMA(mb_, 0)
+#define G3C_MFMA(b_, m_, q_)                                                                       \
+    acc[m_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[m_][q_], b_[0], acc[m_][0], 0, 0, 0);  \
+    acc[m_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[m_][q_], b_[1], acc[m_][1], 0, 0, 0);
+#define G3C_MFMA6(b_, ma_, mb_)                                                                    \
+    G3C_MFMA(b_, ma_, 2) G3C_MFMA(b_, mb_, 2) G3C_MFMA(b_, ma_, 1) G3C_MFMA(b_, mb_, 1) G3C_MFMA(b_, ma_, 0) G3C_MFMA(b_, mb_, 0)
 
-    bf16x8 bq[2], aq[4][3];
+    bf16x8 bq[2], bh[2], aq[4][3];
     G3_WAIT_VM(0);                                          // stores of a previous segment
     G3C_ISSUE(0)
     if (nkb > 1) G3C_ISSUE(1)
@@ -590,17 +613,20 @@ __device__ __forceinline__ void gemm3c_segment(const unsigned char* __restrict__
     if (nkb > 2) G3_WAIT_VM(8); else if (nkb > 1) G3_WAIT_VM(4); else G3_WAIT_VM(0);      // block 0 landed
     if (grp == 1) G3_RAW_BARRIER()
     for (int s = 0; s < nkb; ++s) {
+        const bool hi_blk = G3C_FLAG(s);
         G3_RAW_BARRIER()                                        // X_s
         if (s + 3 < nkb) G3C_ISSUE(s + 3)
         G3C_READ(s)
-        G3C_MFMA6(0, 1)
+        G3C_MFMA6(bq, 0, 1)
+        if (hi_blk) { G3C_MFMA6(bh, 0, 1) }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this image is free once both groups pass here
         // block s+1 must have landed before Y_s; s+2, s+3 may stay in flight
         if (s + 1 < nkb) {
             if (s + 3 < nkb) G3_WAIT_VM(8); else if (s + 2 < nkb) G3_WAIT_VM(4); else G3_WAIT_VM(0);
         }
         G3_RAW_BARRIER()                                        // Y_s
-        G3C_MFMA6(2, 3)
+        G3C_MFMA6(bq, 2, 3)
+        if (hi_blk) { G3C_MFMA6(bh, 2, 3) }
     }
     if (grp == 0) G3_RAW_BARRIER()
 #undef G3C_MFMA6
@@ -608,6 +634,7 @@ __device__ __forceinline__ void gemm3c_segment(const unsigned char* __restrict__
 #undef G3C_READ
 #undef G3_FRAG
 #undef G3C_ISSUE
+#undef G3C_FLAG
 
     const int j = j0 + wn * 64 + li;
 #pragma unroll
@@ -624,7 +651,9 @@ __device__ __forceinline__ void gemm3c_segment(const unsigned char* __restrict__
 }
 
 __global__ __launch_bounds__(512) void gemm3c_kernel(const unsigned char* __restrict__ A3,
-                                                     const unsigned char* __restrict__ B1, int Kb,
+                                                     const unsigned char* __restrict__ B1,
+                                                     const unsigned char* __restrict__ Bhi,
+                                                     const unsigned int* __restrict__ hiflag, int Kb,
                                                      float* __restrict__ C, int ldc, long long c_split_stride,
                                                      int kb_per)
 {
@@ -638,11 +667,14 @@ __global__ __launch_bounds__(512) void gemm3c_kernel(const unsigned char* __rest
     }
     const int kb0 = z * kb_per;
     const int nkb = min(kb_per, Kb - kb0);
-    gemm3c_segment(A3, B1, Kb, C + (size_t)z * c_split_stride, ldc, blockIdx.y * G3_MW, jt * G3C_JW, kb0, nkb, smem3);
+    gemm3c_segment(A3, B1, Bhi, hiflag, Kb, C + (size_t)z * c_split_stride, ldc, blockIdx.y * G3_MW, jt * G3C_JW, kb0,
+                   nkb, smem3);
 }
 
 __global__ __launch_bounds__(512) void gemm3c_streamk_kernel(const unsigned char* __restrict__ A3,
-                                                             const unsigned char* __restrict__ B1, int Kb,
+                                                             const unsigned char* __restrict__ B1,
+                                                             const unsigned char* __restrict__ Bhi,
+                                                             const unsigned int* __restrict__ hiflag, int Kb,
                                                              float* __restrict__ C0, float* __restrict__ C1,
                                                              float* __restrict__ C2, int ldc, int MG, int T)
 {
@@ -654,7 +686,7 @@ __global__ __launch_bounds__(512) void gemm3c_streamk_kernel(const unsigned char
         const int tile = (int)(u / Kb), kb = (int)(u % Kb);
         const int ke = (int)min((long long)Kb, kb + (u1 - u));
         const int jt = tile / MG, mg = tile % MG;
-        gemm3c_segment(A3, B1, Kb, (kb == 0) ? C0 : (ke == Kb ? C1 : C2), ldc, mg * G3_MW, jt * G3C_JW, kb,
+        gemm3c_segment(A3, B1, Bhi, hiflag, Kb, (kb == 0) ? C0 : (ke == Kb ? C1 : C2), ldc, mg * G3_MW, jt * G3C_JW, kb,
                        ke - kb, smem3);
         u += ke - kb;
         G3_WAIT_VM(0);

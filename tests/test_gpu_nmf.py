@@ -73,55 +73,71 @@ def test_split_operand_gemm_is_f32_accurate(engine, monkeypatch, g3mode):
     assert np.array_equal(out, out2)
 
 
-def test_count_path_gemm_is_exact_product_accurate(engine):
-    """Count-structured operand (kernels_counts.hip.h): B holds integers <= 256 as ONE bf16 plane, A three
-    planes -- every partial product is exact, so the only error is the f32 accumulation."""
+@pytest.mark.parametrize("big", [False, True])
+def test_count_path_gemm_is_exact_product_accurate(engine, big):
+    """Count-structured operand (kernels_counts.hip.h): B holds integers <= 256 as ONE bf16 plane (big: a few
+    entries up to 65 535 -> a second, block-flagged plane), A three planes -- every partial product is exact,
+    so the only error is the f32 accumulation."""
     rs = np.random.RandomState(3)
-    for K, J, ns in [(16, 40, 1), (64, 300, 1), (2048, 1000, 1), (4096, 520, 4), (2048, 130, 7)]:
+    for K, J, ns in [(16, 40, 1), (64, 300, 1), (2048, 1000, 1), (4096, 520, 4), (2048, 130, 7), (4144, 300, 1)]:
         A = (rs.standard_normal((256, K)) * np.exp(rs.standard_normal((256, K)))).astype(np.float32)
         B = rs.poisson(3.0, size=(J, K)).astype(np.float32)
         B[0, :3] = [256, 255, 0]
+        if big:
+            idx = rs.randint(0, J * K, size=max(3, J * K // 5000))
+            B.ravel()[idx] = rs.choice([257, 300, 511, 512, 4097, 65535, 65280], size=idx.size)
         ref = A.astype(np.float64) @ B.astype(np.float64).T
         out, _ = engine.debug_gemm3c(A, B, nsplit=ns)
         assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-6, (K, J, ns)
         scale = np.abs(A).astype(np.float64) @ B.astype(np.float64).T
-        assert (np.abs(out - ref) / np.maximum(scale, 1e-30)).max() < 1e-6, (K, J, ns)
+        # (a 65 535 next to Poisson(3) entries: every later f32 accumulation rounds at the size of that one
+        #  term -- the same for any f32 accumulator -- hence the wider bound for `big`)
+        assert (np.abs(out - ref) / np.maximum(scale, 1e-30)).max() < (2e-5 if big else 1e-6), (K, J, ns)
         out2, _ = engine.debug_gemm3c(A, B, nsplit=ns)
         assert np.array_equal(out, out2)
 
 
 def test_count_structure_is_detected_only_where_it_exists(engine):
-    """X = counts / std (cnmf.py:546) has the structure (gemm_mode 3); the same matrix with one entry
-    nudged off the integer grid, or with a count above 256, does not (general three-plane path, 2)."""
+    """X = counts / std (cnmf.py:546) has the structure (gemm_mode 3), also with a few counts above 256 (second
+    plane); the same matrix with one entry nudged off the integer grid, or with a count above 65 535, does not
+    (general three-plane path, 2)."""
     C, _ = synth.topic_counts(1024, 520, 6, 5.0, 0.3, 2)
     C = C[:, C.sum(axis=0) > 0]
     C = C[C.sum(axis=1) > 0]
     X = (C / C.std(axis=0, ddof=1)).astype(np.float64)
     ks, seeds = [9] * 29, list(range(1, 30))
     results = {}
-    for tag in ("counts", "nudged", "big"):
+    for tag in ("counts", "big", "nudged", "huge"):
         Xt = X.copy()
         if tag == "nudged":
             i, g = np.argwhere(C > 0)[0]
             Xt[i, g] *= 1.37
-        if tag == "big":
-            Xt[3, 5] = X[:, 5][X[:, 5] > 0].min() * 300
+        if tag == "big":                                  # counts of 300, 700 and 2000 in three places
+            for (i, g, c) in ((3, 5, 300), (700, 400, 700), (11, 17, 2000)):
+                Xt[i, g] = X[:, g][X[:, g] > 0].min() * c / C[:, g][C[:, g] > 0].min()
+        if tag == "huge":
+            Xt[3, 5] = X[:, 5][X[:, 5] > 0].min() * 70000
         engine.set_matrix(Xt)
         H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=20, warn=False)
         assert engine.last_stats["kc"] == 256
         results[tag] = (engine.last_stats["gemm_mode"], H)
-    assert results["counts"][0] == 3 and results["nudged"][0] == 2 and results["big"][0] == 2
-    # and the count path computes the same factorisation as the exact-f32 pipe
+    assert [results[t][0] for t in ("counts", "big", "nudged", "huge")] == [3, 3, 2, 2]
+    # and the count path (with and without the second plane) computes the same factorisation as the exact-f32 pipe
     import os
-    os.environ["CNMF_GEMM3"] = "0"
-    try:
-        engine.set_matrix(X)
-        H0, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=20, warn=False)
-        assert engine.last_stats["gemm_mode"] == 0
-    finally:
-        del os.environ["CNMF_GEMM3"]
-    for a, b in zip(results["counts"][1], H0):
-        assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
+    for tag in ("counts", "big"):
+        Xt = X.copy()
+        if tag == "big":
+            for (i, g, c) in ((3, 5, 300), (700, 400, 700), (11, 17, 2000)):
+                Xt[i, g] = X[:, g][X[:, g] > 0].min() * c / C[:, g][C[:, g] > 0].min()
+        os.environ["CNMF_GEMM3"] = "0"
+        try:
+            engine.set_matrix(Xt)
+            H0, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=20, warn=False)
+            assert engine.last_stats["gemm_mode"] == 0
+        finally:
+            del os.environ["CNMF_GEMM3"]
+        for a, b in zip(results[tag][1], H0):
+            assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max()), tag
 
 
 @pytest.mark.parametrize("g3mode", ["0", "1", "2", "3"])
