@@ -638,7 +638,9 @@ static int ensure_counts(cnmf_ctx* ctx)
 // the split-operand path needs whole 256 x 128 tiles
 static bool gemm3_enabled(const cnmf_ctx* ctx, int KC)
 {
-    return gemm3_mode() != 0 && KC % G3_MW == 0 && ctx->G_pad % gemm3_jw() == 0 && ctx->N_pad % gemm3_jw() == 0;
+    // (the plane builders index 16-cell blocks with blockIdx.y: up to 65 535 x 16 cells)
+    return gemm3_mode() != 0 && KC % G3_MW == 0 && ctx->G_pad % gemm3_jw() == 0 && ctx->N_pad % gemm3_jw() == 0 &&
+           ctx->N_pad / 16 <= 65535 && ctx->G_pad / 16 <= 65535;
 }
 
 static int pick_nsplit3(const cnmf_ctx* ctx, int KC, int jw)
