@@ -72,8 +72,10 @@ def worker_filter(iterable, worker_index, total_workers):
 
 
 class cNMF:
-    def __init__(self, output_dir=".", name=None, device=0, engine=None):
-        """Same constructor semantics as the reference (cnmf.py:268-296) plus the GPU index."""
+    def __init__(self, output_dir=".", name=None, device=0, engine=None, compress_merged=True):
+        """Same constructor semantics as the reference (cnmf.py:268-296) plus the GPU index.
+        ``compress_merged=False`` writes the merged-spectra files without zlib (same npz container, read
+        by the reference's ``load_df_from_npz`` alike): zlib over 130 MB costs ~2 s of a 12 s job."""
         self.output_dir = output_dir
         if name is None:
             import datetime
@@ -88,6 +90,9 @@ class cNMF:
         self._engine = engine
         self._engine_key = None
         self.spectra_cache = {}          # (k, iter) -> spectra ndarray kept from factorize
+        self.merged_cache = {}           # k -> merged spectra DataFrame kept from combine (skips a reload)
+        self._resident_alias = {}        # id(matrix object) -> engine key it is resident under
+        self.compress_merged = compress_merged
         self.last_factorize_stats = None
 
     # ------------------------------------------------------------------ paths (cnmf.py:298-330)
@@ -140,8 +145,12 @@ class cNMF:
         return self._engine
 
     def _load_norm_counts(self):
-        df = load_df_from_npz(self.paths["normalized_counts"])
-        return df
+        """The normalised matrix file, kept in memory between the stages of one process."""
+        path = self.paths["normalized_counts"]
+        key = (path, os.path.getmtime(path))
+        if getattr(self, "_norm_counts_cache", (None, None))[0] != key:
+            self._norm_counts_cache = (key, load_df_from_npz(path))
+        return self._norm_counts_cache[1]
 
     # ------------------------------------------------------------------ ledger (cnmf.py:564-658)
     def get_nmf_iter_params(self, ks, n_iter=100, random_state_seed=None, beta_loss="kullback-leibler",
@@ -267,7 +276,8 @@ class cNMF:
         kw = dict(nmf_kwargs)
         self._check_kwargs(kw)
         Xv = X.values if isinstance(X, pd.DataFrame) else X
-        eng = self._get_engine(Xv, ("obj", id(X), getattr(Xv, "shape", None)))
+        # (a matrix that consensus() already made resident under its file key is not uploaded again)
+        eng = self._get_engine(Xv, self._resident_alias.get(id(X), ("obj", id(X), getattr(Xv, "shape", None))))
         mu = kw.get("solver", "cd") == "mu"
         if kw.get("update_H", True) is False:
             H = np.asarray(kw["H"])
@@ -392,7 +402,8 @@ class cNMF:
             combined_spectra.append(spectra)
         if len(combined_spectra) > 0:
             combined_spectra = pd.concat(combined_spectra, axis=0)
-            save_df_to_npz(combined_spectra, self.paths["merged_spectra"] % k)
+            (save_df_to_npz if self.compress_merged else save_df_to_npz_fast)(combined_spectra, self.paths["merged_spectra"] % k)
+            self.merged_cache[k] = (os.path.getmtime(self.paths["merged_spectra"] % k), combined_spectra)
             if remove_individual_iterations:
                 for i, p in run_params_subset.iterrows():
                     f = self.paths["iter_spectra"] % (int(p["n_components"]), int(p["iter"]))
@@ -419,15 +430,20 @@ class cNMF:
     def consensus(self, k, density_threshold=0.5, local_neighborhood_size=0.30, show_clustering=False,
                   build_ref=False, skip_density_and_return_after_stats=False, close_clustergram_fig=False,
                   refit_usage=True, normalize_tpm_spectra=False, norm_counts=None):
-        merged_spectra = load_df_from_npz(self.paths["merged_spectra"] % k)
+        cached = self.merged_cache.get(k)
+        if cached is not None and cached[0] == os.path.getmtime(self.paths["merged_spectra"] % k):
+            merged_spectra = cached[1].copy()                # this process wrote that very file
+        else:
+            merged_spectra = load_df_from_npz(self.paths["merged_spectra"] % k)
         if norm_counts is None:
             norm_counts = self._load_norm_counts()
         density_threshold_str = str(density_threshold)
         if skip_density_and_return_after_stats:
             density_threshold_str = "2"
         density_threshold_repl = density_threshold_str.replace(".", "_")
-        eng = self._get_engine(norm_counts.values, ("norm_counts", self.paths["normalized_counts"],
-                                                    os.path.getmtime(self.paths["normalized_counts"])))
+        nc_key = ("norm_counts", self.paths["normalized_counts"], os.path.getmtime(self.paths["normalized_counts"]))
+        eng = self._get_engine(norm_counts.values, nc_key)
+        self._resident_alias = {id(norm_counts): nc_key}     # the refit below reuses this upload
         cached = os.path.isfile(self.paths["local_density_cache"] % k) and not skip_density_and_return_after_stats
         out = eng.consensus(merged_spectra.values, k, density_threshold=density_threshold,
                             local_neighborhood_size=local_neighborhood_size,

@@ -1,4 +1,5 @@
-"""End-to-end wall-clock on one MI355X for the north-star configuration:
+"""End-to-end wall-clock on one MI355X for the north-star configuration (merged spectra written without
+zlib unless COMPRESS_MERGED=1 -- same npz container):
 N=50 000 cells x 2000 HVGs, K=5..13, n_iter=100 (900 restarts), through the host mirror of the
 reference's cNMF object: prepare_from_matrix -> factorize -> combine -> k_selection_stats -> consensus."""
 import json, os, sys, tempfile, time
@@ -13,7 +14,7 @@ t = {}
 t0 = time.perf_counter(); X = synth.make_config("C3", dtype=np.float32); t["synthesize_input_s"] = time.perf_counter() - t0
 df = pd.DataFrame(X, index=["c%d" % i for i in range(X.shape[0])], columns=["g%d" % j for j in range(X.shape[1])])
 out = tempfile.mkdtemp(prefix="cnmf_e2e_")
-obj = cNMF(output_dir=out, name="c3")
+obj = cNMF(output_dir=out, name="c3", compress_merged=os.environ.get("COMPRESS_MERGED", "0") == "1")
 t0 = time.perf_counter(); obj.prepare_from_matrix(df, components=list(range(5, 14)), n_iter=n_iter, seed=14, beta_loss="frobenius"); t["prepare_from_matrix_s"] = time.perf_counter() - t0
 import io, contextlib
 buf = io.StringIO()
