@@ -467,6 +467,16 @@ static hipError_t launch_gemm3(hipStream_t st, const unsigned char* A3, const un
 }
 
 
+// plane split of a packed factor + finalize of the sweep that produced it, in one launch (kernels_sweep.hip.h)
+static hipError_t launch_split3_finalize(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst,
+                                         int TR, const double* kscale, const FinalizeArgs& fa, int nslots, int fin_y)
+{
+    const int bx = K / 64, by = rows / 64;
+    split3_finalize_kernel<<<bx * by + nslots * fin_y, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale, bx, by,
+                                                                  fa, fin_y);
+    return hipGetLastError();
+}
+
 // ---- stream-K plan for the split-operand pass A (tile = 256 components x 128 cells, up to 2 cuts per tile)
 struct StreamK3 {
     bool on = false;
@@ -951,6 +961,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int n_active = 0;
     int64_t it = 0;          // batch iterations enqueued so far
     int snap_nslots[RING] = {0};
+    bool h3_valid = false;           // H3 holds the planes of the current H (split-operand modes)
     // stamps restart at 1 in every call: forget the ones a previous call left in the ring (nothing is in flight here)
     memset(ctx->h_snap, 0, (size_t)ctx->kc_alloc * RING * sizeof(SlotDesc));
     hipEvent_t ev_begin = events.get(), ev_end = events.get();
@@ -1059,8 +1070,10 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         // pass A : XHt[KC][N] = H_all . X^T                       (sklearn _nmf.py:387)
         SplitInfo spA{nullptr, nullptr, 1, 1, 1};
         if (use3) {
-            // count path: the per-gene scale rides on the factor, H' = H * d
-            HIP_TRY(ctx, launch_split3(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, usec ? ctx->d_scale : nullptr));
+            // H3 was produced together with the previous iteration's H finalize; rows installed since then
+            // (and the very first iteration) need a split of their own.  Count path: H' = H * d.
+            if (n_new > 0 || !h3_valid)
+                HIP_TRY(ctx, launch_split3(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, usec ? ctx->d_scale : nullptr));
             if (time_gemm) hipEventRecord(gev[gev.size() - 4], st);
             if (sk3.on) {
                 if (usec)
@@ -1090,10 +1103,17 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         // W half-step                                             (sklearn _nmf.py:500)
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
                                   ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k, tiers, spA));
-        finalize_kernel<<<dim3(nslots, fin_y), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
-                                                ctx->d_slots, 0, prm->tol, prm->max_iter, 1, max_k);
-        // (writing the planes from inside the sweep was measured slower: 2-byte stores, lower occupancy)
-        if (use3) HIP_TRY(ctx, launch_split3(st, ctx->Wt, ctx->N_pad, KC, ctx->N_pad, ctx->Wt3, G3_MW));
+        if (use3) {
+            // finalize of the W sweep + the plane split of its result in one launch (writing the planes from
+            // inside the sweep was measured slower: 2-byte stores, lower occupancy)
+            const FinalizeArgs fa{ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H, ctx->d_slots, 0, prm->tol,
+                                  prm->max_iter, 1, max_k, nullptr, 0};
+            HIP_TRY(ctx, launch_split3_finalize(st, ctx->Wt, ctx->N_pad, KC, ctx->N_pad, ctx->Wt3, G3_MW, nullptr, fa,
+                                                nslots, fin_y));
+        } else {
+            finalize_kernel<<<dim3(nslots, fin_y), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
+                                                    ctx->d_slots, 0, prm->tol, prm->max_iter, 1, max_k);
+        }
         if (time_gemm) hipEventRecord(gev[gev.size() - 2], st);
         // pass B : XtW[S][KC][G] = Wt_all . X  (split over cells)  (sklearn _nmf.py:505-507)
         const int nsB = use3 ? nsplit3 : nsplit;
@@ -1118,9 +1138,17 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         SlotDesc* snap = ctx->h_snap + (size_t)(it % RING) * KC0;
         SlotDesc* snap_dev = nullptr;
         HIP_TRY(ctx, hipHostGetDevicePointer((void**)&snap_dev, snap, 0));
-        finalize_kernel<<<dim3(nslots, fin_y), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W,
-                                                ctx->d_slots, 1, prm->tol, prm->max_iter, 1, max_k,
-                                                snap_dev, (int)(it + 1));
+        if (use3) {
+            const FinalizeArgs fa{ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W, ctx->d_slots, 1, prm->tol,
+                                  prm->max_iter, 1, max_k, snap_dev, (int)(it + 1)};
+            HIP_TRY(ctx, launch_split3_finalize(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW,
+                                                usec ? ctx->d_scale : nullptr, fa, nslots, fin_y));
+            h3_valid = true;
+        } else {
+            finalize_kernel<<<dim3(nslots, fin_y), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W,
+                                                    ctx->d_slots, 1, prm->tol, prm->max_iter, 1, max_k,
+                                                    snap_dev, (int)(it + 1));
+        }
         HIP_TRY(ctx, hipGetLastError());
         snap_nslots[it % RING] = nslots;
         column_iters += KC;

@@ -138,13 +138,13 @@ __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __re
 // The same through LDS for the per-iteration split of the packed factors: a workgroup converts 64 rows
 // x 64 k (four blocks).  Reads: 16 lanes cover 256 contiguous bytes of a row; writes: the 64 rows of
 // one block are 6 KB contiguous in the block-major layout.  (rows, K, TR multiples of 64.)
-__global__ __launch_bounds__(256) void split3_tiled_kernel(const float* __restrict__ src, int ld, int K, int TR,
-                                                           unsigned short* __restrict__ dst,
-                                                           const double* __restrict__ kscale = nullptr)
+// `tile` = unsigned short [4][64][48] ([block][row][h16|m16|l16], 24 KB of LDS)
+__device__ __forceinline__ void split3_tiled_body(const float* __restrict__ src, int ld, int K, int TR,
+                                                  unsigned short* __restrict__ dst, const double* __restrict__ kscale,
+                                                  int bx, int by, unsigned short (*tile)[64][48])
 {
-    __shared__ __attribute__((aligned(16))) unsigned short tile[4][64][48];      // [block][row][h16|m16|l16]
     const int t = threadIdx.x;
-    const int k0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int k0 = bx * 64, r0 = by * 64;
     const int kq = t & 15, rr = t >> 4;                  // float4 index along k, row within a pass of 16
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -178,6 +178,14 @@ __global__ __launch_bounds__(256) void split3_tiled_kernel(const float* __restri
         g4[t] = s4[t];
         if (t < 128) g4[256 + t] = s4[256 + t];
     }
+}
+
+__global__ __launch_bounds__(256) void split3_tiled_kernel(const float* __restrict__ src, int ld, int K, int TR,
+                                                           unsigned short* __restrict__ dst,
+                                                           const double* __restrict__ kscale = nullptr)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short tile[4][64][48];
+    split3_tiled_body(src, ld, K, TR, dst, kscale, blockIdx.x, blockIdx.y, tile);
 }
 
 // One K segment [kb0, kb0 + nkb) (in 16-k blocks) of one 256 x 128 tile, stored to C.

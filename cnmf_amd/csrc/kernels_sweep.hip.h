@@ -335,23 +335,35 @@ __device__ __forceinline__ void publish_slot(SlotDesc* dst, const SlotDesc& s, i
 
 // same launch; the flag copy `was_active` taken at entry keeps the other three consistent
 // enough: a block that sees the cleared flag skips a gram nobody will read again.
-__global__ __launch_bounds__(256) void finalize_kernel(
-    const float* __restrict__ gram_part, const double* __restrict__ viol_part, int nparts,
-    float* __restrict__ gram_out, float l2_reg,
-    SlotDesc* __restrict__ slots, int phase, double tol, int max_iter, int want_gram, int gld,
-    SlotDesc* snap_out = nullptr, int stamp = 0)
+struct FinalizeArgs {
+    const float* gram_part; const double* viol_part; int nparts;
+    float* gram_out; float l2_reg;
+    SlotDesc* slots; int phase; double tol; int max_iter, want_gram, gld;
+    SlotDesc* snap_out; int stamp;
+};
+
+// `red` = 256 doubles of LDS; (slot, by) = the block's coordinates in the (slots, ceil(kmax^2/256)) grid
+__device__ __forceinline__ void finalize_body(const FinalizeArgs& a, int slot, int by, double* red)
 {
-    const int slot = blockIdx.x;
+    const float* __restrict__ gram_part = a.gram_part;
+    const double* __restrict__ viol_part = a.viol_part;
+    const int nparts = a.nparts;
+    float* __restrict__ gram_out = a.gram_out;
+    const float l2_reg = a.l2_reg;
+    SlotDesc* __restrict__ slots = a.slots;
+    const int phase = a.phase, max_iter = a.max_iter, want_gram = a.want_gram, gld = a.gld, stamp = a.stamp;
+    const double tol = a.tol;
+    SlotDesc* snap_out = a.snap_out;
     SlotDesc* sd = &slots[slot];
     const int tid = threadIdx.x;
     if (!sd->active) {
         // the host's view of this iteration (zero-copy snapshot, see publish_slot): unchanged state
-        if (snap_out && blockIdx.y == 0 && tid == 0) publish_slot(snap_out + slot, *sd, stamp);
+        if (snap_out && by == 0 && tid == 0) publish_slot(snap_out + slot, *sd, stamp);
         return;
     }
     const int k = sd->k;
     if (want_gram) {
-        const int e = blockIdx.y * 256 + tid;          // grid.y covers kmax*kmax entries
+        const int e = by * 256 + tid;          // grid.y covers kmax*kmax entries
         if (e < k * k) {
             const int r = e / k, c = e % k;
             const size_t gsz = (size_t)gld * gld;
@@ -370,8 +382,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(
             gram_out[(size_t)slot * GRAM_SZ + r * GRAM_LD + c] = s;
         }
     }
-    if (blockIdx.y != 0) return;
-    __shared__ double red[256];
+    if (by != 0) return;
     double v = 0.0;
     for (int pI = tid; pI < nparts; pI += 256) v += viol_part[(size_t)slot * nparts + pI];
     red[tid] = v;
@@ -400,6 +411,37 @@ __global__ __launch_bounds__(256) void finalize_kernel(
             if (done) sd->active = 0;
         }
         if (snap_out) publish_slot(snap_out + slot, *sd, stamp);
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(
+    const float* __restrict__ gram_part, const double* __restrict__ viol_part, int nparts,
+    float* __restrict__ gram_out, float l2_reg,
+    SlotDesc* __restrict__ slots, int phase, double tol, int max_iter, int want_gram, int gld,
+    SlotDesc* snap_out = nullptr, int stamp = 0)
+{
+    __shared__ double red[256];
+    const FinalizeArgs a{gram_part, viol_part, nparts, gram_out, l2_reg, slots, phase, tol, max_iter, want_gram, gld,
+                         snap_out, stamp};
+    finalize_body(a, blockIdx.x, blockIdx.y, red);
+}
+
+// Horizontal fusion for the split-operand modes: ONE launch carries the plane split of a factor (the first
+// split_bx * split_by workgroups) and the finalize of the sweep that produced it (the rest) -- the two only
+// read what the sweep wrote, and the ~9 us latency of the tiny finalize disappears behind the split.
+__global__ __launch_bounds__(256) void split3_finalize_kernel(const float* __restrict__ src, int ld, int K, int TR,
+                                                              unsigned short* __restrict__ dst,
+                                                              const double* __restrict__ kscale, int split_bx,
+                                                              int split_by, FinalizeArgs fa, int fin_y)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 64 * 48 * 2];
+    const int b = blockIdx.x, nsplit = split_bx * split_by;
+    if (b < nsplit) {
+        split3_tiled_body(src, ld, K, TR, dst, kscale, b % split_bx, b / split_bx,
+                          reinterpret_cast<unsigned short (*)[64][48]>(lds));
+    } else {
+        const int f = b - nsplit;
+        finalize_body(fa, f / fin_y, f % fin_y, reinterpret_cast<double*>(lds));
     }
 }
 
