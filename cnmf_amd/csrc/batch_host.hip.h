@@ -1,0 +1,698 @@
+// The restart engine: batch buffers, the slot scheduler (run_batch) and the NNLS refit
+// (included by cnmf_hip.hip after gemm_host.hip.h).
+#pragma once
+
+// ------------------------------------------------------------------ batch buffers
+static int sweep_max_parts()
+{
+    static const int v = getenv("CNMF_SWEEP_PARTS") ? atoi(getenv("CNMF_SWEEP_PARTS")) : 64;
+    return std::max(1, v);
+}
+static int sweep_chunks(int L) { const int64_t m = 256ll * sweep_max_parts(); return std::max(1, (int)(((int64_t)L + m - 1) / m)); }
+static int sweep_parts(int L) { int c = sweep_chunks(L); return (L + 256 * c - 1) / (256 * c); }
+
+static int pick_nsplit(const cnmf_ctx* ctx, int KC)
+{
+    if (const char* s = getenv("CNMF_NSPLIT")) { int v = atoi(s); if (v > 0) return v; }
+    // pass B grid = ceil(G_pad/128) x (KC/128 or 1) x nsplit ; aim at ~2 workgroups per CU
+    const int jt = (ctx->G_pad + 127) / 128;
+    const int mg = std::max(1, KC / 128);
+    int s = std::max(1, 512 / (jt * mg));
+    const int max_by_k = std::max(1, ctx->N_pad / 256);   // at least 256 cells of K per split
+    return std::min(s, max_by_k);
+}
+
+// splits that actually receive work once the per-split K range is rounded up to whole stages
+static int effective_splits(int Ktot, int nsplit)
+{
+    const int Kper = round_up((Ktot + nsplit - 1) / nsplit, BK);
+    return (Ktot + Kper - 1) / Kper;
+}
+
+// pass A on few cells: fewer than one 128-cell tile per CU -> split the gene (K) range too, so
+// that ~2 workgroups per CU are in flight; the planes are summed by reduce_splits_kernel.
+static int pick_nsplit_A(const cnmf_ctx* ctx, int KC)
+{
+    if (const char* s = getenv("CNMF_NSPLIT_A")) { int v = atoi(s); if (v > 0) return effective_splits(ctx->G_pad, v); }
+    const int T = (ctx->N_pad / 128) * std::max(1, KC / 128);
+    if (T > 256) return 1;                                  // stream-K territory
+    int s = std::max(1, 512 / T);
+    s = std::min(s, std::max(1, ctx->G_pad / (4 * BK)));    // at least 4 stages per split
+    return effective_splits(ctx->G_pad, std::min(s, 16));
+}
+
+// pass A of the split-operand kernels on few cell tiles (no stream-K below 3/4 of the workgroup slots):
+// K splits so that about one workgroup per slot is in flight, >= 8 blocks each
+static int pick_nsplit_A3(const cnmf_ctx* ctx, int KC, int jw)
+{
+    const int T = std::max(1, ctx->N_pad / jw) * std::max(1, KC / G3_MW);
+    const int Kb = ctx->G_pad / G3_BK;
+    int s = std::max(1, std::min(gemm3_wg_slots() / T, Kb / 8));
+    const int kb_per = (Kb + s - 1) / s;
+    return (Kb + kb_per - 1) / kb_per;
+}
+
+static int ensure_batch(cnmf_ctx* ctx, int KC, int max_k = KMAX, int min_k = 1)
+{
+    const bool use3 = gemm3_enabled(ctx, KC);
+    const int nsplit = use3 ? std::max(pick_nsplit(ctx, KC), std::max(pick_nsplit3(ctx, KC, G3_JW), pick_nsplit3(ctx, KC, G3C_JW)))
+                            : pick_nsplit(ctx, KC);
+    const int nsplitA = use3 ? std::max(pick_nsplit_A(ctx, KC), std::max(pick_nsplit_A3(ctx, KC, G3_JW), pick_nsplit_A3(ctx, KC, G3C_JW)))
+                             : pick_nsplit_A(ctx, KC);
+    const int parts = std::max(sweep_parts((int)ctx->N), sweep_parts((int)ctx->G));
+    const size_t gp_need = (size_t)(KC / std::max(1, min_k) + 1) * parts * max_k * max_k;
+    if (ctx->kc_alloc == KC && ctx->nsplit_alloc == nsplit && ctx->nsplitA_alloc == nsplitA &&
+        ctx->parts_alloc == parts && ctx->gram_part_floats >= gp_need && (!use3 || ctx->H3)) return CNMF_OK;
+    free_batch(ctx);
+    const size_t hb = (size_t)KC * ctx->G_pad * sizeof(float);
+    const size_t wb = (size_t)KC * ctx->N_pad * sizeof(float);
+    HIP_TRY(ctx, hipMalloc(&ctx->H, hb));
+    HIP_TRY(ctx, hipMalloc(&ctx->Wt, wb));
+    HIP_TRY(ctx, hipMalloc(&ctx->XHt, wb * nsplitA));
+    HIP_TRY(ctx, hipMalloc(&ctx->XHt1, wb));
+    if (use3) {
+        HIP_TRY(ctx, hipMalloc(&ctx->XHt2, wb));
+        HIP_TRY(ctx, hipMalloc(&ctx->H3, (size_t)KC * (ctx->G_pad / 16) * G3_ROWB));
+        HIP_TRY(ctx, hipMalloc(&ctx->Wt3, (size_t)KC * (ctx->N_pad / 16) * G3_ROWB));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->Wt3, 0, (size_t)KC * (ctx->N_pad / 16) * G3_ROWB, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->d_split, (size_t)(KC / 32 + 1) * (ctx->N_pad / 128 + 1)));
+    HIP_TRY(ctx, hipMalloc(&ctx->XtW, hb * nsplit));
+    HIP_TRY(ctx, hipMalloc(&ctx->gramH, (size_t)KC * GRAM_SZ * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(&ctx->gramW, (size_t)KC * GRAM_SZ * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(&ctx->gram_part, gp_need * sizeof(float)));
+    ctx->gram_part_floats = gp_need;
+    HIP_TRY(ctx, hipMalloc(&ctx->viol_part, (size_t)KC * parts * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_slots, (size_t)KC * sizeof(SlotDesc)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_slot_list, (size_t)KC * RING * sizeof(int)));
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_slots, (size_t)KC * sizeof(SlotDesc)));
+    // device-written, host-polled: coherent mapped pinned memory (zero-copy snapshots of the slot table)
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_snap, (size_t)KC * RING * sizeof(SlotDesc),
+                               hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ctx->h_snap, 0, (size_t)KC * RING * sizeof(SlotDesc));
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_slot_list, (size_t)KC * RING * sizeof(int)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->H, 0, hb, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->Wt, 0, wb, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->XHt, 0, wb * nsplitA, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->XtW, 0, hb * nsplit, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_slots, 0, (size_t)KC * sizeof(SlotDesc), ctx->stream));
+    ctx->kc_alloc = KC; ctx->nsplit_alloc = nsplit; ctx->nsplitA_alloc = nsplitA; ctx->parts_alloc = parts;
+    return CNMF_OK;
+}
+
+static int ensure_stage(cnmf_ctx* ctx, size_t wfloats, size_t hfloats)
+{
+    if (wfloats > ctx->stageW_sz) {
+        hipFree(ctx->stageW); ctx->stageW = nullptr;
+        HIP_TRY(ctx, hipMalloc(&ctx->stageW, wfloats * sizeof(float)));
+        ctx->stageW_sz = wfloats;
+    }
+    if (hfloats > ctx->stageH_sz) {
+        hipFree(ctx->stageH); ctx->stageH = nullptr;
+        HIP_TRY(ctx, hipMalloc(&ctx->stageH, hfloats * sizeof(float)));
+        ctx->stageH_sz = hfloats;
+    }
+    return CNMF_OK;
+}
+
+// simple first-fit interval allocator over the packed component columns
+struct ColAlloc {
+    std::vector<std::pair<int, int>> free_;   // (begin, length), sorted by begin
+    explicit ColAlloc(int n) { free_.push_back({0, n}); }
+    int alloc(int k) {
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].second >= k) {
+                int b = free_[i].first;
+                free_[i].first += k; free_[i].second -= k;
+                if (free_[i].second == 0) free_.erase(free_.begin() + i);
+                return b;
+            }
+        return -1;
+    }
+    void release(int b, int k) {
+        auto it = std::lower_bound(free_.begin(), free_.end(), std::make_pair(b, 0));
+        it = free_.insert(it, {b, k});
+        if (it + 1 != free_.end() && it->first + it->second == (it + 1)->first) {
+            it->second += (it + 1)->second; free_.erase(it + 1);
+        }
+        if (it != free_.begin() && (it - 1)->first + (it - 1)->second == it->first) {
+            (it - 1)->second += it->second; free_.erase(it);
+        }
+    }
+};
+
+struct HostSlot { int state = 0; int restart = -1; int off = 0; int k = 0; int64_t installed_at = 0; };
+
+// Poll the stamps of one zero-copy snapshot (finalize_kernel -> publish_slot) until all `n` slots carry
+// `stamp`.  The snapshot is `lag` iterations old when it is needed, so this normally returns at once.
+static int wait_snapshot(cnmf_ctx* ctx, const SlotDesc* sp, int n, int stamp)
+{
+    for (int s = 0; s < n; ++s) {
+        const volatile int* flag = &sp[s].pad_;
+        long spins = 0;
+        while (*flag != stamp) {
+            if (++spins % 4096 == 0) {
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q == hipSuccess) {                       // stream drained: the stamp must be there
+                    if (*flag == stamp) break;
+                    SET_ERR(ctx, "slot snapshot %d was never published (slot %d)", stamp, s);
+                    return CNMF_EHIP;
+                }
+                if (q != hipErrorNotReady) {
+                    SET_ERR(ctx, "stream failed while waiting for a slot snapshot: %s", hipGetErrorString(q));
+                    return CNMF_EHIP;
+                }
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return CNMF_OK;
+}
+
+static int pick_kc(int64_t total_k, int max_k, int kc_max)
+{
+    if (kc_max <= 0) kc_max = 256;
+    if (const char* s = getenv("CNMF_KC")) { int v = atoi(s); if (v >= 32) kc_max = v; }
+    kc_max = std::max(32, std::min(256, (kc_max / 32) * 32));
+    int kc = 32;
+    while (kc < kc_max && kc < total_k) kc *= 2;
+    kc = std::min(kc, kc_max);
+    if (kc < max_k) kc = round_up(max_k, 32);
+    return kc;
+}
+
+static int validate_params(cnmf_ctx* ctx, const cnmf_cd_params* p)
+{
+    if (!p) { SET_ERR(ctx, "params is NULL"); return CNMF_EINVAL; }
+    if (!(p->tol >= 0) || p->max_iter < 1) { SET_ERR(ctx, "bad tol/max_iter"); return CNMF_EINVAL; }
+    if (p->l1_reg_W < 0 || p->l2_reg_W < 0 || p->l1_reg_H < 0 || p->l2_reg_H < 0) {
+        SET_ERR(ctx, "negative regularisation"); return CNMF_EINVAL;
+    }
+    return CNMF_OK;
+}
+
+// ------------------------------------------------------------------ the restart hot loop
+static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, const uint32_t* seeds,
+                     const double* avg, const float* W0, const float* H0, const cnmf_cd_params* prm,
+                     float* H_out, float* W_out, bool resident, int32_t* n_iter_out,
+                     double* viol_out, cnmf_batch_stats* stats)
+{
+    if (!ctx) { SET_ERR(ctx, "ctx is NULL"); return CNMF_EINVAL; }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    refresh_gemm3_mode();
+    int rc = validate_params(ctx, prm);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !kk)) { SET_ERR(ctx, "bad restart list"); return CNMF_EINVAL; }
+    if (init_mode == 0 && n > 0 && (!W0 || !H0)) { SET_ERR(ctx, "init_mode 0 needs W0 and H0"); return CNMF_EINVAL; }
+    if (init_mode == 1 && n > 0 && (!seeds || !avg)) { SET_ERR(ctx, "init_mode 1 needs seeds and avg"); return CNMF_EINVAL; }
+    if (init_mode != 0 && init_mode != 1) { SET_ERR(ctx, "unknown init_mode %d", init_mode); return CNMF_EINVAL; }
+    if (!resident && n > 0 && !H_out) { SET_ERR(ctx, "H_out is NULL"); return CNMF_EINVAL; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (n == 0) return CNMF_OK;
+
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    int64_t total_k = 0; int max_k = 0, min_k = 1 << 30;
+    std::vector<size_t> hoff(n + 1, 0), woff(n + 1, 0);
+    for (int r = 0; r < n; ++r) {
+        if (kk[r] < 1) { SET_ERR(ctx, "n_components must be >= 1 (restart %d)", r); return CNMF_EINVAL; }
+        if (kk[r] > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d is not supported by the device sweep", kk[r], KMAX); return CNMF_EUNSUPPORTED; }
+        total_k += kk[r]; max_k = std::max(max_k, (int)kk[r]); min_k = std::min(min_k, (int)kk[r]);
+        hoff[r + 1] = hoff[r] + (size_t)kk[r] * G;
+        woff[r + 1] = woff[r] + (size_t)kk[r] * N;
+    }
+    int KC = pick_kc(total_k, max_k, prm->kc_max);
+    const int KC0 = KC;
+    rc = ensure_batch(ctx, KC, max_k, min_k);
+    if (rc) return rc;
+    rc = ensure_stage(ctx, (size_t)N * KMAX, (size_t)G * KMAX);
+    if (rc) return rc;
+    int nsplit = std::min(pick_nsplit(ctx, KC), ctx->nsplit_alloc);
+    bool use3 = gemm3_enabled(ctx, KC);            // split-operand bf16 MFMA path (whole 256-column tiles only)
+    bool usec = false;                             // ... with X as one integer plane (count-structured data)
+    if (use3 && gemm3_mode() == 3) {
+        rc = ensure_counts(ctx);
+        if (rc) return rc;
+        usec = ctx->count_state == 1;
+    }
+    const int gemm_mode_used = !use3 ? 0 : (usec ? 3 : std::min(gemm3_mode(), 2));
+    if (use3 && !usec) { rc = ensure_planes(ctx); if (rc) return rc; }
+    const int jwA = usec ? G3C_JW : G3_JW;         // width of a pass-A / pass-B tile
+    const int nsplit3 = use3 ? pick_nsplit3(ctx, KC, jwA) : 1;
+    const int fin_y = (max_k * max_k + 255) / 256;       // finalize blocks per slot
+    const int lag = std::max(1, std::min(RING - 2, prm->lag > 0 ? prm->lag : 2));
+    hipStream_t st = ctx->stream;
+
+    // device result buffers
+    DevPool pool;
+    EventPool events;
+    float* d_Hres = nullptr; float* d_Wres = nullptr;
+    if (resident) {
+        const size_t need = (ctx->spectra_rows + (size_t)total_k) * G;
+        if (need > ctx->spectra_cap) {
+            float* nb = nullptr;
+            const size_t cap = std::max(need, ctx->spectra_cap * 2);
+            HIP_TRY(ctx, hipMalloc(&nb, cap * sizeof(float)));
+            hipError_t ce = hipSuccess;
+            if (ctx->spectra_rows)
+                ce = hipMemcpyAsync(nb, ctx->spectra, ctx->spectra_rows * G * sizeof(float), hipMemcpyDeviceToDevice, st);
+            if (ce == hipSuccess) ce = hipStreamSynchronize(st);
+            if (ce != hipSuccess) { hipFree(nb); HIP_TRY(ctx, ce); }
+            hipFree(ctx->spectra);
+            ctx->spectra = nb; ctx->spectra_cap = cap;
+        }
+        d_Hres = ctx->spectra + ctx->spectra_rows * G;
+    } else {
+        d_Hres = pool.get<float>(hoff[n]);
+    }
+    if (W_out) d_Wres = pool.get<float>(woff[n]);
+    POOL_TRY(ctx, pool);
+
+    // init_mode 1: sklearn's init='random' for EVERY restart of the call, generated up front on the
+    // device (one workgroup per restart) into a component-major store; install = row copy.
+    float *d_H0 = nullptr, *d_Wt0 = nullptr;
+    RngJob* d_jobs = nullptr;
+    if (init_mode == 1) {
+        d_H0 = pool.get<float>(hoff[n]);
+        d_Wt0 = pool.get<float>(woff[n]);
+        d_jobs = pool.get<RngJob>((size_t)n);
+        POOL_TRY(ctx, pool);
+        std::vector<RngJob> jobs(n);
+        int rowoff = 0;
+        for (int r = 0; r < n; ++r) {
+            jobs[r] = RngJob{seeds[r], kk[r], rowoff, avg[r], (long long)kk[r] * ((long long)G + N)};
+            rowoff += kk[r];
+        }
+        HIP_TRY(ctx, hipMemcpy(d_jobs, jobs.data(), (size_t)n * sizeof(RngJob), hipMemcpyHostToDevice));
+        rng_kernel<1><<<n, 256, 0, st>>>(d_jobs, nullptr, d_H0, G, G, d_Wt0, N, N);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+
+    // restarts in descending rank so that freed slots can always be reused
+    std::vector<int> order(n);
+    for (int r = 0; r < n; ++r) order[r] = r;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kk[a] > kk[b]; });
+    size_t next = 0;                 // first queue position that may still be pending
+    int n_pending = n;
+
+    ColAlloc cols(KC);
+    std::vector<HostSlot> hs(KC0);
+    int nslots = 0;          // highest used slot index + 1
+    int n_active = 0;
+    int64_t it = 0;          // batch iterations enqueued so far
+    int snap_nslots[RING] = {0};
+    bool h3_valid = false;           // H3 holds the planes of the current H (split-operand modes)
+    // stamps restart at 1 in every call: forget the ones a previous call left in the ring (nothing is in flight here)
+    memset(ctx->h_snap, 0, (size_t)ctx->kc_alloc * RING * sizeof(SlotDesc));
+    hipEvent_t ev_begin = events.get(), ev_end = events.get();
+    POOL_TRY(ctx, events);
+    HIP_TRY(ctx, hipEventRecord(ev_begin, st));
+    // HIP events around the two GEMM passes of every `time_stride`-th iteration (an event record costs
+    // ~6 us of queue time: bracketing every launch would take 4 % off the throughput it measures)
+    const int time_stride = !stats ? 0 : (prm->profile > 0 ? prm->profile : (getenv("CNMF_TIME_GEMM") ? 1 : 0));
+    std::vector<hipEvent_t> gev;   // (a0,a1,b0,b1) per iteration when timing is requested
+
+    const int chunksW = sweep_chunks(N), partsW = sweep_parts(N);
+    const int chunksH = sweep_chunks(G), partsH = sweep_parts(G);
+    const float l1W = (float)prm->l1_reg_W, l2W = (float)prm->l2_reg_W;
+    const float l1H = (float)prm->l1_reg_H, l2H = (float)prm->l2_reg_H;
+    const int gvarA = getenv("CNMF_GEMM_A") ? atoi(getenv("CNMF_GEMM_A")) : 0;
+    const int gvarB = getenv("CNMF_GEMM_B") ? atoi(getenv("CNMF_GEMM_B")) : 0;
+    int64_t restart_iters = 0, column_iters = 0, restart_col_iters = 0;
+    const bool dbg = getenv("CNMF_DEBUG") != nullptr;
+    int64_t dbg_it[9] = {0}, dbg_live[9] = {0};
+    const int wg_slots = getenv("CNMF_SK_WGS") ? atoi(getenv("CNMF_SK_WGS")) : 2 * 256;                    // T-layout pass A: 2 workgroups per CU (73.7 KB LDS each)
+    StreamK sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
+    if (sk.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
+    int nsplitA = (sk.on && gvarA == 0) ? 1 : std::min(pick_nsplit_A(ctx, KC), ctx->nsplitA_alloc);
+    StreamK3 sk3;
+    if (use3) {
+        sk3 = plan_streamk3(KC, ctx->N_pad, ctx->G_pad, gemm3_wg_slots(), jwA);
+        if (sk3.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk3.flags.data(), sk3.flags.size(), hipMemcpyHostToDevice, st));
+        else nsplitA = std::min(pick_nsplit_A3(ctx, KC, jwA), ctx->nsplitA_alloc);   // few tiles: K split + reduce
+    }
+    int n_done = 0;
+
+    auto retire = [&](int s, const SlotDesc& snap) -> int {
+        HostSlot& h = hs[s];
+        const int r = h.restart, k = h.k;
+        dim3 gH((G + 255) / 256, k), gW((N + 255) / 256, k);
+        extract_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, G, h.off, k, d_Hres + hoff[r], 0);
+        if (d_Wres) extract_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, h.off, k, d_Wres + woff[r], 1);
+        clear_rows_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, h.off, k);
+        clear_rows_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, h.off, k);
+        HIP_TRY(ctx, hipGetLastError());
+        if (n_iter_out) n_iter_out[r] = snap.iter;
+        if (viol_out) viol_out[r] = snap.viol_last;
+        restart_iters += snap.iter;
+        restart_col_iters += (int64_t)snap.iter * k;
+        cols.release(h.off, k);
+        h.state = 0; h.restart = -1;
+        --n_active; ++n_done;
+        return CNMF_OK;
+    };
+
+    // ---- step 1: refill free columns from the pending list (n_new = slots installed)
+    auto refill = [&](int& n_new) -> int {
+        n_new = 0;
+        int* new_list = ctx->h_slot_list + (size_t)(it % RING) * KC0;
+        // pending restarts are sorted by descending rank; a hole too small for the head of the
+        // queue is filled with the largest pending rank that fits (restarts are independent, so
+        // the order they run in is free) -> the packed columns stay full in the main phase
+        int failed_k = 1 << 30;                       // smallest rank that did not fit in this pass
+        for (size_t pi = next; pi < order.size() && n_pending > 0; ++pi) {
+            const int r = order[pi];
+            if (r < 0) { if (pi == next) ++next; continue; }      // already taken
+            const int k = kk[r];
+            if (k >= failed_k) continue;
+            const int off = cols.alloc(k);
+            if (off < 0) { failed_k = k; continue; }
+            order[pi] = -1; --n_pending;
+            if (pi == next) ++next;
+            int s = 0;
+            while (s < KC0 && hs[s].state != 0) ++s;
+            hs[s].state = 1; hs[s].restart = r; hs[s].off = off; hs[s].k = k; hs[s].installed_at = it;
+            nslots = std::max(nslots, s + 1);
+            dim3 gI((std::max(N, G) + 255) / 256, k);
+            if (init_mode == 0) {
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->stageH, H0 + hoff[r], (size_t)k * G * sizeof(float), hipMemcpyHostToDevice, st));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->stageW, W0 + woff[r], (size_t)k * N * sizeof(float), hipMemcpyHostToDevice, st));
+                install_kernel<<<gI, 256, 0, st>>>(ctx->stageH, ctx->stageW, ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, off, k);
+            } else {
+                install_cm_kernel<<<gI, 256, 0, st>>>(d_H0 + hoff[r], d_Wt0 + woff[r], ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, off);
+            }
+            HIP_TRY(ctx, hipGetLastError());
+            SlotDesc* d = &ctx->h_slots[s];
+            memset(d, 0, sizeof *d);
+            d->off = off; d->k = k; d->active = 1; d->iter = 0; d->restart = r;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots + s, d, sizeof(SlotDesc), hipMemcpyHostToDevice, st));
+            new_list[n_new++] = s;
+            ++n_active;
+        }
+        if (n_new) {
+            int* dl = ctx->d_slot_list + (size_t)(it % RING) * KC0;
+            HIP_TRY(ctx, hipMemcpyAsync(dl, new_list, n_new * sizeof(int), hipMemcpyHostToDevice, st));
+            gram_rows_kernel<<<n_new, 256, 0, st>>>(ctx->H, ctx->G_pad, G, ctx->d_slots, dl, ctx->gramH, l2W);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        return CNMF_OK;
+    };
+
+    // ---- step 2: enqueue one coordinate-descent outer iteration for every slot in flight
+    auto iterate = [&](int n_new) -> int {
+        int tiers = 0;
+        for (int s2 = 0; s2 < nslots; ++s2)
+            if (hs[s2].state) tiers |= hs[s2].k <= 16 ? 1 : (hs[s2].k <= 32 ? 2 : 4);
+        const bool time_gemm = time_stride > 0 && it % time_stride == 0;
+        if (time_gemm) {
+            for (int i = 0; i < 4; ++i) gev.push_back(events.get());
+            POOL_TRY(ctx, events);
+            hipEventRecord(gev[gev.size() - 4], st);
+        }
+        // pass A : XHt[KC][N] = H_all . X^T                       (sklearn _nmf.py:387)
+        SplitInfo spA{nullptr, nullptr, 1, 1, 1};
+        if (use3) {
+            // H3 was produced together with the previous iteration's H finalize; rows installed since then
+            // (and the very first iteration) need a split of their own.  Count path: H' = H * d.
+            if (n_new > 0 || !h3_valid)
+                HIP_TRY(ctx, launch_split3(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, usec ? ctx->d_scale : nullptr));
+            if (time_gemm) hipEventRecord(gev[gev.size() - 4], st);
+            if (sk3.on) {
+                if (usec)
+                    HIP_TRY(ctx, launch_gemm3c_streamk(st, sk3, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->XHt, ctx->XHt1,
+                                                       ctx->XHt2, ctx->N_pad));
+                else
+                    HIP_TRY(ctx, launch_gemm3_streamk(st, sk3, ctx->H3, ctx->X3, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
+                spA = SplitInfo{ctx->XHt1, ctx->d_split, jwA, G3_MW, sk3.MG, ctx->XHt2};
+            } else if (usec) {
+                HIP_TRY(ctx, launch_gemm3c(st, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
+                                           (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
+            } else {
+                HIP_TRY(ctx, launch_gemm3(st, ctx->H3, ctx->X3, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
+                                          (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
+            }
+        } else if (sk.on && gvarA == 0) {
+            HIP_TRY(ctx, launch_streamk_passA(st, sk, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt,
+                                              ctx->XHt1, ctx->N_pad, ctx->N_pad));
+            spA = SplitInfo{ctx->XHt1, ctx->d_split, 128, sk.mw, sk.MG};
+        } else
+            HIP_TRY(ctx, launch_gemm<false>(st, gvarA, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt,
+                                            ctx->N_pad, (long long)KC * ctx->N_pad, KC, ctx->G_pad, ctx->N_pad, nsplitA));
+        if (time_gemm) hipEventRecord(gev[gev.size() - 3], st);
+        if (!spA.plane1)
+            HIP_TRY(ctx, launch_reduce_splits(st, ctx->XHt, nsplitA, (long long)KC * ctx->N_pad,
+                                              (long long)KC * ctx->N_pad));
+        // W half-step                                             (sklearn _nmf.py:500)
+        HIP_TRY(ctx, launch_sweep(st, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
+                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k, tiers, spA));
+        if (use3) {
+            // finalize of the W sweep + the plane split of its result in one launch (writing the planes from
+            // inside the sweep was measured slower: 2-byte stores, lower occupancy)
+            const FinalizeArgs fa{ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H, ctx->d_slots, 0, prm->tol,
+                                  prm->max_iter, 1, max_k, nullptr, 0};
+            HIP_TRY(ctx, launch_split3_finalize(st, ctx->Wt, ctx->N_pad, KC, ctx->N_pad, ctx->Wt3, G3_MW, nullptr, fa,
+                                                nslots, fin_y));
+        } else {
+            finalize_kernel<<<dim3(nslots, fin_y), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H,
+                                                    ctx->d_slots, 0, prm->tol, prm->max_iter, 1, max_k);
+        }
+        if (time_gemm) hipEventRecord(gev[gev.size() - 2], st);
+        // pass B : XtW[S][KC][G] = Wt_all . X  (split over cells)  (sklearn _nmf.py:505-507)
+        const int nsB = use3 ? nsplit3 : nsplit;
+        if (usec)
+            HIP_TRY(ctx, launch_gemm3c(st, ctx->Wt3, ctx->Ct1, ctx->Ct1h, ctx->hiB, ctx->N_pad / 16, ctx->XtW, ctx->G_pad,
+                                       (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3));
+        else if (use3)
+            HIP_TRY(ctx, launch_gemm3(st, ctx->Wt3, ctx->Xt3, ctx->N_pad / 16, ctx->XtW, ctx->G_pad,
+                                      (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3));
+        else
+            HIP_TRY(ctx, launch_gemm<true>(st, gvarB, ctx->Wt, ctx->N_pad, ctx->X, ctx->G_pad, ctx->XtW,
+                                           ctx->G_pad, (long long)KC * ctx->G_pad, KC, ctx->N_pad,
+                                           ctx->G_pad, nsplit));
+        if (time_gemm) hipEventRecord(gev[gev.size() - 1], st);
+        // H half-step
+        HIP_TRY(ctx, launch_reduce_splits(st, ctx->XtW, nsB, (long long)KC * ctx->G_pad,
+                                          (long long)KC * ctx->G_pad, usec ? ctx->d_scale : nullptr, ctx->G_pad));
+        HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
+                                  ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers));
+        // the H finalize also publishes every slot's state into the host-mapped ring entry of this
+        // iteration (stamp it + 1): no copy kernel and no event per iteration
+        SlotDesc* snap = ctx->h_snap + (size_t)(it % RING) * KC0;
+        SlotDesc* snap_dev = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&snap_dev, snap, 0));
+        if (use3) {
+            const FinalizeArgs fa{ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W, ctx->d_slots, 1, prm->tol,
+                                  prm->max_iter, 1, max_k, snap_dev, (int)(it + 1)};
+            HIP_TRY(ctx, launch_split3_finalize(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW,
+                                                usec ? ctx->d_scale : nullptr, fa, nslots, fin_y));
+            h3_valid = true;
+        } else {
+            finalize_kernel<<<dim3(nslots, fin_y), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W,
+                                                    ctx->d_slots, 1, prm->tol, prm->max_iter, 1, max_k,
+                                                    snap_dev, (int)(it + 1));
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        snap_nslots[it % RING] = nslots;
+        column_iters += KC;
+        if (dbg) {
+            int live = 0;
+            for (int s2 = 0; s2 < nslots; ++s2) if (hs[s2].state) live += hs[s2].k;
+            dbg_it[KC / 32] += 1; dbg_live[KC / 32] += live;
+        }
+        ++it;
+        return CNMF_OK;
+    };
+
+    // ---- step 3: look at the snapshot `lag` iterations behind the GPU and retire what has converged
+    auto inspect = [&]() -> int {
+        const int64_t si = it - 1 - lag;   // snapshot index to inspect now
+        if (si < 0) return CNMF_OK;
+        const SlotDesc* sp = ctx->h_snap + (size_t)(si % RING) * KC0;
+        int rc2 = wait_snapshot(ctx, sp, snap_nslots[si % RING], (int)(si + 1));
+        if (rc2) return rc2;
+        for (int s = 0; s < snap_nslots[si % RING]; ++s)
+            if (hs[s].state == 1 && hs[s].installed_at <= si && sp[s].active == 0 && sp[s].restart == hs[s].restart) {
+                rc2 = retire(s, sp[s]);
+                if (rc2) return rc2;
+            }
+        return CNMF_OK;
+    };
+
+    // ---- step 4: tail compaction -- nothing left to refill with and at most half of the packed
+    // columns still iterate: repack the live slots into a narrower batch so the two GEMM passes
+    // shrink with the work (their cost is proportional to KC).
+    const bool no_compact = getenv("CNMF_NO_COMPACT") != nullptr;
+    auto compact = [&]() -> int {
+        if (n_pending == 0 && n_active > 0 && KC > 32 && !no_compact) {
+            int live_cols = 0;
+            for (int s = 0; s < nslots; ++s) if (hs[s].state) live_cols += hs[s].k;
+            int KCn = 32;
+            while (KCn < live_cols) KCn *= 2;
+            if (KCn < KC) {
+                std::vector<int> idx;
+                for (int s = 0; s < nslots; ++s) if (hs[s].state) idx.push_back(s);
+                std::sort(idx.begin(), idx.end(), [&](int a, int b) { return hs[a].off < hs[b].off; });
+                int pos = 0;
+                for (int s : idx) {
+                    HostSlot& h = hs[s];
+                    if (h.off != pos) {
+                        dim3 gH((G + 255) / 256, h.k), gW((N + 255) / 256, h.k), gI((std::max(N, G) + 255) / 256, h.k);
+                        extract_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, G, h.off, h.k, ctx->stageH, 0);
+                        extract_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, h.off, h.k, ctx->stageW, 0);
+                        install_cm_kernel<<<gI, 256, 0, st>>>(ctx->stageH, ctx->stageW, ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, pos);
+                        set_slot_off_kernel<<<1, 1, 0, st>>>(ctx->d_slots, s, pos);
+                        h.off = pos;
+                    }
+                    pos += h.k;
+                }
+                if (pos < KCn) {
+                    dim3 gc((ctx->G_pad + 255) / 256, KCn - pos), gw((ctx->N_pad + 255) / 256, KCn - pos);
+                    clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, pos, KCn - pos);
+                    clear_rows_kernel<<<gw, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, pos, KCn - pos);
+                }
+                HIP_TRY(ctx, hipGetLastError());
+                KC = KCn;
+                cols = ColAlloc(KC);
+                for (int s : idx) cols.alloc(hs[s].k);
+                const int cap = (ctx->nsplit_alloc * KC0) / KC;
+                nsplit = std::max(1, std::min(pick_nsplit(ctx, KC), cap));
+                use3 = usec = false;                // fewer than 256 packed columns: the f32 pipe takes over
+                sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
+                nsplitA = (sk.on && gvarA == 0) ? 1
+                        : std::max(1, std::min(pick_nsplit_A(ctx, KC), (ctx->nsplitA_alloc * KC0) / KC));
+                if (sk.on) {
+                    // the flags of the old plan may still be read by an in-flight sweep: same stream -> ordered
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
+                }
+            }
+        }
+        return CNMF_OK;
+    };
+
+    while (true) {
+        int n_new = 0;
+        if ((rc = refill(n_new))) return rc;
+        if (n_active == 0 && n_pending == 0) break;
+        if ((rc = iterate(n_new))) return rc;
+        if ((rc = inspect())) return rc;
+        if ((rc = compact())) return rc;
+    }
+
+    if (dbg)
+        for (int i = 1; i <= 8; ++i)
+            if (dbg_it[i]) fprintf(stderr, "[cnmf] KC=%d: %lld iterations, mean host-live columns %.1f\n", i * 32,
+                                   (long long)dbg_it[i], (double)dbg_live[i] / dbg_it[i]);
+    HIP_TRY(ctx, hipEventRecord(ev_end, st));
+    if (!resident)
+        HIP_TRY(ctx, hipMemcpyAsync(H_out, d_Hres, hoff[n] * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (W_out)
+        HIP_TRY(ctx, hipMemcpyAsync(W_out, d_Wres, woff[n] * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (resident) ctx->spectra_rows += (size_t)total_k;
+    if (stats) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, ev_begin, ev_end);
+        stats->gpu_ms = ms;
+        stats->outer_iterations = it;
+        stats->restart_iterations = restart_iters;
+        stats->column_iterations = column_iters;
+        stats->restart_column_iterations = restart_col_iters;
+        stats->kc = KC0; stats->nsplit = gemm_mode_used ? nsplit3 : ctx->nsplit_alloc;
+        stats->gemm_mode = gemm_mode_used;
+        for (size_t i = 0; i + 3 < gev.size(); i += 4) {
+            float a = 0.f, b = 0.f;
+            hipEventElapsedTime(&a, gev[i], gev[i + 1]);
+            hipEventElapsedTime(&b, gev[i + 2], gev[i + 3]);
+            stats->passA_ms += a; stats->passB_ms += b;
+            stats->passA_launches++; stats->passB_launches++;
+        }
+    }
+    return CNMF_OK;
+}
+
+extern "C" int cnmf_nmf_cd_batch(cnmf_ctx* ctx, int n, const int32_t* k, int init_mode,
+                                 const uint32_t* seeds, const double* avg, const float* W0,
+                                 const float* H0, const cnmf_cd_params* prm, float* H_out,
+                                 float* W_out, int32_t* n_iter_out, double* viol_out,
+                                 cnmf_batch_stats* stats)
+{
+    return run_batch(ctx, n, k, init_mode, seeds, avg, W0, H0, prm, H_out, W_out, false, n_iter_out, viol_out, stats);
+}
+
+extern "C" int cnmf_nmf_cd_batch_resident(cnmf_ctx* ctx, int n, const int32_t* k, int init_mode,
+                                          const uint32_t* seeds, const double* avg, const float* W0,
+                                          const float* H0, const cnmf_cd_params* prm,
+                                          int32_t* n_iter_out, double* viol_out,
+                                          cnmf_batch_stats* stats)
+{
+    return run_batch(ctx, n, k, init_mode, seeds, avg, W0, H0, prm, nullptr, nullptr, true, n_iter_out, viol_out, stats);
+}
+
+// ------------------------------------------------------------------ NNLS refit
+extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_params* prm,
+                         float* W_out, int32_t* n_iter_out, double* viol_out)
+{
+    if (!ctx) { SET_ERR(ctx, "ctx is NULL"); return CNMF_EINVAL; }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    int rc = validate_params(ctx, prm);
+    if (rc) return rc;
+    if (!Hin || !W_out || k < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    const int KC = k <= 32 ? 32 : 64;
+    rc = ensure_batch(ctx, KC, k, k);
+    if (rc) return rc;
+    rc = ensure_stage(ctx, (size_t)N * KMAX, (size_t)G * KMAX);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageH, Hin, (size_t)k * G * sizeof(float), hipMemcpyHostToDevice, st));
+    dim3 gI((std::max(N, G) + 255) / 256, k);
+    install_kernel<<<gI, 256, 0, st>>>(ctx->stageH, nullptr, ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, 0, k);
+    if (k < KC) {   // unused component rows of the 32-wide tile must be zero
+        dim3 gc((ctx->G_pad + 255) / 256, KC - k), gw((ctx->N_pad + 255) / 256, KC - k);
+        clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, k, KC - k);
+        clear_rows_kernel<<<gw, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, k, KC - k);
+    }
+    SlotDesc* d = &ctx->h_slots[0];
+    memset(d, 0, sizeof *d);
+    d->off = 0; d->k = k; d->active = 1; d->restart = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots, d, sizeof(SlotDesc), hipMemcpyHostToDevice, st));
+    ctx->h_slot_list[0] = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slot_list, ctx->h_slot_list, sizeof(int), hipMemcpyHostToDevice, st));
+    gram_rows_kernel<<<1, 256, 0, st>>>(ctx->H, ctx->G_pad, G, ctx->d_slots, ctx->d_slot_list, ctx->gramH, (float)prm->l2_reg_W);
+    HIP_TRY(ctx, launch_gemm<false>(st, 0, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt, ctx->N_pad, 0, KC, ctx->G_pad, ctx->N_pad, 1));
+    const int chunksW = sweep_chunks(N), partsW = sweep_parts(N);
+    DevPool pool;
+    EventPool events;
+    hipEvent_t ev = events.get(hipEventDisableTiming);
+    float* d_W = pool.get<float>((size_t)N * k);
+    POOL_TRY(ctx, events);
+    POOL_TRY(ctx, pool);
+    const int burst = 8;        // sweeps enqueued between two looks at the slot state
+    int done = 0;
+    SlotDesc* snap = ctx->h_snap;
+    for (int it = 0; it < prm->max_iter && !done; it += burst) {
+        for (int b = 0; b < burst; ++b) {
+            HIP_TRY(ctx, launch_sweep(st, 1, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
+                                      ctx->d_slots, (float)prm->l1_reg_W, ctx->gram_part, ctx->viol_part,
+                                      chunksW, partsW, 0, k, k <= 16 ? 1 : (k <= 32 ? 2 : 4)));
+            finalize_kernel<<<dim3(1, 1), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, 0.f,
+                                               ctx->d_slots, 2, prm->tol, prm->max_iter, 0, k);
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(snap, ctx->d_slots, sizeof(SlotDesc), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipEventRecord(ev, st));
+        HIP_TRY(ctx, hipEventSynchronize(ev));
+        done = (snap->active == 0);
+    }
+    dim3 gW((N + 255) / 256, k);
+    extract_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, 0, k, d_W, 1);
+    HIP_TRY(ctx, hipMemcpyAsync(W_out, d_W, (size_t)N * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    dim3 gH((ctx->G_pad + 255) / 256, k), gWc((ctx->N_pad + 255) / 256, k);
+    clear_rows_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, 0, k);
+    clear_rows_kernel<<<gWc, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, 0, k);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (n_iter_out) *n_iter_out = snap->iter;
+    if (viol_out) *viol_out = snap->viol_last;
+    return CNMF_OK;
+}

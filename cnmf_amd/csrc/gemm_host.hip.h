@@ -1,0 +1,377 @@
+// Host side of the GEMM / sweep kernels: launchers, stream-K plans, operand planes, count-structure
+// detection (included by cnmf_hip.hip after runtime.hip.h).
+#pragma once
+
+// ------------------------------------------------------------------ GEMM dispatch
+// variant : 0 = auto; 1 = "S" (waves split components, 32 j per workgroup);
+//           2 = "T" (every wave owns all the workgroup's components, 128 j per workgroup)
+//           3 = 2x2 wave grid (64 j per workgroup)
+struct GemmPlan { int variant; int mw; int jw; };
+
+template <int MTW, int WM, int WN, bool NN, int TBK = BK>
+static hipError_t launch_gemm_t(hipStream_t st, const float* A, int lda, const float* B, int ldb,
+                                float* C, int ldc, long long cstride, int KC, int Ktot, int J,
+                                int nsplit)
+{
+    constexpr int MW = WM * MTW * 32, JW = WN * 32;
+    const int Kper = round_up((Ktot + nsplit - 1) / nsplit, BK);
+    dim3 grid((J + JW - 1) / JW, KC / MW, nsplit);
+    static bool attr_set = false;
+    constexpr size_t lds = gemm_lds_bytes<MTW, WM, WN, NN, TBK>();
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_kernel<MTW, WM, WN, NN, TBK>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    gemm_kernel<MTW, WM, WN, NN, TBK><<<grid, 256, lds, st>>>(A, lda, B, ldb, C, ldc, cstride, Kper,
+                                                             Ktot, J);
+    return hipGetLastError();
+}
+
+template <bool NN>
+static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int lda, const float* B,
+                              int ldb, float* C, int ldc, long long cstride, int KC, int Ktot,
+                              int J, int nsplit)
+{
+#define GO(MTW, WM, WN) \
+    return launch_gemm_t<MTW, WM, WN, NN>(st, A, lda, B, ldb, C, ldc, cstride, KC, Ktot, J, nsplit)
+    if (variant == 0) variant = 2;
+    if (variant == 1 && KC < 128) variant = (KC >= 64) ? 3 : 2;
+    if (variant == 3 && KC < 64) variant = 2;
+    switch (variant) {
+        case 1:  // S: 4 waves x (MTW tiles of 32 comps), 32 j
+            if (KC % 256 == 0 && KC >= 256 && getenv("CNMF_S_MTW2")) GO(2, 4, 1);
+            GO(1, 4, 1);
+        case 3:  // 2x2
+            if (KC % 128 == 0) GO(2, 2, 2);
+            GO(1, 2, 2);
+        default:  // T: every wave all comps of the M group, 128 j
+            if (KC % 128 == 0) GO(4, 1, 4);
+            if (KC % 64 == 0) GO(2, 1, 4);
+            GO(1, 1, 4);
+    }
+#undef GO
+}
+
+// ------------------------------------------------------------------ sweep dispatch
+static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, int L, const float* P,
+                               const float* gram, const SlotDesc* slots, float l1, float* gram_part,
+                               double* viol_part, int chunks, int parts, int want_gram, int kmax, int tiers,
+                               SplitInfo sp = SplitInfo{nullptr, nullptr, 1, 1, 1})
+{
+    dim3 grid(parts, nslots);
+    static bool attr_set = false;
+    if (!attr_set) {      // ranks above 32 need more than the default 64 KB of dynamic LDS
+        hipFuncSetAttribute((const void*)sweep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        hipFuncSetAttribute((const void*)sweep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        hipFuncSetAttribute((const void*)sweep_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        attr_set = true;
+    }
+    // one launch per rank tier present among the live slots; a launch skips the slots of other tiers at once
+    const size_t lds = sweep_lds_bytes(kmax);
+    const int kg = sweep_kg(kmax);
+    if (tiers & 1) sweep_kernel<0><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax);
+    if (tiers & 2) sweep_kernel<1><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax);
+    if (tiers & 4) sweep_kernel<2><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax);
+    return hipGetLastError();
+}
+
+// ---- stream-K pass A (T layout: 128 components x 128 cells per tile)
+struct StreamK {
+    bool on = false;
+    int MG = 1, T = 0, nk = 0, P = 0, mw = 128;      // mw: component rows per workgroup tile
+    std::vector<unsigned char> split;
+};
+
+static StreamK plan_streamk(int KC, int N_pad, int G_pad, int n_wg_slots)
+{
+    StreamK sk;
+    if (KC % 128 != 0 || getenv("CNMF_NO_STREAMK")) return sk;
+    sk.MG = KC / sk.mw;
+    sk.T = sk.MG * (N_pad / 128);
+    sk.nk = G_pad / BK;                                    // stages per tile, as the kernel counts them
+    sk.P = n_wg_slots;
+    if (sk.T <= sk.P) sk.P = n_wg_slots / 2;              // one workgroup per CU
+    if (sk.T <= sk.P || sk.T % sk.P == 0) return sk;      // nothing to balance
+    sk.on = true;
+    sk.split.assign(sk.T, 0);
+    const long long U = (long long)sk.T * sk.nk;
+    for (int p = 1; p < sk.P; ++p) {
+        const long long b = U * p / sk.P;                  // first unit of workgroup p
+        if (b % sk.nk) sk.split[b / sk.nk] = 1;            // boundary inside a tile -> that tile is cut
+    }
+    return sk;
+}
+
+static hipError_t launch_streamk_passA(hipStream_t st, const StreamK& sk, const float* A, int lda,
+                                       const float* B, int ldb, float* C0, float* C1, int ldc, int Jtot)
+{
+    constexpr size_t lds = gemm_lds_bytes<4, 1, 4, false>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_streamk_kernel<4, 1, 4, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    gemm_streamk_kernel<4, 1, 4, false><<<sk.P, 256, lds, st>>>(A, lda, B, ldb, C0, C1, ldc, sk.MG, sk.T,
+                                                               sk.nk, Jtot);
+    return hipGetLastError();
+}
+
+static hipError_t launch_reduce_splits(hipStream_t st, float* P, int nsplit, long long split_stride,
+                                       long long n_floats, const double* colscale = nullptr, int ld = 1)
+{
+    if (nsplit <= 1 && !colscale) return hipSuccess;
+    const long long nv = n_floats / 4;
+    reduce_splits_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, st>>>(P, nsplit, split_stride, P, nv, colscale, ld);
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------ split-operand GEMM launchers
+// planes of a K-contiguous f32 matrix, block-major with row tiles of TR rows (rows % TR == 0)
+static hipError_t launch_split3(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst, int TR,
+                                const double* kscale = nullptr)
+{
+    if (rows % 64 == 0 && K % 64 == 0 && TR % 64 == 0) {        // tiled through LDS: both sides coalesced
+        dim3 grid(K / 64, rows / 64);
+        split3_tiled_kernel<<<grid, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale);
+        return hipGetLastError();
+    }
+    const long long total = (long long)rows * (K / 16);
+    split3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(src, ld, rows, K, TR, (unsigned short*)dst, kscale);
+    return hipGetLastError();
+}
+
+// CNMF_GEMM3: 0 = exact-f32 matrix pipe only, 1 = split-operand bf16 path, two register-staged 4-wave
+// workgroups per CU (the simple reference variant), 2 = split-operand bf16 path, one 8-wave LDS-DMA
+// ping-pong workgroup per CU; 3 (default) = 2, plus the count-structured path (one integer plane for X, 3 MFMAs
+// per product on 256 x 256 tiles) whenever the resident matrix has that structure.  Read on every call so that
+// tests can switch it.
+// (Tried and dropped, all within 3 % of variant 2 at the 50k x 2000 shape: the same ping-pong with register
+//  staging; 256 x 256 tiles with the two wave groups half a block apart (2/3 of the DMA bytes per flop).)
+static thread_local int g_gemm3_mode = CNMF_GEMM3_DEFAULT;
+static void refresh_gemm3_mode()            // at every API entry that launches GEMMs (not inside the hot loop)
+{
+    const char* e = getenv("CNMF_GEMM3");
+    const int mode = e ? atoi(e) : CNMF_GEMM3_DEFAULT;
+    g_gemm3_mode = (mode < 0 || mode > 3) ? CNMF_GEMM3_DEFAULT : mode;
+}
+static int gemm3_mode() { return g_gemm3_mode; }
+static int gemm3_wg_slots() { return gemm3_mode() >= 2 ? 256 : 512; }
+static int gemm3_jw() { return G3_JW; }     // j extent of a tile = row tile of the B planes
+
+static hipError_t launch_gemm3(hipStream_t st, const unsigned char* A3, const unsigned char* B3, int Kb,
+                               float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm3g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3G_LDS_BYTES);
+        attr_set = true;
+    }
+    const int kb_per = (Kb + nsplit - 1) / nsplit;
+    dim3 grid(Jpad / gemm3_jw(), KC / G3_MW, (Kb + kb_per - 1) / kb_per);
+    if (gemm3_mode() >= 2)
+        gemm3g_kernel<<<grid, 512, G3G_LDS_BYTES, st>>>(A3, B3, Kb, C, ldc, cstride, kb_per);
+    else
+        gemm3_kernel<<<grid, 256, G3_LDS_BYTES, st>>>(A3, B3, Kb, C, ldc, cstride, kb_per);
+    return hipGetLastError();
+}
+
+
+// plane split of a packed factor + finalize of the sweep that produced it, in one launch (kernels_sweep.hip.h)
+static hipError_t launch_split3_finalize(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst,
+                                         int TR, const double* kscale, const FinalizeArgs& fa, int nslots, int fin_y)
+{
+    const int bx = K / 64, by = rows / 64;
+    split3_finalize_kernel<<<bx * by + nslots * fin_y, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale, bx, by,
+                                                                  fa, fin_y);
+    return hipGetLastError();
+}
+
+// ---- stream-K plan for the split-operand pass A (tile = 256 components x 128 cells, up to 2 cuts per tile)
+struct StreamK3 {
+    bool on = false;
+    int T = 0, Kb = 0, P = 0, MG = 1;
+    std::vector<unsigned char> flags;     // bit 0: >= 1 cut (plane 1 holds the tail), bit 1: 2 cuts (plane 2 the middle)
+};
+
+static StreamK3 plan_streamk3(int KC, int N_pad, int G_pad, int n_wg_slots, int jw)
+{
+    StreamK3 sk;
+    sk.MG = KC / G3_MW;
+    sk.T = sk.MG * (N_pad / jw);
+    sk.Kb = G_pad / G3_BK;
+    sk.P = n_wg_slots;
+    if (sk.T < sk.P / 2 + sk.P / 4 || sk.P > 2 * sk.T || getenv("CNMF_NO_STREAMK")) return sk;   // few tiles: K split + reduce instead
+    sk.on = true;
+    sk.flags.assign(sk.T, 0);
+    const long long U = (long long)sk.T * sk.Kb;
+    for (int p = 1; p < sk.P; ++p) {
+        const long long b = U * p / sk.P;
+        if (b % sk.Kb) {
+            unsigned char& f = sk.flags[b / sk.Kb];
+            f = f ? 3 : 1;
+        }
+    }
+    return sk;
+}
+
+static hipError_t launch_gemm3_streamk(hipStream_t st, const StreamK3& sk, const unsigned char* A3,
+                                       const unsigned char* B3, float* C0, float* C1, float* C2, int ldc)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm3_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
+        hipFuncSetAttribute((const void*)gemm3g_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3G_LDS_BYTES);
+        attr_set = true;
+    }
+    if (gemm3_mode() >= 2)
+        gemm3g_streamk_kernel<<<sk.P, 512, G3G_LDS_BYTES, st>>>(A3, B3, sk.Kb, C0, C1, C2, ldc, sk.MG, sk.T);
+    else
+        gemm3_streamk_kernel<<<sk.P, 256, G3_LDS_BYTES, st>>>(A3, B3, sk.Kb, C0, C1, C2, ldc, sk.MG, sk.T);
+    return hipGetLastError();
+}
+
+// planes of X (pass A) and of X^T (pass B), built once per matrix on first use
+static int ensure_planes(cnmf_ctx* ctx)
+{
+    const int TR = gemm3_jw();
+    if (ctx->X3 && ctx->Xt3 && ctx->planes_tr == TR) return CNMF_OK;
+    hipFree(ctx->X3); hipFree(ctx->Xt3); ctx->X3 = ctx->Xt3 = nullptr;
+    ctx->planes_tr = TR;
+    const size_t bA = (size_t)ctx->N_pad * (ctx->G_pad / 16) * G3_ROWB;
+    const size_t bB = (size_t)ctx->G_pad * (ctx->N_pad / 16) * G3_ROWB;
+    HIP_TRY(ctx, hipMalloc(&ctx->X3, bA));
+    HIP_TRY(ctx, hipMalloc(&ctx->Xt3, bB));
+    HIP_TRY(ctx, launch_split3(ctx->stream, ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->X3, TR));
+    dim3 grid((ctx->G_pad + 255) / 256, ctx->N_pad / 16);
+    split3_transpose_kernel<<<grid, 256, 0, ctx->stream>>>(ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->N_pad,
+                                                            TR, (unsigned short*)ctx->Xt3);
+    HIP_TRY(ctx, hipGetLastError());
+    return CNMF_OK;
+}
+
+// ---- count-structured data: launchers of the 256 x 256 integer-plane kernel
+// Bhi / hiflag: second integer plane and its block flags (nullptr when no count exceeds 256)
+static hipError_t launch_gemm3c(hipStream_t st, const unsigned char* A3, const unsigned char* B1,
+                                const unsigned char* Bhi, const unsigned int* hiflag, int Kb,
+                                float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm3c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, g3c_lds_bytes(true));
+        attr_set = true;
+    }
+    const int kb_per = (Kb + nsplit - 1) / nsplit;
+    dim3 grid(Jpad / G3C_JW, KC / G3_MW, (Kb + kb_per - 1) / kb_per);
+    gemm3c_kernel<<<grid, 512, g3c_lds_bytes(Bhi != nullptr), st>>>(A3, B1, Bhi, hiflag, Kb, C, ldc, cstride, kb_per);
+    return hipGetLastError();
+}
+
+static hipError_t launch_gemm3c_streamk(hipStream_t st, const StreamK3& sk, const unsigned char* A3,
+                                        const unsigned char* B1, const unsigned char* Bhi,
+                                        const unsigned int* hiflag, float* C0, float* C1, float* C2, int ldc)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm3c_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, g3c_lds_bytes(true));
+        attr_set = true;
+    }
+    gemm3c_streamk_kernel<<<sk.P, 512, g3c_lds_bytes(Bhi != nullptr), st>>>(A3, B1, Bhi, hiflag, sk.Kb, C0, C1, C2, ldc,
+                                                                            sk.MG, sk.T);
+    return hipGetLastError();
+}
+
+// Examine the resident matrix once: is every column (integers <= 256) x one constant?  If so build the
+// integer planes of X and X^T and the per-gene scale (kernels_counts.hip.h).
+static int ensure_counts(cnmf_ctx* ctx)
+{
+    if (ctx->count_state != 0) return CNMF_OK;
+    ctx->count_state = -1;
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    if (ctx->N_pad % G3C_JW || ctx->G_pad % G3C_JW || getenv("CNMF_NO_COUNTS")) return CNMF_OK;
+    hipStream_t st = ctx->stream;
+    const int chunks = (N + CNT_ROWS - 1) / CNT_ROWS;
+    DevPool pool;
+    float* part = pool.get<float>((size_t)chunks * G);
+    float* vmin = pool.get<float>(G);
+    unsigned* fail = pool.get<unsigned>(G, true, st);
+    float* unit = pool.get<float>(G);
+    double* psx = pool.get<double>((size_t)chunks * G);
+    double* psn = pool.get<double>((size_t)chunks * G);
+    POOL_TRY(ctx, pool);
+    dim3 grid((G + 255) / 256, chunks);
+    col_minpos_kernel<<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, part);
+    col_min_combine_kernel<<<(G + 255) / 256, 256, 0, st>>>(part, chunks, G, vmin);
+    count_check_kernel<<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, vmin, fail);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<float> h_v(G), h_unit(G);
+    std::vector<unsigned> h_fail(G);
+    HIP_TRY(ctx, hipMemcpyAsync(h_v.data(), vmin, (size_t)G * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(h_fail.data(), fail, (size_t)G * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int g = 0; g < G; ++g) {
+        int m = 0;
+        for (int c = 1; c <= CNT_MAXMULT && !m; ++c) if (!(h_fail[g] & (1u << (c - 1)))) m = c;
+        if (!m) return CNMF_OK;                            // this gene is not (small integers) x constant
+        h_unit[g] = h_v[g] > 0.f ? h_v[g] / (float)m : 0.f;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(unit, h_unit.data(), (size_t)G * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_scale, (size_t)ctx->G_pad * sizeof(double)));
+    count_sums_kernel<<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, unit, psx, psn);
+    count_scale_kernel<<<(ctx->G_pad + 255) / 256, 256, 0, st>>>(psx, psn, chunks, G, ctx->G_pad, ctx->d_scale);
+    // does any count exceed 256?  then a second plane (256 hi) with per-block flags rides along
+    unsigned* any_big = pool.get<unsigned>(1, true, st);
+    POOL_TRY(ctx, pool);
+    count_max_kernel<<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, unit, any_big);
+    unsigned h_big = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&h_big, any_big, sizeof h_big, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const size_t bytes = (size_t)ctx->N_pad * ctx->G_pad * 2;
+    HIP_TRY(ctx, hipMalloc(&ctx->C1, bytes));
+    HIP_TRY(ctx, hipMalloc(&ctx->Ct1, bytes));
+    if (h_big) {
+        const size_t nfA = (size_t)(ctx->N_pad / G3C_JW) * ((ctx->G_pad / 16 + 31) / 32) * sizeof(unsigned int);
+        const size_t nfB = (size_t)(ctx->G_pad / G3C_JW) * ((ctx->N_pad / 16 + 31) / 32) * sizeof(unsigned int);
+        HIP_TRY(ctx, hipMalloc(&ctx->C1h, bytes));
+        HIP_TRY(ctx, hipMalloc(&ctx->Ct1h, bytes));
+        HIP_TRY(ctx, hipMalloc(&ctx->hiA, nfA));
+        HIP_TRY(ctx, hipMalloc(&ctx->hiB, nfB));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->hiA, 0, nfA, st));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->hiB, 0, nfB, st));
+    }
+    {
+        const long long total = (long long)ctx->N_pad * (ctx->G_pad / 16);
+        count_planes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+            ctx->X, ctx->G_pad, N, G, ctx->N_pad, ctx->G_pad, G3C_JW, unit, (unsigned short*)ctx->C1,
+            (unsigned short*)ctx->C1h, ctx->hiA);
+        dim3 gt((ctx->G_pad + 255) / 256, ctx->N_pad / 16);
+        count_planes_transpose_kernel<<<gt, 256, 0, st>>>(
+            ctx->X, ctx->G_pad, N, G, ctx->G_pad, ctx->N_pad, G3C_JW, unit, (unsigned short*)ctx->Ct1,
+            (unsigned short*)ctx->Ct1h, ctx->hiB);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));                // the pool's scratch is freed on return
+    ctx->count_state = 1;
+    return CNMF_OK;
+}
+
+// the split-operand path needs whole 256 x 128 tiles
+static bool gemm3_enabled(const cnmf_ctx* ctx, int KC)
+{
+    // (the plane builders index 16-cell blocks with blockIdx.y: up to 65 535 x 16 cells)
+    return gemm3_mode() != 0 && KC % G3_MW == 0 && ctx->G_pad % gemm3_jw() == 0 && ctx->N_pad % gemm3_jw() == 0 &&
+           ctx->N_pad / 16 <= 65535 && ctx->G_pad / 16 <= 65535;
+}
+
+static int pick_nsplit3(const cnmf_ctx* ctx, int KC, int jw)
+{
+    // pass B grid = (G_pad/jw) x (KC/256) x nsplit; aim at one (two) workgroups per CU, >= 16 blocks per split
+    const int tiles = std::max(1, ctx->G_pad / jw) * std::max(1, KC / G3_MW);
+    const int Kb = ctx->N_pad / G3_BK;
+    int s = std::max(1, std::min(gemm3_wg_slots() / std::max(1, tiles), Kb / 16));
+    const int kb_per = (Kb + s - 1) / s;
+    return (Kb + kb_per - 1) / kb_per;
+}

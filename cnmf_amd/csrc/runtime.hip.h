@@ -1,0 +1,108 @@
+// Context, error plumbing and scope-bound device resources of libcnmf_hip (included by cnmf_hip.hip).
+#pragma once
+
+static thread_local std::string g_last_error;
+
+struct cnmf_comm;
+
+struct cnmf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // data matrix
+    int64_t N = 0, G = 0;
+    int N_pad = 0, G_pad = 0;
+    float* X = nullptr;
+    unsigned char *X3 = nullptr, *Xt3 = nullptr;   // bf16 planes of X and X^T (split-operand GEMM), built on first use
+    int planes_tr = 0;                             // row-tile height they were built with
+    // count structure X = n * d (kernels_counts.hip.h): 0 = not examined, 1 = present, -1 = absent
+    int count_state = 0;
+    unsigned char *C1 = nullptr, *Ct1 = nullptr;   // integer planes of n and n^T (one bf16 plane, 256-row tiles)
+    unsigned char *C1h = nullptr, *Ct1h = nullptr; // second planes (256 hi) when some count exceeds 256, else NULL
+    unsigned int *hiA = nullptr, *hiB = nullptr;   // their flags: one bit per (tile row, block)
+    double* d_scale = nullptr;                     // per-gene scale d [G_pad]
+
+    // batch buffers (sized for kc_alloc columns)
+    int kc_alloc = 0, nsplit_alloc = 0, nsplitA_alloc = 0, parts_alloc = 0;
+    size_t gram_part_floats = 0;
+    float *H = nullptr, *Wt = nullptr, *XHt = nullptr, *XHt1 = nullptr, *XHt2 = nullptr, *XtW = nullptr;
+    unsigned char *H3 = nullptr, *Wt3 = nullptr;   // planes of the packed factors, refreshed every iteration
+    unsigned char* d_split = nullptr;   // stream-K cut flags of the current plan
+    float *gramH = nullptr, *gramW = nullptr, *gram_part = nullptr;
+    double* viol_part = nullptr;
+    SlotDesc* d_slots = nullptr;
+    int* d_slot_list = nullptr;
+    SlotDesc* h_slots = nullptr;      // pinned: per-slot install descriptors
+    SlotDesc* h_snap = nullptr;       // pinned: snapshot ring [RING][kc_alloc]
+    int* h_slot_list = nullptr;       // pinned ring of new-slot lists
+    float *stageW = nullptr, *stageH = nullptr;
+    size_t stageW_sz = 0, stageH_sz = 0;
+
+    // resident spectra store (device) for the gather / consensus
+    float* spectra = nullptr;
+    size_t spectra_cap = 0, spectra_rows = 0;
+
+    cnmf_comm* comm = nullptr;        // RCCL communicator (comm_host.hip.h); NULL = single GPU
+};
+
+static constexpr int RING = 8;
+#ifndef CNMF_GEMM3_DEFAULT
+#define CNMF_GEMM3_DEFAULT 3
+#endif
+
+#define SET_ERR(ctx, ...)                                                   \
+    do {                                                                    \
+        char buf_[512];                                                     \
+        snprintf(buf_, sizeof buf_, __VA_ARGS__);                           \
+        if (ctx) (ctx)->err = buf_;                                         \
+        g_last_error = buf_;                                                \
+    } while (0)
+
+#define HIP_TRY(ctx, call)                                                  \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) {                                             \
+            SET_ERR(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? CNMF_ENOMEM : CNMF_EHIP;   \
+        }                                                                   \
+    } while (0)
+
+// Scope-bound device allocations / events: released when the entry point returns, on EVERY path
+// (the HIP_TRY early returns included; hipFree waits for work that still uses the buffer).
+struct DevPool {
+    std::vector<void*> ptrs;
+    hipError_t err = hipSuccess;
+    template <typename T> T* get(size_t n, bool zero = false, hipStream_t st = nullptr) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) { err = e; return nullptr; }
+        ptrs.push_back(p);
+        if (zero) hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(T), st);
+        return (T*)p;
+    }
+    ~DevPool() { for (void* p : ptrs) hipFree(p); }
+};
+
+struct EventPool {
+    std::vector<hipEvent_t> evs;
+    hipError_t err = hipSuccess;
+    hipEvent_t get(unsigned flags = hipEventDefault) {
+        hipEvent_t e = nullptr;
+        hipError_t r = hipEventCreateWithFlags(&e, flags);
+        if (r != hipSuccess) { err = r; return nullptr; }
+        evs.push_back(e);
+        return e;
+    }
+    ~EventPool() { for (hipEvent_t e : evs) hipEventDestroy(e); }
+};
+
+#define POOL_TRY(ctx, pool)                                                                   \
+    do {                                                                                      \
+        if ((pool).err != hipSuccess) {                                                       \
+            SET_ERR(ctx, "device allocation failed: %s (%s:%d)", hipGetErrorString((pool).err), __FILE__, __LINE__); \
+            return ((pool).err == hipErrorOutOfMemory) ? CNMF_ENOMEM : CNMF_EHIP;             \
+        }                                                                                     \
+    } while (0)
+
+static inline int round_up(int64_t v, int m) { return (int)(((v + m - 1) / m) * m); }
