@@ -65,3 +65,24 @@ def test_six_partial_products_are_float32_accurate():
     # five terms would NOT do: without am*bm the error is ~2^-17
     five = ah * bh + (ah * bm + am * bh) + (ah * bl + al * bh)
     assert (np.abs(five - exact)[nz] / np.abs(exact)[nz]).max() > 2.0 ** -20
+
+
+def test_count_planes_are_exact():
+    """The count path (kernels_counts.hip.h): every integer n <= 65 535 is lo + hi256 with lo <= 256 and
+    hi256 a multiple of 256 <= 65 280 -- both exactly representable in bfloat16 -- so (ah + am + al) * n is
+    formed from exact partial products."""
+    n = np.arange(0, 65536, dtype=np.float32)
+    hi = np.where(n <= 256, 0.0, np.floor(n / 256.0) * 256.0).astype(np.float32)
+    lo = (n - hi).astype(np.float32)
+    assert np.array_equal(lo + hi, n)
+    assert lo.max() <= 256 and hi.max() == 65280
+    for p in (lo, hi):
+        assert np.array_equal(bf16_rne(p), p)                    # exact in bf16
+    # and the products with a three-plane operand are exact in float32 arithmetic of the planes
+    a = _samples(4096, 5)
+    ah, am, al = (q.astype(np.float64) for q in split3(a))
+    for c in (1.0, 3.0, 255.0, 256.0):
+        exact = a.astype(np.float64) * c
+        assert np.array_equal(ah * c + am * c + al * c, exact)
+        for q in (ah, am, al):                                   # each partial product fits a float32
+            assert np.array_equal((q * c).astype(np.float32).astype(np.float64), q * c)
