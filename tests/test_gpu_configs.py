@@ -147,3 +147,26 @@ def test_streamk_split_operand_path_at_scale(engine, monkeypatch):
         H_ref, _, _ = sklearn_ref.nmf(X64, 9, seeds[r], max_iter=25)
         maxabs, relfro = nmf_cd.spectra_error(H_ref, Hc[r])
         assert maxabs <= 1e-4 and relfro <= 1e-3, (r, maxabs, relfro)
+
+
+def test_C3_full_width_default_path_soak(engine):
+    """The north-star shape with 256 packed columns on the default path (count structure detected ->
+    stream-K launch of the integer-plane kernel over 196 cell tiles, cut pieces added by the sweep):
+    three runs must agree bit for bit (the kernels synchronise by hand-counted vmcnt / raw barriers),
+    and two restarts are checked against scikit-learn stopped at the same iteration."""
+    X = synth.make_config("C3", dtype=np.float32)
+    engine.set_matrix(X)
+    ks = [9] * 20 + [13] * 5 + [5] * 2                      # 20*9 + 65 + 10 = 255 columns
+    seeds = [int(s) for s in np.random.RandomState(9).randint(1, 2**31 - 1, size=len(ks))]
+    runs = []
+    for _ in range(3):
+        H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=30, warn=False)
+        assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] == 3
+        runs.append(H)
+    for other in runs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(runs[0], other))
+    X64 = X.astype(np.float64)
+    for r in (0, 22):
+        H_ref, _, n_ref = sklearn_ref.nmf(X64, ks[r], seeds[r], max_iter=30)
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, runs[0][r])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (r, maxabs, relfro)
