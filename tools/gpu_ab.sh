@@ -1,2 +1,2 @@
 #!/bin/bash
-python -m pytest tests/test_gpu_configs.py -m gpu -x -q -k soak 2>&1 | grep "passed\|failed\|rror\|^E" | tail -5
+for m in 3 4; do echo "== mode $m"; CNMF_GEMM3=$m timeout 300 python tools/probe_gemm3c.py 2>&1 | grep -v amdgpu.ids | tail -7; done
