@@ -301,6 +301,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int n_active = 0;
     int64_t it = 0;          // batch iterations enqueued so far
     int snap_nslots[RING] = {0};
+    const bool no_defrag = getenv("CNMF_NO_DEFRAG") != nullptr;
+    int64_t last_defrag = -8, n_defrag = 0;
     bool h3_valid = false;           // H3 holds the planes of the current H (split-operand modes)
     // stamps restart at 1 in every call: forget the ones a previous call left in the ring (nothing is in flight here)
     memset(ctx->h_snap, 0, (size_t)ctx->kc_alloc * RING * sizeof(SlotDesc));
@@ -352,6 +354,36 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         return CNMF_OK;
     };
 
+    // Move the live slots to the left end of the packed columns (ascending offset order, through the stage
+    // buffers) and zero everything from the first free column up to `width`.  Used by the tail compaction
+    // (narrower batch) and by the refill's defragmentation (same width).
+    auto repack_left = [&](int width) -> int {
+        std::vector<int> idx;
+        for (int s = 0; s < nslots; ++s) if (hs[s].state) idx.push_back(s);
+        std::sort(idx.begin(), idx.end(), [&](int a, int b) { return hs[a].off < hs[b].off; });
+        int pos = 0;
+        for (int s : idx) {
+            HostSlot& h = hs[s];
+            if (h.off != pos) {
+                dim3 gH((G + 255) / 256, h.k), gW((N + 255) / 256, h.k), gI((std::max(N, G) + 255) / 256, h.k);
+                extract_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, G, h.off, h.k, ctx->stageH, 0);
+                extract_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, h.off, h.k, ctx->stageW, 0);
+                install_cm_kernel<<<gI, 256, 0, st>>>(ctx->stageH, ctx->stageW, ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, pos);
+                set_slot_off_kernel<<<1, 1, 0, st>>>(ctx->d_slots, s, pos);
+                h.off = pos;
+            }
+            pos += h.k;
+        }
+        if (pos < width) {
+            dim3 gc((ctx->G_pad + 255) / 256, width - pos), gw((ctx->N_pad + 255) / 256, width - pos);
+            clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, pos, width - pos);
+            clear_rows_kernel<<<gw, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, pos, width - pos);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        h3_valid = false;                 // rows of H moved: its planes are stale
+        return CNMF_OK;
+    };
+
     // ---- step 1: refill free columns from the pending list (n_new = slots installed)
     auto refill = [&](int& n_new) -> int {
         n_new = 0;
@@ -359,6 +391,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         // pending restarts are sorted by descending rank; a hole too small for the head of the
         // queue is filled with the largest pending rank that fits (restarts are independent, so
         // the order they run in is free) -> the packed columns stay full in the main phase
+        for (int attempt = 0; attempt < 2; ++attempt) {
         int failed_k = 1 << 30;                       // smallest rank that did not fit in this pass
         for (size_t pi = next; pi < order.size() && n_pending > 0; ++pi) {
             const int r = order[pi];
@@ -388,6 +421,23 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots + s, d, sizeof(SlotDesc), hipMemcpyHostToDevice, st));
             new_list[n_new++] = s;
             ++n_active;
+        }
+        // Defragmentation: a pending restart did not fit although enough columns are free in total (holes
+        // left by retired slots of other ranks).  Repacking costs about one iteration and buys a restart
+        // that runs for hundreds -- at most once every 8 iterations.
+        if (attempt == 0 && n_pending > 0 && failed_k < (1 << 30) && !no_defrag && it - last_defrag >= 8) {
+            int live_cols = 0;
+            for (int s2 = 0; s2 < nslots; ++s2) if (hs[s2].state) live_cols += hs[s2].k;
+            if (KC - live_cols >= failed_k) {
+                int rcd = repack_left(KC);
+                if (rcd) return rcd;
+                cols = ColAlloc(KC);
+                for (int s2 = 0; s2 < nslots; ++s2) if (hs[s2].state) cols.alloc(hs[s2].k);
+                last_defrag = it; ++n_defrag;
+                continue;                               // place again into the contiguous free tail
+            }
+        }
+        break;
         }
         if (n_new) {
             int* dl = ctx->d_slot_list + (size_t)(it % RING) * KC0;
@@ -529,31 +579,11 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             int KCn = 32;
             while (KCn < live_cols) KCn *= 2;
             if (KCn < KC) {
-                std::vector<int> idx;
-                for (int s = 0; s < nslots; ++s) if (hs[s].state) idx.push_back(s);
-                std::sort(idx.begin(), idx.end(), [&](int a, int b) { return hs[a].off < hs[b].off; });
-                int pos = 0;
-                for (int s : idx) {
-                    HostSlot& h = hs[s];
-                    if (h.off != pos) {
-                        dim3 gH((G + 255) / 256, h.k), gW((N + 255) / 256, h.k), gI((std::max(N, G) + 255) / 256, h.k);
-                        extract_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, G, h.off, h.k, ctx->stageH, 0);
-                        extract_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, h.off, h.k, ctx->stageW, 0);
-                        install_cm_kernel<<<gI, 256, 0, st>>>(ctx->stageH, ctx->stageW, ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, pos);
-                        set_slot_off_kernel<<<1, 1, 0, st>>>(ctx->d_slots, s, pos);
-                        h.off = pos;
-                    }
-                    pos += h.k;
-                }
-                if (pos < KCn) {
-                    dim3 gc((ctx->G_pad + 255) / 256, KCn - pos), gw((ctx->N_pad + 255) / 256, KCn - pos);
-                    clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, pos, KCn - pos);
-                    clear_rows_kernel<<<gw, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, pos, KCn - pos);
-                }
-                HIP_TRY(ctx, hipGetLastError());
+                int rcp = repack_left(KCn);
+                if (rcp) return rcp;
                 KC = KCn;
                 cols = ColAlloc(KC);
-                for (int s : idx) cols.alloc(hs[s].k);
+                for (int s = 0; s < nslots; ++s) if (hs[s].state) cols.alloc(hs[s].k);
                 const int cap = (ctx->nsplit_alloc * KC0) / KC;
                 nsplit = std::max(1, std::min(pick_nsplit(ctx, KC), cap));
                 use3 = usec = false;                // fewer than 256 packed columns: the f32 pipe takes over
@@ -578,6 +608,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if ((rc = compact())) return rc;
     }
 
+    if (dbg) fprintf(stderr, "[cnmf] %lld defragmentations\n", (long long)n_defrag);
     if (dbg)
         for (int i = 1; i <= 8; ++i)
             if (dbg_it[i]) fprintf(stderr, "[cnmf] KC=%d: %lld iterations, mean host-live columns %.1f\n", i * 32,
