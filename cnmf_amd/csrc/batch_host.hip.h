@@ -572,12 +572,16 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     // columns still iterate: repack the live slots into a narrower batch so the two GEMM passes
     // shrink with the work (their cost is proportional to KC).
     const bool no_compact = getenv("CNMF_NO_COMPACT") != nullptr;
+    const bool f32_tail = getenv("CNMF_F32_TAIL") != nullptr;      // (A/B knob: compact the count path at 128 / 64 too)
     auto compact = [&]() -> int {
         if (n_pending == 0 && n_active > 0 && KC > 32 && !no_compact) {
             int live_cols = 0;
             for (int s = 0; s < nslots; ++s) if (hs[s].state) live_cols += hs[s].k;
             int KCn = 32;
             while (KCn < live_cols) KCn *= 2;
+            // On the count path a 256-column iteration (~250 us of GEMM at 50k x 2000) costs no more than a
+            // 64-column one on the f32 pipe and far less than a 128-column one: leave it only for 32 columns.
+            if (usec && KCn > 32 && !f32_tail) KCn = KC;
             if (KCn < KC) {
                 int rcp = repack_left(KCn);
                 if (rcp) return rcp;
