@@ -222,6 +222,14 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         woff[r + 1] = woff[r] + (size_t)kk[r] * N;
     }
     int KC = pick_kc(total_k, max_k, prm->kc_max);
+    // 65..128 columns of a count-structured matrix: the 256-column integer-plane kernels (half empty) are still
+    // faster than 128 columns on the f32 pipe
+    if (KC == 128 && prm->kc_max <= 0 && !getenv("CNMF_KC") && gemm3_mode() == 3 && gemm3_enabled(ctx, 256) &&
+        (int64_t)ctx->N_pad * ctx->G_pad >= (1ll << 24)) {
+        rc = ensure_counts(ctx);
+        if (rc) return rc;
+        if (ctx->count_state == 1) KC = 256;
+    }
     const int KC0 = KC;
     rc = ensure_batch(ctx, KC, max_k, min_k);
     if (rc) return rc;

@@ -170,3 +170,20 @@ def test_C3_full_width_default_path_soak(engine):
         H_ref, _, n_ref = sklearn_ref.nmf(X64, ks[r], seeds[r], max_iter=30)
         maxabs, relfro = nmf_cd.spectra_error(H_ref, runs[0][r])
         assert maxabs <= 1e-4 and relfro <= 1e-3, (r, maxabs, relfro)
+
+
+def test_mid_size_job_is_promoted_to_the_count_kernels(engine):
+    """65..128 packed columns of a large count-structured matrix run on the 256-column integer-plane kernels
+    (half empty) rather than on 128 columns of the f32 pipe; the result is the usual one."""
+    X = synth.make_config("C3", dtype=np.float32, n_cells=10000)
+    engine.set_matrix(X)
+    ks, seeds = [9] * 12, list(range(21, 33))               # 108 columns
+    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
+    assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] == 3
+    H_ref, _, _ = sklearn_ref.nmf(X.astype(np.float64), 9, seeds[3], max_iter=25)
+    maxabs, relfro = nmf_cd.spectra_error(H_ref, H[3])
+    assert maxabs <= 1e-4 and relfro <= 1e-3, (maxabs, relfro)
+    Hk, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False, kc_max=128)   # explicit cap: f32 pipe
+    assert engine.last_stats["kc"] == 128 and engine.last_stats["gemm_mode"] == 0
+    for a, b in zip(H, Hk):
+        assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
