@@ -223,6 +223,26 @@ class cNMF:
             alpha_usage=alpha_usage, alpha_spectra=alpha_spectra, init=init, max_iter=max_NMF_iter)
         self.save_nmf_iter_params(replicate_params, run_params)
 
+    def select_highvar_genes(self, tpm, numgenes=2000, expected_fano_threshold=None, minimal_mean=0.5):
+        """``get_highvar_genes`` (cnmf.py:192-246 / 136-188) with the per-gene moments computed on the device:
+        ``tpm`` is the cells x ALL-genes TPM matrix (DataFrame, ndarray or scipy CSR).  Returns
+        ``(gene_stats DataFrame, fano params, list of selected columns)``.  The matrix is uploaded to this
+        object's context and replaced by the next ``prepare_from_*`` call."""
+        from .hvg import highvar_genes_from_moments
+        cols = tpm.columns if isinstance(tpm, pd.DataFrame) else None
+        vals = tpm.values if isinstance(tpm, pd.DataFrame) else tpm
+        eng = self.engine
+        eng.set_matrix(vals)
+        self._engine_key = None
+        mean, var = eng.col_mean_var()
+        stats, params = highvar_genes_from_moments(mean, var, numgenes=numgenes,
+                                                   expected_fano_threshold=expected_fano_threshold,
+                                                   minimal_mean=minimal_mean)
+        if cols is not None:
+            stats.index = cols
+        chosen = list(stats.index[stats["high_var"].values])
+        return stats, params, chosen
+
     def prepare_from_counts(self, counts, components, n_iter=100, seed=None, beta_loss="frobenius",
                             alpha_usage=0.0, alpha_spectra=0.0, init="random", max_NMF_iter=1000, tpm=None):
         """``get_norm_counts`` + the tail of ``prepare`` (cnmf.py:540-556, 452-459) with the

@@ -121,6 +121,17 @@ class Engine:
         self._check(self._lib.cnmf_get_matrix(self._ctx, _fp(out)))
         return out
 
+    def col_mean_var(self):
+        """Per-gene mean and POPULATION variance (ddof=0) of the resident matrix in float64 -- the
+        O(cells x genes) part of the reference's high-variance-gene statistics (cnmf.py:195-196, 126-129)."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        dblp = C.POINTER(C.c_double)
+        mean, ssd = np.empty(G), np.empty(G)
+        self._check(self._lib.cnmf_col_moments(self._ctx, mean.ctypes.data_as(dblp), ssd.ctypes.data_as(dblp)))
+        return mean, ssd / N
+
     def scale_genes_unit_variance(self):
         """``X /= X.std(axis=0, ddof=1)`` on the resident matrix -- the dense branch of the reference's
         ``get_norm_counts`` (cnmf.py:540-548), statistics in float64.  Returns ``(std, row_sums)``;
