@@ -312,10 +312,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ({1: "f32 (operands split into 3 bf16 planes, 6 bf16 MFMAs per product, f32 accumulate)",
-                       2: "f32 (operands split into 3 bf16 planes, 6 bf16 MFMAs per product, f32 accumulate)",
-                       3: "f32 (X as one integer bf16 plane x per-gene scale, factors as 3 bf16 planes, 3 exact bf16 "
-                          "MFMAs per product, f32 accumulate)"}.get(agg["gemm_mode"], "f32")),
+            # f32 results; the products run on the bf16 matrix pipe from exact operand planes
+            "dtype": ({1: "f32 (3x3 bf16 planes, f32 accumulate)", 2: "f32 (3x3 bf16 planes, f32 accumulate)",
+                       3: "f32 (exact integer bf16 plane x 3 bf16 planes, f32 accumulate)"}.get(agg["gemm_mode"], "f32")),
             "data": "synthetic",
             "config": {"workload": "%s: %d cells x %d HVGs synthetic dense, K=%d..%d, %d restarts per K per step "
                                    "per GPU, sklearn CD solver tol=1e-4 max_iter=1000, init=random from ledger seeds"
