@@ -148,8 +148,14 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
+        # (test hook: CNMF_BENCH_BACKEND=gloo CNMF_BENCH_ONE_GPU=1 runs several ranks on ONE GPU to exercise the
+        #  N > 1 bookkeeping -- ledger sharding, ragged gather, max-over-ranks -- where only one GPU exists)
+        backend = os.environ.get("CNMF_BENCH_BACKEND", "nccl")
+        if os.environ.get("CNMF_BENCH_ONE_GPU"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend=backend)
+    tdev = "cpu" if os.environ.get("CNMF_BENCH_BACKEND", "nccl") == "gloo" else "cuda"
 
     from cnmf_amd import synth
     from cnmf_amd.engine import Engine
@@ -198,7 +204,7 @@ def main():
             return
         rows = [(i, int(H.shape[0]), step) for i, H in enumerate(H_list)]
         hdr, blk = cd.pack_local(rows, H_list, G)
-        cd.allgather_spectra(hdr, blk, G, device="cuda:%d" % local_rank)
+        cd.allgather_spectra(hdr, blk, G, device=None if tdev == "cpu" else "cuda:%d" % local_rank)
         torch.cuda.synchronize()
 
     def run_step(step, profile):
@@ -235,10 +241,10 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([agg["restarts"], agg["restart_iters"]], dtype=torch.float64, device="cuda")
+        cnt = torch.tensor([agg["restarts"], agg["restart_iters"]], dtype=torch.float64, device=tdev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         total_restarts, total_riters = float(cnt[0].item()), float(cnt[1].item())
     else:
