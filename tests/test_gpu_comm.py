@@ -56,3 +56,28 @@ def test_rccl_communicator_world1_and_resident_store(tmp_path):
         # a new matrix invalidates the store
         eng.set_matrix(X[:100])
         assert eng.spectra_rows == 0
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 bookkeeping (ledger sharding by rank, ragged gather of spectra, barrier, max-over-ranks
+    timing, summed restart counts) with two real ranks -- on the one GPU a test box has, over gloo
+    (CNMF_BENCH_BACKEND / CNMF_BENCH_ONE_GPU test hooks; the driver's multi-GPU runs use nccl = RCCL)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CNMF_BENCH_BACKEND="gloo", CNMF_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29561", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "C1", "--kmin", "6", "--kmax", "7",
+           "--restarts-per-k", "3", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]                   # exactly ONE JSON line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["restarts_per_step_per_gpu"] == 6 and d["config"]["gather"] == "torch"
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 12) < 1e-6      # 2 ranks x 6 restarts
+    assert "cpu_baseline" not in d                             # rank 0 at N = 1 only
