@@ -71,7 +71,24 @@ def worker_filter(iterable, worker_index, total_workers):
     return (p for i, p in enumerate(iterable) if (i - worker_index) % total_workers == 0)
 
 
+def ledger_seeds(ks, n_iter, random_state_seed):
+    """The (k, iter, nmf_seed) rows of the restart ledger (cnmf.py:593-605): one draw of ``len(ks) * n_iter`` seeds
+    from numpy's legacy global RNG (the UN-deduplicated ks set the count, cnmf.py:599), assigned to the product of
+    the sorted de-duplicated ks and range(n_iter)."""
+    if type(ks) is int:
+        ks = [ks]
+    k_list = sorted(set(list(ks)))
+    n_runs = len(ks) * n_iter
+    np.random.seed(seed=random_state_seed)
+    nmf_seeds = np.random.randint(low=1, high=(2 ** 31) - 1, size=n_runs)
+    return [(k, r, nmf_seeds[i]) for i, (k, r) in enumerate(itertools.product(k_list, range(n_iter)))]
+
+
 class cNMF:
+    # the R x R distance matrix only leaves the device when a consumer exists (the reference's plotting block,
+    # integration/hip_backend.py sets this): 8 R^2 bytes of host memory otherwise bought nothing
+    materialize_topics_dist = False
+
     def __init__(self, output_dir=".", name=None, device=0, engine=None, compress_merged=True):
         """Same constructor semantics as the reference (cnmf.py:268-296) plus the GPU index.
         ``compress_merged=False`` writes the merged-spectra files without zlib (same npz container, read
@@ -91,9 +108,11 @@ class cNMF:
         self._engine_key = None
         self.spectra_cache = {}          # (k, iter) -> spectra ndarray kept from factorize
         self.merged_cache = {}           # k -> merged spectra DataFrame kept from combine (skips a reload)
-        self._resident_alias = {}        # id(matrix object) -> engine key it is resident under
+        self._resident_obj = None        # STRONG reference to the matrix object that is resident (identity check:
+                                         # while we hold it CPython cannot hand its id() to another object)
         self.compress_merged = compress_merged
         self.last_factorize_stats = None
+        self.last_factorize_jobs = []
 
     # ------------------------------------------------------------------ paths (cnmf.py:298-330)
     def _initialize_dirs(self):
@@ -136,13 +155,29 @@ class cNMF:
         return self._engine
 
     def _get_engine(self, X, key):
-        """One resident upload per distinct matrix (X is NOT re-read per restart/worker)."""
+        """One resident upload per distinct matrix (X is NOT re-read per restart/worker).  ``key`` identifies a
+        FILE-backed matrix (path, mtime); ``key=None`` = an ad-hoc matrix, which is uploaded on every call
+        unless it is the very object that is resident (``_resident_obj``, held by strong reference -- never
+        id(): CPython reuses the ids of freed temporaries)."""
         if self._engine is None:
             self._engine = Engine(self.device)
-        if self._engine_key != key:
+        if key is None:
+            self._engine.set_matrix(X)
+            self._engine_key = None
+            self._resident_obj = None
+        elif self._engine_key != key:
             self._engine.set_matrix(X)
             self._engine_key = key
+            self._resident_obj = None
         return self._engine
+
+    def _forget_results(self):
+        """A new prepare invalidates everything derived from the previous matrix / ledger."""
+        self.spectra_cache.clear()
+        self.merged_cache.clear()
+        self._resident_obj = None
+        self._engine_key = None
+        self._norm_counts_cache = (None, None)
 
     def _load_norm_counts(self):
         """The normalised matrix file, kept in memory between the stages of one process."""
@@ -158,13 +193,16 @@ class cNMF:
         if type(ks) is int:
             ks = [ks]
         k_list = sorted(set(list(ks)))
-        n_runs = len(ks) * n_iter
-        np.random.seed(seed=random_state_seed)
-        nmf_seeds = np.random.randint(low=1, high=(2 ** 31) - 1, size=n_runs)
+        from ._lib import CNMF_KMAX
+        if k_list and max(k_list) > CNMF_KMAX:
+            # fail at prepare time, not after the restarts were paid for (the device sweep / k-means hold a
+            # rank in registers; the reference CLI cannot reach this either, cnmf.py:1251)
+            raise NotImplementedError("n_components=%d > %d is not supported by the device engine"
+                                      % (max(k_list), CNMF_KMAX))
         replicate_params = []
-        for i, (k, r) in enumerate(itertools.product(k_list, range(n_iter))):
+        for k, r, nmf_seed in ledger_seeds(ks, n_iter, random_state_seed):
             done = os.path.exists(self.paths["iter_spectra"] % (k, r))
-            replicate_params.append([k, r, nmf_seeds[i], done])
+            replicate_params.append([k, r, nmf_seed, done])
         replicate_params = pd.DataFrame(replicate_params, columns=["n_components", "iter", "nmf_seed", "completed"])
         n_completed = replicate_params["completed"].sum()
         if n_completed > 0:
@@ -210,6 +248,7 @@ class cNMF:
                             "and re-run or adjust the number of overdispersed genes. Quitting!"
                             % (zerocells.sum(), ", ".join(map(str, examples[:4]))))
         self._initialize_dirs()
+        self._forget_results()
         save_df_to_npz_fast(norm_counts, self.paths["normalized_counts"])
         with open(self.paths["nmf_genes_list"], "w") as F:
             F.write("\n".join(map(str, norm_counts.columns)))
@@ -234,6 +273,7 @@ class cNMF:
         eng = self.engine
         eng.set_matrix(vals)
         self._engine_key = None
+        self._resident_obj = None
         mean, var = eng.col_mean_var()
         stats, params = highvar_genes_from_moments(mean, var, numgenes=numgenes,
                                                    expected_fano_threshold=expected_fano_threshold,
@@ -258,6 +298,7 @@ class cNMF:
         eng = self.engine
         eng.set_matrix(np.ascontiguousarray(counts.values, dtype=np.float32))
         self._engine_key = None
+        self._resident_obj = None
         _, row_sums = eng.scale_genes_unit_variance()
         zerocells = row_sums == 0
         if zerocells.sum() > 0:
@@ -266,7 +307,9 @@ class cNMF:
                             "and re-run or adjust the number of overdispersed genes. Quitting!"
                             % (zerocells.sum(), ", ".join(map(str, examples[:4]))))
         norm_counts = pd.DataFrame(eng.get_matrix().astype(np.float64), index=counts.index, columns=counts.columns)
-        x_mean, x_dtype = eng.x_mean, eng.x_dtype
+        # the init scale must be the one every OTHER worker derives from the file (set_matrix: X.mean() of the
+        # float64 matrix), bit for bit -- not the device's own row-sum total
+        x_mean, x_dtype = norm_counts.values.mean(), eng.x_dtype
         self.prepare_from_matrix(norm_counts, components, n_iter=n_iter, seed=seed, beta_loss=beta_loss,
                                  alpha_usage=alpha_usage, alpha_spectra=alpha_spectra, init=init,
                                  max_NMF_iter=max_NMF_iter, tpm=tpm)
@@ -296,8 +339,11 @@ class cNMF:
         kw = dict(nmf_kwargs)
         self._check_kwargs(kw)
         Xv = X.values if isinstance(X, pd.DataFrame) else X
-        # (a matrix that consensus() already made resident under its file key is not uploaded again)
-        eng = self._get_engine(Xv, self._resident_alias.get(id(X), ("obj", id(X), getattr(Xv, "shape", None))))
+        # (the matrix object consensus()/factorize() made resident is not uploaded again; anything else is)
+        if self._resident_obj is not None and X is self._resident_obj and self._engine is not None:
+            eng = self._engine
+        else:
+            eng = self._get_engine(Xv, None)
         mu = kw.get("solver", "cd") == "mu"
         if kw.get("update_H", True) is False:
             H = np.asarray(kw["H"])
@@ -354,6 +400,7 @@ class cNMF:
         else:
             jobs = list(worker_filter(run_params.index[run_params["completed"] == False],   # noqa: E712
                                       worker_i, total_workers))
+        self.last_factorize_jobs = [int(j) for j in jobs]     # ledger rows THIS call ran (dist.factorize_distributed)
         if not jobs:
             return
         eng = self._get_engine(norm_counts.values, ("norm_counts", self.paths["normalized_counts"],
@@ -447,9 +494,14 @@ class cNMF:
         return self.refit_usage(X.T, usage.T).T
 
     # ------------------------------------------------------------------ consensus (cnmf.py:823-985)
-    def consensus(self, k, density_threshold=0.5, local_neighborhood_size=0.30, show_clustering=False,
-                  build_ref=False, skip_density_and_return_after_stats=False, close_clustergram_fig=False,
+    def consensus(self, k, density_threshold=0.5, local_neighborhood_size=0.30, show_clustering=True,
+                  build_ref=True, skip_density_and_return_after_stats=False, close_clustergram_fig=False,
                   refit_usage=True, normalize_tpm_spectra=False, norm_counts=None):
+        """cnmf.py:823-985 without the plotting block and ``build_reference`` (out of scope, SURVEY section 2
+        #10/#11): same signature and defaults as the reference, so positional (cnmf.py:1290) and keyword-less
+        calls bind alike.  With ``show_clustering=True`` AND ``self.materialize_topics_dist`` the distance matrix
+        is fetched as ``self.topics_dist`` for the reference's unchanged plotting code (integration/hip_backend.py);
+        ``build_ref`` and ``close_clustergram_fig`` have nothing to act on here and are ignored."""
         cached = self.merged_cache.get(k)
         if cached is not None and cached[0] == os.path.getmtime(self.paths["merged_spectra"] % k):
             merged_spectra = cached[1].copy()                # this process wrote that very file
@@ -463,16 +515,54 @@ class cNMF:
         density_threshold_repl = density_threshold_str.replace(".", "_")
         nc_key = ("norm_counts", self.paths["normalized_counts"], os.path.getmtime(self.paths["normalized_counts"]))
         eng = self._get_engine(norm_counts.values, nc_key)
-        self._resident_alias = {id(norm_counts): nc_key}     # the refit below reuses this upload
-        cached = os.path.isfile(self.paths["local_density_cache"] % k) and not skip_density_and_return_after_stats
-        out = eng.consensus(merged_spectra.values, k, density_threshold=density_threshold,
-                            local_neighborhood_size=local_neighborhood_size,
-                            skip_density=skip_density_and_return_after_stats,
-                            want_silhouette=skip_density_and_return_after_stats,
-                            return_dist=show_clustering)
-        if not skip_density_and_return_after_stats and not cached:
-            local_density = pd.DataFrame(out["local_density"], columns=["local_density"], index=merged_spectra.index)
-            save_df_to_npz(local_density, self.paths["local_density_cache"] % k)
+        self._resident_obj = norm_counts                      # the refit below reuses this upload
+        R = merged_spectra.shape[0]
+        n_neighbors = int(local_neighborhood_size * R / k)    # cnmf.py:879
+        # local-density cache (cnmf.py:887-899).  The reference reuses the file whenever it exists -- also after
+        # `local_neighborhood_size` or the merged spectra changed.  Here the file is reused when it is the
+        # reference's own (no side-car) or when the side-car written next to it names the same neighbourhood
+        # and spectra count; otherwise the density is recomputed and the file refreshed.
+        cache_path = self.paths["local_density_cache"] % k
+        meta_path = cache_path + ".meta.json"
+        cached_density = None
+        if not skip_density_and_return_after_stats and os.path.isfile(cache_path):
+            ok = True
+            if os.path.isfile(meta_path):
+                import json
+                try:
+                    meta = json.load(open(meta_path))
+                    ok = meta.get("n_neighbors") == n_neighbors and meta.get("n_spectra") == R
+                except ValueError:
+                    ok = False
+            if ok:
+                ld = load_df_from_npz(cache_path)
+                if ld.shape[0] == R:
+                    cached_density = np.asarray(ld.iloc[:, 0].values, dtype=np.float64)
+        if cached_density is not None:
+            keep = cached_density < density_threshold          # strict <, cnmf.py:903
+            if keep.sum() == 0:
+                raise RuntimeError("Zero components remain after density filtering. Consider increasing density threshold")
+            sub = eng.consensus(merged_spectra.values[keep], k, skip_density=True, want_silhouette=False,
+                                return_dist=False)
+            labels = -np.ones(R, dtype=np.int32)
+            labels[keep] = sub["labels"]
+            out = dict(sub, local_density=cached_density, density_filter=keep, labels=labels)
+            if show_clustering:
+                out["topics_dist"] = None      # like the reference with a cached density (cnmf.py:886, 988-990)
+        else:
+            out = eng.consensus(merged_spectra.values, k, density_threshold=density_threshold,
+                                local_neighborhood_size=local_neighborhood_size,
+                                skip_density=skip_density_and_return_after_stats,
+                                want_silhouette=skip_density_and_return_after_stats,
+                                return_dist=(show_clustering and self.materialize_topics_dist
+                                             and not skip_density_and_return_after_stats))
+            if not skip_density_and_return_after_stats:
+                import json
+                local_density = pd.DataFrame(out["local_density"], columns=["local_density"], index=merged_spectra.index)
+                save_df_to_npz(local_density, cache_path)
+                with open(meta_path, "w") as F:
+                    json.dump({"n_neighbors": n_neighbors, "n_spectra": int(R),
+                               "local_neighborhood_size": float(local_neighborhood_size)}, F)
         # artefacts the (unchanged) plotting block of the reference consumes (cnmf.py:986-1079)
         self.topics_dist = out.get("topics_dist")
         self.density_filter = pd.Series(out["density_filter"], index=merged_spectra.index)
@@ -541,7 +631,8 @@ class cNMF:
         stats = []
         for k in sorted(set(run_params.n_components)):
             stats.append(self.consensus(k, skip_density_and_return_after_stats=True,
-                                        show_clustering=False, norm_counts=norm_counts).stats)
+                                        show_clustering=False, close_clustergram_fig=True,
+                                        norm_counts=norm_counts).stats)
         stats = pd.DataFrame(stats)
         stats.reset_index(drop=True, inplace=True)
         save_df_to_npz(stats, self.paths["k_selection_stats"])

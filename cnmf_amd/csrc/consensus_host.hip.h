@@ -117,9 +117,12 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
         double* ddens = pool.get<double>(R);
         if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
         const size_t lds = (size_t)R * sizeof(double);
-        if (lds > 150 * 1024) { SET_ERR(ctx, "R=%d spectra exceed the single-pass KNN row buffer", R); return CNMF_EUNSUPPORTED; }
-        CONS_TRY(hipFuncSetAttribute((const void*)knn_density_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        knn_density_kernel<<<R, 256, lds, st>>>(dD, Rp, R, prm->n_neighbors + 1, prm->n_neighbors, ddens);
+        if (lds <= 150 * 1024 && !getenv("CNMF_KNN_GLOBAL")) {
+            CONS_TRY(hipFuncSetAttribute((const void*)knn_density_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            knn_density_kernel<true><<<R, 256, lds, st>>>(dD, Rp, R, prm->n_neighbors + 1, prm->n_neighbors, ddens);
+        } else {                      // more than 19 200 merged spectra: selection passes over the L2-resident row
+            knn_density_kernel<false><<<R, 256, 0, st>>>(dD, Rp, R, prm->n_neighbors + 1, prm->n_neighbors, ddens);
+        }
         CONS_TRY(hipGetLastError());
         CONS_TRY(hipMemcpyAsync(density.data(), ddens, (size_t)R * sizeof(double), hipMemcpyDeviceToHost, st));
         CONS_TRY(hipStreamSynchronize(st));

@@ -193,15 +193,22 @@ __global__ void dist_epilogue_kernel(double* __restrict__ Dm, int ld, int R, con
 
 // density[i] = (sum of the m smallest entries of row i) / n      (m = n+1, self distance 0 included)
 // Exact selection by bisection on the IEEE bit pattern (non-negative doubles order like uint64).
+// LDS = true: the row is staged in LDS (R <= 19 200); false: the ~64 selection passes re-read the row from
+// global memory (it stays in L2) -- any R.
+template <bool LDS>
 __global__ __launch_bounds__(256) void knn_density_kernel(const double* __restrict__ Dm, int ld, int R,
                                                           int m, int n, double* __restrict__ density)
 {
-    extern __shared__ __attribute__((aligned(16))) double rowbuf[];
+    extern __shared__ __attribute__((aligned(16))) double rowbuf_lds[];
     __shared__ double red[4];
     __shared__ int cnt_s[4];
     const int i = blockIdx.x, tid = threadIdx.x;
-    for (int j = tid; j < R; j += 256) rowbuf[j] = Dm[(size_t)i * ld + j];
-    __syncthreads();
+    const double* __restrict__ grow = Dm + (size_t)i * ld;
+    if (LDS) {
+        for (int j = tid; j < R; j += 256) rowbuf_lds[j] = grow[j];
+        __syncthreads();
+    }
+#define rowbuf (LDS ? (const double*)rowbuf_lds : grow)
     unsigned long long lo = 0ull, hi = 0x7ff0000000000000ull;   // find smallest T with count(x<=T) >= m
     while (lo < hi) {
         const unsigned long long mid = lo + ((hi - lo) >> 1);
@@ -226,6 +233,7 @@ __global__ __launch_bounds__(256) void knn_density_kernel(const double* __restri
     __syncthreads();
     c = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
     if (tid == 0) density[i] = (s + (double)(m - c) * T) / (double)n;
+#undef rowbuf
 }
 
 // gather rows: out[q][:] = in[idx[q]][:]   (zero-padded destination rows are cleared by the caller)

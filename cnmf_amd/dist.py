@@ -90,7 +90,12 @@ def comm_bootstrap_file(engine, rank, world, path, timeout=300.0):
             time.sleep(0.05)
         with open(path, "rb") as f:
             uid = f.read()
-    engine.comm_init(uid, rank, world)
+    engine.comm_init(uid, rank, world)          # collective: once it returns every rank has read the file
+    if rank == 0:
+        try:
+            os.remove(path)                      # never leave a stale id behind for a later launch
+        except OSError:
+            pass
 
 
 def comm_bootstrap_torch(engine):
@@ -130,19 +135,22 @@ def unpack(headers, blocks):
     return out
 
 
-def factorize_distributed(obj, rank, world, device=None, gather="torch", **factorize_kwargs):
+def factorize_distributed(obj, rank, world, device=None, gather="rccl", **factorize_kwargs):
     """``cNMF.factorize`` on this rank's shard, then the gather: afterwards every rank's
-    ``obj.spectra_cache`` holds every restart, so ``obj.combine()`` needs no files.
-    ``gather="rccl"`` uses the library's own communicator (``obj.engine`` must have had
-    ``comm_init``, e.g. via ``comm_bootstrap_file``); ``"torch"`` uses torch.distributed."""
+    ``obj.spectra_cache`` holds every restart that was run, so ``obj.combine()`` needs no files.
+    ``gather="rccl"`` (default) uses the library's own communicator (``obj.engine`` must have had
+    ``comm_init``, e.g. via ``comm_bootstrap_file``); ``"torch"`` uses torch.distributed (gloo in the CPU
+    tests).  The rows exchanged are the ones ``factorize`` actually ran (``obj.last_factorize_jobs``): with
+    ``skip_completed_runs=True`` the shard is taken over the INCOMPLETE rows (cnmf.py:729-733), not over the
+    whole ledger."""
     import pandas as pd
     from .cnmf import load_df_from_npz
     run_params = load_df_from_npz(obj.paths["nmf_replicate_parameters"])
     obj.factorize(worker_i=rank, total_workers=world, **factorize_kwargs)
     rows, spectra = [], []
     genes = None
-    for idx in shard(len(run_params), rank, world):
-        p = run_params.iloc[idx]
+    for idx in obj.last_factorize_jobs:
+        p = run_params.loc[idx]
         key = (int(p["n_components"]), int(p["iter"]))
         if key in obj.spectra_cache:
             df = obj.spectra_cache[key]

@@ -67,7 +67,8 @@ def test_bench_two_ranks_on_one_gpu():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CNMF_BENCH_BACKEND="gloo", CNMF_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, CNMF_BENCH_BACKEND="gloo", CNMF_BENCH_ONE_GPU="1", CNMF_GATHER="torch",
+               MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29561", os.path.join(root, "bench.py"),
            "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "C1", "--kmin", "6", "--kmax", "7",
@@ -81,3 +82,27 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["config"]["restarts_per_step_per_gpu"] == 6 and d["config"]["gather"] == "torch"
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 12) < 1e-6      # 2 ranks x 6 restarts
     assert "cpu_baseline" not in d                             # rank 0 at N = 1 only
+
+
+def test_bench_default_multi_gpu_transport_is_the_library_rccl_gather(tmp_path):
+    """bench.py's N > 1 code path with its DEFAULT transport -- the in-library RCCL gather, barrier and
+    max-over-ranks, bootstrapped through a file, no torch anywhere -- driven at world = 1 (CNMF_BENCH_FORCE_DIST;
+    RCCL refuses two ranks on one device, "Duplicate GPU detected", so a one-GPU box cannot form a larger
+    communicator; the N = 2 packing/unpacking is covered over gloo above and in tests/test_dist_gloo.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CNMF_BENCH_FORCE_DIST="1", CNMF_RCCL_ID_FILE=str(tmp_path / "id"))
+    env.pop("CNMF_GATHER", None); env.pop("CNMF_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+           "--workload", "C1", "--kmin", "6", "--kmax", "7", "--restarts-per-k", "3", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["gather"] == "rccl" and d["n_gpus"] == 1
+    assert d["config"]["torch_in_process"] is False            # the launcher's env is all the N > 1 path needs
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 6) < 1e-6

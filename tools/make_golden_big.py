@@ -1,0 +1,76 @@
+"""Golden vectors for the FULL-SIZE configs, produced by scikit-learn itself (float64) in the build container.
+
+The GPU box has no time budget for hundreds of float64 outer iterations at 50 000 x 2000, so the
+oracle runs here and its output is committed (`tests/golden/ref_c3_long.npz`, `ref_c4_csr.npz`);
+`tests/test_gpu_golden_big.py` regenerates the same seeded inputs on the GPU box and compares.
+
+C3 (north-star shape, 50 000 x 2000): for k = 5, 11, 13 the first ledger seed (cnmf.py:593-610, seed 14,
+K = 5..13, n_iter = 100) whose run needs >= 300 outer iterations: spectra after exactly 150 iterations
+(`max_iter=150`, the same truncation the device is asked for) and at convergence (tol 1e-4, max_iter 1000).
+C4 (200 000 x 2000 CSR, ~8 % dense, K = 20): two restarts x 10 outer iterations on the sparse input.
+
+    python tools/make_golden_big.py        # ~15 min on 8 cores
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import scipy.sparse as sp
+
+from cnmf_amd import synth
+from oracle import sklearn_ref
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def c4_matrix():
+    """The C4 input of tests/test_gpu_configs.py (same seeded construction)."""
+    rs = np.random.RandomState(3)
+    N, G = 200_000, 2000
+    X = sp.random(N, G, density=0.08, format="csr", dtype=np.float32, random_state=rs,
+                  data_rvs=lambda n: rs.gamma(1.0, 1.0, size=n).astype(np.float32))
+    return X[np.asarray(X.sum(axis=1)).ravel() > 0]
+
+
+def make_c3():
+    X = synth.make_config("C3", dtype=np.float32).astype(np.float64)
+    led = sklearn_ref.ledger(list(range(5, 14)), 100, 14)
+    out = {"x_checksum": np.array([X.sum(), (X * X).sum()])}
+    for k in (5, 11, 13):
+        for (kk, it, seed) in led:
+            if kk != k:
+                continue
+            t0 = time.time()
+            H_full, _, n_full = sklearn_ref.nmf(X, k, seed)
+            print("C3 k=%d iter=%d seed=%d: n_iter=%d (%.0f s)" % (k, it, seed, n_full, time.time() - t0), flush=True)
+            if n_full >= 300:
+                H150, _, n150 = sklearn_ref.nmf(X, k, seed, max_iter=150)
+                assert n150 == 150
+                out["k%d_seed" % k] = np.array([seed, it, n_full], dtype=np.int64)
+                out["k%d_H150" % k] = H150.astype(np.float32)
+                out["k%d_Hfull" % k] = H_full.astype(np.float32)
+                break
+    np.savez_compressed(os.path.join(OUT, "ref_c3_long.npz"), **out)
+
+
+def make_c4():
+    X = c4_matrix()
+    out = {"shape": np.array(X.shape), "x_checksum": np.array([float(X.data.astype(np.float64).sum())])}
+    X64 = X.astype(np.float64)
+    for seed in (11, 12):
+        t0 = time.time()
+        H, _, n = sklearn_ref.nmf(X64, 20, seed, max_iter=10)
+        print("C4 seed=%d: n_iter=%d (%.0f s)" % (seed, n, time.time() - t0), flush=True)
+        out["seed%d_H10" % seed] = H.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "ref_c4_csr.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c3", "c4"]
+    if "c4" in which:
+        make_c4()
+    if "c3" in which:
+        make_c3()
