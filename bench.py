@@ -38,7 +38,9 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf
 # bf16 MFMAs per f32-accurate product (kernels_gemm3.hip.h), by cnmf_batch_stats.gemm_mode:
 #   1/2: both operands as three planes, ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh)
 #   3  : count-structured X = (integers <= 256) x per-gene scale -> ONE integer plane, (ah + am + al)*n, all exact
-SPLIT_MFMAS_PER_PRODUCT = {1: 6, 2: 6, 3: 3}
+#   4  : the same on the f16 pipe (kernels_gemm2h.hip.h): counts <= 2048 in one f16 plane, the factor as TWO f16 planes
+#        with a per-row exponent (within 1 ulp_f32 of the f32 value, exact for 3 in 4), partial products exact
+SPLIT_MFMAS_PER_PRODUCT = {1: 6, 2: 6, 3: 3, 4: 2}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -178,7 +180,7 @@ def pmc_traffic(key, split_operand):
     collected in separate rocprofv3 --pmc passes (tools/gpu_pmc_bench.sh) and committed under
     profiles/ -- counters cannot be read from inside an un-profiled run.  None if absent."""
     name = {0: "r1_pmc_traffic.json", 1: "r1_pmc_traffic_split.json", 2: "r1_pmc_traffic_split.json",
-            3: "r1_pmc_traffic_counts.json"}[split_operand]
+            3: "r1_pmc_traffic_counts.json", 4: "r2_pmc_traffic_f16.json"}[split_operand]
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         return {"hbm_bytes_per_launch": d[key]["hbm_bytes_per_launch"],
@@ -378,7 +380,11 @@ def main():
             # so the roofline of the scheme in f32-equivalent flops is the dense bf16 peak / 6 (/ 3)
             per_product = SPLIT_MFMAS_PER_PRODUCT[agg["gemm_mode"]]
             peak = BF16_MFMA_PEAK_TFLOPS / per_product
-            if agg["gemm_mode"] == 3:
+            if agg["gemm_mode"] == 4:
+                kern = ("gemm2h_streamk_kernel (pass A: X.Ht; X = one integer f16 plane x per-gene scale, factor = 2 f16 planes)"
+                        if dom == "A" else
+                        "gemm2h_kernel (pass B: Xt.W; X = one integer f16 plane x per-gene scale, factor = 2 f16 planes)")
+            elif agg["gemm_mode"] == 3:
                 kern = ("gemm3c_streamk_kernel (pass A: X.Ht; X = one integer bf16 plane x per-gene scale, factor = 3 planes)"
                         if dom == "A" else
                         "gemm3c_kernel (pass B: Xt.W; X = one integer bf16 plane x per-gene scale, factor = 3 planes)")
@@ -388,12 +394,12 @@ def main():
         else:
             peak = FP32_MFMA_PEAK_TFLOPS
             kern = "gemm_streamk_kernel<NT> (pass A: X.Ht)" if dom == "A" else "gemm_kernel<NN> (pass B: Xt.W)"
-        xbytes = {0: 4, 1: 6, 2: 6, 3: 2}[agg["gemm_mode"]]     # bytes per element of X as the GEMM reads it
+        xbytes = {0: 4, 1: 6, 2: 6, 3: 2, 4: 2}[agg["gemm_mode"]]     # bytes per element of X as the GEMM reads it
         roof = {
             "bound": "mfma",
             "kernel": kern,
             "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "flop_basis": ("f32-equivalent flops (2.N.G per column and pass); peak = bf16 dense MFMA peak / %d MFMAs per product"
+            "flop_basis": ("f32-equivalent flops (2.N.G per column and pass); peak = bf16/f16 dense MFMA peak / %d MFMAs per product"
                            % SPLIT_MFMAS_PER_PRODUCT[agg["gemm_mode"]] if split else "f32 flops; peak = f32 MFMA peak"),
             "frac": ach / peak,
             "traffic": (pmc_traffic("passA" if dom == "A" else "passB", agg["gemm_mode"]) or {}).get("hbm_bytes_per_launch"),
@@ -410,11 +416,14 @@ def main():
         }
         if split:
             roof["matrix_pipe"] = {
-                "scheme": ("X = n * d detected (n integer <= 256: one exact bf16 plane; d per gene, folded into the factor); "
+                "scheme": ("X = n * d detected (n integer <= 2048: one exact f16 plane; d per gene, folded into the factor); "
+                           "factor = 2 f16 planes of a * 2^s_row (within 1 ulp_f32, exact for 3 values in 4); 2 exact partial "
+                           "products per product; f32 accumulate" if agg["gemm_mode"] == 4 else
+                           "X = n * d detected (n integer <= 256: one exact bf16 plane; d per gene, folded into the factor); "
                            "factor = 3 bf16 planes; 3 exact partial products per product; f32 accumulate"
                            if agg["gemm_mode"] == 3 else
                            "x = h + m + l (3 bf16 planes); a*b from the 6 partial products of weight >= 2^-18; f32 accumulate"),
-                "bf16_tflops_issued": ach * per_product * agg["col_iters"] / max(agg["rc_iters"], 1),
+                "mfma_tflops_issued": ach * per_product * agg["col_iters"] / max(agg["rc_iters"], 1),
                 "bf16_dense_peak": BF16_MFMA_PEAK_TFLOPS,
                 "vs_f32_matrix_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                 "note": "launch averages include the tail launches (< 256 packed columns) that run on the exact-f32 pipe",
@@ -429,7 +438,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # f32 results; the products run on the bf16 matrix pipe from exact operand planes
             "dtype": ({1: "f32 (3x3 bf16 planes, f32 accumulate)", 2: "f32 (3x3 bf16 planes, f32 accumulate)",
-                       3: "f32 (exact integer bf16 plane x 3 bf16 planes, f32 accumulate)"}.get(agg["gemm_mode"], "f32")),
+                       3: "f32 (exact integer bf16 plane x 3 bf16 planes, f32 accumulate)",
+                       4: "f32 (exact integer f16 plane x 2 f16 planes with per-row exponent, f32 accumulate)"}.get(agg["gemm_mode"], "f32")),
             "data": "synthetic",
             "config": {"workload": "%s: %d cells x %d HVGs synthetic dense, K=%d..%d, %d restarts per K per step "
                                    "per GPU, sklearn CD solver tol=1e-4 max_iter=1000, init=random from ledger seeds"

@@ -24,7 +24,7 @@ SYMBOLS = [
     "cnmf_comm_unique_id", "cnmf_comm_init", "cnmf_comm_finalize", "cnmf_comm_rank", "cnmf_comm_world",
     "cnmf_allgather_bytes", "cnmf_allgather_spectra",
     "cnmf_spectra_rows", "cnmf_spectra_reset", "cnmf_spectra_fetch",
-    "cnmf_debug_gemm", "cnmf_debug_gemm3", "cnmf_debug_gemm3c", "cnmf_debug_standard_normal",
+    "cnmf_debug_gemm", "cnmf_debug_gemm3", "cnmf_debug_gemm3c", "cnmf_debug_gemm2h", "cnmf_debug_standard_normal",
 ]
 
 COMM_ID_BYTES = 128
@@ -168,6 +168,8 @@ def load():
     lib.cnmf_debug_gemm3.argtypes = [vp, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
     lib.cnmf_debug_gemm3c.restype = i32
     lib.cnmf_debug_gemm3c.argtypes = [vp, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
+    lib.cnmf_debug_gemm2h.restype = i32
+    lib.cnmf_debug_gemm2h.argtypes = [vp, f32p, f32p, f32p, i32, i32, i32, i32, i32, dblp, i32]
     lib.cnmf_debug_standard_normal.restype = i32
     lib.cnmf_debug_standard_normal.argtypes = [vp, C.c_uint32, i64, dblp]
     _lib = lib

@@ -75,6 +75,15 @@ static int ensure_batch(cnmf_ctx* ctx, int KC, int max_k = KMAX, int min_k = 1)
         HIP_TRY(ctx, hipMalloc(&ctx->H3, (size_t)KC * (ctx->G_pad / 16) * G3_ROWB));
         HIP_TRY(ctx, hipMalloc(&ctx->Wt3, (size_t)KC * (ctx->N_pad / 16) * G3_ROWB));
         HIP_TRY(ctx, hipMemsetAsync(ctx->Wt3, 0, (size_t)KC * (ctx->N_pad / 16) * G3_ROWB, ctx->stream));
+        // f16 two-plane split: row-maximum partials written by the sweeps ([KC][parts]) and 2^-s per row
+        HIP_TRY(ctx, hipMalloc(&ctx->rmaxH, (size_t)KC * parts * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(&ctx->rmaxW, (size_t)KC * parts * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(&ctx->iscaleH, (size_t)KC * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(&ctx->iscaleW, (size_t)KC * sizeof(float)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->rmaxH, 0, (size_t)KC * parts * sizeof(float), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->rmaxW, 0, (size_t)KC * parts * sizeof(float), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->iscaleH, 0, (size_t)KC * sizeof(float), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->iscaleW, 0, (size_t)KC * sizeof(float), ctx->stream));
     }
     HIP_TRY(ctx, hipMalloc(&ctx->d_split, (size_t)(KC / 32 + 1) * (ctx->N_pad / 128 + 1)));
     HIP_TRY(ctx, hipMalloc(&ctx->XtW, hb * nsplit));
@@ -224,7 +233,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int KC = pick_kc(total_k, max_k, prm->kc_max);
     // 65..128 columns of a count-structured matrix: the 256-column integer-plane kernels (half empty) are still
     // faster than 128 columns on the f32 pipe
-    if (KC == 128 && prm->kc_max <= 0 && !getenv("CNMF_KC") && gemm3_mode() == 3 && gemm3_enabled(ctx, 256) &&
+    if (KC == 128 && prm->kc_max <= 0 && !getenv("CNMF_KC") && gemm3_mode() >= 3 && gemm3_enabled(ctx, 256) &&
         (int64_t)ctx->N_pad * ctx->G_pad >= (1ll << 24)) {
         rc = ensure_counts(ctx);
         if (rc) return rc;
@@ -238,12 +247,15 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int nsplit = std::min(pick_nsplit(ctx, KC), ctx->nsplit_alloc);
     bool use3 = gemm3_enabled(ctx, KC);            // split-operand bf16 MFMA path (whole 256-column tiles only)
     bool usec = false;                             // ... with X as one integer plane (count-structured data)
-    if (use3 && gemm3_mode() == 3) {
+    if (use3 && gemm3_mode() >= 3) {
         rc = ensure_counts(ctx);
         if (rc) return rc;
         usec = ctx->count_state == 1;
     }
-    const int gemm_mode_used = !use3 ? 0 : (usec ? 3 : std::min(gemm3_mode(), 2));
+    bool use2h = usec && ctx->count_fmt == 4;      // ... on the f16 pipe: two factor planes, 2 MFMAs per product
+    const int gemm_mode_used = !use3 ? 0 : (usec ? (use2h ? 4 : 3) : std::min(gemm3_mode(), 2));
+    const int KbA = ctx->G_pad / 16, KbB = ctx->N_pad / 16;
+    const int nsubA = use2h ? gemm2h_nsub(ctx->C1h != nullptr, KbA) : 1, nsubB = use2h ? gemm2h_nsub(ctx->Ct1h != nullptr, KbB) : 1;
     if (use3 && !usec) { rc = ensure_planes(ctx); if (rc) return rc; }
     const int jwA = usec ? G3C_JW : G3_JW;         // width of a pass-A / pass-B tile
     const int nsplit3 = use3 ? pick_nsplit3(ctx, KC, jwA) : 1;
@@ -337,7 +349,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int nsplitA = (sk.on && gvarA == 0) ? 1 : std::min(pick_nsplit_A(ctx, KC), ctx->nsplitA_alloc);
     StreamK3 sk3;
     if (use3) {
-        sk3 = plan_streamk3(KC, ctx->N_pad, ctx->G_pad, gemm3_wg_slots(), jwA);
+        sk3 = plan_streamk3(KC, ctx->N_pad, ctx->G_pad, gemm3_wg_slots(), jwA, nsubA);
         if (sk3.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk3.flags.data(), sk3.flags.size(), hipMemcpyHostToDevice, st));
         else nsplitA = std::min(pick_nsplit_A3(ctx, KC, jwA), ctx->nsplitA_alloc);   // few tiles: K split + reduce
     }
@@ -389,6 +401,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         }
         HIP_TRY(ctx, hipGetLastError());
         h3_valid = false;                 // rows of H moved: its planes are stale
+        // moved rows of slots that no longer iterate are not swept again: refresh their row maxima here
+        if (use2h) HIP_TRY(ctx, launch_rowmax_part(st, ctx->Wt, ctx->N_pad, N, KC, chunksW * 256, nullptr, partsW, ctx->rmaxW));
         return CNMF_OK;
     };
 
@@ -472,16 +486,26 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (use3) {
             // H3 was produced together with the previous iteration's H finalize; rows installed since then
             // (and the very first iteration) need a split of their own.  Count path: H' = H * d.
-            if (n_new > 0 || !h3_valid)
+            if ((n_new > 0 || !h3_valid) && use2h) {
+                HIP_TRY(ctx, launch_rowmax_part(st, ctx->H, ctx->G_pad, G, KC, chunksH * 256, ctx->d_scale, partsH, ctx->rmaxH));
+                HIP_TRY(ctx, launch_split2h(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, ctx->d_scale, ctx->rmaxH,
+                                            partsH, ctx->iscaleH));
+            } else if (n_new > 0 || !h3_valid)
                 HIP_TRY(ctx, launch_split3(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, usec ? ctx->d_scale : nullptr));
             if (time_gemm) hipEventRecord(gev[gev.size() - 4], st);
             if (sk3.on) {
-                if (usec)
+                if (use2h)
+                    HIP_TRY(ctx, launch_gemm2h_streamk(st, sk3, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->iscaleH, KbA,
+                                                       ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
+                else if (usec)
                     HIP_TRY(ctx, launch_gemm3c_streamk(st, sk3, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->XHt, ctx->XHt1,
                                                        ctx->XHt2, ctx->N_pad));
                 else
                     HIP_TRY(ctx, launch_gemm3_streamk(st, sk3, ctx->H3, ctx->X3, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
                 spA = SplitInfo{ctx->XHt1, ctx->d_split, jwA, G3_MW, sk3.MG, ctx->XHt2};
+            } else if (use2h) {
+                HIP_TRY(ctx, launch_gemm2h(st, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->iscaleH, KbA, ctx->XHt, ctx->N_pad,
+                                           (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
             } else if (usec) {
                 HIP_TRY(ctx, launch_gemm3c(st, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
                                            (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
@@ -498,12 +522,18 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                                             ctx->N_pad, (long long)KC * ctx->N_pad, KC, ctx->G_pad, ctx->N_pad, nsplitA));
         if (time_gemm) hipEventRecord(gev[gev.size() - 3], st);
         if (!spA.plane1)
-            HIP_TRY(ctx, launch_reduce_splits(st, ctx->XHt, nsplitA, (long long)KC * ctx->N_pad,
-                                              (long long)KC * ctx->N_pad));
+            HIP_TRY(ctx, launch_reduce_splits(st, ctx->XHt, use2h ? gemm2h_splits(KbA, nsplitA, nsubA) : nsplitA,
+                                              (long long)KC * ctx->N_pad, (long long)KC * ctx->N_pad));
         // W half-step                                             (sklearn _nmf.py:500)
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
-                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k, tiers, spA));
-        if (use3) {
+                                  ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k, tiers, spA,
+                                  use2h ? ctx->rmaxW : nullptr, nullptr));
+        if (use2h) {
+            const FinalizeArgs fa{ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H, ctx->d_slots, 0, prm->tol,
+                                  prm->max_iter, 1, max_k, nullptr, 0};
+            HIP_TRY(ctx, launch_split2h_finalize(st, ctx->Wt, ctx->N_pad, KC, ctx->N_pad, ctx->Wt3, G3_MW, nullptr, ctx->rmaxW,
+                                                 partsW, ctx->iscaleW, fa, nslots, fin_y));
+        } else if (use3) {
             // finalize of the W sweep + the plane split of its result in one launch (writing the planes from
             // inside the sweep was measured slower: 2-byte stores, lower occupancy)
             const FinalizeArgs fa{ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H, ctx->d_slots, 0, prm->tol,
@@ -516,8 +546,11 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         }
         if (time_gemm) hipEventRecord(gev[gev.size() - 2], st);
         // pass B : XtW[S][KC][G] = Wt_all . X  (split over cells)  (sklearn _nmf.py:505-507)
-        const int nsB = use3 ? nsplit3 : nsplit;
-        if (usec)
+        const int nsB = use2h ? gemm2h_splits(KbB, nsplit3, nsubB) : (use3 ? nsplit3 : nsplit);
+        if (use2h)
+            HIP_TRY(ctx, launch_gemm2h(st, ctx->Wt3, ctx->Ct1, ctx->Ct1h, ctx->hiB, ctx->iscaleW, KbB, ctx->XtW, ctx->G_pad,
+                                       (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3));
+        else if (usec)
             HIP_TRY(ctx, launch_gemm3c(st, ctx->Wt3, ctx->Ct1, ctx->Ct1h, ctx->hiB, ctx->N_pad / 16, ctx->XtW, ctx->G_pad,
                                        (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3));
         else if (use3)
@@ -532,13 +565,21 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         HIP_TRY(ctx, launch_reduce_splits(st, ctx->XtW, nsB, (long long)KC * ctx->G_pad,
                                           (long long)KC * ctx->G_pad, usec ? ctx->d_scale : nullptr, ctx->G_pad));
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
-                                  ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers));
+                                  ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers,
+                                  SplitInfo{nullptr, nullptr, 1, 1, 1}, use2h ? ctx->rmaxH : nullptr,
+                                  use2h ? ctx->d_scale : nullptr));
         // the H finalize also publishes every slot's state into the host-mapped ring entry of this
         // iteration (stamp it + 1): no copy kernel and no event per iteration
         SlotDesc* snap = ctx->h_snap + (size_t)(it % RING) * KC0;
         SlotDesc* snap_dev = nullptr;
         HIP_TRY(ctx, hipHostGetDevicePointer((void**)&snap_dev, snap, 0));
-        if (use3) {
+        if (use2h) {
+            const FinalizeArgs fa{ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W, ctx->d_slots, 1, prm->tol,
+                                  prm->max_iter, 1, max_k, snap_dev, (int)(it + 1)};
+            HIP_TRY(ctx, launch_split2h_finalize(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, ctx->d_scale,
+                                                 ctx->rmaxH, partsH, ctx->iscaleH, fa, nslots, fin_y));
+            h3_valid = true;
+        } else if (use3) {
             const FinalizeArgs fa{ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W, ctx->d_slots, 1, prm->tol,
                                   prm->max_iter, 1, max_k, snap_dev, (int)(it + 1)};
             HIP_TRY(ctx, launch_split3_finalize(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW,
@@ -598,7 +639,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                 for (int s = 0; s < nslots; ++s) if (hs[s].state) cols.alloc(hs[s].k);
                 const int cap = (ctx->nsplit_alloc * KC0) / KC;
                 nsplit = std::max(1, std::min(pick_nsplit(ctx, KC), cap));
-                use3 = usec = false;                // fewer than 256 packed columns: the f32 pipe takes over
+                use3 = usec = use2h = false;        // fewer than 256 packed columns: the f32 pipe takes over
                 sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
                 nsplitA = (sk.on && gvarA == 0) ? 1
                         : std::max(1, std::min(pick_nsplit_A(ctx, KC), (ctx->nsplitA_alloc * KC0) / KC));

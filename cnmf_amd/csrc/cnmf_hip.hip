@@ -34,6 +34,7 @@
 #include "kernels_gemm.hip.h"
 #include "kernels_gemm3.hip.h"
 #include "kernels_counts.hip.h"
+#include "kernels_gemm2h.hip.h"
 #include "kernels_rng.hip.h"
 #include "kernels_sweep.hip.h"
 
@@ -87,6 +88,8 @@ static void free_batch(cnmf_ctx* c)
 {
     hipFree(c->H); hipFree(c->Wt); hipFree(c->XHt); hipFree(c->XHt1); hipFree(c->XHt2); hipFree(c->XtW); hipFree(c->d_split);
     hipFree(c->H3); hipFree(c->Wt3);
+    hipFree(c->rmaxH); hipFree(c->rmaxW); hipFree(c->iscaleH); hipFree(c->iscaleW);
+    c->rmaxH = c->rmaxW = c->iscaleH = c->iscaleW = nullptr;
     c->XHt1 = c->XHt2 = nullptr; c->d_split = nullptr; c->H3 = c->Wt3 = nullptr;
     hipFree(c->gramH); hipFree(c->gramW); hipFree(c->gram_part); hipFree(c->viol_part);
     hipFree(c->d_slots); hipFree(c->d_slot_list);
@@ -128,7 +131,7 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     ctx->C1 = ctx->Ct1 = ctx->C1h = ctx->Ct1h = nullptr; ctx->hiA = ctx->hiB = nullptr;
-    ctx->d_scale = nullptr; ctx->count_state = 0;
+    ctx->d_scale = nullptr; ctx->count_state = 0; ctx->count_fmt = 0;
     ctx->spectra_rows = 0;            // spectra of another matrix are not comparable
     ctx->N = N; ctx->G = G;
     ctx->N_pad = round_up(N, N >= 512 ? 256 : 128);  // whole 256-wide tiles for the split-operand GEMMs

@@ -193,6 +193,73 @@ extern "C" int cnmf_debug_gemm3c(cnmf_ctx* ctx, const float* A, const float* Bn,
     return CNMF_OK;
 }
 
+// C[KC][J] = A[KC][K] . Bn[J][K]^T through the f16 two-plane count kernel (kernels_gemm2h.hip.h): Bn holds
+// non-negative integers <= 65535, A arbitrary non-negative float32.  KC % 256 == 0, K % 64 == 0.  nsub = 1 | 2 sub-blocks
+// per barrier pair (2 only without a second count plane, K % 32 == 0).
+extern "C" int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, int KC, int K, int J,
+                                 int nsplit, int nsub, double* ms_out, int reps)
+{
+    if (!ctx || !A || !Bn || !C) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    if (KC % 256 || K % 64 || J < 1 || nsplit < 1) { SET_ERR(ctx, "debug_gemm2h needs KC %% 256 == 0, K %% 64 == 0"); return CNMF_EINVAL; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int Jp = round_up(J, G3C_JW), Kb = K / 16;
+    bool has_hi = false;
+    for (size_t i = 0; i < (size_t)J * K && !has_hi; ++i) has_hi = Bn[i] > G2_COUNT_BASE;
+    DevPool pool;
+    EventPool events;
+    float* dA = pool.get<float>((size_t)KC * K);
+    float* dB = pool.get<float>((size_t)J * K);
+    float* dUnit = pool.get<float>(K);
+    float* dRmax = pool.get<float>(KC);
+    float* dInv = pool.get<float>(KC);
+    unsigned char* dA2 = pool.get<unsigned char>((size_t)KC * Kb * G2_ROWB);
+    unsigned char* dB1 = pool.get<unsigned char>((size_t)Jp * Kb * 32);
+    unsigned char* dBh = has_hi ? pool.get<unsigned char>((size_t)Jp * Kb * 32) : nullptr;
+    unsigned int* dFl = pool.get<unsigned int>((size_t)(Jp / G3C_JW) * ((Kb + 31) / 32), true, st);
+    float* dC = pool.get<float>((size_t)nsplit * KC * Jp);
+    hipEvent_t e0 = events.get(), e1 = events.get();
+    POOL_TRY(ctx, pool);
+    POOL_TRY(ctx, events);
+    std::vector<float> ones(K, 1.0f);
+    HIP_TRY(ctx, hipMemcpyAsync(dA, A, (size_t)KC * K * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dB, Bn, (size_t)J * K * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dUnit, ones.data(), (size_t)K * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, launch_rowmax_part(st, dA, K, K, KC, K, nullptr, 1, dRmax));
+    HIP_TRY(ctx, launch_split2h(st, dA, K, KC, K, dA2, G3_MW, nullptr, dRmax, 1, dInv));
+    {
+        const long long total = (long long)Jp * Kb;
+        count_planes_f16_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dB, K, J, K, Jp, K, G3C_JW, dUnit,
+                                                                               (unsigned short*)dB1, (unsigned short*)dBh, dFl);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    reps = std::max(1, reps);
+    const int ns = (!has_hi && nsub == 2 && Kb % 2 == 0) ? 2 : 1;
+    for (int i = 0; i < reps + 1; ++i) {
+        if (i == 1) hipEventRecord(e0, st);
+        hipError_t e;
+        if (has_hi) e = launch_gemm2h_t<1, true>(st, dA2, dB1, dBh, dFl, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
+        else if (ns == 2) e = launch_gemm2h_t<2, false>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
+        else e = launch_gemm2h_t<1, false>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
+        HIP_TRY(ctx, e);
+    }
+    hipEventRecord(e1, st);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const int zs = gemm2h_splits(Kb, nsplit, ns);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) *ms_out = ms / reps;
+    std::vector<float> hc((size_t)zs * KC * Jp);
+    HIP_TRY(ctx, hipMemcpy(hc.data(), dC, hc.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int c = 0; c < KC; ++c)
+        for (int j = 0; j < J; ++j) {
+            float v = hc[(size_t)c * Jp + j];
+            for (int z = 1; z < zs; ++z) v += hc[((size_t)z * KC + c) * Jp + j];
+            C[(size_t)c * J + j] = v;
+        }
+    return CNMF_OK;
+}
+
 extern "C" int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t n, double* out)
 {
     if (!ctx || !out || n < 0) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }

@@ -57,22 +57,35 @@ static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int l
 static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, int L, const float* P,
                                const float* gram, const SlotDesc* slots, float l1, float* gram_part,
                                double* viol_part, int chunks, int parts, int want_gram, int kmax, int tiers,
-                               SplitInfo sp = SplitInfo{nullptr, nullptr, 1, 1, 1})
+                               SplitInfo sp = SplitInfo{nullptr, nullptr, 1, 1, 1},
+                               float* rmax_part = nullptr, const double* rmax_scale = nullptr)
 {
     dim3 grid(parts, nslots);
     static bool attr_set = false;
     if (!attr_set) {      // ranks above 32 need more than the default 64 KB of dynamic LDS
-        hipFuncSetAttribute((const void*)sweep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
-        hipFuncSetAttribute((const void*)sweep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
-        hipFuncSetAttribute((const void*)sweep_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        hipFuncSetAttribute((const void*)sweep_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        hipFuncSetAttribute((const void*)sweep_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        hipFuncSetAttribute((const void*)sweep_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        hipFuncSetAttribute((const void*)sweep_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        hipFuncSetAttribute((const void*)sweep_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+        hipFuncSetAttribute((const void*)sweep_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
         attr_set = true;
     }
-    // one launch per rank tier present among the live slots; a launch skips the slots of other tiers at once
+    // one launch per rank tier present among the live slots; a launch skips the slots of other tiers at once.
+    // rmax_scale != nullptr selects the exact row-maximum report (the H half-step of the f16 plane split).
     const size_t lds = sweep_lds_bytes(kmax);
     const int kg = sweep_kg(kmax);
-    if (tiers & 1) sweep_kernel<0><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax);
-    if (tiers & 2) sweep_kernel<1><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax);
-    if (tiers & 4) sweep_kernel<2><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax);
+#define CNMF_SWEEP(T_, R_) sweep_kernel<T_, R_><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax, rmax_part, rmax_scale)
+    if (rmax_part && rmax_scale) {
+        if (tiers & 1) CNMF_SWEEP(0, true);
+        if (tiers & 2) CNMF_SWEEP(1, true);
+        if (tiers & 4) CNMF_SWEEP(2, true);
+    } else {
+        if (tiers & 1) CNMF_SWEEP(0, false);
+        if (tiers & 2) CNMF_SWEEP(1, false);
+        if (tiers & 4) CNMF_SWEEP(2, false);
+    }
+#undef CNMF_SWEEP
     return hipGetLastError();
 }
 
@@ -146,8 +159,9 @@ static hipError_t launch_split3(hipStream_t st, const float* src, int ld, int ro
 // CNMF_GEMM3: 0 = exact-f32 matrix pipe only, 1 = split-operand bf16 path, two register-staged 4-wave
 // workgroups per CU (the simple reference variant), 2 = split-operand bf16 path, one 8-wave LDS-DMA
 // ping-pong workgroup per CU; 3 (default) = 2, plus the count-structured path (one integer plane for X, 3 MFMAs
-// per product on 256 x 256 tiles) whenever the resident matrix has that structure.  Read on every call so that
-// tests can switch it.
+// per product on 256 x 256 tiles) whenever the resident matrix has that structure; 4 (default) = 3 on the f16 matrix
+// pipe (kernels_gemm2h.hip.h): counts <= 2048 in one f16 plane, the factor as two f16 planes with a per-row exponent,
+// 2 MFMAs per product.  Read on every call so that tests can switch it.
 // (Tried and dropped, all within 3 % of variant 2 at the 50k x 2000 shape: the same ping-pong with register
 //  staging; 256 x 256 tiles with the two wave groups half a block apart (2/3 of the DMA bytes per flop).)
 static thread_local int g_gemm3_mode = CNMF_GEMM3_DEFAULT;
@@ -155,7 +169,7 @@ static void refresh_gemm3_mode()            // at every API entry that launches 
 {
     const char* e = getenv("CNMF_GEMM3");
     const int mode = e ? atoi(e) : CNMF_GEMM3_DEFAULT;
-    g_gemm3_mode = (mode < 0 || mode > 3) ? CNMF_GEMM3_DEFAULT : mode;
+    g_gemm3_mode = (mode < 0 || mode > 4) ? CNMF_GEMM3_DEFAULT : mode;
 }
 static int gemm3_mode() { return g_gemm3_mode; }
 static int gemm3_wg_slots() { return gemm3_mode() >= 2 ? 256 : 512; }
@@ -190,19 +204,23 @@ static hipError_t launch_split3_finalize(hipStream_t st, const float* src, int l
     return hipGetLastError();
 }
 
+static hipError_t launch_split2h_finalize(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst,
+                                          int TR, const double* kscale, const float* rmax_part, int parts,
+                                          float* inv_scale, const FinalizeArgs& fa, int nslots, int fin_y);
+
 // ---- stream-K plan for the split-operand pass A (tile = 256 components x 128 cells, up to 2 cuts per tile)
 struct StreamK3 {
     bool on = false;
-    int T = 0, Kb = 0, P = 0, MG = 1;
+    int T = 0, Kb = 0, P = 0, MG = 1;     // Kb: work units per tile (16-k blocks / `unit`)
     std::vector<unsigned char> flags;     // bit 0: >= 1 cut (plane 1 holds the tail), bit 1: 2 cuts (plane 2 the middle)
 };
 
-static StreamK3 plan_streamk3(int KC, int N_pad, int G_pad, int n_wg_slots, int jw)
+static StreamK3 plan_streamk3(int KC, int N_pad, int G_pad, int n_wg_slots, int jw, int unit = 1)
 {
     StreamK3 sk;
     sk.MG = KC / G3_MW;
     sk.T = sk.MG * (N_pad / jw);
-    sk.Kb = G_pad / G3_BK;
+    sk.Kb = G_pad / (G3_BK * unit);
     sk.P = n_wg_slots;
     if (sk.T < sk.P / 2 + sk.P / 4 || sk.P > 2 * sk.T || getenv("CNMF_NO_STREAMK")) return sk;   // few tiles: K split + reduce instead
     sk.on = true;
@@ -284,12 +302,112 @@ static hipError_t launch_gemm3c_streamk(hipStream_t st, const StreamK3& sk, cons
     return hipGetLastError();
 }
 
+// ---- f16 two-plane count path (kernels_gemm2h.hip.h)
+// 16-k sub-blocks per barrier pair of the production launches (CNMF_G2_NSUB = 1 | 2)
+static int g2_nsub()
+{
+    static const int v = getenv("CNMF_G2_NSUB") ? atoi(getenv("CNMF_G2_NSUB")) : 2;
+    return v == 1 ? 1 : 2;
+}
+
+template <int NSUB, bool HI>
+static hipError_t launch_gemm2h_t(hipStream_t st, const unsigned char* A2, const unsigned char* B1,
+                                  const unsigned char* Bhi, const unsigned int* hiflag, const float* rscale, int Kb,
+                                  float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
+{
+    static bool attr_set = false;
+    constexpr int lds = g2_lds_bytes(NSUB, HI);
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm2h_kernel<NSUB, HI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    int kb_per = (Kb + nsplit - 1) / nsplit;
+    kb_per = ((kb_per + NSUB - 1) / NSUB) * NSUB;            // whole steps
+    dim3 grid(Jpad / G3C_JW, KC / G3_MW, (Kb + kb_per - 1) / kb_per);
+    gemm2h_kernel<NSUB, HI><<<grid, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, kb_per);
+    return hipGetLastError();
+}
+
+// number of K splits the launch above will actually use (the partial planes the reduce must add)
+static int gemm2h_splits(int Kb, int nsplit, int nsub)
+{
+    int kb_per = (Kb + nsplit - 1) / nsplit;
+    kb_per = ((kb_per + nsub - 1) / nsub) * nsub;
+    return (Kb + kb_per - 1) / kb_per;
+}
+
+static hipError_t launch_gemm2h(hipStream_t st, const unsigned char* A2, const unsigned char* B1,
+                                const unsigned char* Bhi, const unsigned int* hiflag, const float* rscale, int Kb,
+                                float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
+{
+    if (Bhi) return launch_gemm2h_t<1, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
+    if (g2_nsub() == 2 && Kb % 2 == 0)
+        return launch_gemm2h_t<2, false>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
+    return launch_gemm2h_t<1, false>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
+}
+static int gemm2h_nsub(bool hi, int Kb) { return (!hi && g2_nsub() == 2 && Kb % 2 == 0) ? 2 : 1; }
+
+template <int NSUB, bool HI>
+static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, const unsigned char* A2,
+                                          const unsigned char* B1, const unsigned char* Bhi,
+                                          const unsigned int* hiflag, const float* rscale, int Kb, float* C0, float* C1,
+                                          float* C2, int ldc)
+{
+    static bool attr_set = false;
+    constexpr int lds = g2_lds_bytes(NSUB, HI);
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm2h_streamk_kernel<NSUB, HI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    gemm2h_streamk_kernel<NSUB, HI><<<sk.P, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T);
+    return hipGetLastError();
+}
+
+// (the plan `sk` must have been made with unit = gemm2h_nsub(Bhi != nullptr, Kb))
+static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, const unsigned char* A2,
+                                        const unsigned char* B1, const unsigned char* Bhi, const unsigned int* hiflag,
+                                        const float* rscale, int Kb, float* C0, float* C1, float* C2, int ldc)
+{
+    if (Bhi) return launch_gemm2h_streamk_t<1, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc);
+    if (gemm2h_nsub(false, Kb) == 2)
+        return launch_gemm2h_streamk_t<2, false>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
+    return launch_gemm2h_streamk_t<1, false>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
+}
+
+// f16 planes of a packed factor (rows, K multiples of 64) from the sweep's row-maximum partials
+static hipError_t launch_split2h(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst, int TR,
+                                 const double* kscale, const float* rmax_part, int parts, float* inv_scale)
+{
+    dim3 grid(K / 64, rows / 64);
+    split2h_tiled_kernel<<<grid, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale, rmax_part, parts, inv_scale);
+    return hipGetLastError();
+}
+
+// row-maximum partials of rows the sweep has not produced (installed / moved slots): [rows][parts]
+static hipError_t launch_rowmax_part(hipStream_t st, const float* V, int ld, int L, int rows, int span,
+                                     const double* kscale, int parts, float* rmax_part)
+{
+    dim3 grid(parts, rows / 4);
+    rowmax_part_kernel<<<grid, 256, 0, st>>>(V, ld, L, span, kscale, parts, rmax_part);
+    return hipGetLastError();
+}
+
 // Examine the resident matrix once: is every column (integers <= 256) x one constant?  If so build the
 // integer planes of X and X^T and the per-gene scale (kernels_counts.hip.h).
 static int ensure_counts(cnmf_ctx* ctx)
 {
+    const int fmt = gemm3_mode() == 4 ? 4 : 3;      // plane format the current mode multiplies
+    if (ctx->count_state == 1 && ctx->count_fmt != fmt) {
+        // the mode was switched between two calls on the same matrix (tests, A/B runs): rebuild the planes
+        hipStreamSynchronize(ctx->stream);
+        hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
+        hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
+        ctx->C1 = ctx->Ct1 = ctx->C1h = ctx->Ct1h = nullptr; ctx->hiA = ctx->hiB = nullptr;
+        ctx->d_scale = nullptr; ctx->count_state = 0;
+    }
     if (ctx->count_state != 0) return CNMF_OK;
     ctx->count_state = -1;
+    ctx->count_fmt = fmt;
     const int N = (int)ctx->N, G = (int)ctx->G;
     if (ctx->N_pad % G3C_JW || ctx->G_pad % G3C_JW || getenv("CNMF_NO_COUNTS")) return CNMF_OK;
     hipStream_t st = ctx->stream;
@@ -325,7 +443,7 @@ static int ensure_counts(cnmf_ctx* ctx)
     // does any count exceed 256?  then a second plane (256 hi) with per-block flags rides along
     unsigned* any_big = pool.get<unsigned>(1, true, st);
     POOL_TRY(ctx, pool);
-    count_max_kernel<<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, unit, any_big);
+    count_max_base_kernel<<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, unit, fmt == 4 ? G2_COUNT_BASE : 256.0f, any_big);
     unsigned h_big = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&h_big, any_big, sizeof h_big, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -344,13 +462,22 @@ static int ensure_counts(cnmf_ctx* ctx)
     }
     {
         const long long total = (long long)ctx->N_pad * (ctx->G_pad / 16);
-        count_planes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
-            ctx->X, ctx->G_pad, N, G, ctx->N_pad, ctx->G_pad, G3C_JW, unit, (unsigned short*)ctx->C1,
-            (unsigned short*)ctx->C1h, ctx->hiA);
         dim3 gt((ctx->G_pad + 255) / 256, ctx->N_pad / 16);
-        count_planes_transpose_kernel<<<gt, 256, 0, st>>>(
-            ctx->X, ctx->G_pad, N, G, ctx->G_pad, ctx->N_pad, G3C_JW, unit, (unsigned short*)ctx->Ct1,
-            (unsigned short*)ctx->Ct1h, ctx->hiB);
+        if (fmt == 4) {
+            count_planes_f16_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+                ctx->X, ctx->G_pad, N, G, ctx->N_pad, ctx->G_pad, G3C_JW, unit, (unsigned short*)ctx->C1,
+                (unsigned short*)ctx->C1h, ctx->hiA);
+            count_planes_f16_transpose_kernel<<<gt, 256, 0, st>>>(
+                ctx->X, ctx->G_pad, N, G, ctx->G_pad, ctx->N_pad, G3C_JW, unit, (unsigned short*)ctx->Ct1,
+                (unsigned short*)ctx->Ct1h, ctx->hiB);
+        } else {
+            count_planes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+                ctx->X, ctx->G_pad, N, G, ctx->N_pad, ctx->G_pad, G3C_JW, unit, (unsigned short*)ctx->C1,
+                (unsigned short*)ctx->C1h, ctx->hiA);
+            count_planes_transpose_kernel<<<gt, 256, 0, st>>>(
+                ctx->X, ctx->G_pad, N, G, ctx->G_pad, ctx->N_pad, G3C_JW, unit, (unsigned short*)ctx->Ct1,
+                (unsigned short*)ctx->Ct1h, ctx->hiB);
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));                // the pool's scratch is freed on return
@@ -374,4 +501,14 @@ static int pick_nsplit3(const cnmf_ctx* ctx, int KC, int jw)
     int s = std::max(1, std::min(gemm3_wg_slots() / std::max(1, tiles), Kb / 16));
     const int kb_per = (Kb + s - 1) / s;
     return (Kb + kb_per - 1) / kb_per;
+}
+
+static hipError_t launch_split2h_finalize(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst,
+                                          int TR, const double* kscale, const float* rmax_part, int parts,
+                                          float* inv_scale, const FinalizeArgs& fa, int nslots, int fin_y)
+{
+    const int bx = K / 64, by = rows / 64;
+    split2h_finalize_kernel<<<bx * by + nslots * fin_y, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale,
+                                                                    rmax_part, parts, inv_scale, bx, by, fa, fin_y);
+    return hipGetLastError();
 }

@@ -1,0 +1,458 @@
+// Count-structured data on the f16 matrix pipe: 2 MFMAs per f32-class product (gfx950 only).
+//
+// kernels_counts.hip.h explains the structure X[i][g] = n[i][g] * d[g] (n integer).  gemm3c_* (kernels_gemm3.hip.h)
+// multiplies the integer plane (bf16: n <= 256 exact) with the factor's THREE bf16 planes: 3 MFMAs per product.
+// Here both operands are f16 (same MFMA rate as bf16, 11 significand bits instead of 8):
+//   * n <= 2048 is exact in ONE f16 plane (the second, flagged plane is needed only for counts > 2048: n = lo +
+//     2048 hi, hi <= 31);
+//   * the factor row  a[c][:]  is held as TWO f16 planes of  y = a * 2^s_c :  h = f16(y), m = f16(y - h).
+//     y - h is exact in f32 and has at most 13 significant bits, so  h + m = y  exactly for 3 values in 4 and
+//     |y - h - m| <= 1 ulp_f32(y) otherwise (when the 13th bit is set and the value is odd): the factor is
+//     represented to ~23.5 bits, every partial product (11 x 11 bits) is exact, accumulation is f32.
+//     s_c is a per-ROW exponent (max_j y = 2^14 .. 2^15, from the row maximum the sweep that produced the row
+//     reports), so f16's narrow exponent range costs nothing: entries down to 2^-14 of the row maximum keep all 22
+//     bits, smaller ones an ABSOLUTE error <= 2^-39 of the row maximum.  The product is scaled back by 2^-s_c
+//     (exact) when the tile is stored.
+//   => 2 MFMAs per product instead of 3, 24 KB instead of 32 KB of operands per 16-k block.
+//
+// Plane layouts, block-major like the bf16 ones ([row tile of 256][16-k block][row][...]), one (tile, block) = one
+// contiguous run = the LDS image the DMA writes:
+//   factor : 64 B per row and block = four 16-B slots  c = 2 q + hf  (q: 0 = h, 1 = m; hf = 8-k half), stored at
+//            slot  c ^ ((row >> 2) & 3)  -- a ds_read_b128 lane group (16 rows, one slot each) then covers all 16
+//            bank groups: conflict-free without padding;
+//   counts : 32 B per row and block = two slots, stored at  hf ^ ((row >> 3) & 1)  (same argument).
+// The kernel body is gemm3c's (256 x 256 tile, 8 waves in two groups half a block apart, 4 LDS-DMA images, counted
+// vmcnt, raw barriers) with NSUB 16-k sub-blocks per barrier pair: NSUB = 2 halves the number of barriers per flop.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels_gemm3.hip.h"
+
+namespace cnmf {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int G2_ROWB = 64;                        // factor bytes per row and 16-k block
+constexpr int G2_A = G3_MW * G2_ROWB;              // 16 384 B of factor planes per 16-k block
+constexpr int G2_B = G3C_JW * 32;                  //  8 192 B of one count plane per 16-k block
+constexpr float G2_COUNT_BASE = 2048.0f;           // lo plane holds n <= 2048, hi plane 2048 * hi (hi <= 31)
+
+constexpr int g2_imgs(int nsub) { return nsub == 1 ? 4 : 3; }
+constexpr int g2_img_bytes(int nsub, bool with_hi) { return nsub * (G2_A + (with_hi ? 2 : 1) * G2_B); }
+constexpr int g2_lds_bytes(int nsub, bool with_hi) { return g2_imgs(nsub) * g2_img_bytes(nsub, with_hi); }
+
+__device__ __forceinline__ unsigned short f16_bits(float x)
+{
+    const _Float16 h = (_Float16)x;                // v_cvt_f16_f32, round to nearest even
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float f16_to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+
+// exponent shift of a row whose largest entry is mx:  mx * 2^s in [2^14, 2^15)   (0 for an empty row)
+__device__ __forceinline__ int g2_row_shift(float mx)
+{
+    if (!(mx > 0.f)) return 0;
+    int e;
+    frexpf(mx, &e);                                // mx = f * 2^e, f in [0.5, 1)  ->  mx in [2^(e-1), 2^e)
+    const int s = 15 - e;
+    return s > 120 ? 120 : (s < -110 ? -110 : s);
+}
+
+// y -> (h, m)
+__device__ __forceinline__ void split2h(float y, unsigned short& h, unsigned short& m)
+{
+    h = f16_bits(y);
+    m = f16_bits(y - f16_to_f32(h));
+}
+
+// ---- planes of the packed factor, through LDS (64 rows x 64 k per workgroup, as split3_tiled_body).
+//   rmax_part [rows][parts] : per-row maxima of the values to convert (after kscale), one per sweep workgroup
+//   inv_scale [rows]        : 2^-s_c, written by the workgroups of the first k column (bx == 0)
+// `tile` = unsigned short [4][64][32] (16 KB), `red` = float [4][64]
+__device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src, int ld, int K, int TR,
+                                                   unsigned short* __restrict__ dst, const double* __restrict__ kscale,
+                                                   const float* __restrict__ rmax_part, int parts,
+                                                   float* __restrict__ inv_scale, int bx, int by,
+                                                   unsigned short (*tile)[64][32], float (*red)[64])
+{
+    const int t = threadIdx.x;
+    const int k0 = bx * 64, r0 = by * 64;
+    {
+        const int row = t & 63, qt = t >> 6;
+        float mx = 0.f;
+        for (int p = qt; p < parts; p += 4) mx = fmaxf(mx, rmax_part[(size_t)(r0 + row) * parts + p]);
+        red[qt][row] = mx;
+    }
+    __syncthreads();
+    const int kq = t & 15, rr = t >> 4;                  // float4 index along k, row within a pass of 16
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = rr + 16 * i;
+        const int sh = g2_row_shift(fmaxf(fmaxf(red[0][row], red[1][row]), fmaxf(red[2][row], red[3][row])));
+        if (bx == 0 && kq == 0) inv_scale[r0 + row] = ldexpf(1.0f, -sh);
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * ld + k0 + kq * 4);
+        float x[4] = {v.x, v.y, v.z, v.w};
+        if (kscale) {                                     // count-structured data: the per-gene scale rides on the factor
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = (float)((double)x[e] * kscale[k0 + kq * 4 + e]);
+        }
+        unsigned short p[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2h(ldexpf(x[e], sh), p[0][e], p[1][e]);
+        // 16-k block kq >> 2, 8-k half (kq >> 1) & 1, element offset (kq & 1) * 4 inside the slot
+        const int hf = (kq >> 1) & 1, swz = (row >> 2) & 3;       // (r0, TR multiples of 64: row bits 2..3 are local)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            uint2 w;
+            w.x = p[q][0] | ((unsigned)p[q][1] << 16); w.y = p[q][2] | ((unsigned)p[q][3] << 16);
+            *reinterpret_cast<uint2*>(&tile[kq >> 2][row][((2 * q + hf) ^ swz) * 8 + (kq & 1) * 4]) = w;
+        }
+    }
+    __syncthreads();
+    const int Kb = K / 16;
+    const int tr = r0 / TR, rin = r0 % TR;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        unsigned short* g = dst + (((size_t)tr * Kb + (k0 / 16 + b)) * TR + rin) * 32;
+        const u32x4* s4 = reinterpret_cast<const u32x4*>(&tile[b][0][0]);          // 64 rows x 64 B = 256 chunks
+        reinterpret_cast<u32x4*>(g)[t] = s4[t];
+    }
+}
+
+__global__ __launch_bounds__(256) void split2h_tiled_kernel(const float* __restrict__ src, int ld, int K, int TR,
+                                                            unsigned short* __restrict__ dst,
+                                                            const double* __restrict__ kscale,
+                                                            const float* __restrict__ rmax_part, int parts,
+                                                            float* __restrict__ inv_scale)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short tile[4][64][32];
+    __shared__ float red[4][64];
+    split2h_tiled_body(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, blockIdx.x, blockIdx.y, tile, red);
+}
+
+// per-row maxima of a packed factor in the partials layout the sweep writes ([rows][parts], part p = rows' columns
+// [p * span, (p+1) * span)): used for rows the sweep has not produced (freshly installed or moved slots).
+// grid = (parts, rows / 4): one wave per row and part.
+__global__ __launch_bounds__(256) void rowmax_part_kernel(const float* __restrict__ V, int ld, int L, int span,
+                                                          const double* __restrict__ kscale, int parts,
+                                                          float* __restrict__ rmax_part)
+{
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, p = blockIdx.x;
+    const int j0 = p * span, j1 = min(L, j0 + span);
+    float mx = 0.f;
+    for (int j = j0 + lane; j < j1; j += 64) {
+        float x = V[(size_t)row * ld + j];
+        if (kscale) x = (float)((double)x * kscale[j]);
+        mx = fmaxf(mx, x);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) rmax_part[(size_t)row * parts + p] = mx;
+}
+
+// ---- count planes in f16: [row tile][16-k block][row][16 f16], slots swapped for rows with bit 3 set
+__device__ __forceinline__ void count_lo_hi_2048(float n, float& lo, float& hi)
+{
+    if (n <= G2_COUNT_BASE) { lo = n; hi = 0.f; }
+    else { hi = floorf(n * (1.0f / G2_COUNT_BASE)); lo = n - G2_COUNT_BASE * hi; hi *= G2_COUNT_BASE; }
+}
+
+__device__ __forceinline__ void store_plane_row_swz(unsigned short* d, const unsigned short* p, int row_in_tile)
+{
+    const int swz = (row_in_tile >> 3) & 1;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        u32x4 w;
+        w.x = p[8 * hf + 0] | ((unsigned)p[8 * hf + 1] << 16); w.y = p[8 * hf + 2] | ((unsigned)p[8 * hf + 3] << 16);
+        w.z = p[8 * hf + 4] | ((unsigned)p[8 * hf + 5] << 16); w.w = p[8 * hf + 6] | ((unsigned)p[8 * hf + 7] << 16);
+        *reinterpret_cast<u32x4*>(d + (hf ^ swz) * 8) = w;
+    }
+}
+
+// rows = cells, k = genes (pass A's operand).  One thread per (row, block).
+__global__ __launch_bounds__(256) void count_planes_f16_kernel(const float* __restrict__ X, int ld, int N, int G,
+                                                               int rows_pad, int K, int TR,
+                                                               const float* __restrict__ unit,
+                                                               unsigned short* __restrict__ dst,
+                                                               unsigned short* __restrict__ dst_hi,
+                                                               unsigned int* __restrict__ hiflag)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int Kb = K / 16;
+    if (t >= (long long)rows_pad * Kb) return;
+    const int row = (int)(t / Kb), kb = (int)(t % Kb);
+    unsigned short p[16], ph[16];
+    bool any_hi = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int g = kb * 16 + i;
+        float n = 0.f, lo, hi;
+        if (row < N && g < G) { const float u = unit[g]; if (u > 0.f) n = rintf(X[(size_t)row * ld + g] / u); }
+        count_lo_hi_2048(n, lo, hi);
+        p[i] = f16_bits(lo); ph[i] = f16_bits(hi);           // both exact
+        any_hi |= hi != 0.f;
+    }
+    const size_t blk = (size_t)(row / TR) * Kb + kb;
+    store_plane_row_swz(dst + (blk * TR + (row % TR)) * 16, p, row % TR);
+    if (dst_hi) {
+        store_plane_row_swz(dst_hi + (blk * TR + (row % TR)) * 16, ph, row % TR);
+        if (any_hi) atomicOr(&hiflag[(size_t)(row / TR) * ((Kb + 31) / 32) + (kb >> 5)], 1u << (kb & 31));
+    }
+}
+
+// rows = genes, k = cells (pass B's operand).  One thread per (gene row j, block); lanes run along j.
+__global__ __launch_bounds__(256) void count_planes_f16_transpose_kernel(const float* __restrict__ X, int ld, int N, int G,
+                                                                         int rows_pad, int K, int TR,
+                                                                         const float* __restrict__ unit,
+                                                                         unsigned short* __restrict__ dst,
+                                                                         unsigned short* __restrict__ dst_hi,
+                                                                         unsigned int* __restrict__ hiflag)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int kb = blockIdx.y;
+    if (j >= rows_pad) return;
+    const int Kb = K / 16;
+    const float u = (j < G) ? unit[j] : 0.f;
+    unsigned short p[16], ph[16];
+    bool any_hi = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = kb * 16 + i;
+        float n = 0.f, lo, hi;
+        if (u > 0.f && c < N) n = rintf(X[(size_t)c * ld + j] / u);
+        count_lo_hi_2048(n, lo, hi);
+        p[i] = f16_bits(lo); ph[i] = f16_bits(hi);
+        any_hi |= hi != 0.f;
+    }
+    const size_t blk = (size_t)(j / TR) * Kb + kb;
+    store_plane_row_swz(dst + (blk * TR + (j % TR)) * 16, p, j % TR);
+    if (dst_hi) {
+        store_plane_row_swz(dst_hi + (blk * TR + (j % TR)) * 16, ph, j % TR);
+        if (any_hi) atomicOr(&hiflag[(size_t)(j / TR) * ((Kb + 31) / 32) + (kb >> 5)], 1u << (kb & 31));
+    }
+}
+
+// does any column need the second plane?  (max n > base)
+__global__ __launch_bounds__(256) void count_max_base_kernel(const float* __restrict__ X, int ld, int N, int G,
+                                                             const float* __restrict__ unit, float base,
+                                                             unsigned* __restrict__ any_big)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    const float u = unit[g];
+    if (u <= 0.f) return;
+    const int r0 = blockIdx.y * 256, r1 = min(N, r0 + 256);
+    bool big = false;
+    for (int r = r0; r < r1; ++r) big |= rintf(X[(size_t)r * ld + g] / u) > base;
+    if (big) atomicOr(any_big, 1u);
+}
+
+// ------------------------------------------------------------------------------------------
+// One K segment [kb0, kb0 + nkb) (in 16-k blocks; kb0 and nkb multiples of NSUB) of one 256 x 256 tile.
+//   A2 : f16 planes of the component-major factor (rows m0..), B1 : f16 count plane (rows j0..),
+//   Bhi / hiflag : second count plane and its per-(tile, block) flags (nullptr: none),
+//   rscale : 2^-s_c per component row, applied to the stored product.
+// Timeline exactly as gemm3c_segment, in units of "steps" of NSUB blocks.
+template <int NSUB, bool HI>
+__device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__ A2, const unsigned char* __restrict__ B1,
+                                               const unsigned char* __restrict__ Bhi,
+                                               const unsigned int* __restrict__ hiflag,
+                                               const float* __restrict__ rscale,
+                                               int Kb, float* __restrict__ C, int ldc, int m0, int j0, int kb0,
+                                               int nkb, unsigned char* smem)
+{
+    constexpr int IMGS = g2_imgs(NSUB);
+    constexpr int IMG = g2_img_bytes(NSUB, HI);
+    constexpr int OFF_B = NSUB * G2_A;                   // image: [A sub-blocks][B sub-blocks][hi sub-blocks]
+    constexpr int OFF_H = OFF_B + NSUB * G2_B;
+    constexpr int NA = NSUB * 2, NB = NSUB;              // DMA instructions per step and wave (8 KB each over the workgroup)
+    constexpr int NDMA = NA + NB;                        // minimum per step (flagged steps issue NB more)
+    const int tid = threadIdx.x;                         // 0..511
+    const int lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, h = lane >> 5;
+    const int nst = nkb / NSUB;                          // steps in this segment
+
+    const size_t jblk = ((size_t)(j0 / G3C_JW) * Kb + kb0);
+    const unsigned char* abase = A2 + ((size_t)(m0 / G3_MW) * Kb + kb0) * G2_A + tid * 16;
+    const unsigned char* bbase = B1 + jblk * G2_B + tid * 16;
+    const unsigned char* hbase = HI ? Bhi + jblk * G2_B + tid * 16 : nullptr;
+    // flag bits of blocks kb0 .. kb0 + nkb - 1 (at most 5 words for up to 129 blocks; longer segments: all set)
+    unsigned int fw[5] = {0u, 0u, 0u, 0u, 0u};
+    if (HI) {
+        const int KW = (Kb + 31) >> 5, w0 = kb0 >> 5;
+        const unsigned int* fr = hiflag + (size_t)(j0 / G3C_JW) * KW;
+#pragma unroll
+        for (int w = 0; w < 5; ++w)
+            fw[w] = (nkb > 129) ? 0xFFFFFFFFu : ((w0 + w < KW) ? __builtin_amdgcn_readfirstlane(fr[w0 + w]) : 0u);
+    }
+    const int fbit0 = kb0 & 31;
+
+    f32x16_3 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // fragment addresses inside an image: factor row (grp*128 + m*32 + li), slot (2q + h) ^ ((li >> 2) & 3);
+    // count row (wn*64 + n*32 + li), slot h ^ ((li >> 3) & 1)
+    const int a_row = (grp * 128 + li) * G2_ROWB;
+    const int a_s0 = ((0 + h) ^ ((li >> 2) & 3)) * 16, a_s1 = ((2 + h) ^ ((li >> 2) & 3)) * 16;
+    const int b_off = OFF_B + (wn * 64 + li) * 32 + (h ^ ((li >> 3) & 1)) * 16;
+
+#define G2_BLKFLAG(b_) (HI && ((fw[(fbit0 + (b_)) >> 5 > 4 ? 4 : (fbit0 + (b_)) >> 5] >> ((fbit0 + (b_)) & 31)) & 1u))
+#define G2_ISSUE(s_)                                                                               \
+    {                                                                                              \
+        unsigned char* d_ = smem + ((s_) % IMGS) * IMG + wave * 1024;                              \
+        const unsigned char* a_ = abase + (size_t)(s_) * (NSUB * G2_A);                            \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i)                                             \
+            __builtin_amdgcn_global_load_lds(G3_AS1(a_ + i * 8192), G3_AS3(d_ + i * 8192), 16, 0, 0); \
+        /* the count planes are read once per pass: non-temporal */                                \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                             \
+            __builtin_amdgcn_global_load_lds(G3_AS1(bbase + (size_t)(s_) * (NSUB * G2_B) + i * 8192), \
+                                             G3_AS3(d_ + OFF_B + i * 8192), 16, 0, 2);             \
+        if (HI) {                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i)                                         \
+                if (G2_BLKFLAG((s_) * NSUB + i))                                                   \
+                    __builtin_amdgcn_global_load_lds(G3_AS1(hbase + (size_t)(s_) * (NSUB * G2_B) + i * 8192), \
+                                                     G3_AS3(d_ + OFF_H + i * 8192), 16, 0, 2);     \
+        }                                                                                          \
+    }
+#define G2_FRAG(ptr_) __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ptr_))
+#define G2_READ(s_)                                                                                \
+    {                                                                                              \
+        const unsigned char* bb = smem + ((s_) % IMGS) * IMG;                                      \
+        _Pragma("unroll") for (int u = 0; u < NSUB; ++u) {                                         \
+            _Pragma("unroll") for (int n = 0; n < 2; ++n) bq[u][n] = G2_FRAG(bb + b_off + u * G2_B + n * 32 * 32); \
+            if (HI) { _Pragma("unroll") for (int n = 0; n < 2; ++n)                                \
+                          bh[u][n] = G2_FRAG(bb + b_off + NSUB * G2_B + u * G2_B + n * 32 * 32); } \
+            _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                        \
+                aq[u][m][0] = G2_FRAG(bb + u * G2_A + a_row + m * 32 * G2_ROWB + a_s0);            \
+                aq[u][m][1] = G2_FRAG(bb + u * G2_A + a_row + m * 32 * G2_ROWB + a_s1);            \
+            }                                                                                      \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+// two component tiles at a time, small plane first: consecutive MFMAs cycle through four accumulators
+#define G2_MFMA(b_, u_, m_, q_)                                                                    \
+    acc[m_][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[u_][m_][q_], b_[u_][0], acc[m_][0], 0, 0, 0); \
+    acc[m_][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[u_][m_][q_], b_[u_][1], acc[m_][1], 0, 0, 0);
+#define G2_MFMA4(b_, u_, ma_, mb_)                                                                 \
+    G2_MFMA(b_, u_, ma_, 1) G2_MFMA(b_, u_, mb_, 1) G2_MFMA(b_, u_, ma_, 0) G2_MFMA(b_, u_, mb_, 0)
+#define G2_HALF(ma_, mb_)                                                                          \
+    _Pragma("unroll") for (int u = 0; u < NSUB; ++u) {                                             \
+        G2_MFMA4(bq, u, ma_, mb_)                                                                  \
+        if (HI) { if (hi_blk[u]) { G2_MFMA4(bh, u, ma_, mb_) } }                                   \
+    }
+// "the step after this one has landed; the ones behind it may stay in flight"
+#define G2_WAIT_AHEAD(cnt_)                                                                        \
+    {                                                                                              \
+        if constexpr ((cnt_) * NDMA == 0) G3_WAIT_VM(0);                                           \
+        else if constexpr ((cnt_) * NDMA == 3) G3_WAIT_VM(3);                                      \
+        else if constexpr ((cnt_) * NDMA == 6) G3_WAIT_VM(6);                                      \
+        else if constexpr ((cnt_) * NDMA == 12) G3_WAIT_VM(12);                                    \
+        else G3_WAIT_VM(0);                                                                        \
+    }
+
+    f16x8 bq[NSUB][2], bh[NSUB][2], aq[NSUB][4][2];
+    constexpr int AHEAD = IMGS - 1;                      // steps requested ahead of the one being multiplied
+    G3_WAIT_VM(0);                                          // stores of a previous segment
+    G2_ISSUE(0)
+    if (nst > 1) G2_ISSUE(1)
+    if (AHEAD > 2 && nst > 2) G2_ISSUE(2)
+    // step 0 landed (everything issued after it may stay in flight)
+    if (AHEAD > 2 && nst > 2) G2_WAIT_AHEAD(2) else if (nst > 1) G2_WAIT_AHEAD(1) else G2_WAIT_AHEAD(0)
+    if (grp == 1) G3_RAW_BARRIER()
+    for (int s = 0; s < nst; ++s) {
+        bool hi_blk[NSUB];
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) hi_blk[u] = G2_BLKFLAG(s * NSUB + u);
+        G3_RAW_BARRIER()                                        // X_s
+        if (s + AHEAD < nst) G2_ISSUE(s + AHEAD)
+        G2_READ(s)
+        G2_HALF(0, 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this image is free once both groups pass here
+        // step s+1 must have landed before Y_s; later ones may stay in flight
+        if (s + 1 < nst) {
+            if (AHEAD > 2 && s + 3 < nst) G2_WAIT_AHEAD(2) else if (s + 2 < nst) G2_WAIT_AHEAD(1) else G2_WAIT_AHEAD(0)
+        }
+        G3_RAW_BARRIER()                                        // Y_s
+        G2_HALF(2, 3)
+    }
+    if (grp == 0) G3_RAW_BARRIER()
+#undef G2_WAIT_AHEAD
+#undef G2_HALF
+#undef G2_MFMA4
+#undef G2_MFMA
+#undef G2_READ
+#undef G2_FRAG
+#undef G2_ISSUE
+#undef G2_BLKFLAG
+
+    const int j = j0 + wn * 64 + li;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int cbase = m0 + grp * 128 + m * 32 + 4 * h;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = cbase + (r & 3) + 8 * (r >> 2);
+                C[(size_t)row * ldc + j + n * 32] = acc[m][n][r] * rscale[row];
+            }
+    }
+}
+
+// pass B (and pass A on few tiles): split-K launch, XCD-aware order as gemm3c_kernel.  kb_per is a multiple of NSUB.
+template <int NSUB, bool HI>
+__global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __restrict__ A2,
+                                                     const unsigned char* __restrict__ B1,
+                                                     const unsigned char* __restrict__ Bhi,
+                                                     const unsigned int* __restrict__ hiflag,
+                                                     const float* __restrict__ rscale, int Kb,
+                                                     float* __restrict__ C, int ldc, long long c_split_stride,
+                                                     int kb_per)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    int jt = blockIdx.x, z = blockIdx.z;
+    if (gridDim.y == 1 && (gridDim.z & 7) == 0) {
+        const int L = blockIdx.x + gridDim.x * blockIdx.z;
+        const int xcd = L & 7, idx = L >> 3;
+        z = xcd + 8 * (idx / (int)gridDim.x);
+        jt = idx % (int)gridDim.x;
+    }
+    const int kb0 = z * kb_per;
+    const int nkb = min(kb_per, Kb - kb0);
+    gemm2h_segment<NSUB, HI>(A2, B1, Bhi, hiflag, rscale, Kb, C + (size_t)z * c_split_stride, ldc, blockIdx.y * G3_MW,
+                             jt * G3C_JW, kb0, nkb, smem3);
+}
+
+// pass A: stream-K over persistent workgroups, unit = one step of NSUB blocks (Kb % NSUB == 0)
+template <int NSUB, bool HI>
+__global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char* __restrict__ A2,
+                                                             const unsigned char* __restrict__ B1,
+                                                             const unsigned char* __restrict__ Bhi,
+                                                             const unsigned int* __restrict__ hiflag,
+                                                             const float* __restrict__ rscale, int Kb,
+                                                             float* __restrict__ C0, float* __restrict__ C1,
+                                                             float* __restrict__ C2, int ldc, int MG, int T)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const int Ks = Kb / NSUB;                             // steps per tile
+    const long long U = (long long)T * Ks;
+    long long u = U * blockIdx.x / gridDim.x;
+    const long long u1 = U * (blockIdx.x + 1) / gridDim.x;
+    while (u < u1) {
+        const int tile = (int)(u / Ks), ks = (int)(u % Ks);
+        const int ke = (int)min((long long)Ks, ks + (u1 - u));
+        const int jt = tile / MG, mg = tile % MG;
+        gemm2h_segment<NSUB, HI>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
+                                 jt * G3C_JW, ks * NSUB, (ke - ks) * NSUB, smem3);
+        u += ke - ks;
+        G3_WAIT_VM(0);
+        __syncthreads();                 // the images are refilled by the next segment's DMA
+    }
+}
+
+}  // namespace cnmf

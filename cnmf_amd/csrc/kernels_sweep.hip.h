@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels_gemm.hip.h"
+#include "kernels_gemm2h.hip.h"
 
 namespace cnmf {
 
@@ -25,13 +26,13 @@ constexpr int GRAM_LD = KMAX;       // final gram matrices are stored [slot][64]
 constexpr int GRAM_SZ = KMAX * KMAX;
 
 // dynamic LDS of sweep_kernel for a batch whose largest rank is kmax:
-//   Gs [KG][KG+4] | vred [4] doubles | Ws [4][64][wstride]      (KG = 16 / 32 / 64)
+//   Gs [KG][KG+4] | vred [4] doubles | rmx [4][64] | Ws [4][64][wstride]      (KG = 16 / 32 / 64)
 static inline int sweep_kg(int kmax) { return kmax <= 16 ? 16 : (kmax <= 32 ? 32 : 64); }
 static inline int sweep_wstride(int kmax) { return sweep_kg(kmax) + 1; }
 static inline size_t sweep_lds_bytes(int kmax)
 {
     const int kg = sweep_kg(kmax);
-    return sizeof(float) * (size_t)(kg * (kg + 4) + 8 + 4 * 64 * sweep_wstride(kmax));
+    return sizeof(float) * (size_t)(kg * (kg + 4) + 8 + 256 + 4 * 64 * sweep_wstride(kmax));
 }
 
 struct SlotDesc {                   // one restart in flight (device + host mirror)
@@ -61,19 +62,26 @@ struct SplitInfo {                  // further partial planes of a stream-K prod
 //   KP <= 32 : v_mfma_f32_32x32x2_f32  (32 MFMAs of 64 cycles per 64 rows)
 //   KP <= 64 : 2 x 2 tiles of 32x32x2
 // Partials are written compactly: entry (r,c) at r*gld + c, gld = largest rank of the batch.
-template <int KP>
+// RMX: also report the largest updated entry per component (x rmax_scale[row]) EXACTLY, at the price of KP
+// registers (the H half-step: few rows).  Without it (the W half-step: keeps 5 waves per SIMD) the report is the
+// bound  sqrt(sum_rows w^2)  from the diagonal of the workgroup's Gram partial -- at most sqrt(rows per workgroup)
+// = 32 x the true maximum, which the f16 plane split tolerates (kernels_gemm2h.hip.h: 5 bits of exponent slack only
+// move the threshold below which tiny entries keep an absolute rather than a relative accuracy).
+template <int KP, bool RMX>
 __device__ __forceinline__ void sweep_body(
     float* __restrict__ V, int ldv, int L, const float* __restrict__ P, const SplitInfo& sp,
     const float* __restrict__ gram, const SlotDesc& sd, int slot, float l1_reg,
     float* __restrict__ gram_part, double* __restrict__ viol_part,
-    int chunks_per_block, int want_gram, float* lds, int kg, int gld)
+    int chunks_per_block, int want_gram, float* lds, int kg, int gld,
+    float* __restrict__ rmax_part, const double* __restrict__ rmax_scale)
 {
     constexpr int GMODE = (KP <= 16) ? 0 : ((KP <= 32) ? 1 : 2);
     constexpr int GR = (GMODE == 0) ? 16 : ((GMODE == 1) ? 32 : 64);       // gram tile edge
     const int gs = kg + 4, wstride = kg + 1;
     float* Gsb = lds;                                                     // [kg][kg+4]
     double* vred = reinterpret_cast<double*>(lds + kg * gs);
-    float* Wsb = lds + kg * gs + 8;
+    float* rmx = lds + kg * gs + 8;                                       // [4][64] per-wave row maxima
+    float* Wsb = rmx + 256;
 #define GS(t_, r_) Gsb[(t_) * gs + (r_)]
 #define WS(wv_, r_, c_) Wsb[((wv_) * 64 + (r_)) * wstride + (c_)]
     const int k = sd.k, off = sd.off;
@@ -91,6 +99,11 @@ __device__ __forceinline__ void sweep_body(
 #pragma unroll
         for (int r = 0; r < 16; ++r) gacc[a][r] = 0.f;
     float viol = 0.f;
+    // largest updated entry per component over this workgroup's rows (x the per-row scale of the f16 plane split,
+    // kernels_gemm2h.hip.h) -- only when the caller wants it
+    float mx[RMX ? KP : 1];
+#pragma unroll
+    for (int c = 0; c < (RMX ? KP : 1); ++c) mx[c] = 0.f;
 
     for (int ch = 0; ch < chunks_per_block; ++ch) {
         const int row = (blockIdx.x * chunks_per_block + ch) * 256 + tid;
@@ -168,6 +181,11 @@ __device__ __forceinline__ void sweep_body(
 #pragma unroll
             for (int c = 0; c < KP; ++c)
                 if (c < k) V[(size_t)(off + c) * ldv + row] = w[c];
+            if constexpr (RMX) {
+                const float dsc = rmax_scale ? (float)rmax_scale[row] : 1.0f;
+#pragma unroll
+                for (int c = 0; c < KP; ++c) mx[c] = fmaxf(mx[c], w[c] * dsc);
+            }
         }
         if (want_gram) {
             // Gram of the updated rows on the (otherwise idle) matrix pipe: acc += Wrows^T . Wrows
@@ -203,6 +221,16 @@ __device__ __forceinline__ void sweep_body(
         }
     }
 
+    // ---- row maxima: wave reduce -> LDS -> one partial per (component, workgroup)
+    if constexpr (RMX) {
+#pragma unroll
+        for (int c = 0; c < KP; ++c) {
+            float v = mx[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+            if (lane == 0) rmx[wave * 64 + c] = v;
+        }
+    }
     // ---- violation: wave reduce (double) -> block partial
     double dv = (double)viol;
 #pragma unroll
@@ -239,6 +267,13 @@ __device__ __forceinline__ void sweep_body(
     }
     if (tid == 0)
         viol_part[(size_t)slot * gridDim.x + blockIdx.x] = vred[0] + vred[1] + vred[2] + vred[3];
+    if (rmax_part && tid < k && (RMX || want_gram)) {
+        float v;
+        if constexpr (RMX) v = fmaxf(fmaxf(rmx[tid], rmx[64 + tid]), fmaxf(rmx[128 + tid], rmx[192 + tid]));
+        else v = sqrtf(gred[(0 * GR + tid) * (GR + 1) + tid] + gred[(1 * GR + tid) * (GR + 1) + tid] +
+                       gred[(2 * GR + tid) * (GR + 1) + tid] + gred[(3 * GR + tid) * (GR + 1) + tid]) * 1.0001f;
+        rmax_part[(size_t)(off + tid) * gridDim.x + blockIdx.x] = v;
+    }
 #undef WS
 #undef GS
 }
@@ -248,8 +283,9 @@ __device__ __forceinline__ void sweep_body(
 // TIER 0 handles ranks <= 16, TIER 1 ranks 17..32, TIER 2 ranks 33..64: one kernel for all ranks would
 // give the common small-rank case the register allocation of the largest (232 VGPR + 64 AGPR = one
 // wave per SIMD).  The host launches only the tiers present in the batch.
-template <int TIER>
-__global__ __launch_bounds__(256) void sweep_kernel(
+// (TIER 0 without the exact report is the W half-step of the common ranks: held to 5 waves per SIMD)
+template <int TIER, bool RMX = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 && !RMX) ? 5 : 1, 8))) void sweep_kernel(
     float* __restrict__ V, int ldv, int L,
     const float* __restrict__ P,             // [KC][ldv] products (split-K already reduced)
     SplitInfo sp,
@@ -258,15 +294,17 @@ __global__ __launch_bounds__(256) void sweep_kernel(
     float l1_reg,
     float* __restrict__ gram_part,           // [nslots][gridDim.x][32][32]
     double* __restrict__ viol_part,          // [nslots][gridDim.x]
-    int chunks_per_block, int want_gram, int kg, int gld)
+    int chunks_per_block, int want_gram, int kg, int gld,
+    float* __restrict__ rmax_part = nullptr,     // [KC][gridDim.x] largest updated entry per component and workgroup
+    const double* __restrict__ rmax_scale = nullptr)
 {
     const int slot = blockIdx.y;
     const SlotDesc sd = slots[slot];
     if (!sd.active) return;
     extern __shared__ __attribute__((aligned(16))) float sweep_lds[];
 #define CNMF_SW(KP_)                                                                              \
-        sweep_body<KP_>(V, ldv, L, P, sp, gram, sd, slot, l1_reg, gram_part, viol_part,           \
-                        chunks_per_block, want_gram, sweep_lds, kg, gld);
+        sweep_body<KP_, RMX>(V, ldv, L, P, sp, gram, sd, slot, l1_reg, gram_part, viol_part,      \
+                        chunks_per_block, want_gram, sweep_lds, kg, gld, rmax_part, rmax_scale);
     const int k = sd.k;
     if (TIER == 0) {
         if (k > 16) return;
@@ -439,6 +477,26 @@ __global__ __launch_bounds__(256) void split3_finalize_kernel(const float* __res
     if (b < nsplit) {
         split3_tiled_body(src, ld, K, TR, dst, kscale, b % split_bx, b / split_bx,
                           reinterpret_cast<unsigned short (*)[64][48]>(lds));
+    } else {
+        const int f = b - nsplit;
+        finalize_body(fa, f / fin_y, f % fin_y, reinterpret_cast<double*>(lds));
+    }
+}
+
+// The same for the f16 two-plane split (kernels_gemm2h.hip.h).
+__global__ __launch_bounds__(256) void split2h_finalize_kernel(const float* __restrict__ src, int ld, int K, int TR,
+                                                               unsigned short* __restrict__ dst,
+                                                               const double* __restrict__ kscale,
+                                                               const float* __restrict__ rmax_part, int parts,
+                                                               float* __restrict__ inv_scale, int split_bx,
+                                                               int split_by, FinalizeArgs fa, int fin_y)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 64 * 32 * 2 + 4 * 64 * 4];
+    const int b = blockIdx.x, nsplit = split_bx * split_by;
+    if (b < nsplit) {
+        split2h_tiled_body(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, b % split_bx, b / split_bx,
+                           reinterpret_cast<unsigned short (*)[64][32]>(lds),
+                           reinterpret_cast<float (*)[64]>(lds + 4 * 64 * 32 * 2));
     } else {
         const int f = b - nsplit;
         finalize_body(fa, f / fin_y, f % fin_y, reinterpret_cast<double*>(lds));

@@ -74,7 +74,7 @@ static void invalidate_planes(cnmf_ctx* ctx)
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     ctx->C1 = ctx->Ct1 = ctx->C1h = ctx->Ct1h = nullptr; ctx->hiA = ctx->hiB = nullptr;
-    ctx->d_scale = nullptr; ctx->count_state = 0;
+    ctx->d_scale = nullptr; ctx->count_state = 0; ctx->count_fmt = 0;
     ctx->spectra_rows = 0;
 }
 

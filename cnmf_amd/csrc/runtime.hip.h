@@ -22,6 +22,7 @@ struct cnmf_ctx {
     unsigned char *C1h = nullptr, *Ct1h = nullptr; // second planes (256 hi) when some count exceeds 256, else NULL
     unsigned int *hiA = nullptr, *hiB = nullptr;   // their flags: one bit per (tile row, block)
     double* d_scale = nullptr;                     // per-gene scale d [G_pad]
+    int count_fmt = 0;                             // 3 = bf16 planes (base 256), 4 = f16 planes (base 2048, swizzled slots)
 
     // batch buffers (sized for kc_alloc columns)
     int kc_alloc = 0, nsplit_alloc = 0, nsplitA_alloc = 0, parts_alloc = 0;
@@ -29,6 +30,8 @@ struct cnmf_ctx {
     float *H = nullptr, *Wt = nullptr, *XHt = nullptr, *XHt1 = nullptr, *XHt2 = nullptr, *XtW = nullptr;
     unsigned char *H3 = nullptr, *Wt3 = nullptr;   // planes of the packed factors, refreshed every iteration
     unsigned char* d_split = nullptr;   // stream-K cut flags of the current plan
+    // f16 two-plane factor split (kernels_gemm2h.hip.h): per-row maxima reported by the sweeps, 2^-s per row
+    float *rmaxH = nullptr, *rmaxW = nullptr, *iscaleH = nullptr, *iscaleW = nullptr;
     float *gramH = nullptr, *gramW = nullptr, *gram_part = nullptr;
     double* viol_part = nullptr;
     SlotDesc* d_slots = nullptr;
@@ -48,7 +51,7 @@ struct cnmf_ctx {
 
 static constexpr int RING = 8;
 #ifndef CNMF_GEMM3_DEFAULT
-#define CNMF_GEMM3_DEFAULT 3
+#define CNMF_GEMM3_DEFAULT 4
 #endif
 
 #define SET_ERR(ctx, ...)                                                   \

@@ -565,6 +565,19 @@ class Engine:
                                                 C.byref(ms), int(reps)))
         return Cout, ms.value
 
+    def debug_gemm2h(self, A, Bn, nsplit=1, nsub=2, reps=0):
+        """A [KC, K] . Bn [J, K]^T through the f16 two-plane count kernel (A >= 0, Bn: integers <= 65535);
+        returns (C, ms)."""
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        Bn = np.ascontiguousarray(Bn, dtype=np.float32)
+        KC, K = A.shape
+        J = Bn.shape[0]
+        Cout = np.empty((KC, J), dtype=np.float32)
+        ms = C.c_double(0.0)
+        self._check(self._lib.cnmf_debug_gemm2h(self._ctx, _fp(A), _fp(Bn), _fp(Cout), KC, K, J, int(nsplit),
+                                                int(nsub), C.byref(ms), int(reps)))
+        return Cout, ms.value
+
     def debug_standard_normal(self, seed, n):
         out = np.empty(max(n, 1), dtype=np.float64)
         self._check(self._lib.cnmf_debug_standard_normal(self._ctx, C.c_uint32(seed), n,

@@ -243,6 +243,11 @@ int cnmf_debug_gemm3(cnmf_ctx* ctx, const float* A, const float* B, float* C, in
  * A arbitrary float32 (three planes); 3 exact bf16 MFMAs per product on 256 x 256 tiles.           */
 int cnmf_debug_gemm3c(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, int KC, int K, int J,
                       int nsplit, double* ms_out, int reps);
+/* the same on the f16 matrix pipe (the default for count-structured data): Bn <= 2048 in ONE f16 plane (a
+ * flagged second plane above that), A >= 0 as TWO f16 planes with a per-row exponent; 2 MFMAs per product.
+ * KC % 256 == 0, K % 64 == 0; nsub = 16-k sub-blocks per barrier pair (1 | 2).                          */
+int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, int KC, int K, int J,
+                      int nsplit, int nsub, double* ms_out, int reps);
 /* numpy RandomState(seed).standard_normal(n) reproduced on the device. */
 int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t n, double* out);
 

@@ -136,15 +136,16 @@ def test_streamk_split_operand_path_at_scale(engine, monkeypatch):
         assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
     # the default: count structure detected (the synthetic matrix is counts / std) -> integer-plane kernels,
     # here with few 256-cell tiles (102 < 192: K split + reduce instead of stream-K)
-    monkeypatch.setenv("CNMF_GEMM3", "3")
-    Hc, _, nc, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
-    assert engine.last_stats["gemm_mode"] == 3
-    Hc2, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
-    assert all(np.array_equal(a, b) for a, b in zip(Hc, Hc2))
-    for r in (0, 14, 28):
-        H_ref, _, _ = sklearn_ref.nmf(X64, 9, seeds[r], max_iter=25)
-        maxabs, relfro = nmf_cd.spectra_error(H_ref, Hc[r])
-        assert maxabs <= 1e-4 and relfro <= 1e-3, (r, maxabs, relfro)
+    refs = {r: sklearn_ref.nmf(X64, 9, seeds[r], max_iter=25)[0] for r in (0, 14, 28)}
+    for mode in ("3", "4"):                               # three bf16 planes / two f16 planes (the default)
+        monkeypatch.setenv("CNMF_GEMM3", mode)
+        Hc, _, nc, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
+        assert engine.last_stats["gemm_mode"] == int(mode)
+        Hc2, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
+        assert all(np.array_equal(a, b) for a, b in zip(Hc, Hc2))
+        for r in (0, 14, 28):
+            maxabs, relfro = nmf_cd.spectra_error(refs[r], Hc[r])
+            assert maxabs <= 1e-4 and relfro <= 1e-3, (mode, r, maxabs, relfro)
 
 
 def test_C3_full_width_default_path_soak(engine):
@@ -159,7 +160,7 @@ def test_C3_full_width_default_path_soak(engine):
     runs = []
     for _ in range(3):
         H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=30, warn=False)
-        assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] == 3
+        assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] == 4
         runs.append(H)
     for other in runs[1:]:
         assert all(np.array_equal(a, b) for a, b in zip(runs[0], other))
@@ -177,7 +178,7 @@ def test_mid_size_job_is_promoted_to_the_count_kernels(engine):
     engine.set_matrix(X)
     ks, seeds = [9] * 12, list(range(21, 33))               # 108 columns
     H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
-    assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] == 3
+    assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] == 4
     H_ref, _, _ = sklearn_ref.nmf(X.astype(np.float64), 9, seeds[3], max_iter=25)
     maxabs, relfro = nmf_cd.spectra_error(H_ref, H[3])
     assert maxabs <= 1e-4 and relfro <= 1e-3, (maxabs, relfro)

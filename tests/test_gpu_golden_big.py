@@ -1,0 +1,112 @@
+"""FULL-SIZE parity against scikit-learn's own output (float64), committed as golden vectors.
+
+The float64 reference cannot run hundreds of outer iterations at 50 000 x 2000 inside the GPU box's time
+budget, so `tools/make_golden_big.py` ran it in the build container (unmodified scikit-learn 1.7.2 through
+`oracle/sklearn_ref.py`, the reference's own call, cnmf.py:672) and committed the spectra:
+
+* `tests/golden/ref_c3_long.npz` -- C3 (the bench shape), k = 5, 11, 13: ledger seeds whose runs need 421, 760
+  and 1000 outer iterations, i.e. the regime the benchmark spends its time in (k != K_true, long trajectories),
+  after exactly 150 iterations and at the stopping rule;
+* `tests/golden/ref_c4_csr.npz` -- C4 (200 000 x 2000 CSR), K = 20, two restarts x 10 iterations.
+
+The device runs them on the DEFAULT path inside a full 256-column batch that needs refills and repacking.
+No assertion here is conditional.
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from cnmf_amd import synth
+from cnmf_amd.cnmf import ledger_seeds
+from oracle import nmf_cd
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _fillers(n9=20, n13=5, n7=6, seed=77):
+    ks = [9] * n9 + [13] * n13 + [7] * n7
+    seeds = [int(s) for s in np.random.RandomState(seed).randint(1, 2 ** 31 - 1, size=len(ks))]
+    return ks, seeds
+
+
+def test_C3_long_restarts_vs_sklearn_golden(engine):
+    g = np.load(os.path.join(GOLD, "ref_c3_long.npz"))
+    X = synth.make_config("C3", dtype=np.float32)
+    X64 = X.astype(np.float64)
+    assert np.allclose([X64.sum(), (X64 * X64).sum()], g["x_checksum"], rtol=1e-12)      # the very same input
+    led = {(k, it): int(s) for k, it, s in ledger_seeds(list(range(5, 14)), 100, 14)}
+    ks3 = [5, 11, 13]
+    seeds3 = []
+    for k in ks3:
+        seed, it, n_full = (int(v) for v in g["k%d_seed" % k])
+        assert led[(k, it)] == seed and n_full >= 300          # a real ledger row of the north-star job, and a long one
+        seeds3.append(seed)
+    engine.set_matrix(X)
+    fk, fs = _fillers()
+    ks, seeds = ks3 + fk, seeds3 + fs                          # 29 + 287 = 316 columns > 256: queue + refill
+    # (a) the same truncations as the oracle: 50 and 150 outer iterations, 256 columns live, default (count) path.
+    #     k != K_true = 9 trajectories are ill-conditioned -- rounding-level perturbations are amplified with the
+    #     iteration count; the golden file records how far scikit-learn's OWN float32 path has drifted from its
+    #     float64 path on the same restart at the same truncation (k = 13 at 150 iterations: 8e-4 / 4e-4).  The
+    #     device must stay within the usual 1e-4 / 1e-3, or within 4 x that measured float32 drift where float32
+    #     itself cannot do better.
+    for T in (50, 150):
+        H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=T, warn=False)
+        st = engine.last_stats
+        assert st["kc"] == 256 and st["gemm_mode"] >= 3
+        for r, k in enumerate(ks3):
+            assert int(n_iter[r]) == T
+            dev = g["k%d_f32dev%d" % (k, T)]
+            maxabs, relfro = nmf_cd.spectra_error(g["k%d_H%d" % (k, T)], H[r])
+            assert maxabs <= max(1e-4, 4 * dev[0]) and relfro <= max(1e-3, 4 * dev[1]), (k, T, maxabs, relfro, dev)
+    # (b) to the stopping rule (tol 1e-4, max_iter 1000): iteration count, objective and spectra.  The OBJECTIVE is a
+    #     stable functional of the trajectory and is held tightly; the spectra of these long ill-conditioned runs to
+    #     5e-3 / 5e-3 (after 400-1000 iterations the float32 drift of (a) has grown accordingly; 2e-2 for the run that
+    #     stops at max_iter without converging) and the iteration count to 5 %.
+    H, W, n_iter, viol = engine.nmf_batch(ks, seeds=seeds, warn=False, return_W=True)
+    assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] >= 3
+    for r, k in enumerate(ks3):
+        n_full = int(g["k%d_seed" % k][2])
+        assert abs(int(n_iter[r]) - n_full) <= max(3, n_full // 20), (k, int(n_iter[r]), n_full)
+        obj = engine.prediction_error(W[r], H[r])
+        obj_ref = float(g["k%d_objfull" % k][0])
+        assert abs(obj - obj_ref) <= 2e-5 * obj_ref, (k, obj, obj_ref)
+        maxabs, relfro = nmf_cd.spectra_error(g["k%d_Hfull" % k], H[r])
+        lim = 5e-3 if n_full < 1000 else 2e-2          # (k = 13 has NOT converged at max_iter: a point on a moving path)
+        assert maxabs <= lim and relfro <= lim, (k, maxabs, relfro)
+        if n_full < 1000:
+            assert viol[r] <= 1e-4
+
+
+def _c4_matrix():
+    rs = np.random.RandomState(3)
+    X = sp.random(200_000, 2000, density=0.08, format="csr", dtype=np.float32, random_state=rs,
+                  data_rvs=lambda n: rs.gamma(1.0, 1.0, size=n).astype(np.float32))
+    return X[np.asarray(X.sum(axis=1)).ravel() > 0]
+
+
+def test_C4_csr_restarts_vs_sklearn_golden(engine):
+    g = np.load(os.path.join(GOLD, "ref_c4_csr.npz"))
+    X = _c4_matrix()
+    assert tuple(g["shape"]) == X.shape
+    assert abs(float(X.data.astype(np.float64).sum()) - float(g["x_checksum"][0])) <= 1e-9 * float(g["x_checksum"][0])
+    engine.set_matrix(X)                                       # CSR upload, densified on the device
+    # two restarts alone (exact-f32 pipe) ...
+    H, _, n_iter, _ = engine.nmf_batch([20, 20], seeds=[11, 12], max_iter=10, warn=False)
+    for r, seed in enumerate((11, 12)):
+        assert int(n_iter[r]) == 10
+        maxabs, relfro = nmf_cd.spectra_error(g["seed%d_H10" % seed], H[r])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (seed, maxabs, relfro)
+    # ... and inside a full-width batch (13 x 20 = 260 columns: 256-column split-operand kernels + one refill)
+    ks = [20] * 13
+    seeds = [11, 12] + list(range(201, 212))
+    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=10, warn=False)
+    assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] >= 2
+    for r, seed in enumerate((11, 12)):
+        assert int(n_iter[r]) == 10
+        maxabs, relfro = nmf_cd.spectra_error(g["seed%d_H10" % seed], H[r])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (seed, maxabs, relfro)

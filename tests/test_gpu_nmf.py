@@ -97,10 +97,42 @@ def test_count_path_gemm_is_exact_product_accurate(engine, big):
         assert np.array_equal(out, out2)
 
 
+@pytest.mark.parametrize("big", [False, True])
+@pytest.mark.parametrize("nsub", [1, 2])
+def test_f16_count_path_gemm_accuracy(engine, big, nsub):
+    """The default product for count-structured data (kernels_gemm2h.hip.h): B <= 2048 as ONE f16 plane (big: a few
+    entries up to 65 535 -> the flagged second plane), A >= 0 as TWO f16 planes with a per-row exponent.  The factor
+    is represented to within 1 ulp_f32 (exactly for 3 values in 4), every partial product is exact: held to the
+    same bounds as the three-plane bf16 product above, with rows whose scale differs by 2^+-40."""
+    rs = np.random.RandomState(13)
+    for K, J, ns in [(64, 40, 1), (128, 300, 1), (2048, 1000, 1), (4096, 520, 4), (2048, 130, 7), (4160, 300, 3)]:
+        A = np.abs(rs.standard_normal((256, K)) * np.exp(rs.standard_normal((256, K)))).astype(np.float32)
+        A[rs.rand(256, K) < 0.3] = 0.0                           # NMF factors are sparse
+        A *= np.exp2(rs.randint(-40, 41, size=(256, 1))).astype(np.float32)       # per-row exponents
+        A[5] = 0.0                                                # an empty row
+        B = rs.poisson(3.0, size=(J, K)).astype(np.float32)
+        B[0, :4] = [2048, 2047, 257, 0]
+        if big:
+            idx = rs.randint(0, J * K, size=max(3, J * K // 5000))
+            B.ravel()[idx] = rs.choice([2049, 3000, 4097, 65535, 63488], size=idx.size)
+        A64, B64 = A.astype(np.float64), B.astype(np.float64)
+        ref = A64 @ B64.T
+        out, _ = engine.debug_gemm2h(A, B, nsplit=ns, nsub=nsub)
+        rowmax = np.abs(ref).max(axis=1, keepdims=True)
+        rowmax[rowmax == 0] = 1.0
+        # the bound of the exact-f32 pipe (2e-6), here per output ROW (rows differ by 2^80 in scale)
+        assert (np.abs(out - ref) / rowmax).max() < 2e-6, (K, J, ns)
+        assert not out[5].any()
+        scale = np.maximum(A64 @ B64.T, 1e-300)
+        assert (np.abs(out - ref) / scale).max() < (2e-5 if big else 3e-6), (K, J, ns)
+        out2, _ = engine.debug_gemm2h(A, B, nsplit=ns, nsub=nsub)
+        assert np.array_equal(out, out2)
+
+
 def test_count_structure_is_detected_only_where_it_exists(engine):
-    """X = counts / std (cnmf.py:546) has the structure (gemm_mode 3), also with a few counts above 256 (second
-    plane); the same matrix with one entry nudged off the integer grid, or with a count above 65 535, does not
-    (general three-plane path, 2)."""
+    """X = counts / std (cnmf.py:546) has the structure (gemm_mode 4: f16 planes), also with a few counts above
+    2048 (second plane); the same matrix with one entry nudged off the integer grid, or with a count above 65 535,
+    does not (general three-plane path, 2)."""
     C, _ = synth.topic_counts(1024, 520, 6, 5.0, 0.3, 2)
     C = C[:, C.sum(axis=0) > 0]
     C = C[C.sum(axis=1) > 0]
@@ -112,8 +144,8 @@ def test_count_structure_is_detected_only_where_it_exists(engine):
         if tag == "nudged":
             i, g = np.argwhere(C > 0)[0]
             Xt[i, g] *= 1.37
-        if tag == "big":                                  # counts of 300, 700 and 2000 in three places
-            for (i, g, c) in ((3, 5, 300), (700, 400, 700), (11, 17, 2000)):
+        if tag == "big":                                  # counts of 300, 2500 and 5000 in three places
+            for (i, g, c) in ((3, 5, 300), (700, 400, 2500), (11, 17, 5000)):
                 Xt[i, g] = X[:, g][X[:, g] > 0].min() * c / C[:, g][C[:, g] > 0].min()
         if tag == "huge":
             Xt[3, 5] = X[:, 5][X[:, 5] > 0].min() * 70000
@@ -121,13 +153,13 @@ def test_count_structure_is_detected_only_where_it_exists(engine):
         H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=20, warn=False)
         assert engine.last_stats["kc"] == 256
         results[tag] = (engine.last_stats["gemm_mode"], H)
-    assert [results[t][0] for t in ("counts", "big", "nudged", "huge")] == [3, 3, 2, 2]
+    assert [results[t][0] for t in ("counts", "big", "nudged", "huge")] == [4, 4, 2, 2]
     # and the count path (with and without the second plane) computes the same factorisation as the exact-f32 pipe
     import os
     for tag in ("counts", "big"):
         Xt = X.copy()
         if tag == "big":
-            for (i, g, c) in ((3, 5, 300), (700, 400, 700), (11, 17, 2000)):
+            for (i, g, c) in ((3, 5, 300), (700, 400, 2500), (11, 17, 5000)):
                 Xt[i, g] = X[:, g][X[:, g] > 0].min() * c / C[:, g][C[:, g] > 0].min()
         os.environ["CNMF_GEMM3"] = "0"
         try:
@@ -140,11 +172,12 @@ def test_count_structure_is_detected_only_where_it_exists(engine):
             assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max()), tag
 
 
-@pytest.mark.parametrize("g3mode", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("g3mode", ["0", "1", "2", "3", "4"])
 def test_full_width_batch_matches_oracle_in_every_gemm_mode(engine, monkeypatch, g3mode):
     """256 packed columns (the width at which the split-operand GEMM takes over): every restart
     against its independent float64 oracle run, for the exact-f32 pipe (0), both general split-operand
-    variants (1, 2) and the count-structured path (3, the default).  Same tolerance in all four."""
+    variants (1, 2), the count-structured path on three bf16 planes (3) and on two f16 planes (4, the
+    default).  Same tolerance in all five."""
     monkeypatch.setenv("CNMF_GEMM3", g3mode)
     X64 = synth.make_config("C1", dtype=np.float64)
     engine.set_matrix(X64)
@@ -153,7 +186,7 @@ def test_full_width_batch_matches_oracle_in_every_gemm_mode(engine, monkeypatch,
     seeds = [int(s) for s in rs.randint(1, 2**31 - 1, size=44)]
     assert sum(ks) > 256
     H, _, n_iter, viol = engine.nmf_batch(ks, seeds=seeds)
-    assert engine.last_stats["kc"] == 256
+    assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] == min(int(g3mode), 4)
     for k, seed, h, n in list(zip(ks, seeds, H, n_iter))[::3]:
         _, H_ref, n_ref = nmf_cd.nmf(X64, k, seed=seed)
         _check(H_ref, n_ref, h, n, slack=3)

@@ -5,8 +5,10 @@ oracle runs here and its output is committed (`tests/golden/ref_c3_long.npz`, `r
 `tests/test_gpu_golden_big.py` regenerates the same seeded inputs on the GPU box and compares.
 
 C3 (north-star shape, 50 000 x 2000): for k = 5, 11, 13 the first ledger seed (cnmf.py:593-610, seed 14,
-K = 5..13, n_iter = 100) whose run needs >= 300 outer iterations: spectra after exactly 150 iterations
-(`max_iter=150`, the same truncation the device is asked for) and at convergence (tol 1e-4, max_iter 1000).
+K = 5..13, n_iter = 100) whose run needs >= 300 outer iterations: spectra after exactly 50 and 150 iterations
+(`max_iter`, the same truncation the device is asked for) and at the stopping rule (tol 1e-4, max_iter 1000), the
+final objective, and -- as calibration of what float32 can deliver on these ill-conditioned trajectories -- the
+drift of scikit-learn's own float32 path from its float64 path at the same truncations.
 C4 (200 000 x 2000 CSR, ~8 % dense, K = 20): two restarts x 10 outer iterations on the sparse input.
 
     python tools/make_golden_big.py        # ~15 min on 8 cores
@@ -36,7 +38,9 @@ def c4_matrix():
 
 
 def make_c3():
-    X = synth.make_config("C3", dtype=np.float32).astype(np.float64)
+    from oracle import nmf_cd
+    X32 = synth.make_config("C3", dtype=np.float32)
+    X = X32.astype(np.float64)
     led = sklearn_ref.ledger(list(range(5, 14)), 100, 14)
     out = {"x_checksum": np.array([X.sum(), (X * X).sum()])}
     for k in (5, 11, 13):
@@ -44,15 +48,25 @@ def make_c3():
             if kk != k:
                 continue
             t0 = time.time()
-            H_full, _, n_full = sklearn_ref.nmf(X, k, seed)
+            H_full, W_full, n_full = sklearn_ref.nmf(X, k, seed)
             print("C3 k=%d iter=%d seed=%d: n_iter=%d (%.0f s)" % (k, it, seed, n_full, time.time() - t0), flush=True)
-            if n_full >= 300:
-                H150, _, n150 = sklearn_ref.nmf(X, k, seed, max_iter=150)
-                assert n150 == 150
-                out["k%d_seed" % k] = np.array([seed, it, n_full], dtype=np.int64)
-                out["k%d_H150" % k] = H150.astype(np.float32)
-                out["k%d_Hfull" % k] = H_full.astype(np.float32)
-                break
+            if n_full < 300:
+                continue
+            out["k%d_seed" % k] = np.array([seed, it, n_full], dtype=np.int64)
+            out["k%d_Hfull" % k] = H_full.astype(np.float32)
+            out["k%d_objfull" % k] = np.array([((X - W_full @ H_full) ** 2).sum()])
+            for T in (50, 150):
+                H64, _, n = sklearn_ref.nmf(X, k, seed, max_iter=T)
+                assert n == T
+                out["k%d_H%d" % (k, T)] = H64.astype(np.float32)
+                # calibration: how far scikit-learn's OWN float32 path drifts from its float64 path on this
+                # restart at the same truncation (k != K_true = 9 trajectories are ill-conditioned: rounding-level
+                # perturbations are amplified) -- the device is held to a small multiple of this
+                H32, _, _ = sklearn_ref.nmf(X32, k, seed, max_iter=T)
+                dev = nmf_cd.spectra_error(H64, H32)
+                out["k%d_f32dev%d" % (k, T)] = np.array(dev)
+                print("   T=%d sklearn float32 vs float64: maxabs %.2e relfro %.2e" % (T, dev[0], dev[1]), flush=True)
+            break
     np.savez_compressed(os.path.join(OUT, "ref_c3_long.npz"), **out)
 
 
