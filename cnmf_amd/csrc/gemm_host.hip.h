@@ -309,8 +309,18 @@ static int g2_nsub()
     static const int v = getenv("CNMF_G2_NSUB") ? atoi(getenv("CNMF_G2_NSUB")) : 2;
     return v == 1 ? 1 : 2;
 }
+// instruction-stream variant of the NSUB = 2 kernels (kernels_gemm2h.hip.h): bit 0 = DMA pieces spread through the
+// MFMA stream, bit 1 = s_setprio around the MFMA halves
+#ifndef CNMF_G2_VAR_DEFAULT
+#define CNMF_G2_VAR_DEFAULT 1
+#endif
+static int g2_var()
+{
+    static const int v = getenv("CNMF_G2_VAR") ? atoi(getenv("CNMF_G2_VAR")) : CNMF_G2_VAR_DEFAULT;
+    return v & 3;
+}
 
-template <int NSUB, bool HI>
+template <int NSUB, bool HI, int VAR = 0>
 static hipError_t launch_gemm2h_t(hipStream_t st, const unsigned char* A2, const unsigned char* B1,
                                   const unsigned char* Bhi, const unsigned int* hiflag, const float* rscale, int Kb,
                                   float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
@@ -318,13 +328,13 @@ static hipError_t launch_gemm2h_t(hipStream_t st, const unsigned char* A2, const
     static bool attr_set = false;
     constexpr int lds = g2_lds_bytes(NSUB, HI);
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm2h_kernel<NSUB, HI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)gemm2h_kernel<NSUB, HI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     int kb_per = (Kb + nsplit - 1) / nsplit;
     kb_per = ((kb_per + NSUB - 1) / NSUB) * NSUB;            // whole steps
     dim3 grid(Jpad / G3C_JW, KC / G3_MW, (Kb + kb_per - 1) / kb_per);
-    gemm2h_kernel<NSUB, HI><<<grid, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, kb_per);
+    gemm2h_kernel<NSUB, HI, VAR><<<grid, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, kb_per);
     return hipGetLastError();
 }
 
@@ -341,13 +351,19 @@ static hipError_t launch_gemm2h(hipStream_t st, const unsigned char* A2, const u
                                 float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
 {
     if (Bhi) return launch_gemm2h_t<1, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
-    if (g2_nsub() == 2 && Kb % 2 == 0)
-        return launch_gemm2h_t<2, false>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
+    if (g2_nsub() == 2 && Kb % 2 == 0) {
+        switch (g2_var()) {
+            case 1: return launch_gemm2h_t<2, false, 1>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
+            case 2: return launch_gemm2h_t<2, false, 2>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
+            case 3: return launch_gemm2h_t<2, false, 3>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
+            default: return launch_gemm2h_t<2, false, 0>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
+        }
+    }
     return launch_gemm2h_t<1, false>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
 }
 static int gemm2h_nsub(bool hi, int Kb) { return (!hi && g2_nsub() == 2 && Kb % 2 == 0) ? 2 : 1; }
 
-template <int NSUB, bool HI>
+template <int NSUB, bool HI, int VAR = 0>
 static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, const unsigned char* A2,
                                           const unsigned char* B1, const unsigned char* Bhi,
                                           const unsigned int* hiflag, const float* rscale, int Kb, float* C0, float* C1,
@@ -356,10 +372,10 @@ static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, co
     static bool attr_set = false;
     constexpr int lds = g2_lds_bytes(NSUB, HI);
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm2h_streamk_kernel<NSUB, HI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)gemm2h_streamk_kernel<NSUB, HI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    gemm2h_streamk_kernel<NSUB, HI><<<sk.P, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T);
+    gemm2h_streamk_kernel<NSUB, HI, VAR><<<sk.P, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T);
     return hipGetLastError();
 }
 
@@ -369,16 +385,32 @@ static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, cons
                                         const float* rscale, int Kb, float* C0, float* C1, float* C2, int ldc)
 {
     if (Bhi) return launch_gemm2h_streamk_t<1, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc);
-    if (gemm2h_nsub(false, Kb) == 2)
-        return launch_gemm2h_streamk_t<2, false>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
+    if (gemm2h_nsub(false, Kb) == 2) {
+        switch (g2_var()) {
+            case 1: return launch_gemm2h_streamk_t<2, false, 1>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
+            case 2: return launch_gemm2h_streamk_t<2, false, 2>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
+            case 3: return launch_gemm2h_streamk_t<2, false, 3>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
+            default: return launch_gemm2h_streamk_t<2, false, 0>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
+        }
+    }
     return launch_gemm2h_streamk_t<1, false>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
+}
+
+// column groups of the split launch: every workgroup (64 rows) walks its k tiles with stride `groups`, so that all
+// workgroups are resident at once (<= 8 per CU) and the row scale is reduced once per workgroup
+static int split2h_col_groups(int K, int rows)
+{
+    const int tiles = K / 64, rg = std::max(1, rows / 64);
+    const int cap = std::max(1, (256 * 7) / rg);
+    int per = (tiles + cap - 1) / cap;                     // k tiles per workgroup
+    return (tiles + per - 1) / per;
 }
 
 // f16 planes of a packed factor (rows, K multiples of 64) from the sweep's row-maximum partials
 static hipError_t launch_split2h(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst, int TR,
                                  const double* kscale, const float* rmax_part, int parts, float* inv_scale)
 {
-    dim3 grid(K / 64, rows / 64);
+    dim3 grid(split2h_col_groups(K, rows), rows / 64);
     split2h_tiled_kernel<<<grid, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale, rmax_part, parts, inv_scale);
     return hipGetLastError();
 }
@@ -507,7 +539,7 @@ static hipError_t launch_split2h_finalize(hipStream_t st, const float* src, int 
                                           int TR, const double* kscale, const float* rmax_part, int parts,
                                           float* inv_scale, const FinalizeArgs& fa, int nslots, int fin_y)
 {
-    const int bx = K / 64, by = rows / 64;
+    const int bx = split2h_col_groups(K, rows), by = rows / 64;
     split2h_finalize_kernel<<<bx * by + nslots * fin_y, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale,
                                                                     rmax_part, parts, inv_scale, bx, by, fa, fin_y);
     return hipGetLastError();

@@ -71,11 +71,11 @@ __device__ __forceinline__ void split2h(float y, unsigned short& h, unsigned sho
 __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src, int ld, int K, int TR,
                                                    unsigned short* __restrict__ dst, const double* __restrict__ kscale,
                                                    const float* __restrict__ rmax_part, int parts,
-                                                   float* __restrict__ inv_scale, int bx, int by,
+                                                   float* __restrict__ inv_scale, int bx, int nbx, int by,
                                                    unsigned short (*tile)[64][32], float (*red)[64])
 {
     const int t = threadIdx.x;
-    const int k0 = bx * 64, r0 = by * 64;
+    const int r0 = by * 64;
     {
         const int row = t & 63, qt = t >> 6;
         float mx = 0.f;
@@ -84,37 +84,47 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
     }
     __syncthreads();
     const int kq = t & 15, rr = t >> 4;                  // float4 index along k, row within a pass of 16
+    int sh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = rr + 16 * i;
-        const int sh = g2_row_shift(fmaxf(fmaxf(red[0][row], red[1][row]), fmaxf(red[2][row], red[3][row])));
-        if (bx == 0 && kq == 0) inv_scale[r0 + row] = ldexpf(1.0f, -sh);
-        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * ld + k0 + kq * 4);
-        float x[4] = {v.x, v.y, v.z, v.w};
-        if (kscale) {                                     // count-structured data: the per-gene scale rides on the factor
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = (float)((double)x[e] * kscale[k0 + kq * 4 + e]);
-        }
-        unsigned short p[2][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split2h(ldexpf(x[e], sh), p[0][e], p[1][e]);
-        // 16-k block kq >> 2, 8-k half (kq >> 1) & 1, element offset (kq & 1) * 4 inside the slot
-        const int hf = (kq >> 1) & 1, swz = (row >> 2) & 3;       // (r0, TR multiples of 64: row bits 2..3 are local)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            uint2 w;
-            w.x = p[q][0] | ((unsigned)p[q][1] << 16); w.y = p[q][2] | ((unsigned)p[q][3] << 16);
-            *reinterpret_cast<uint2*>(&tile[kq >> 2][row][((2 * q + hf) ^ swz) * 8 + (kq & 1) * 4]) = w;
-        }
+        sh[i] = g2_row_shift(fmaxf(fmaxf(red[0][row], red[1][row]), fmaxf(red[2][row], red[3][row])));
+        if (bx == 0 && kq == 0) inv_scale[r0 + row] = ldexpf(1.0f, -sh[i]);
     }
-    __syncthreads();
     const int Kb = K / 16;
     const int tr = r0 / TR, rin = r0 % TR;
+    // the workgroup converts the k tiles bx, bx + nbx, ... of its 64 rows (the row scale is computed once)
+    for (int kt = bx; kt < K / 64; kt += nbx) {
+        const int k0 = kt * 64;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        unsigned short* g = dst + (((size_t)tr * Kb + (k0 / 16 + b)) * TR + rin) * 32;
-        const u32x4* s4 = reinterpret_cast<const u32x4*>(&tile[b][0][0]);          // 64 rows x 64 B = 256 chunks
-        reinterpret_cast<u32x4*>(g)[t] = s4[t];
+        for (int i = 0; i < 4; ++i) {
+            const int row = rr + 16 * i;
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * ld + k0 + kq * 4);
+            float x[4] = {v.x, v.y, v.z, v.w};
+            if (kscale) {                                 // count-structured data: the per-gene scale rides on the factor
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = (float)((double)x[e] * kscale[k0 + kq * 4 + e]);
+            }
+            unsigned short p[2][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2h(ldexpf(x[e], sh[i]), p[0][e], p[1][e]);
+            // 16-k block kq >> 2, 8-k half (kq >> 1) & 1, element offset (kq & 1) * 4 inside the slot
+            const int hf = (kq >> 1) & 1, swz = (row >> 2) & 3;   // (r0, TR multiples of 64: row bits 2..3 are local)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                uint2 w;
+                w.x = p[q][0] | ((unsigned)p[q][1] << 16); w.y = p[q][2] | ((unsigned)p[q][3] << 16);
+                *reinterpret_cast<uint2*>(&tile[kq >> 2][row][((2 * q + hf) ^ swz) * 8 + (kq & 1) * 4]) = w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            unsigned short* g = dst + (((size_t)tr * Kb + (k0 / 16 + b)) * TR + rin) * 32;
+            const u32x4* s4 = reinterpret_cast<const u32x4*>(&tile[b][0][0]);      // 64 rows x 64 B = 256 chunks
+            reinterpret_cast<u32x4*>(g)[t] = s4[t];
+        }
+        __syncthreads();
     }
 }
 
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(256) void split2h_tiled_kernel(const float* __restr
 {
     __shared__ __attribute__((aligned(16))) unsigned short tile[4][64][32];
     __shared__ float red[4][64];
-    split2h_tiled_body(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, blockIdx.x, blockIdx.y, tile, red);
+    split2h_tiled_body(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, blockIdx.x, gridDim.x, blockIdx.y, tile, red);
 }
 
 // per-row maxima of a packed factor in the partials layout the sweep writes ([rows][parts], part p = rows' columns
@@ -252,7 +262,12 @@ __global__ __launch_bounds__(256) void count_max_base_kernel(const float* __rest
 //   Bhi / hiflag : second count plane and its per-(tile, block) flags (nullptr: none),
 //   rscale : 2^-s_c per component row, applied to the stored product.
 // Timeline exactly as gemm3c_segment, in units of "steps" of NSUB blocks.
-template <int NSUB, bool HI>
+// VAR (A/B knobs of the instruction stream; NSUB = 2 without a second count plane only):
+//   bit 0: the six LDS-DMA pieces of a step are spread through the MFMA stream (one after every 4th MFMA of the step's
+//          first 24) instead of issued in one burst behind the X barrier -- a burst of DMA issues in front of 20
+//          ds_read_b128 is the expensive place for them (MI355X_MICROARCH.md, "LDS-DMA piece issue cost");
+//   bit 1: s_setprio(1) around the MFMA halves.
+template <int NSUB, bool HI, int VAR = 0>
 __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__ A2, const unsigned char* __restrict__ B1,
                                                const unsigned char* __restrict__ Bhi,
                                                const unsigned int* __restrict__ hiflag,
@@ -357,6 +372,8 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
 
     f16x8 bq[NSUB][2], bh[NSUB][2], aq[NSUB][4][2];
     constexpr int AHEAD = IMGS - 1;                      // steps requested ahead of the one being multiplied
+    constexpr bool SPREAD = (VAR & 1) && NSUB == 2 && !HI;
+    constexpr bool PRIO = (VAR & 2) != 0;
     G3_WAIT_VM(0);                                          // stores of a previous segment
     G2_ISSUE(0)
     if (nst > 1) G2_ISSUE(1)
@@ -364,21 +381,68 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
     // step 0 landed (everything issued after it may stay in flight)
     if (AHEAD > 2 && nst > 2) G2_WAIT_AHEAD(2) else if (nst > 1) G2_WAIT_AHEAD(1) else G2_WAIT_AHEAD(0)
     if (grp == 1) G3_RAW_BARRIER()
-    for (int s = 0; s < nst; ++s) {
-        bool hi_blk[NSUB];
+    if constexpr (!SPREAD) {
+        for (int s = 0; s < nst; ++s) {
+            bool hi_blk[NSUB];
 #pragma unroll
-        for (int u = 0; u < NSUB; ++u) hi_blk[u] = G2_BLKFLAG(s * NSUB + u);
-        G3_RAW_BARRIER()                                        // X_s
-        if (s + AHEAD < nst) G2_ISSUE(s + AHEAD)
-        G2_READ(s)
-        G2_HALF(0, 1)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this image is free once both groups pass here
-        // step s+1 must have landed before Y_s; later ones may stay in flight
-        if (s + 1 < nst) {
-            if (AHEAD > 2 && s + 3 < nst) G2_WAIT_AHEAD(2) else if (s + 2 < nst) G2_WAIT_AHEAD(1) else G2_WAIT_AHEAD(0)
+            for (int u = 0; u < NSUB; ++u) hi_blk[u] = G2_BLKFLAG(s * NSUB + u);
+            G3_RAW_BARRIER()                                        // X_s
+            if (s + AHEAD < nst) G2_ISSUE(s + AHEAD)
+            G2_READ(s)
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            G2_HALF(0, 1)
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this image is free once both groups pass here
+            // step s+1 must have landed before Y_s; later ones may stay in flight
+            if (s + 1 < nst) {
+                if (AHEAD > 2 && s + 3 < nst) G2_WAIT_AHEAD(2) else if (s + 2 < nst) G2_WAIT_AHEAD(1) else G2_WAIT_AHEAD(0)
+            }
+            G3_RAW_BARRIER()                                        // Y_s
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            G2_HALF(2, 3)
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
         }
-        G3_RAW_BARRIER()                                        // Y_s
-        G2_HALF(2, 3)
+    } else {
+        // NSUB = 2, six pieces per step (A 0..3, B 4..5): pieces 0-2 ride in the first half, 3-5 in the second
+#define G2_PIECE(s_, i_)                                                                           \
+        {                                                                                          \
+            unsigned char* d_ = smem + ((s_) % IMGS) * IMG + wave * 1024;                          \
+            if ((i_) < NA)                                                                         \
+                __builtin_amdgcn_global_load_lds(G3_AS1(abase + (size_t)(s_) * (NSUB * G2_A) + (i_) * 8192), \
+                                                 G3_AS3(d_ + (i_) * 8192), 16, 0, 0);              \
+            else                                                                                   \
+                __builtin_amdgcn_global_load_lds(G3_AS1(bbase + (size_t)(s_) * (NSUB * G2_B) + ((i_) - NA) * 8192), \
+                                                 G3_AS3(d_ + OFF_B + ((i_) - NA) * 8192), 16, 0, 2); \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }
+        for (int s = 0; s < nst; ++s) {
+            const bool more = s + AHEAD < nst;
+            G3_RAW_BARRIER()                                        // X_s
+            G2_READ(s)
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            G2_MFMA(bq, 0, 0, 1) G2_MFMA(bq, 0, 1, 1)
+            if (more) G2_PIECE(s + AHEAD, 0)
+            G2_MFMA(bq, 0, 0, 0) G2_MFMA(bq, 0, 1, 0)
+            if (more) G2_PIECE(s + AHEAD, 1)
+            G2_MFMA(bq, 1, 0, 1) G2_MFMA(bq, 1, 1, 1)
+            if (more) G2_PIECE(s + AHEAD, 2)
+            G2_MFMA(bq, 1, 0, 0) G2_MFMA(bq, 1, 1, 0)
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // step s+1 must have landed before Y_s; the three pieces of step s+2 just issued may stay in flight
+            if (s + 1 < nst) { if (more) G3_WAIT_VM(3); else G3_WAIT_VM(0); }
+            G3_RAW_BARRIER()                                        // Y_s
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            G2_MFMA(bq, 0, 2, 1) G2_MFMA(bq, 0, 3, 1)
+            if (more) G2_PIECE(s + AHEAD, 3)
+            G2_MFMA(bq, 0, 2, 0) G2_MFMA(bq, 0, 3, 0)
+            if (more) G2_PIECE(s + AHEAD, 4)
+            G2_MFMA(bq, 1, 2, 1) G2_MFMA(bq, 1, 3, 1)
+            if (more) G2_PIECE(s + AHEAD, 5)
+            G2_MFMA(bq, 1, 2, 0) G2_MFMA(bq, 1, 3, 0)
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+        }
+#undef G2_PIECE
     }
     if (grp == 0) G3_RAW_BARRIER()
 #undef G2_WAIT_AHEAD
@@ -405,7 +469,7 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
 }
 
 // pass B (and pass A on few tiles): split-K launch, XCD-aware order as gemm3c_kernel.  kb_per is a multiple of NSUB.
-template <int NSUB, bool HI>
+template <int NSUB, bool HI, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __restrict__ A2,
                                                      const unsigned char* __restrict__ B1,
                                                      const unsigned char* __restrict__ Bhi,
@@ -424,12 +488,12 @@ __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __rest
     }
     const int kb0 = z * kb_per;
     const int nkb = min(kb_per, Kb - kb0);
-    gemm2h_segment<NSUB, HI>(A2, B1, Bhi, hiflag, rscale, Kb, C + (size_t)z * c_split_stride, ldc, blockIdx.y * G3_MW,
-                             jt * G3C_JW, kb0, nkb, smem3);
+    gemm2h_segment<NSUB, HI, VAR>(A2, B1, Bhi, hiflag, rscale, Kb, C + (size_t)z * c_split_stride, ldc, blockIdx.y * G3_MW,
+                                  jt * G3C_JW, kb0, nkb, smem3);
 }
 
 // pass A: stream-K over persistent workgroups, unit = one step of NSUB blocks (Kb % NSUB == 0)
-template <int NSUB, bool HI>
+template <int NSUB, bool HI, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char* __restrict__ A2,
                                                              const unsigned char* __restrict__ B1,
                                                              const unsigned char* __restrict__ Bhi,
@@ -447,8 +511,8 @@ __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char
         const int tile = (int)(u / Ks), ks = (int)(u % Ks);
         const int ke = (int)min((long long)Ks, ks + (u1 - u));
         const int jt = tile / MG, mg = tile % MG;
-        gemm2h_segment<NSUB, HI>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
-                                 jt * G3C_JW, ks * NSUB, (ke - ks) * NSUB, smem3);
+        gemm2h_segment<NSUB, HI, VAR>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
+                                      jt * G3C_JW, ks * NSUB, (ke - ks) * NSUB, smem3);
         u += ke - ks;
         G3_WAIT_VM(0);
         __syncthreads();                 // the images are refilled by the next segment's DMA

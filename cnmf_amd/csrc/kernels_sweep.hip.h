@@ -121,6 +121,8 @@ __device__ __forceinline__ void sweep_body(
             cut1 = sp.split[rt * sp.mgroups + g1];
         }
         float w[KP], p[KP];
+        float dsc = 1.0f;                          // per-row scale of the exact row-maximum report (issued with the loads)
+        if constexpr (RMX) { if (rmax_scale) dsc = (float)rmax_scale[min(row, L - 1)]; }
         {
             // branch-free load phase: every lane issues all 2*KP (3*KP) loads back to back with
             // clamped (always valid) addresses; the values of dead lanes / columns >= k are
@@ -182,7 +184,6 @@ __device__ __forceinline__ void sweep_body(
             for (int c = 0; c < KP; ++c)
                 if (c < k) V[(size_t)(off + c) * ldv + row] = w[c];
             if constexpr (RMX) {
-                const float dsc = rmax_scale ? (float)rmax_scale[row] : 1.0f;
 #pragma unroll
                 for (int c = 0; c < KP; ++c) mx[c] = fmaxf(mx[c], w[c] * dsc);
             }
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256) void split2h_finalize_kernel(const float* __re
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 64 * 32 * 2 + 4 * 64 * 4];
     const int b = blockIdx.x, nsplit = split_bx * split_by;
     if (b < nsplit) {
-        split2h_tiled_body(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, b % split_bx, b / split_bx,
+        split2h_tiled_body(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, b % split_bx, split_bx, b / split_bx,
                            reinterpret_cast<unsigned short (*)[64][32]>(lds),
                            reinterpret_cast<float (*)[64]>(lds + 4 * 64 * 32 * 2));
     } else {
