@@ -129,6 +129,8 @@ class cNMF:
                 "nmf_run_parameters": t(".nmf_idvrun_params.yaml"),
                 "nmf_genes_list": o(".overdispersed_genes.txt"),
                 "tpm": t(".tpm.df.npz"),
+                "tpm_sparse": t(".tpm.csr.npz"),              # scipy CSR stand-in for a sparse tpm.h5ad (cnmf.py:303)
+                "tpm_sparse_genes": t(".tpm.csr.genes.txt"),
                 "tpm_stats": t(".tpm_stats.df.npz"),
                 "iter_spectra": t(".spectra.k_%d.iter_%d.df.npz"),
                 "iter_usages": t(".usages.k_%d.iter_%d.df.npz"),
@@ -252,7 +254,24 @@ class cNMF:
         save_df_to_npz_fast(norm_counts, self.paths["normalized_counts"])
         with open(self.paths["nmf_genes_list"], "w") as F:
             F.write("\n".join(map(str, norm_counts.columns)))
-        if tpm is not None:
+        for stale in (self.paths["tpm"], self.paths["tpm_sparse"], self.paths["tpm_sparse_genes"]):
+            if tpm is not None and os.path.exists(stale):
+                os.remove(stale)
+        if tpm is not None and isinstance(tpm, tuple):
+            # (scipy sparse cells x ALL genes, gene names): the reference keeps a sparse tpm.h5ad (cnmf.py:423-447);
+            # statistics as get_mean_var does for sparse input (cnmf.py:126-134: population variance)
+            import scipy.sparse as sp
+            mat, genes = tpm
+            mat = sp.csr_matrix(mat)
+            sp.save_npz(self.paths["tpm_sparse"], mat, compressed=False)
+            with open(self.paths["tpm_sparse_genes"], "w") as F:
+                F.write("\n".join(map(str, genes)))
+            m64 = mat.astype(np.float64)
+            mean = np.asarray(m64.mean(axis=0)).ravel()
+            var = np.asarray(m64.multiply(m64).mean(axis=0)).ravel() - mean ** 2
+            stats = pd.DataFrame([mean, np.sqrt(np.maximum(var, 0.0))], index=["__mean", "__std"], columns=list(genes)).T
+            save_df_to_npz(stats, self.paths["tpm_stats"])
+        elif tpm is not None:
             save_df_to_npz(tpm, self.paths["tpm"])
             stats = pd.DataFrame([tpm.values.mean(axis=0), tpm.values.std(axis=0, ddof=0)],
                                  index=["__mean", "__std"], columns=tpm.columns).T
@@ -591,25 +610,61 @@ class cNMF:
         median_spectra.index = rf_usages.columns
 
         spectra_tpm = usage_coef = None
-        if os.path.exists(self.paths["tpm"]):
-            # consensus tail (cnmf.py:948-975): TPM spectra by NNLS on the transposed TPM matrix,
-            # z-score spectra by OLS, final usage refit on std-scaled HVG TPM
-            tpm = load_df_from_npz(self.paths["tpm"])
+        have_dense, have_sparse = os.path.exists(self.paths["tpm"]), os.path.exists(self.paths["tpm_sparse"])
+        if have_dense or have_sparse:
+            # consensus tail (cnmf.py:948-975) on the device.  The TPM matrix (cells x ALL genes, dense or CSR) is
+            # uploaded ONCE and serves all three steps:
+            #   refit_spectra  -> NNLS over the gene rows with the product W^T.X (no transposed upload)
+            #   OLS z-scores   -> X^T Y with Y z-scored on the fly, float64 accumulation (cnmf.py:55-125)
+            #   final refit    -> usages on tpm[:, hvgs] / std as a product with the resident matrix
+            if have_sparse:
+                import scipy.sparse as sp
+                tpm_x = sp.load_npz(self.paths["tpm_sparse"]).tocsr()
+                tpm_genes = pd.Index(open(self.paths["tpm_sparse_genes"]).read().split("\n"))
+            else:
+                tpm = load_df_from_npz(self.paths["tpm"])
+                tpm_x, tpm_genes = tpm.values, tpm.columns
             tpm_stats = load_df_from_npz(self.paths["tpm_stats"])
-            tdt = tpm.values.dtype if tpm.values.dtype in (np.float32, np.float64) else np.float64
-            spectra_tpm = self.refit_spectra(tpm.values.astype(tdt), norm_usages.values.astype(tdt))
-            spectra_tpm = pd.DataFrame(spectra_tpm, index=rf_usages.columns, columns=tpm.columns)
+            tdt = tpm_x.dtype if tpm_x.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+            eng = self._get_engine(tpm_x, None)
+            kw = yaml.load(open(self.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
+            solver_kw = dict(tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 1000),
+                             alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
+            if kw.get("solver", "cd") == "mu":
+                # (the multiplicative-update refit keeps the generic path: transposed upload)
+                spectra_tpm = self.refit_spectra(np.asarray(tpm_x.todense()) if have_sparse else tpm_x.astype(tdt),
+                                                 norm_usages.values.astype(tdt))
+                eng = self._get_engine(tpm_x, None)
+            else:
+                spectra_tpm, _ = eng.nnls_spectra(norm_usages.values.astype(tdt), **solver_kw)
+            spectra_tpm = pd.DataFrame(np.asarray(spectra_tpm, dtype=tdt), index=rf_usages.columns, columns=tpm_genes)
             if normalize_tpm_spectra:
                 spectra_tpm = spectra_tpm.div(spectra_tpm.sum(axis=1), axis=0) * 1e6
-            usage_coef = _ols_all_cols(rf_usages.values.astype(np.float64), tpm.values.astype(np.float64))
-            usage_coef = pd.DataFrame(usage_coef, index=rf_usages.columns, columns=tpm.columns)
+            # z-score spectra: Beta = lstsq(X^T X, X^T Y) with Y = (tpm - mean) / std, var floored at 1e-12
+            mean, pvar = eng.col_mean_var()                 # float64 column mean / population variance
+            var = np.where(pvar < 1e-12, 1e-12, pvar)
+            Xd = rf_usages.values.astype(np.float64)
+            XtY = eng.xt_matmul_f64(Xd, mean=mean, std=np.sqrt(var))
+            usage_coef, *_ = np.linalg.lstsq(Xd.T @ Xd, XtY, rcond=None)
+            usage_coef = pd.DataFrame(usage_coef, index=rf_usages.columns, columns=tpm_genes)
             if refit_usage:
                 hvgs = open(self.paths["nmf_genes_list"]).read().split("\n")
-                norm_tpm = tpm.loc[:, hvgs].astype(np.float64)
-                norm_tpm = norm_tpm / norm_tpm.values.std(axis=0, ddof=1)
+                hidx = tpm_genes.get_indexer(hvgs)
+                if (hidx < 0).any():
+                    raise KeyError("high-variance genes missing from the TPM matrix")
+                n_cells = eng.shape[0]
+                # std with ddof=1 of the HVG columns (dense: X.std(ddof=1); sparse: sc.pp.scale(zero_center=False))
+                std1 = np.sqrt(pvar[hidx] * n_cells / (n_cells - 1.0))
                 spectra_tpm_rf = spectra_tpm.loc[:, hvgs].div(tpm_stats.loc[hvgs, "__std"], axis=1)
-                rf = self.refit_usage(norm_tpm, spectra_tpm_rf.astype(norm_tpm.values.dtype))
-                rf_usages = pd.DataFrame(np.asarray(rf), index=norm_counts.index, columns=spectra_tpm_rf.index)
+                Hrf = spectra_tpm_rf.values.astype(np.float64)
+                H_prod = np.zeros((Hrf.shape[0], len(tpm_genes)), dtype=np.float64)
+                H_prod[:, hidx] = Hrf / std1
+                if kw.get("solver", "cd") == "mu":
+                    norm_tpm = (np.asarray(tpm_x[:, hidx].todense()) if have_sparse else tpm_x[:, hidx]).astype(np.float64) / std1
+                    rf = self.refit_usage(norm_tpm, Hrf.astype(norm_tpm.dtype))
+                else:
+                    rf, _ = eng.nnls_gram(H_prod, Hrf @ Hrf.T, **solver_kw)
+                rf_usages = pd.DataFrame(np.asarray(rf, dtype=xdt), index=norm_counts.index, columns=spectra_tpm_rf.index)
 
         save_df_to_npz(median_spectra, self.paths["consensus_spectra"] % (k, density_threshold_repl))
         save_df_to_npz(rf_usages, self.paths["consensus_usages"] % (k, density_threshold_repl))
@@ -623,18 +678,41 @@ class cNMF:
         return median_spectra, rf_usages
 
     # ------------------------------------------------------------------ k selection (cnmf.py:1119-1135)
-    def k_selection_stats(self):
-        """The numerical half of ``k_selection_plot``: one stats-mode consensus per k; writes
-        ``k_selection_stats.df.npz`` like the reference (plotting is out of scope)."""
+    def k_selection_stats(self, batched=True):
+        """The numerical half of ``k_selection_plot`` (cnmf.py:1119-1135); writes ``k_selection_stats.df.npz`` like the
+        reference (plotting is out of scope).  ``batched=True`` (default): ONE device call for all k -- the norm counts
+        are uploaded once, the |K| stats-mode consensuses run back to back, their usage refits as one batched NNLS
+        (all spectra are columns of a single X.H^T pass) and the prediction errors with the usages still on the device.
+        ``batched=False``: the reference's loop, one ``consensus(k, skip_density_and_return_after_stats=True)`` per k."""
         run_params = load_df_from_npz(self.paths["nmf_replicate_parameters"])
         norm_counts = self._load_norm_counts()
-        stats = []
-        for k in sorted(set(run_params.n_components)):
-            stats.append(self.consensus(k, skip_density_and_return_after_stats=True,
-                                        show_clustering=False, close_clustergram_fig=True,
-                                        norm_counts=norm_counts).stats)
-        stats = pd.DataFrame(stats)
-        stats.reset_index(drop=True, inplace=True)
+        ks = sorted(set(int(k) for k in run_params.n_components))
+        kw = yaml.load(open(self.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
+        if batched and kw.get("solver", "cd") == "cd":
+            merged = {}
+            for k in ks:
+                cached = self.merged_cache.get(k)
+                if cached is not None and cached[0] == os.path.getmtime(self.paths["merged_spectra"] % k):
+                    merged[k] = cached[1].values
+                else:
+                    merged[k] = load_df_from_npz(self.paths["merged_spectra"] % k).values
+            nc_key = ("norm_counts", self.paths["normalized_counts"], os.path.getmtime(self.paths["normalized_counts"]))
+            eng = self._get_engine(norm_counts.values, nc_key)
+            self._resident_obj = norm_counts
+            res = eng.kselect_stats(merged, nnls_tol=kw.get("tol", 1e-4), nnls_max_iter=kw.get("max_iter", 1000),
+                                    alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
+            stats = pd.DataFrame([[k, 0.5, res[k]["silhouette"], res[k]["prediction_error"]] for k in ks],
+                                 columns=["k", "local_density_threshold", "silhouette", "prediction_error"])
+            stats["k"] = stats["k"].astype(float)
+            stats.columns.name = None
+        else:
+            stats = []
+            for k in ks:
+                stats.append(self.consensus(k, skip_density_and_return_after_stats=True,
+                                            show_clustering=False, close_clustergram_fig=True,
+                                            norm_counts=norm_counts).stats)
+            stats = pd.DataFrame(stats)
+            stats.reset_index(drop=True, inplace=True)
         save_df_to_npz(stats, self.paths["k_selection_stats"])
         return stats
 

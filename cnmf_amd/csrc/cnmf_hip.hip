@@ -210,5 +210,6 @@ extern "C" int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* N, int64_t* G)
 #include "mu_host.hip.h"
 #include "comm_host.hip.h"
 #include "normalize_host.hip.h"
+#include "tail_host.hip.h"
 
 #include "debug_host.hip.h"

@@ -1,0 +1,414 @@
+// Consensus tail + k-selection on the device (included by cnmf_hip.hip after batch_host / consensus_host).
+//
+//   cnmf_xt_matmul_f64   W^T . X  (optionally W^T . zscore(X)) in float64 -- the X^T Y accumulation of
+//                        efficient_ols_all_cols (cnmf.py:55-125) and the product behind refit_spectra
+//   cnmf_nnls_spectra    NNLS for the SPECTRA with the usages fixed: cNMF.refit_spectra (cnmf.py:805-820) without
+//                        uploading the transposed matrix -- min_H ||X - W H||, H >= 0 is a coordinate descent over
+//                        the GENE rows of H^T whose constant product is W^T.X (a pass over the resident matrix)
+//   cnmf_nnls_gram       cnmf_nnls with the Gram matrix given by the caller (the final usage refit on the
+//                        std-scaled HVG columns of the resident TPM matrix, cnmf.py:960-975, without a second upload)
+//   cnmf_nnls_batch      several usage refits (one per k) packed as columns of ONE X.H^T pass, swept together,
+//                        optional ||X - W H||^2 per refit with W kept on the device
+//   cnmf_kselect_stats   the loop of k_selection_plot (cnmf.py:1119-1135): |K| stats-mode consensuses, their
+//                        refits batched, prediction errors -- one call, X uploaded once
+#pragma once
+
+namespace cnmf {
+
+// part[rb][t][g] = sum over the rows of block rb of W[i][t] * z(X[i][g]),  z(x) = (x - mean[g]) * inv_std[g] when
+// zs != 0, x otherwise.  Lane per gene, W rows broadcast from LDS, float64 accumulation in row order.
+template <int KT>
+__global__ __launch_bounds__(256) void xtw_f64_kernel(const float* __restrict__ X, int ldx, int N, int G,
+                                                      const double* __restrict__ W, int k, int zs,
+                                                      const double* __restrict__ mean,
+                                                      const double* __restrict__ inv_std, int rows_per_block,
+                                                      double* __restrict__ part)
+{
+    __shared__ double Ws[64 * KT];                       // 64 rows of W at a time
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int rb = blockIdx.y * rows_per_block, re = min(rb + rows_per_block, N);
+    const double mu = (zs && g < G) ? mean[g] : 0.0, is = (zs && g < G) ? inv_std[g] : 1.0;
+    double acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) acc[t] = 0.0;
+    for (int i0 = rb; i0 < re; i0 += 64) {
+        const int nr = min(64, re - i0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nr * k; e += 256) Ws[(e / k) * KT + (e % k)] = W[(size_t)(i0 + e / k) * k + (e % k)];
+        __syncthreads();
+        if (g < G)
+            for (int r = 0; r < nr; ++r) {
+                const double z = ((double)X[(size_t)(i0 + r) * ldx + g] - mu) * is;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) acc[t] = fma(Ws[r * KT + t], z, acc[t]);     // (columns >= k hold stale data
+            }                                                                              //  of no consequence: never stored)
+    }
+    if (g < G)
+        for (int t = 0; t < k; ++t) part[((size_t)blockIdx.y * k + t) * G + g] = acc[t];
+}
+
+// out[t][g] = sum_rb part[rb][t][g]   (block order: deterministic)
+__global__ __launch_bounds__(256) void sum_parts_f64_kernel(const double* __restrict__ part, int nparts, long long n,
+                                                            double* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
+    out[i] = s;
+}
+
+// component-major float32 rows [k][ld] (first L entries) -> [L][k] float64
+__global__ void rows_to_f64_kernel(const float* __restrict__ V, int ldv, int L, int off, int k, double* __restrict__ out)
+{
+    const int c = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < k && i < L) out[(size_t)i * k + c] = (double)V[(size_t)(off + c) * ldv + i];
+}
+
+// float64 [k][G] -> component-major float32 rows of a padded [.][ld] buffer
+__global__ void f64_to_rows_kernel(const double* __restrict__ src, int G, float* __restrict__ V, int ldv, int off, int k)
+{
+    const int c = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < k && g < G) V[(size_t)(off + c) * ldv + g] = (float)src[(size_t)c * G + g];
+}
+
+__global__ void f32_to_f64_kernel(const float* __restrict__ src, long long n, double* __restrict__ dst)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
+}
+
+__global__ void set_gram_kernel(const float* __restrict__ g, int k, float* __restrict__ gram_out, int slot, float l2)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < k * k) {
+        const int r = e / k, c = e % k;
+        gram_out[(size_t)slot * GRAM_SZ + r * GRAM_LD + c] = g[e] + (r == c ? l2 : 0.f);
+    }
+}
+
+}  // namespace cnmf
+
+// d_out [k][G] (device, float64) = W^T . z(X)
+static int xtw_f64_device(cnmf_ctx* ctx, DevPool& pool, const double* dW, int k, int zs, const double* dmean,
+                          const double* dinv, double* d_out)
+{
+    using namespace cnmf;
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    hipStream_t st = ctx->stream;
+    const int gx = (G + 255) / 256;
+    // enough row blocks to fill the chip (~4 workgroups per CU), at least 64 rows each
+    int nrb = std::max(1, std::min((N + 63) / 64, (1024 + gx - 1) / gx));
+    const int rpb = round_up((N + nrb - 1) / nrb, 64);
+    nrb = (N + rpb - 1) / rpb;
+    double* dpart = pool.get<double>((size_t)nrb * k * G);
+    POOL_TRY(ctx, pool);
+    dim3 grid(gx, nrb);
+#define CNMF_XTW(KT_) xtw_f64_kernel<KT_><<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, dW, k, zs, dmean, dinv, rpb, dpart)
+    if (k <= 8) CNMF_XTW(8); else if (k <= 16) CNMF_XTW(16); else if (k <= 32) CNMF_XTW(32); else CNMF_XTW(64);
+#undef CNMF_XTW
+    const long long n = (long long)k * G;
+    sum_parts_f64_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dpart, nrb, n, d_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return CNMF_OK;
+}
+
+extern "C" int cnmf_xt_matmul_f64(cnmf_ctx* ctx, int k, const double* W, int zscore, const double* mean,
+                                  const double* inv_std, double* out)
+{
+    if (!ctx || !W || !out || k < 1 || (zscore && (!mean || !inv_std))) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (k > KMAX) { SET_ERR(ctx, "k=%d > %d", k, KMAX); return CNMF_EUNSUPPORTED; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    DevPool pool;
+    double* dW = pool.get<double>((size_t)N * k);
+    double* dmean = zscore ? pool.get<double>(G) : nullptr;
+    double* dinv = zscore ? pool.get<double>(G) : nullptr;
+    double* dout = pool.get<double>((size_t)k * G);
+    POOL_TRY(ctx, pool);
+    HIP_TRY(ctx, hipMemcpyAsync(dW, W, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, st));
+    if (zscore) {
+        HIP_TRY(ctx, hipMemcpyAsync(dmean, mean, (size_t)G * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dinv, inv_std, (size_t)G * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    int rc = xtw_f64_device(ctx, pool, dW, k, zscore, dmean, dinv, dout);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, dout, (size_t)k * G * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return CNMF_OK;
+}
+
+// sweeps of `nslots` NNLS problems (slots 0..nslots-1 installed, products in P, Gram matrices in `gram`) until every
+// slot has stopped by sklearn's rule (phase 2 of finalize_kernel: the violation of the one half-step), polled every
+// `burst` sweeps.  V = the factor being solved (component-major, L valid entries per row).
+static int nnls_sweep_loop(cnmf_ctx* ctx, int nslots, float* V, int ldv, int L, const float* P, const float* gram,
+                           float l1, const cnmf_cd_params* prm, int kmax, int tiers)
+{
+    hipStream_t st = ctx->stream;
+    const int chunks = sweep_chunks(L), parts = sweep_parts(L);
+    EventPool events;
+    hipEvent_t ev = events.get(hipEventDisableTiming);
+    POOL_TRY(ctx, events);
+    const int burst = 8;
+    SlotDesc* snap = ctx->h_snap;
+    bool done = false;
+    for (int it = 0; it < prm->max_iter && !done; it += burst) {
+        for (int b = 0; b < burst; ++b) {
+            HIP_TRY(ctx, launch_sweep(st, nslots, V, ldv, L, P, gram, ctx->d_slots, l1, ctx->gram_part, ctx->viol_part,
+                                      chunks, parts, 0, kmax, tiers));
+            finalize_kernel<<<dim3(nslots, 1), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, parts, ctx->gramW, 0.f,
+                                                          ctx->d_slots, 2, prm->tol, prm->max_iter, 0, kmax);
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(snap, ctx->d_slots, (size_t)nslots * sizeof(SlotDesc), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipEventRecord(ev, st));
+        HIP_TRY(ctx, hipEventSynchronize(ev));
+        done = true;
+        for (int s = 0; s < nslots; ++s) done = done && (snap[s].active == 0);
+    }
+    return CNMF_OK;
+}
+
+static int tiers_of(const int32_t* ks, int n)
+{
+    int t = 0;
+    for (int i = 0; i < n; ++i) t |= ks[i] <= 16 ? 1 : (ks[i] <= 32 ? 2 : 4);
+    return t;
+}
+
+// install n slots (ranks ks, consecutive offsets) with all-zero factors of the side being solved
+static int install_nnls_slots(cnmf_ctx* ctx, int n, const int32_t* ks)
+{
+    int off = 0;
+    for (int s = 0; s < n; ++s) {
+        SlotDesc* d = &ctx->h_slots[s];
+        memset(d, 0, sizeof *d);
+        d->off = off; d->k = ks[s]; d->active = 1; d->restart = s;
+        ctx->h_slot_list[s] = s;
+        off += ks[s];
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots, ctx->h_slots, (size_t)n * sizeof(SlotDesc), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slot_list, ctx->h_slot_list, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    return CNMF_OK;
+}
+
+// ------------------------------------------------------------------ refit_spectra (cnmf.py:805-820)
+extern "C" int cnmf_nnls_spectra(cnmf_ctx* ctx, int k, const double* W, const cnmf_cd_params* prm, float* H_out,
+                                 int32_t* n_iter_out, double* viol_out)
+{
+    using namespace cnmf;
+    if (!ctx || !W || !H_out || k < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    int rc = validate_params(ctx, prm);
+    if (rc) return rc;
+    if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    const int KC = k <= 32 ? 32 : 64;
+    rc = ensure_batch(ctx, KC, k, k);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    DevPool pool;
+    double* dW = pool.get<double>((size_t)N * k);
+    double* dXtW = pool.get<double>((size_t)k * G);
+    float* dgram = pool.get<float>((size_t)k * k);
+    float* dH = pool.get<float>((size_t)k * G);
+    POOL_TRY(ctx, pool);
+    HIP_TRY(ctx, hipMemcpyAsync(dW, W, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, st));
+    // constant product W^T.X (float64 accumulation) and Gram W^T.W (float64 on the host: k x k)
+    rc = xtw_f64_device(ctx, pool, dW, k, 0, nullptr, nullptr, dXtW);
+    if (rc) return rc;
+    std::vector<float> g((size_t)k * k);
+    for (int a = 0; a < k; ++a)
+        for (int b = a; b < k; ++b) {
+            double s = 0.0;
+            for (int i = 0; i < N; ++i) s += W[(size_t)i * k + a] * W[(size_t)i * k + b];
+            g[(size_t)a * k + b] = g[(size_t)b * k + a] = (float)s;
+        }
+    HIP_TRY(ctx, hipMemcpyAsync(dgram, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    // slot 0: H rows start from zero (sklearn _nmf.py:1232-1233 for the transposed problem)
+    dim3 gc((ctx->G_pad + 255) / 256, KC);
+    clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, 0, KC);
+    clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->XtW, ctx->G_pad, ctx->G_pad, 0, KC);
+    dim3 gf((G + 255) / 256, k);
+    f64_to_rows_kernel<<<gf, 256, 0, st>>>(dXtW, G, ctx->XtW, ctx->G_pad, 0, k);
+    set_gram_kernel<<<(k * k + 255) / 256, 256, 0, st>>>(dgram, k, ctx->gramW, 0, (float)prm->l2_reg_W);
+    const int32_t ks1[1] = {k};
+    rc = install_nnls_slots(ctx, 1, ks1);
+    if (rc) return rc;
+    rc = nnls_sweep_loop(ctx, 1, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW, (float)prm->l1_reg_W, prm, k, tiers_of(ks1, 1));
+    if (rc) return rc;
+    extract_kernel<<<gf, 256, 0, st>>>(ctx->H, ctx->G_pad, G, 0, k, dH, 0);
+    HIP_TRY(ctx, hipMemcpyAsync(H_out, dH, (size_t)k * G * sizeof(float), hipMemcpyDeviceToHost, st));
+    clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, 0, KC);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (n_iter_out) *n_iter_out = ctx->h_snap[0].iter;
+    if (viol_out) *viol_out = ctx->h_snap[0].viol_last;
+    return CNMF_OK;
+}
+
+// ------------------------------------------------------------------ batched usage refits
+// n refits with fixed spectra H_r [k_r][G] (packed), W_r from zero.  One X.H^T pass for all of them (exact-f32 matrix
+// pipe, up to 256 packed columns per pass), swept together.  gram_in (nullable): [sum k_r^2] caller-supplied Gram
+// matrices H_r.H_r^T to use INSTEAD of the Gram of the rows multiplied (cnmf_nnls_gram).  W_out (nullable):
+// [N][k_r] blocks; err_out (nullable): ||X - W_r H_r||^2 (float64, W_r taken from the device).
+static int nnls_batch_impl(cnmf_ctx* ctx, int n, const int32_t* ks, const float* Hin, const float* gram_in,
+                           const cnmf_cd_params* prm, float* W_out, int32_t* n_iter_out, double* viol_out,
+                           double* err_out)
+{
+    using namespace cnmf;
+    if (!ctx || !ks || !Hin || n < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    int rc = validate_params(ctx, prm);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    hipStream_t st = ctx->stream;
+    int done_n = 0;
+    size_t hoff = 0, woff = 0, goff = 0;
+    while (done_n < n) {
+        // next group of refits: as many as fit into 256 packed columns
+        int m = 0, cols = 0, kmax = 0;
+        while (done_n + m < n && cols + ks[done_n + m] <= 256) {
+            if (ks[done_n + m] < 1 || ks[done_n + m] > KMAX) { SET_ERR(ctx, "bad rank %d", ks[done_n + m]); return CNMF_EUNSUPPORTED; }
+            cols += ks[done_n + m]; kmax = std::max(kmax, (int)ks[done_n + m]); ++m;
+        }
+        if (m == 0) { SET_ERR(ctx, "bad rank %d", ks[done_n]); return CNMF_EUNSUPPORTED; }
+        const int32_t* kg = ks + done_n;
+        int KC = 32;
+        while (KC < cols) KC *= 2;
+        rc = ensure_batch(ctx, KC, kmax, 1);
+        if (rc) return rc;
+        rc = ensure_stage(ctx, (size_t)N * KMAX, (size_t)G * KMAX);
+        if (rc) return rc;
+        DevPool pool;
+        float* dHin = pool.get<float>((size_t)cols * G);
+        float* dW = W_out ? pool.get<float>((size_t)N * kmax) : nullptr;
+        POOL_TRY(ctx, pool);
+        HIP_TRY(ctx, hipMemcpyAsync(dHin, Hin + hoff, (size_t)cols * G * sizeof(float), hipMemcpyHostToDevice, st));
+        dim3 gc((ctx->G_pad + 255) / 256, KC), gw((ctx->N_pad + 255) / 256, KC);
+        clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, 0, KC);
+        clear_rows_kernel<<<gw, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, 0, KC);
+        dim3 gI((G + 255) / 256, cols);
+        install_kernel<<<gI, 256, 0, st>>>(dHin, nullptr, ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, 0, 0, cols);
+        rc = install_nnls_slots(ctx, m, kg);
+        if (rc) return rc;
+        if (gram_in) {
+            float* dg = pool.get<float>((size_t)kmax * kmax);
+            POOL_TRY(ctx, pool);
+            size_t go = goff;
+            for (int s = 0; s < m; ++s) {
+                HIP_TRY(ctx, hipMemcpyAsync(dg, gram_in + go, (size_t)kg[s] * kg[s] * sizeof(float), hipMemcpyHostToDevice, st));
+                set_gram_kernel<<<(kg[s] * kg[s] + 255) / 256, 256, 0, st>>>(dg, kg[s], ctx->gramH, s, (float)prm->l2_reg_W);
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+                go += (size_t)kg[s] * kg[s];
+            }
+        } else {
+            gram_rows_kernel<<<m, 256, 0, st>>>(ctx->H, ctx->G_pad, G, ctx->d_slots, ctx->d_slot_list, ctx->gramH, (float)prm->l2_reg_W);
+        }
+        // ONE pass over X for every refit of the group
+        HIP_TRY(ctx, launch_gemm<false>(st, 0, ctx->H, ctx->G_pad, ctx->X, ctx->G_pad, ctx->XHt, ctx->N_pad, 0, KC, ctx->G_pad, ctx->N_pad, 1));
+        rc = nnls_sweep_loop(ctx, m, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH, (float)prm->l1_reg_W, prm, kmax, tiers_of(kg, m));
+        if (rc) return rc;
+        int off = 0;
+        for (int s = 0; s < m; ++s) {
+            const int k = kg[s];
+            if (n_iter_out) n_iter_out[done_n + s] = ctx->h_snap[s].iter;
+            if (viol_out) viol_out[done_n + s] = ctx->h_snap[s].viol_last;
+            if (W_out) {
+                dim3 gW((N + 255) / 256, k);
+                extract_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, off, k, dW, 1);
+                HIP_TRY(ctx, hipMemcpyAsync(W_out + woff, dW, (size_t)N * k * sizeof(float), hipMemcpyDeviceToHost, st));
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+            }
+            if (err_out) {
+                DevPool p2;
+                double* dW64 = p2.get<double>((size_t)N * k);
+                double* dH64 = p2.get<double>((size_t)k * G);
+                const int rpb = 512;
+                dim3 grid((G + 255) / 256, (N + rpb - 1) / rpb);
+                double* dpart = p2.get<double>((size_t)grid.x * grid.y);
+                double* dsum = p2.get<double>(1);
+                POOL_TRY(ctx, p2);
+                dim3 gW((N + 255) / 256, k);
+                rows_to_f64_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, off, k, dW64);
+                // residual_sq_kernel wants H as [k][G]: the packed input block is exactly that (float32 -> float64)
+                {
+                    const long long nh = (long long)k * G;
+                    f32_to_f64_kernel<<<(unsigned)((nh + 255) / 256), 256, 0, st>>>(dHin + (size_t)off * G, nh, dH64);
+                }
+                const size_t lds = (size_t)k * 256 * sizeof(double);
+                HIP_TRY(ctx, hipFuncSetAttribute((const void*)residual_sq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                residual_sq_kernel<<<grid, 256, lds, st>>>(ctx->X, ctx->G_pad, N, G, dW64, dH64, k, rpb, dpart);
+                sum_kernel<<<1, 256, 0, st>>>(dpart, (int)(grid.x * grid.y), dsum);
+                HIP_TRY(ctx, hipGetLastError());
+                HIP_TRY(ctx, hipMemcpyAsync(&err_out[done_n + s], dsum, sizeof(double), hipMemcpyDeviceToHost, st));
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+            }
+            off += k; woff += (size_t)N * k;
+        }
+        clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, 0, KC);
+        clear_rows_kernel<<<gw, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, 0, KC);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        hoff += (size_t)cols * G;
+        for (int s = 0; s < m; ++s) goff += (size_t)kg[s] * kg[s];
+        done_n += m;
+    }
+    return CNMF_OK;
+}
+
+extern "C" int cnmf_nnls_batch(cnmf_ctx* ctx, int n, const int32_t* ks, const float* Hin, const cnmf_cd_params* prm,
+                               float* W_out, int32_t* n_iter_out, double* viol_out, double* err_out)
+{
+    return nnls_batch_impl(ctx, n, ks, Hin, nullptr, prm, W_out, n_iter_out, viol_out, err_out);
+}
+
+extern "C" int cnmf_nnls_gram(cnmf_ctx* ctx, int k, const float* H_prod, const float* gram, const cnmf_cd_params* prm,
+                              float* W_out, int32_t* n_iter_out, double* viol_out)
+{
+    if (!gram || !W_out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    const int32_t ks1[1] = {k};
+    return nnls_batch_impl(ctx, 1, ks1, H_prod, gram, prm, W_out, n_iter_out, viol_out, nullptr);
+}
+
+// ------------------------------------------------------------------ k selection (cnmf.py:1119-1135, 922-936)
+extern "C" int cnmf_kselect_stats(cnmf_ctx* ctx, int n, const int32_t* ks, const int32_t* R, const double* spectra,
+                                  const cnmf_consensus_params* cprm, const double* uniforms,
+                                  const cnmf_cd_params* prm, double* silhouette_out, double* pred_err_out,
+                                  double* median_out, int32_t* nnls_iter_out)
+{
+    if (!ctx || !ks || !R || !spectra || !cprm || !uniforms || !silhouette_out || !pred_err_out || n < 1) {
+        SET_ERR(ctx, "null argument"); return CNMF_EINVAL;
+    }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    const int G = (int)ctx->G;
+    size_t tot_k = 0;
+    for (int i = 0; i < n; ++i) tot_k += (size_t)ks[i];
+    std::vector<double> med(tot_k * G);
+    std::vector<float> medf(tot_k * G);
+    size_t soff = 0, uoff = 0, moff = 0;
+    for (int i = 0; i < n; ++i) {
+        const int k = ks[i];
+        if (cprm[i].k != k) { SET_ERR(ctx, "consensus params %d: k mismatch", i); return CNMF_EINVAL; }
+        std::vector<int32_t> keep(R[i]), labels(R[i]);
+        std::vector<double> dens(R[i]);
+        double stats[4];
+        int rc = cnmf_consensus(ctx, spectra + soff * G, R[i], G, &cprm[i], uniforms + uoff, dens.data(), keep.data(),
+                                labels.data(), med.data() + moff * G, nullptr, stats);
+        if (rc) return rc;
+        silhouette_out[i] = stats[2];
+        const int n_init = cprm[i].n_init > 0 ? cprm[i].n_init : 10;
+        const int L = 2 + (int)std::log((double)k);
+        uoff += (size_t)n_init * (1 + (size_t)(k - 1) * L);
+        soff += (size_t)R[i];
+        moff += (size_t)k;
+    }
+    // the refit sees the spectra in the data's working precision, like the reference (cnmf.py:919: median_spectra
+    // in norm_counts' dtype; float32 on the device)
+    for (size_t i = 0; i < med.size(); ++i) medf[i] = (float)med[i];
+    if (median_out) memcpy(median_out, med.data(), med.size() * sizeof(double));
+    return nnls_batch_impl(ctx, n, ks, medf.data(), nullptr, prm, nullptr, nnls_iter_out, nullptr, pred_err_out);
+}

@@ -332,6 +332,165 @@ class Engine:
                           % max_iter, ConvergenceWarning)
         return W, int(n_iter.value)
 
+    # ------------------------------------------------------------------ consensus tail + k selection
+    def _check_H(self, H, G):
+        H = np.asarray(H)
+        if H.ndim != 2 or H.shape[1] != G:
+            raise ValueError("Array with wrong shape passed to NMF (input H). Expected (k, %d), but got %s"
+                             % (G, (H.shape,)))
+        if not np.isfinite(H).all():
+            raise ValueError("Input H contains NaN or infinity.")
+        if H.min() < 0:
+            raise ValueError("Negative values in data passed to NMF (input H)")
+        if H.max() == 0:
+            raise ValueError("Array passed to NMF (input H) is full of zeros.")
+        return H
+
+    def nnls_batch(self, H_list, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0, return_W=True,
+                   prediction_error=False):
+        """Several usage refits (``cNMF.refit_usage``, cnmf.py:776-802) as ONE pass over the resident matrix:
+        every ``H`` of ``H_list`` (k_r x G) becomes columns of a single X.H^T product, the W sweeps run together.
+        Returns ``(W_list or None, n_iter, errors or None)`` -- ``errors[r] = ||X - W_r H_r||_F^2`` in float64."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        Hs = [np.ascontiguousarray(self._check_H(H, G), dtype=np.float32) for H in H_list]
+        n = len(Hs)
+        ks = np.ascontiguousarray([h.shape[0] for h in Hs], dtype=np.int32)
+        if n == 0:
+            return ([] if return_W else None), np.zeros(0, np.int32), (np.zeros(0) if prediction_error else None)
+        Hp = np.ascontiguousarray(np.concatenate(Hs, axis=0))
+        prm = self._params(tol, max_iter, alpha_W, 0.0, l1_ratio)
+        W_out = np.empty(int(ks.sum()) * N, dtype=np.float32) if return_W else None
+        n_iter = np.zeros(n, dtype=np.int32)
+        viol = np.zeros(n, dtype=np.float64)
+        err = np.zeros(n, dtype=np.float64) if prediction_error else None
+        i32p, dblp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        self._check(self._lib.cnmf_nnls_batch(self._ctx, n, ks.ctypes.data_as(i32p), _fp(Hp), C.byref(prm),
+                                              _fp(W_out) if return_W else None, n_iter.ctypes.data_as(i32p),
+                                              viol.ctypes.data_as(dblp),
+                                              err.ctypes.data_as(dblp) if prediction_error else None))
+        W_list = None
+        if return_W:
+            offs = np.concatenate([[0], np.cumsum(ks)]).astype(np.int64)
+            W_list = [W_out[offs[r] * N:offs[r + 1] * N].reshape(N, ks[r]) for r in range(n)]
+        return W_list, n_iter, err
+
+    def nnls_gram(self, H_prod, gram, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0):
+        """Usage refit whose product uses the rows ``H_prod`` (k x G) but whose Gram matrix is GIVEN
+        (``gram`` k x k): ``X_sub @ H_sub.T`` for a scaled column subset of the resident matrix is
+        ``X @ H_prod.T`` with ``H_prod`` zero outside the subset (cnmf.py:960-975 without a second upload)."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        Hf = np.ascontiguousarray(self._check_H(H_prod, G), dtype=np.float32)
+        k = int(Hf.shape[0])
+        g = np.ascontiguousarray(gram, dtype=np.float32)
+        if g.shape != (k, k):
+            raise ValueError("gram must be (k, k)")
+        prm = self._params(tol, max_iter, alpha_W, 0.0, l1_ratio)
+        W = np.empty((N, k), dtype=np.float32)
+        n_iter = C.c_int32(0)
+        viol = C.c_double(0.0)
+        self._check(self._lib.cnmf_nnls_gram(self._ctx, k, _fp(Hf), _fp(g), C.byref(prm), _fp(W), C.byref(n_iter),
+                                             C.byref(viol)))
+        return W, int(n_iter.value)
+
+    def nnls_spectra(self, W, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0):
+        """``cNMF.refit_spectra`` (cnmf.py:805-820): NNLS for the spectra (k x G) with the usages ``W`` (N x k)
+        fixed, on the resident matrix -- no transposed upload.  ``alpha_W`` plays the role it has in the reference's
+        transposed call (it regularises the solved factor, scaled by the N 'features' of X.T)."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        if W.ndim != 2 or W.shape[0] != N:
+            raise ValueError("Array with wrong shape passed to NMF (input H). Expected (%d, k), but got %s" % (N, (W.shape,)))
+        if not np.isfinite(W).all():
+            raise ValueError("Input H contains NaN or infinity.")
+        if W.min() < 0:
+            raise ValueError("Negative values in data passed to NMF (input H)")
+        if W.max() == 0:
+            raise ValueError("Array passed to NMF (input H) is full of zeros.")
+        k = int(W.shape[1])
+        # the transposed problem has G samples and N features: l1_reg_W = N * alpha_W * l1_ratio (sklearn _nmf.py:1254)
+        prm = _lib.CdParams(float(tol), int(max_iter), 0, N * alpha_W * l1_ratio, N * alpha_W * (1.0 - l1_ratio),
+                            0.0, 0.0, 0, 0)
+        H = np.empty((k, G), dtype=np.float32)
+        n_iter = C.c_int32(0)
+        viol = C.c_double(0.0)
+        self._check(self._lib.cnmf_nnls_spectra(self._ctx, k, W.ctypes.data_as(C.POINTER(C.c_double)), C.byref(prm),
+                                                _fp(H), C.byref(n_iter), C.byref(viol)))
+        return H, int(n_iter.value)
+
+    def xt_matmul_f64(self, W, mean=None, std=None):
+        """``W.T @ X`` in float64, or ``W.T @ ((X - mean) / std)`` when ``mean``/``std`` (length G) are given --
+        the X^T Y accumulation of ``efficient_ols_all_cols(normalize_y=True)`` (cnmf.py:55-125)."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        if W.ndim != 2 or W.shape[0] != N:
+            raise ValueError("W must be (%d, k)" % N)
+        k = int(W.shape[1])
+        dblp = C.POINTER(C.c_double)
+        zs = mean is not None
+        out = np.empty((k, G), dtype=np.float64)
+        if zs:
+            mean = np.ascontiguousarray(mean, dtype=np.float64)
+            inv = np.ascontiguousarray(1.0 / np.asarray(std, dtype=np.float64))
+            self._check(self._lib.cnmf_xt_matmul_f64(self._ctx, k, W.ctypes.data_as(dblp), 1, mean.ctypes.data_as(dblp),
+                                                     inv.ctypes.data_as(dblp), out.ctypes.data_as(dblp)))
+        else:
+            self._check(self._lib.cnmf_xt_matmul_f64(self._ctx, k, W.ctypes.data_as(dblp), 0, None, None,
+                                                     out.ctypes.data_as(dblp)))
+        return out
+
+    def kselect_stats(self, spectra_by_k, local_neighborhood_size=0.30, random_state=1, n_init=10, max_iter=300,
+                      kmeans_tol=1e-4, nnls_tol=1e-4, nnls_max_iter=1000, alpha_W=0.0, l1_ratio=0.0):
+        """The statistics loop of ``k_selection_plot`` (cnmf.py:1119-1135) in ONE device call: ``spectra_by_k`` maps
+        k -> merged spectra (R_k x G).  Every k goes through the stats branch of the consensus (no density filter,
+        KMeans, medians, silhouette), the |K| usage refits run batched (one pass over X), the prediction errors are
+        computed with the usages still on the device.  Returns ``{k: dict(silhouette, prediction_error,
+        median_spectra, nnls_iter)}``."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        ks = sorted(int(k) for k in spectra_by_k)
+        n = len(ks)
+        S = [np.ascontiguousarray(spectra_by_k[k], dtype=np.float64) for k in ks]
+        for k, s in zip(ks, S):
+            if s.ndim != 2 or s.shape[1] != G:
+                raise ValueError("spectra for k=%d must be (R, %d)" % (k, G))
+        R = np.ascontiguousarray([s.shape[0] for s in S], dtype=np.int32)
+        Sp = np.ascontiguousarray(np.concatenate(S, axis=0))
+        cprm = (_lib.ConsensusParams * n)()
+        us = []
+        for i, k in enumerate(ks):
+            L = 2 + int(np.log(k))
+            us.append(np.random.RandomState(random_state).random_sample(n_init * (1 + (k - 1) * L)))
+            cprm[i] = _lib.ConsensusParams(k, int(local_neighborhood_size * int(R[i]) / k), 2.0, 1, 1, int(n_init),
+                                           int(max_iter), float(kmeans_tol))
+        u = np.ascontiguousarray(np.concatenate(us))
+        prm = self._params(nnls_tol, nnls_max_iter, alpha_W, 0.0, l1_ratio)
+        ks_a = np.ascontiguousarray(ks, dtype=np.int32)
+        sil = np.zeros(n)
+        err = np.zeros(n)
+        med = np.zeros((int(ks_a.sum()), G))
+        nit = np.zeros(n, dtype=np.int32)
+        i32p, dblp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        rc = self._lib.cnmf_kselect_stats(self._ctx, n, ks_a.ctypes.data_as(i32p), R.ctypes.data_as(i32p),
+                                          Sp.ctypes.data_as(dblp), cprm, u.ctypes.data_as(dblp), C.byref(prm),
+                                          sil.ctypes.data_as(dblp), err.ctypes.data_as(dblp), med.ctypes.data_as(dblp),
+                                          nit.ctypes.data_as(i32p))
+        self._check(rc)
+        out, off = {}, 0
+        for i, k in enumerate(ks):
+            out[k] = dict(silhouette=float(sil[i]), prediction_error=float(err[i]), median_spectra=med[off:off + k],
+                          nnls_iter=int(nit[i]))
+            off += k
+        return out
+
     # ------------------------------------------------------------------ NNDSVD init
     def x_matmul(self, Q, trans=False):
         """``X @ Q`` (trans=False, Q is G x c) or ``X.T @ Q`` (trans=True, Q is N x c) on the device."""

@@ -230,6 +230,37 @@ int64_t cnmf_spectra_rows(const cnmf_ctx* ctx);
 int cnmf_spectra_reset(cnmf_ctx* ctx);
 int cnmf_spectra_fetch(cnmf_ctx* ctx, float* out /* [rows][G] */);
 
+/* ---- consensus tail + k selection on the device ------------------------------------------------------------ */
+/* out[k][G] (float64) = W^T . X, or W^T . zscore(X) with z = (x - mean[g]) * inv_std[g]: the X^T Y accumulation of
+ * efficient_ols_all_cols(normalize_y=True) (cnmf.py:55-125, called at :958) over the RESIDENT matrix (the TPM matrix,
+ * dense or uploaded as CSR) in float64 like the reference.  W is [N][k] float64 (k <= CNMF_KMAX).           */
+int cnmf_xt_matmul_f64(cnmf_ctx* ctx, int k, const double* W, int zscore, const double* mean,
+                       const double* inv_std, double* out);
+/* cNMF.refit_spectra (cnmf.py:805-820 = refit_usage(X.T, usage.T).T, sklearn:_nmf.py:1210-1233): NNLS for the
+ * spectra H [k][G] with the usages W [N][k] fixed, H from zero, sklearn's CD stopping rule -- on the resident
+ * matrix, without uploading its transpose (the constant product is W^T.X).  The solved factor takes sklearn's
+ * "W" role: prm->l1_reg_W / l2_reg_W apply to it.                                                          */
+int cnmf_nnls_spectra(cnmf_ctx* ctx, int k, const double* W, const cnmf_cd_params* prm, float* H_out,
+                      int32_t* n_iter_out, double* viol_out);
+/* cnmf_nnls with a caller-supplied Gram matrix gram[k][k] = H.H^T: the rows H_prod [k][G] only enter the product
+ * X.H_prod^T.  Lets the final usage refit of consensus() (cnmf.py:960-975: X = tpm[:, hvgs] / std) run on the
+ * resident TPM matrix: H_prod = spectra / std on the HVG columns and 0 elsewhere, gram from the HVG block.    */
+int cnmf_nnls_gram(cnmf_ctx* ctx, int k, const float* H_prod, const float* gram, const cnmf_cd_params* prm,
+                   float* W_out, int32_t* n_iter_out, double* viol_out);
+/* n usage refits (cnmf.py:776-802) with ranks ks[r] and fixed spectra H_r (packed [sum k][G]) as ONE pass over X
+ * (all H_r are columns of a single X.H^T product) and joint sweeps.  W_out (nullable): [N][k_r] blocks;
+ * err_out (nullable): ||X - W_r.H_r||^2 in float64 (cnmf.py:926-930) with W_r taken from the device.         */
+int cnmf_nnls_batch(cnmf_ctx* ctx, int n, const int32_t* ks, const float* H, const cnmf_cd_params* prm,
+                    float* W_out, int32_t* n_iter_out, double* viol_out, double* err_out);
+/* The statistics loop of k_selection_plot (cnmf.py:1119-1135; per k: the stats branch of consensus, :871-936) in one
+ * call: for each of the n values ks[i] the merged spectra (R[i] rows, concatenated in `spectra`) go through the
+ * consensus core in stats mode (cprm[i]: skip_density = 1, want_silhouette = 1; `uniforms` = the KMeans draws of
+ * every k concatenated), then ALL refits run as one batched cnmf_nnls_batch with the prediction errors.
+ * Outputs: silhouette_out[n], pred_err_out[n], median_out (nullable) [sum k][G], nnls_iter_out (nullable) [n]. */
+int cnmf_kselect_stats(cnmf_ctx* ctx, int n, const int32_t* ks, const int32_t* R, const double* spectra,
+                       const cnmf_consensus_params* cprm, const double* uniforms, const cnmf_cd_params* prm,
+                       double* silhouette_out, double* pred_err_out, double* median_out, int32_t* nnls_iter_out);
+
 /* ---- diagnostics used by the tests ---------------------------------------------------- */
 /* C[KC][J] = A[KC][K] . B  through the engine's MFMA GEMM; mode 0: B is [J][K] (pass A),
  * mode 1: B is [K][J] (pass B, split-K partials summed in split order).                  */

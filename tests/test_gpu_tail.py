@@ -1,0 +1,148 @@
+"""Consensus tail (cnmf.py:939-985, efficient_ols_all_cols 55-125) and the k-selection loop (cnmf.py:1119-1135)
+on the device, held to the REFERENCE'S OWN bar -- sum of squared differences < 1e-4 against the artefacts the
+unmodified reference wrote (tests/golden/ref_small.npz; /root/reference/tests/test_reproducibility.py:96-115) --
+starting from the reference's own merged spectra, through the C-ABI and through the cNMF mirror class, with the TPM
+matrix dense and as CSR."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+from cnmf_amd.cnmf import cNMF, load_df_from_npz, save_df_to_npz
+from oracle import consensus as oc
+from oracle import nmf_cd
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_small.npz")
+TOLERANCE = 1e-4
+
+
+@pytest.fixture(scope="module")
+def g():
+    return dict(np.load(GOLD, allow_pickle=False))
+
+
+def _tail_on_device(engine, g, k, thr, sparse):
+    X = g["norm_counts"]
+    out = engine.consensus(g["merged_k%d" % k], k, density_threshold=thr)
+    engine.set_matrix(X)
+    rf, _ = engine.nnls(out["median_spectra"])
+    rf = rf.astype(np.float64)
+    norm = rf / rf.sum(axis=1, keepdims=True)
+    order = np.argsort(-norm.sum(axis=0), kind="stable")                    # cnmf.py:939-946
+    rf, norm, med = rf[:, order], norm[:, order], out["median_spectra"][order]
+    tpm = g["tpm"]
+    engine.set_matrix(sp.csr_matrix(tpm) if sparse else tpm)                # ONE upload for the three steps below
+    spectra_tpm, _ = engine.nnls_spectra(norm)
+    mean, pvar = engine.col_mean_var()
+    var = np.where(pvar < 1e-12, 1e-12, pvar)
+    XtY = engine.xt_matmul_f64(rf, mean=mean, std=np.sqrt(var))
+    coef, *_ = np.linalg.lstsq(rf.T @ rf, XtY, rcond=None)
+    genes = list(g["genes"])
+    hidx = np.array([list(g["tpm_genes"]).index(x) for x in genes])
+    n = tpm.shape[0]
+    std1 = np.sqrt(pvar[hidx] * n / (n - 1.0))
+    srf = spectra_tpm[:, hidx].astype(np.float64) / g["tpm_stats"][hidx, 1]
+    H_prod = np.zeros((k, tpm.shape[1]))
+    H_prod[:, hidx] = srf / std1
+    usages, _ = engine.nnls_gram(H_prod, srf @ srf.T)
+    return med, usages, spectra_tpm, coef
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+@pytest.mark.parametrize("k,thr", [(5, 0.5), (4, 2.0)])
+def test_consensus_tail_golden_reference(engine, g, k, thr, sparse):
+    med, usages, spectra_tpm, coef = _tail_on_device(engine, g, k, thr, sparse)
+    assert ((med - g["consensus_spectra_k%d" % k]) ** 2).sum() < TOLERANCE
+    assert ((usages - g["consensus_usages_k%d" % k]) ** 2).sum() < TOLERANCE
+    assert ((spectra_tpm - g["gene_spectra_tpm_k%d" % k]) ** 2).sum() < TOLERANCE * 1e6      # TPM units (x 1e6)
+    assert ((coef - g["gene_spectra_score_k%d" % k]) ** 2).sum() < TOLERANCE
+
+
+def test_xt_matmul_f64_and_nnls_spectra_vs_numpy(engine):
+    rs = np.random.RandomState(2)
+    X = (np.abs(rs.standard_normal((700, 333))) * (rs.rand(700, 333) < 0.3)).astype(np.float32)
+    W = np.abs(rs.standard_normal((700, 7)))
+    engine.set_matrix(X)
+    X64 = X.astype(np.float64)
+    assert np.abs(engine.xt_matmul_f64(W) - W.T @ X64).max() <= 1e-11 * np.abs(W.T @ X64).max()
+    mean, var = X64.mean(axis=0), X64.var(axis=0)
+    var[var < 1e-12] = 1e-12
+    ref = W.T @ ((X64 - mean) / np.sqrt(var))
+    m_dev, v_dev = engine.col_mean_var()
+    v_dev = np.where(v_dev < 1e-12, 1e-12, v_dev)
+    out = engine.xt_matmul_f64(W, mean=m_dev, std=np.sqrt(v_dev))
+    assert np.abs(out - ref).max() <= 1e-9 * np.abs(ref).max()
+    # refit_spectra = refit_usage(X.T, usage.T).T (cnmf.py:805-820) against the float64 oracle on the transposed matrix
+    H_ref, n_ref = nmf_cd.nnls(X64.T, W.T)
+    H, n = engine.nnls_spectra(W)
+    assert abs(n - n_ref) <= 2
+    assert np.abs(H.T - H_ref).max() <= 1e-3 * np.abs(H_ref).max()
+
+
+def test_nnls_batch_equals_single_refits(engine, g):
+    X = g["norm_counts"]
+    engine.set_matrix(X)
+    meds = [oc.consensus_core(g["merged_k%d" % k], X, k, stats_mode=True)["median_spectra"] for k in (4, 5, 6)]
+    W_list, n_iter, err = engine.nnls_batch(meds, prediction_error=True)
+    for med, W, n, e in zip(meds, W_list, n_iter, err):
+        W1, n1 = engine.nnls(med)
+        assert n == n1 and np.abs(W - W1).max() <= 1e-6 * np.abs(W1).max()     # same sweeps, same product
+        ref = engine.prediction_error(W1, med)
+        assert abs(e - ref) <= 1e-6 * ref
+    # more packed columns than one pass holds (300 > 256): two groups
+    many = [meds[2]] * 50
+    W_many, n_many, _ = engine.nnls_batch(many)
+    assert all(np.array_equal(w, W_many[0]) for w in W_many) and len(set(n_many)) == 1
+
+
+def test_kselect_stats_golden_reference(engine, g):
+    """k_selection_plot's statistics for K = 4, 5, 6 in ONE device call vs the reference's own numbers."""
+    engine.set_matrix(g["norm_counts"])
+    res = engine.kselect_stats({k: g["merged_k%d" % k] for k in (4, 5, 6)})
+    for k in (4, 5, 6):
+        _, _, sil_ref, err_ref = g["stats_k%d" % k]
+        assert abs(res[k]["silhouette"] - sil_ref) < 1e-8
+        assert abs(res[k]["prediction_error"] - err_ref) <= 2e-5 * err_ref          # X and W are float32 on the device
+        ref = oc.consensus_core(g["merged_k%d" % k], g["norm_counts"], k, stats_mode=True)
+        assert np.abs(res[k]["median_spectra"] - ref["median_spectra"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_mirror_class_consensus_from_reference_merged_spectra(engine, g, tmp_path, sparse):
+    """cNMF.consensus / k_selection_stats of the mirror class on the REFERENCE's merged spectra (the files combine
+    would have written), TPM dense or sparse: every artefact the reference pins, at its own tolerance."""
+    obj = cNMF(output_dir=str(tmp_path), name="gold", engine=engine)
+    nc = pd.DataFrame(g["norm_counts"], index=["c%d" % i for i in range(g["norm_counts"].shape[0])], columns=list(g["genes"]))
+    if sparse:
+        tpm = (sp.csr_matrix(g["tpm"]), list(g["tpm_genes"]))
+    else:
+        tpm = pd.DataFrame(g["tpm"], index=nc.index, columns=list(g["tpm_genes"]))
+    obj.prepare_from_matrix(nc, components=[4, 5, 6], n_iter=12, seed=14, beta_loss="frobenius", tpm=tpm)
+    for k in (4, 5, 6):
+        idx = ["iter%d_topic%d" % (it, t + 1) for it in range(12) for t in range(k)]
+        save_df_to_npz(pd.DataFrame(g["merged_k%d" % k], index=idx, columns=list(g["genes"])), obj.paths["merged_spectra"] % k)
+    stats = obj.k_selection_stats()
+    loop = obj.k_selection_stats(batched=False)
+    for row, lrow, k in zip(stats.itertuples(), loop.itertuples(), (4, 5, 6)):
+        _, _, sil, err = g["stats_k%d" % k]
+        assert row.k == k and abs(row.silhouette - sil) < 1e-8 and abs(row.prediction_error - err) <= 2e-5 * err
+        assert abs(row.silhouette - lrow.silhouette) < 1e-12 and abs(row.prediction_error - lrow.prediction_error) <= 1e-6 * err
+    for k, thr in ((5, 0.5), (4, 2.0)):
+        med, usages = obj.consensus(k, density_threshold=thr)
+        rep = str(thr).replace(".", "_")
+        assert ((med.values - g["consensus_spectra_k%d" % k]) ** 2).sum() < TOLERANCE
+        assert ((usages.values - g["consensus_usages_k%d" % k]) ** 2).sum() < TOLERANCE
+        tpm_sp = load_df_from_npz(obj.paths["gene_spectra_tpm"] % (k, rep)).values
+        assert ((tpm_sp - g["gene_spectra_tpm_k%d" % k]) ** 2).sum() < TOLERANCE * 1e6
+        score = load_df_from_npz(obj.paths["gene_spectra_score"] % (k, rep)).values
+        assert ((score - g["gene_spectra_score_k%d" % k]) ** 2).sum() < TOLERANCE
+        # the density cache is reused on the second call (same neighbourhood) and refreshed when it changes
+        m0 = os.path.getmtime(obj.paths["local_density_cache"] % k)
+        med2, _ = obj.consensus(k, density_threshold=thr)
+        assert os.path.getmtime(obj.paths["local_density_cache"] % k) == m0 and np.array_equal(med2.values, med.values)
+    obj.consensus(5, density_threshold=0.5, local_neighborhood_size=0.2)
+    import json
+    assert json.load(open(obj.paths["local_density_cache"] % 5 + ".meta.json"))["local_neighborhood_size"] == 0.2

@@ -1,0 +1,124 @@
+"""Option B of INTEGRATION.md executed: ``integration/hip_backend.py`` SUBCLASSES THE UNMODIFIED REFERENCE CLASS and
+overrides only the hot path.  This CPU test (build container only: it needs /root/reference, which does not exist on
+the GPU box) runs the reference's own pipeline -- prepare -> factorize -> combine -> k_selection_plot -> consensus,
+the CLI's positional ``consensus`` call (cnmf.py:1290) and the multiprocessing entry ``factorize_mp_signature``
+(cnmf.py:254-262, which pickles the object) -- through the subclass with ``Engine`` replaced by a recorder backed by
+the float64 oracle, and compares every artefact with the plain reference run.  It proves that the override
+signatures bind against the reference as it is, that the engine is called with the arguments the reference's kwargs
+imply, and that nothing else of the reference's behaviour changes."""
+import os
+import pickle
+import sys
+import warnings
+
+import numpy as np
+import pandas as pd
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/src/cnmf"), reason="needs the reference tree (build container)")
+
+
+class RecorderEngine:
+    """The Engine API surface hip_backend.py uses, answered by the float64 oracle; records every call."""
+    calls = []
+
+    def __init__(self, device=0):
+        self.device, self.X = device, None
+        RecorderEngine.calls.append(("create", device))
+
+    def set_matrix(self, X):
+        self.X = np.asarray(X.todense() if hasattr(X, "todense") else X, dtype=np.float64)
+        self.shape = self.X.shape
+        RecorderEngine.calls.append(("set_matrix", self.shape))
+
+    def nmf_batch(self, ks, seeds=None, W0=None, H0=None, tol=1e-4, max_iter=1000, alpha_W=0.0, alpha_H=0.0,
+                  l1_ratio=0.0, return_W=False, **kw):
+        from oracle import nmf_cd
+        RecorderEngine.calls.append(("nmf_batch", len(ks), tol, max_iter))
+        H, W, n = [], [], []
+        for i, k in enumerate(ks):
+            w, h, it = nmf_cd.nmf(self.X, int(k), seed=int(seeds[i]), tol=tol, max_iter=max_iter, alpha_W=alpha_W,
+                                  alpha_H=alpha_H, l1_ratio=l1_ratio)
+            H.append(h); W.append(w); n.append(it)
+        return H, (W if return_W else None), np.array(n), np.zeros(len(ks))
+
+    def nnls(self, H, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0, **kw):
+        from oracle import nmf_cd
+        RecorderEngine.calls.append(("nnls", np.shape(H)))
+        return nmf_cd.nnls(self.X, np.asarray(H, dtype=np.float64), tol=tol, max_iter=max_iter, alpha_W=alpha_W, l1_ratio=l1_ratio)
+
+    def consensus(self, spectra, k, density_threshold=0.5, local_neighborhood_size=0.30, skip_density=False,
+                  want_silhouette=False, random_state=1, n_init=10, max_iter=300, tol=1e-4, return_dist=False):
+        from oracle import consensus as oc
+        RecorderEngine.calls.append(("consensus", np.shape(spectra), k, skip_density, return_dist))
+        l2 = oc.l2_normalise(np.asarray(spectra, dtype=np.float64))
+        labels, _, inertia = oc.kmeans(l2, k, n_init=n_init, random_state=random_state)
+        out = dict(labels=labels, inertia=inertia, silhouette=(oc.silhouette_score(l2, labels) if want_silhouette and k > 1 else 0.0))
+        if return_dist:
+            out["topics_dist"] = oc.euclidean_distances(l2)
+        return out
+
+
+def _run(cls, tmp, name, counts_fn):
+    obj = cls(output_dir=str(tmp), name=name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        obj.prepare(counts_fn, components=[4, 5], n_iter=4, densify=True, seed=14, num_highvar_genes=120, beta_loss="frobenius")
+        obj.factorize(worker_i=0, total_workers=1)
+        obj.combine()
+        obj.k_selection_plot(close_fig=True)
+        # exactly the CLI's call (cnmf.py:1290-1291): positional up to build_ref
+        obj.consensus(4, 2.0, 0.30, True, False, close_clustergram_fig=True)
+        obj.consensus(5, 0.5, 0.30, False, False, close_clustergram_fig=True)
+    return obj
+
+
+def test_option_b_subclass_runs_the_reference_pipeline(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    from oracle import scanpy_shim
+    scanpy_shim.install()
+    import cnmf as ref
+    from cnmf.cnmf import load_df_from_npz, save_df_to_npz, factorize_mp_signature
+    from cnmf_amd import synth
+    import cnmf_amd.engine
+    monkeypatch.setattr(cnmf_amd.engine, "Engine", RecorderEngine)
+    sys.modules.pop("integration.hip_backend", None)
+    from integration import hip_backend
+    monkeypatch.setattr(hip_backend, "Engine", RecorderEngine)
+    assert issubclass(hip_backend.cNMF, ref.cNMF) and hip_backend.cNMF.prepare is ref.cNMF.prepare     # inherited, not copied
+
+    C, _ = synth.topic_counts(200, 300, 4, mu_lib=7.0, sigma_lib=0.3, seed=11)
+    C = C[:, C.sum(axis=0) > 0]
+    counts = pd.DataFrame(C.astype(np.int64), index=["c%d" % i for i in range(C.shape[0])], columns=["g%d" % j for j in range(C.shape[1])])
+    counts_fn = str(tmp_path / "counts.df.npz")
+    save_df_to_npz(counts, counts_fn)
+
+    RecorderEngine.calls = []
+    a = _run(ref.cNMF, tmp_path, "plain", counts_fn)                 # scikit-learn all the way
+    assert RecorderEngine.calls == []
+    b = _run(hip_backend.cNMF, tmp_path, "hip", counts_fn)           # the hot path through the (recorded) engine
+    kinds = [c[0] for c in RecorderEngine.calls]
+    assert kinds.count("nmf_batch") == 1 and ("nmf_batch", 8, 1e-4, 1000) in RecorderEngine.calls    # ONE batched call: 2 k x 4 iters
+    assert "nnls" in kinds and "consensus" in kinds
+    assert ("consensus", (16, 120), 1, True, True) in RecorderEngine.calls      # show_clustering=True: distances from the device
+
+    for k, rep in ((4, "2_0"), (5, "0_5")):
+        for key in ("merged_spectra",):
+            A, B = load_df_from_npz(a.paths[key] % k), load_df_from_npz(b.paths[key] % k)
+            assert list(A.index) == list(B.index) and np.abs(A.values - B.values).max() < 1e-9
+        for key in ("consensus_spectra", "consensus_usages", "gene_spectra_tpm", "gene_spectra_score"):
+            A, B = load_df_from_npz(a.paths[key] % (k, rep)), load_df_from_npz(b.paths[key] % (k, rep))
+            assert A.shape == B.shape and list(A.columns) == list(B.columns)
+            assert ((A.values - B.values) ** 2).sum() < 1e-4 * (1e6 if key == "gene_spectra_tpm" else 1.0)
+    A, B = load_df_from_npz(a.paths["k_selection_stats"]), load_df_from_npz(b.paths["k_selection_stats"])
+    assert np.allclose(A.values.astype(float), B.values.astype(float), rtol=1e-7, atol=1e-9)
+    assert os.path.exists(b.paths["clustering_plot"] % (4, "2_0"))   # the reference's plotting block ran on device arrays
+
+    # the multiprocessing entry point pickles the object (cnmf.py:254-262, 685-687)
+    clone = pickle.loads(pickle.dumps(b))
+    assert isinstance(clone, hip_backend.cNMF) and clone._engine is None
+    os.remove(b.paths["iter_spectra"] % (4, 0))
+    n0 = len(RecorderEngine.calls)
+    factorize_mp_signature((0, 1, clone))
+    assert os.path.exists(b.paths["iter_spectra"] % (4, 0)) and RecorderEngine.calls[n0][0] == "create"
