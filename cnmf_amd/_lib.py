@@ -17,7 +17,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 # every symbol include/cnmf_hip.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
     "cnmf_device_count", "cnmf_create", "cnmf_destroy", "cnmf_last_error", "cnmf_version",
-    "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_get_shape", "cnmf_get_matrix",
+    "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_set_count_detection", "cnmf_get_shape", "cnmf_get_matrix",
     "cnmf_col_moments", "cnmf_scale_columns", "cnmf_row_sums",
     "cnmf_nmf_cd_batch", "cnmf_nmf_cd_batch_resident", "cnmf_nnls",
     "cnmf_consensus", "cnmf_prediction_error", "cnmf_nmf_mu_batch", "cnmf_x_matmul",
@@ -112,6 +112,8 @@ def load():
     lib.cnmf_set_matrix.argtypes = [vp, f32p, i64, i64]
     lib.cnmf_set_matrix_csr.restype = i32
     lib.cnmf_set_matrix_csr.argtypes = [vp, i32p, i32p, f32p, i64, i64]
+    lib.cnmf_set_count_detection.restype = i32
+    lib.cnmf_set_count_detection.argtypes = [vp, i32]
     lib.cnmf_get_shape.restype = i32
     lib.cnmf_get_shape.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     lib.cnmf_get_matrix.restype = i32

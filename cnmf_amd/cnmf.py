@@ -89,7 +89,7 @@ class cNMF:
     # integration/hip_backend.py sets this): 8 R^2 bytes of host memory otherwise bought nothing
     materialize_topics_dist = False
 
-    def __init__(self, output_dir=".", name=None, device=0, engine=None, compress_merged=True):
+    def __init__(self, output_dir=".", name=None, device=0, engine=None, compress_merged=True, detect_counts=True):
         """Same constructor semantics as the reference (cnmf.py:268-296) plus the GPU index.
         ``compress_merged=False`` writes the merged-spectra files without zlib (same npz container, read
         by the reference's ``load_df_from_npz`` alike): zlib over 130 MB costs ~2 s of a 12 s job."""
@@ -104,6 +104,7 @@ class cNMF:
         self.paths = None
         self._initialize_dirs()
         self.device = device
+        self.detect_counts = detect_counts      # False: never use the integer-plane GEMMs (Engine.set_count_detection)
         self._engine = engine
         self._engine_key = None
         self.spectra_cache = {}          # (k, iter) -> spectra ndarray kept from factorize
@@ -153,7 +154,7 @@ class cNMF:
     def engine(self):
         """The per-process device context (one process per GPU)."""
         if self._engine is None:
-            self._engine = Engine(self.device)
+            self._engine = Engine(self.device, detect_counts=self.detect_counts)
         return self._engine
 
     def _get_engine(self, X, key):
@@ -162,7 +163,7 @@ class cNMF:
         unless it is the very object that is resident (``_resident_obj``, held by strong reference -- never
         id(): CPython reuses the ids of freed temporaries)."""
         if self._engine is None:
-            self._engine = Engine(self.device)
+            self._engine = Engine(self.device, detect_counts=self.detect_counts)
         if key is None:
             self._engine.set_matrix(X)
             self._engine_key = None

@@ -193,6 +193,26 @@ extern "C" int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const i
     return CNMF_OK;
 }
 
+// Count-structure detection on / off (default on).  The detection snaps a matrix whose every entry lies within
+// 1e-3 count units of (an integer <= 65 535) x (one constant per gene) onto that grid (kernels_counts.hip.h); a caller
+// whose data could satisfy that by accident -- not X = counts / std -- switches it off: the general split-operand
+// path then multiplies the float32 values as they are.
+extern "C" int cnmf_set_count_detection(cnmf_ctx* ctx, int enabled)
+{
+    if (!ctx) return CNMF_EINVAL;
+    if (ctx->count_detect != (enabled != 0)) {
+        ctx->count_detect = enabled != 0;
+        if (ctx->count_state == -1 || !ctx->count_detect) {      // forget a previous decision
+            hipStreamSynchronize(ctx->stream);
+            hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
+            hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
+            ctx->C1 = ctx->Ct1 = ctx->C1h = ctx->Ct1h = nullptr; ctx->hiA = ctx->hiB = nullptr;
+            ctx->d_scale = nullptr; ctx->count_state = 0; ctx->count_fmt = 0;
+        }
+    }
+    return CNMF_OK;
+}
+
 extern "C" int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* N, int64_t* G)
 {
     if (!ctx) return CNMF_EINVAL;

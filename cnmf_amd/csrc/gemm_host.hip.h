@@ -441,7 +441,7 @@ static int ensure_counts(cnmf_ctx* ctx)
     ctx->count_state = -1;
     ctx->count_fmt = fmt;
     const int N = (int)ctx->N, G = (int)ctx->G;
-    if (ctx->N_pad % G3C_JW || ctx->G_pad % G3C_JW || getenv("CNMF_NO_COUNTS")) return CNMF_OK;
+    if (ctx->N_pad % G3C_JW || ctx->G_pad % G3C_JW || getenv("CNMF_NO_COUNTS") || !ctx->count_detect) return CNMF_OK;
     hipStream_t st = ctx->stream;
     const int chunks = (N + CNT_ROWS - 1) / CNT_ROWS;
     DevPool pool;

@@ -17,6 +17,7 @@ struct cnmf_ctx {
     unsigned char *X3 = nullptr, *Xt3 = nullptr;   // bf16 planes of X and X^T (split-operand GEMM), built on first use
     int planes_tr = 0;                             // row-tile height they were built with
     // count structure X = n * d (kernels_counts.hip.h): 0 = not examined, 1 = present, -1 = absent
+    bool count_detect = true;                      // cnmf_set_count_detection(): look for the count structure at all?
     int count_state = 0;
     unsigned char *C1 = nullptr, *Ct1 = nullptr;   // integer planes of n and n^T (one bf16 plane, 256-row tiles)
     unsigned char *C1h = nullptr, *Ct1h = nullptr; // second planes (256 hi) when some count exceeds 256, else NULL

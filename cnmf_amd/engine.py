@@ -32,7 +32,9 @@ def regularization(n_samples, n_features, alpha_W=0.0, alpha_H=0.0, l1_ratio=0.0
 
 
 class Engine:
-    def __init__(self, device=0):
+    def __init__(self, device=0, detect_counts=True):
+        """``detect_counts=False``: never take the integer-plane (count-structured) GEMM path -- see
+        :meth:`set_count_detection`."""
         self._lib = _lib.load()
         if self._lib.cnmf_device_count() <= 0:
             raise RuntimeError("cnmf_amd: no HIP device visible -- the engine has no CPU fallback")
@@ -44,6 +46,15 @@ class Engine:
         self.x_mean = None
         self.x_dtype = None
         self.last_stats = None
+        if not detect_counts:
+            self.set_count_detection(False)
+
+    def set_count_detection(self, enabled):
+        """The engine recognises ``X = counts / std`` (integers x one constant per gene, tolerance 1e-3 count units;
+        DESIGN.md section 4) and then multiplies exact integer planes.  A matrix that merely happens to lie that close
+        to such a grid would be snapped onto it: switch the detection off for data that is not count-derived
+        (same effect as the environment variable ``CNMF_NO_COUNTS=1``)."""
+        self._check(self._lib.cnmf_set_count_detection(self._ctx, int(bool(enabled))))
 
     # ------------------------------------------------------------------ plumbing
     def close(self):

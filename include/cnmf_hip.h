@@ -82,6 +82,10 @@ const char* cnmf_version(void);
  * cNMF.factorize (cnmf.py:726,741) and cNMF.consensus (cnmf.py:873,919): X (cells x
  * high-variance genes) is uploaded ONCE per context and stays resident in HBM.       */
 int cnmf_set_matrix(cnmf_ctx* ctx, const float* X, int64_t n_cells, int64_t n_genes);
+/* Count-structure detection (default on): the engine recognises X = (integers <= 65 535) x (one constant per gene)
+ * -- what `norm_counts.X /= std` produces (cnmf.py:540-548) -- with a tolerance of 1e-3 count units and then
+ * multiplies the exact integer planes; enabled = 0 keeps every matrix on the general float32-operand path.      */
+int cnmf_set_count_detection(cnmf_ctx* ctx, int enabled);
 /* CSR input (scipy.sparse.csr_matrix of float32, int32 indices/indptr): densify on device. */
 int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const int32_t* indices,
                         const float* data, int64_t n_cells, int64_t n_genes);

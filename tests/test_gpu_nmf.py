@@ -170,6 +170,16 @@ def test_count_structure_is_detected_only_where_it_exists(engine):
             del os.environ["CNMF_GEMM3"]
         for a, b in zip(results[tag][1], H0):
             assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max()), tag
+    # the detection can be switched off (Engine.set_count_detection / cnmf_set_count_detection): general path
+    engine.set_count_detection(False)
+    try:
+        engine.set_matrix(X)
+        Hn, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=20, warn=False)
+        assert engine.last_stats["gemm_mode"] == 2
+        for a, b in zip(results["counts"][1], Hn):
+            assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
+    finally:
+        engine.set_count_detection(True)
 
 
 @pytest.mark.parametrize("g3mode", ["0", "1", "2", "3", "4"])
