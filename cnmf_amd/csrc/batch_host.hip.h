@@ -322,6 +322,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int64_t it = 0;          // batch iterations enqueued so far
     int snap_nslots[RING] = {0};
     const bool no_defrag = getenv("CNMF_NO_DEFRAG") != nullptr;
+    const bool no_psum = getenv("CNMF_NO_PSUM") != nullptr;          // (A/B knob: keep the separate split-K reduce)
     int64_t last_defrag = -8, n_defrag = 0;
     bool h3_valid = false;           // H3 holds the planes of the current H (split-operand modes)
     // stamps restart at 1 in every call: forget the ones a previous call left in the ring (nothing is in flight here)
@@ -561,13 +562,19 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                                            ctx->G_pad, (long long)KC * ctx->G_pad, KC, ctx->N_pad,
                                            ctx->G_pad, nsplit));
         if (time_gemm) hipEventRecord(gev[gev.size() - 1], st);
-        // H half-step
-        HIP_TRY(ctx, launch_reduce_splits(st, ctx->XtW, nsB, (long long)KC * ctx->G_pad,
-                                          (long long)KC * ctx->G_pad, usec ? ctx->d_scale : nullptr, ctx->G_pad));
-        HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
-                                  ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers,
-                                  SplitInfo{nullptr, nullptr, 1, 1, 1}, use2h ? ctx->rmaxH : nullptr,
-                                  use2h ? ctx->d_scale : nullptr));
+        // H half-step.  On the f16 path the split-K partials are summed (and scaled by d) inside the sweep itself.
+        if (use2h && !no_psum) {
+            HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
+                                      ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers,
+                                      psum_info(nsB, (long long)KC * ctx->G_pad, ctx->d_scale), ctx->rmaxH, ctx->d_scale, true));
+        } else {
+            HIP_TRY(ctx, launch_reduce_splits(st, ctx->XtW, nsB, (long long)KC * ctx->G_pad,
+                                              (long long)KC * ctx->G_pad, usec ? ctx->d_scale : nullptr, ctx->G_pad));
+            HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
+                                      ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers,
+                                      SplitInfo{nullptr, nullptr, 1, 1, 1}, use2h ? ctx->rmaxH : nullptr,
+                                      use2h ? ctx->d_scale : nullptr));
+        }
         // the H finalize also publishes every slot's state into the host-mapped ring entry of this
         // iteration (stamp it + 1): no copy kernel and no event per iteration
         SlotDesc* snap = ctx->h_snap + (size_t)(it % RING) * KC0;

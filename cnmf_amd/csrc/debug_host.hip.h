@@ -234,7 +234,7 @@ extern "C" int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn,
         HIP_TRY(ctx, hipGetLastError());
     }
     reps = std::max(1, reps);
-    const int var = (nsub >> 4) & 3;                     // (upper bits of `nsub`: instruction-stream variant, A/B probes)
+    const int var = (nsub >> 4) & 7;                     // (upper bits of `nsub`: instruction-stream variant, A/B probes)
     nsub &= 15;
     const int ns = (!has_hi && nsub == 2 && Kb % 2 == 0) ? 2 : 1;
     for (int i = 0; i < reps + 1; ++i) {
@@ -244,6 +244,8 @@ extern "C" int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn,
         else if (ns == 2 && var == 1) e = launch_gemm2h_t<2, false, 1>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
         else if (ns == 2 && var == 2) e = launch_gemm2h_t<2, false, 2>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
         else if (ns == 2 && var == 3) e = launch_gemm2h_t<2, false, 3>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
+        else if (ns == 2 && var == 4) e = launch_gemm2h_t<2, false, 4>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
+        else if (ns == 2 && var == 5) e = launch_gemm2h_t<2, false, 5>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
         else if (ns == 2) e = launch_gemm2h_t<2, false, 0>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
         else e = launch_gemm2h_t<1, false>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
         HIP_TRY(ctx, e);

@@ -54,11 +54,19 @@ static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int l
 }
 
 // ------------------------------------------------------------------ sweep dispatch
+// SplitInfo of a PSUM sweep (kernels_sweep.hip.h): `nsplit` partial planes `stride` floats apart, scaled per row by
+// `colscale` (nullable).  The fields are re-used: mgroups = nsplit, tile_rows / tile_cols = stride, split = colscale.
+static SplitInfo psum_info(int nsplit, long long stride, const double* colscale)
+{
+    SplitInfo sp{nullptr, reinterpret_cast<const unsigned char*>(colscale), (int)(stride >> 20), (int)(stride & ((1 << 20) - 1)), nsplit};
+    return sp;
+}
+
 static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, int L, const float* P,
                                const float* gram, const SlotDesc* slots, float l1, float* gram_part,
                                double* viol_part, int chunks, int parts, int want_gram, int kmax, int tiers,
                                SplitInfo sp = SplitInfo{nullptr, nullptr, 1, 1, 1},
-                               float* rmax_part = nullptr, const double* rmax_scale = nullptr)
+                               float* rmax_part = nullptr, const double* rmax_scale = nullptr, bool psum = false)
 {
     dim3 grid(parts, nslots);
     static bool attr_set = false;
@@ -76,7 +84,19 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
     const size_t lds = sweep_lds_bytes(kmax);
     const int kg = sweep_kg(kmax);
 #define CNMF_SWEEP(T_, R_) sweep_kernel<T_, R_><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax, rmax_part, rmax_scale)
-    if (rmax_part && rmax_scale) {
+#define CNMF_SWEEP_PSUM(T_) sweep_kernel<T_, true, true><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax, rmax_part, rmax_scale)
+    if (psum) {                 // split-K partial planes summed (and column-scaled) inside the sweep: sp = psum_info(...)
+        static bool attr_psum = false;
+        if (!attr_psum) {
+            hipFuncSetAttribute((const void*)sweep_kernel<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+            hipFuncSetAttribute((const void*)sweep_kernel<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+            hipFuncSetAttribute((const void*)sweep_kernel<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
+            attr_psum = true;
+        }
+        if (tiers & 1) CNMF_SWEEP_PSUM(0);
+        if (tiers & 2) CNMF_SWEEP_PSUM(1);
+        if (tiers & 4) CNMF_SWEEP_PSUM(2);
+    } else if (rmax_part && rmax_scale) {
         if (tiers & 1) CNMF_SWEEP(0, true);
         if (tiers & 2) CNMF_SWEEP(1, true);
         if (tiers & 4) CNMF_SWEEP(2, true);
@@ -85,6 +105,7 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
         if (tiers & 2) CNMF_SWEEP(1, false);
         if (tiers & 4) CNMF_SWEEP(2, false);
     }
+#undef CNMF_SWEEP_PSUM
 #undef CNMF_SWEEP
     return hipGetLastError();
 }
@@ -312,12 +333,12 @@ static int g2_nsub()
 // instruction-stream variant of the NSUB = 2 kernels (kernels_gemm2h.hip.h): bit 0 = DMA pieces spread through the
 // MFMA stream, bit 1 = s_setprio around the MFMA halves
 #ifndef CNMF_G2_VAR_DEFAULT
-#define CNMF_G2_VAR_DEFAULT 1
+#define CNMF_G2_VAR_DEFAULT 4
 #endif
 static int g2_var()
 {
     static const int v = getenv("CNMF_G2_VAR") ? atoi(getenv("CNMF_G2_VAR")) : CNMF_G2_VAR_DEFAULT;
-    return v & 3;
+    return (v >= 0 && v <= 5) ? v : CNMF_G2_VAR_DEFAULT;
 }
 
 template <int NSUB, bool HI, int VAR = 0>
@@ -356,6 +377,8 @@ static hipError_t launch_gemm2h(hipStream_t st, const unsigned char* A2, const u
             case 1: return launch_gemm2h_t<2, false, 1>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
             case 2: return launch_gemm2h_t<2, false, 2>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
             case 3: return launch_gemm2h_t<2, false, 3>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
+            case 4: return launch_gemm2h_t<2, false, 4>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
+            case 5: return launch_gemm2h_t<2, false, 5>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
             default: return launch_gemm2h_t<2, false, 0>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
         }
     }
@@ -390,6 +413,8 @@ static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, cons
             case 1: return launch_gemm2h_streamk_t<2, false, 1>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
             case 2: return launch_gemm2h_streamk_t<2, false, 2>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
             case 3: return launch_gemm2h_streamk_t<2, false, 3>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
+            case 4: return launch_gemm2h_streamk_t<2, false, 4>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
+            case 5: return launch_gemm2h_streamk_t<2, false, 5>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
             default: return launch_gemm2h_streamk_t<2, false, 0>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
         }
     }

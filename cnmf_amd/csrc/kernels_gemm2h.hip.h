@@ -256,6 +256,22 @@ __global__ __launch_bounds__(256) void count_max_base_kernel(const float* __rest
     if (big) atomicOr(any_big, 1u);
 }
 
+// LDS-DMA issued from inline asm (cdna_hip_programming.md section 5.7): hipcc does not see an LDS write, so it neither
+// drains the pending fragment reads in front of it (the builtin makes it wait lgkmcnt(0): a possible alias) nor counts it
+// in vmcnt -- the kernel counts by hand anyway.  M0 is saved and restored inside the statement.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds16_asm_nt(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // ------------------------------------------------------------------------------------------
 // One K segment [kb0, kb0 + nkb) (in 16-k blocks; kb0 and nkb multiples of NSUB) of one 256 x 256 tile.
 //   A2 : f16 planes of the component-major factor (rows m0..), B1 : f16 count plane (rows j0..),
@@ -266,7 +282,11 @@ __global__ __launch_bounds__(256) void count_max_base_kernel(const float* __rest
 //   bit 0: the six LDS-DMA pieces of a step are spread through the MFMA stream (one after every 4th MFMA of the step's
 //          first 24) instead of issued in one burst behind the X barrier -- a burst of DMA issues in front of 20
 //          ds_read_b128 is the expensive place for them (MI355X_MICROARCH.md, "LDS-DMA piece issue cost");
-//   bit 1: s_setprio(1) around the MFMA halves.
+//   VAR 4: VAR 1 with the fragment reads in two batches (see G2_READ_A / G2_READ_B);
+//   VAR 5: VAR 4 with the steady-state DMA pieces issued from inline asm (glds16_asm);
+//   VAR 2 / 3 (timing ablations, results meaningless): the spread stream WITHOUT its MFMAs (fill + fragment reads
+//          only) / WITHOUT its steady-state DMA (MFMAs + fragment reads on stale images).  s_setprio around the MFMA
+//          halves was tried and is neutral (profiles/r2_probe_gemm2h_variants.txt).
 template <int NSUB, bool HI, int VAR = 0>
 __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__ A2, const unsigned char* __restrict__ B1,
                                                const unsigned char* __restrict__ Bhi,
@@ -321,6 +341,12 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
     {                                                                                              \
         unsigned char* d_ = smem + ((s_) % IMGS) * IMG + wave * 1024;                              \
         const unsigned char* a_ = abase + (size_t)(s_) * (NSUB * G2_A);                            \
+        if constexpr (VAR == 5) {                       /* no LDS-DMA builtin anywhere in this variant */ \
+            const unsigned l_ = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)G3_AS3(d_)); \
+            _Pragma("unroll") for (int i = 0; i < NA; ++i) glds16_asm(a_ + i * 8192, l_ + i * 8192); \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i)                                         \
+                glds16_asm_nt(bbase + (size_t)(s_) * (NSUB * G2_B) + i * 8192, l_ + OFF_B + i * 8192); \
+        } else {                                                                                   \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                             \
             __builtin_amdgcn_global_load_lds(G3_AS1(a_ + i * 8192), G3_AS3(d_ + i * 8192), 16, 0, 0); \
         /* the count planes are read once per pass: non-temporal */                                \
@@ -332,6 +358,7 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
                 if (G2_BLKFLAG((s_) * NSUB + i))                                                   \
                     __builtin_amdgcn_global_load_lds(G3_AS1(hbase + (size_t)(s_) * (NSUB * G2_B) + i * 8192), \
                                                      G3_AS3(d_ + OFF_H + i * 8192), 16, 0, 2);     \
+        }                                                                                          \
         }                                                                                          \
     }
 #define G2_FRAG(ptr_) __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ptr_))
@@ -372,8 +399,9 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
 
     f16x8 bq[NSUB][2], bh[NSUB][2], aq[NSUB][4][2];
     constexpr int AHEAD = IMGS - 1;                      // steps requested ahead of the one being multiplied
-    constexpr bool SPREAD = (VAR & 1) && NSUB == 2 && !HI;
-    constexpr bool PRIO = (VAR & 2) != 0;
+    constexpr bool SPREAD = VAR >= 1 && NSUB == 2 && !HI;
+    constexpr bool PRIO = false;
+    constexpr bool NOMFMA = VAR == 2, NODMA = VAR == 3, SPLITRD = VAR >= 4, ASMDMA = VAR == 5;
     G3_WAIT_VM(0);                                          // stores of a previous segment
     G2_ISSUE(0)
     if (nst > 1) G2_ISSUE(1)
@@ -407,7 +435,12 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
 #define G2_PIECE(s_, i_)                                                                           \
         {                                                                                          \
             unsigned char* d_ = smem + ((s_) % IMGS) * IMG + wave * 1024;                          \
-            if ((i_) < NA)                                                                         \
+            if constexpr (ASMDMA) {                                                                \
+                const unsigned l_ = __builtin_amdgcn_readfirstlane(                                \
+                    (unsigned)(unsigned long long)G3_AS3(d_ + ((i_) < NA ? (i_) * 8192 : OFF_B + ((i_) - NA) * 8192))); \
+                if ((i_) < NA) glds16_asm(abase + (size_t)(s_) * (NSUB * G2_A) + (i_) * 8192, l_);  \
+                else glds16_asm_nt(bbase + (size_t)(s_) * (NSUB * G2_B) + ((i_) - NA) * 8192, l_);  \
+            } else if ((i_) < NA)                                                                  \
                 __builtin_amdgcn_global_load_lds(G3_AS1(abase + (size_t)(s_) * (NSUB * G2_A) + (i_) * 8192), \
                                                  G3_AS3(d_ + (i_) * 8192), 16, 0, 0);              \
             else                                                                                   \
@@ -415,33 +448,68 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
                                                  G3_AS3(d_ + OFF_B + ((i_) - NA) * 8192), 16, 0, 2); \
             __builtin_amdgcn_sched_barrier(0);                                                     \
         }
-        for (int s = 0; s < nst; ++s) {
-            const bool more = s + AHEAD < nst;
-            G3_RAW_BARRIER()                                        // X_s
-            G2_READ(s)
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
-            G2_MFMA(bq, 0, 0, 1) G2_MFMA(bq, 0, 1, 1)
-            if (more) G2_PIECE(s + AHEAD, 0)
-            G2_MFMA(bq, 0, 0, 0) G2_MFMA(bq, 0, 1, 0)
-            if (more) G2_PIECE(s + AHEAD, 1)
-            G2_MFMA(bq, 1, 0, 1) G2_MFMA(bq, 1, 1, 1)
-            if (more) G2_PIECE(s + AHEAD, 2)
-            G2_MFMA(bq, 1, 0, 0) G2_MFMA(bq, 1, 1, 0)
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // step s+1 must have landed before Y_s; the three pieces of step s+2 just issued may stay in flight
-            if (s + 1 < nst) { if (more) G3_WAIT_VM(3); else G3_WAIT_VM(0); }
-            G3_RAW_BARRIER()                                        // Y_s
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
-            G2_MFMA(bq, 0, 2, 1) G2_MFMA(bq, 0, 3, 1)
-            if (more) G2_PIECE(s + AHEAD, 3)
-            G2_MFMA(bq, 0, 2, 0) G2_MFMA(bq, 0, 3, 0)
-            if (more) G2_PIECE(s + AHEAD, 4)
-            G2_MFMA(bq, 1, 2, 1) G2_MFMA(bq, 1, 3, 1)
-            if (more) G2_PIECE(s + AHEAD, 5)
-            G2_MFMA(bq, 1, 2, 0) G2_MFMA(bq, 1, 3, 0)
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
+#define G2_MF(u_, m_, q_)                                                                          \
+        if constexpr (NOMFMA) { asm volatile("" :: "v"(aq[u_][m_][q_]), "v"(bq[u_][0]), "v"(bq[u_][1])); }        \
+        else { G2_MFMA(bq, u_, m_, q_) }
+// fragment reads in two batches (VAR 4): the 12 the first half needs, then -- behind the first 8 MFMAs -- the 8 of the
+// second half: at most 12 LDS reads are outstanding, so the waits in front of the MFMAs can be counted (lgkmcnt is a
+// 4-bit counter: behind 20 reads the compiler can only wait for all of them)
+#define G2_READ_A(s_)                                                                              \
+    {                                                                                              \
+        const unsigned char* bb = smem + ((s_) % IMGS) * IMG;                                      \
+        _Pragma("unroll") for (int u = 0; u < NSUB; ++u) {                                         \
+            _Pragma("unroll") for (int n = 0; n < 2; ++n) bq[u][n] = G2_FRAG(bb + b_off + u * G2_B + n * 32 * 32); \
+            _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                        \
+                aq[u][m][1] = G2_FRAG(bb + u * G2_A + a_row + m * 32 * G2_ROWB + a_s1);            \
+                aq[u][m][0] = G2_FRAG(bb + u * G2_A + a_row + m * 32 * G2_ROWB + a_s0);            \
+            }                                                                                      \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+#define G2_READ_B(s_)                                                                              \
+    {                                                                                              \
+        const unsigned char* bb = smem + ((s_) % IMGS) * IMG;                                      \
+        _Pragma("unroll") for (int u = 0; u < NSUB; ++u)                                           \
+            _Pragma("unroll") for (int m = 2; m < 4; ++m) {                                        \
+                aq[u][m][1] = G2_FRAG(bb + u * G2_A + a_row + m * 32 * G2_ROWB + a_s1);            \
+                aq[u][m][0] = G2_FRAG(bb + u * G2_A + a_row + m * 32 * G2_ROWB + a_s0);            \
+            }                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+#define G2_STEP(MORE_)                                                                             \
+        {                                                                                          \
+            G3_RAW_BARRIER()                                        /* X_s */                      \
+            if constexpr (SPLITRD) { G2_READ_A(s) } else { G2_READ(s) }                            \
+            G2_MF(0, 0, 1) G2_MF(0, 1, 1)                                                          \
+            if (MORE_) G2_PIECE(s + AHEAD, 0)                                                      \
+            G2_MF(0, 0, 0) G2_MF(0, 1, 0)                                                          \
+            if constexpr (SPLITRD) { G2_READ_B(s) }                                                \
+            if (MORE_) G2_PIECE(s + AHEAD, 1)                                                      \
+            G2_MF(1, 0, 1) G2_MF(1, 1, 1)                                                          \
+            if (MORE_) G2_PIECE(s + AHEAD, 2)                                                      \
+            G2_MF(1, 0, 0) G2_MF(1, 1, 0)                                                          \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+            /* step s+1 must have landed before Y_s; the three pieces of step s+2 just issued may stay in flight */ \
+            if (s + 1 < nst) { if (MORE_) G3_WAIT_VM(3); else G3_WAIT_VM(0); }                     \
+            G3_RAW_BARRIER()                                        /* Y_s */                      \
+            G2_MF(0, 2, 1) G2_MF(0, 3, 1)                                                          \
+            if (MORE_) G2_PIECE(s + AHEAD, 3)                                                      \
+            G2_MF(0, 2, 0) G2_MF(0, 3, 0)                                                          \
+            if (MORE_) G2_PIECE(s + AHEAD, 4)                                                      \
+            G2_MF(1, 2, 1) G2_MF(1, 3, 1)                                                          \
+            if (MORE_) G2_PIECE(s + AHEAD, 5)                                                      \
+            G2_MF(1, 2, 0) G2_MF(1, 3, 0)                                                          \
         }
+        {
+            int s = 0;
+            const int n_main = NODMA ? 0 : nst - AHEAD;             // steps that still have a step to request
+            for (; s < n_main; ++s) G2_STEP(true)
+            for (; s < nst; ++s) G2_STEP(false)
+        }
+#undef G2_STEP
+#undef G2_READ_B
+#undef G2_READ_A
+#undef G2_MF
 #undef G2_PIECE
     }
     if (grp == 0) G3_RAW_BARRIER()

@@ -67,7 +67,10 @@ struct SplitInfo {                  // further partial planes of a stream-K prod
 // bound  sqrt(sum_rows w^2)  from the diagonal of the workgroup's Gram partial -- at most sqrt(rows per workgroup)
 // = 32 x the true maximum, which the f16 plane split tolerates (kernels_gemm2h.hip.h: 5 bits of exponent slack only
 // move the threshold below which tiny entries keep an absolute rather than a relative accuracy).
-template <int KP, bool RMX>
+// PSUM: the products arrive as `sp.mgroups` split-K partial planes (stride sp.tile_rows * 2^20 + sp.tile_cols floats,
+// see psum_info) that are summed here in split order and scaled by the per-row constant sp.split (reinterpreted as
+// const double*) -- the work of reduce_splits_kernel folded into the H half-step (no extra launch, no extra pass).
+template <int KP, bool RMX, bool PSUM = false>
 __device__ __forceinline__ void sweep_body(
     float* __restrict__ V, int ldv, int L, const float* __restrict__ P, const SplitInfo& sp,
     const float* __restrict__ gram, const SlotDesc& sd, int slot, float l1_reg,
@@ -113,7 +116,7 @@ __device__ __forceinline__ void sweep_body(
         // so two wave-uniform flags cover every element.
         int cut0 = 0, cut1 = 0;
         int mg_edge = 1 << 30;
-        if (sp.plane1) {
+        if (!PSUM && sp.plane1) {
             const int rt = __builtin_amdgcn_readfirstlane(min(row, L - 1) / sp.tile_rows);
             const int g0 = off / sp.tile_cols, g1 = (off + k - 1) / sp.tile_cols;
             mg_edge = (g0 + 1) * sp.tile_cols;
@@ -133,6 +136,37 @@ __device__ __forceinline__ void sweep_body(
                 const size_t idx = (size_t)(off + min(c, k - 1)) * ldv + rowc;
                 w[c] = V[idx];
                 p[c] = P[idx];
+            }
+            if constexpr (PSUM) {
+                const int nsplit = sp.mgroups;
+                const size_t stride = (size_t)sp.tile_rows * (1u << 20) + (size_t)sp.tile_cols;
+                // U planes' loads in flight at a time; the additions keep the split order (bit-identical to
+                // reduce_splits_kernel)
+                constexpr int U = KP <= 16 ? 4 : (KP <= 32 ? 2 : 1);
+                int s = 1;
+                for (; s + U <= nsplit; s += U) {
+                    float q[U][KP];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int c = 0; c < KP; ++c)
+                            q[u][c] = P[(s + u) * stride + (size_t)(off + min(c, k - 1)) * ldv + rowc];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int c = 0; c < KP; ++c) p[c] += q[u][c];
+                }
+                for (; s < nsplit; ++s) {
+#pragma unroll
+                    for (int c = 0; c < KP; ++c)
+                        p[c] += P[s * stride + (size_t)(off + min(c, k - 1)) * ldv + rowc];
+                }
+                const double* colscale = reinterpret_cast<const double*>(sp.split);
+                if (colscale) {
+                    const double cs = colscale[rowc];
+#pragma unroll
+                    for (int c = 0; c < KP; ++c) p[c] = (float)((double)p[c] * cs);
+                }
             }
             if ((cut0 | cut1) & 1) {              // wave-uniform: one branch per chunk
                 float qq[KP];
@@ -285,7 +319,7 @@ __device__ __forceinline__ void sweep_body(
 // give the common small-rank case the register allocation of the largest (232 VGPR + 64 AGPR = one
 // wave per SIMD).  The host launches only the tiers present in the batch.
 // (TIER 0 without the exact report is the W half-step of the common ranks: held to 5 waves per SIMD)
-template <int TIER, bool RMX = false>
+template <int TIER, bool RMX = false, bool PSUM = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 && !RMX) ? 5 : 1, 8))) void sweep_kernel(
     float* __restrict__ V, int ldv, int L,
     const float* __restrict__ P,             // [KC][ldv] products (split-K already reduced)
@@ -304,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 
     if (!sd.active) return;
     extern __shared__ __attribute__((aligned(16))) float sweep_lds[];
 #define CNMF_SW(KP_)                                                                              \
-        sweep_body<KP_, RMX>(V, ldv, L, P, sp, gram, sd, slot, l1_reg, gram_part, viol_part,      \
+        sweep_body<KP_, RMX, PSUM>(V, ldv, L, P, sp, gram, sd, slot, l1_reg, gram_part, viol_part, \
                         chunks_per_block, want_gram, sweep_lds, kg, gld, rmax_part, rmax_scale);
     const int k = sd.k;
     if (TIER == 0) {

@@ -186,3 +186,17 @@ def test_mid_size_job_is_promoted_to_the_count_kernels(engine):
     assert engine.last_stats["kc"] == 128 and engine.last_stats["gemm_mode"] == 0
     for a, b in zip(H, Hk):
         assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
+
+
+def test_reduce_folded_into_the_H_sweep_is_bit_identical(engine, monkeypatch):
+    """On the f16 count path the split-K partial planes of pass B are summed (split order) and scaled by the per-gene
+    constant INSIDE the H half-step; the separate reduce kernel (CNMF_NO_PSUM=1) must give the same bits."""
+    X = synth.make_config("C3", dtype=np.float32, n_cells=12000)
+    engine.set_matrix(X)
+    ks = [9] * 20 + [13] * 4 + [5] * 4
+    seeds = list(range(301, 301 + len(ks)))
+    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=40, warn=False)
+    assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] == 4
+    monkeypatch.setenv("CNMF_NO_PSUM", "1")
+    H2, _, n2, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=40, warn=False)
+    assert list(n2) == list(n_iter) and all(np.array_equal(a, b) for a, b in zip(H, H2))
