@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=30)
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-workers-child", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -74,14 +75,49 @@ def _cpu_worker(job):
 _CPU_X64 = None
 
 
-def cpu_baseline_child(npy_path, max_iter):
-    """Runs in a FRESH interpreter (no HIP context: the worker pool forks).  SURVEY.md section 8d: time
-    (1) one worker with all BLAS threads and (2) cNMF-style ``total_workers`` single-thread processes
-    (how the reference is actually run, Extras/run_parallel.py) on a stratified k sample; report both."""
+def cpu_workers_child(npy_path, iters):
+    """Mode 2 of SURVEY 8d, in its OWN interpreter started with OPENBLAS/OMP/MKL_NUM_THREADS=1 (set before numpy is
+    imported, so that every forked worker is single-threaded by construction): one process per available core, each
+    running ONE scikit-learn restart capped at ``iters`` outer iterations -- how cNMF is parallelised in practice
+    (Extras/run_parallel.py: total_workers independent processes)."""
     global _CPU_X64
     import multiprocessing as mp
-    from oracle import sklearn_ref
     _CPU_X64 = np.load(npy_path).astype(np.float64)
+    ks = (5, 9, 13)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    try:                                                  # cgroup v2 CPU quota, if any
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            ncpu = max(1, min(ncpu, int(float(q) / float(per))))
+    except Exception:
+        pass
+    try:
+        avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+    except Exception:
+        avail = 64 << 30
+    per_worker = int(1.3 * _CPU_X64.nbytes)              # each worker holds its own X^T copy (sklearn _nmf.py:491)
+    workers = max(1, min(ncpu, int(0.5 * avail // per_worker)))
+    jobs = [(ks[i % len(ks)], 2000 + i, iters) for i in range(workers)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(workers) as pool:
+        res = pool.map(_cpu_worker, jobs, chunksize=1)
+    dt = time.perf_counter() - t0
+    it = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)                         # the slowest worker's own clock: excludes fork/teardown
+    print(json.dumps({"restart_iterations_per_s": it / busy, "workers": workers, "iterations": it, "seconds": busy,
+                      "wall_seconds_incl_fork": dt, "iterations_per_worker": iters}))
+
+
+def cpu_baseline_child(npy_path, max_iter):
+    """Runs in a FRESH interpreter (no HIP context).  SURVEY.md section 8d: time (1) one worker with all BLAS threads
+    here and (2) cNMF-style single-thread worker processes (cpu_workers_child, its own interpreter) on a stratified k
+    sample; report both."""
+    import subprocess
+    from oracle import sklearn_ref
+    X64 = np.load(npy_path).astype(np.float64)
     ks = (5, 9, 13)
     try:
         from threadpoolctl import threadpool_info
@@ -94,26 +130,22 @@ def cpu_baseline_child(npy_path, max_iter):
     t0 = time.perf_counter()
     it1 = 0
     for k in ks:
-        _, _, n_it = sklearn_ref.nmf(_CPU_X64, k, seed=1000 + k, max_iter=max_iter)
+        _, _, n_it = sklearn_ref.nmf(X64, k, seed=1000 + k, max_iter=max_iter)
         it1 += n_it
     dt1 = time.perf_counter() - t0
-    # (2) one single-thread process per core; bounded by memory (each worker holds its own X^T copy,
-    #     sklearn _nmf.py:491) -- never more than half of MemAvailable
-    ncpu = os.cpu_count() or 1
+    del X64
+    # (2) single-thread workers, bounded: 3 outer iterations each, 120 s at most
+    env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    mode2 = None
     try:
-        avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
-    except Exception:
-        avail = 64 << 30
-    per_worker = int(1.3 * _CPU_X64.nbytes)
-    workers = max(1, min(ncpu, int(0.5 * avail // per_worker)))
-    iters2 = max(4, max_iter // 5)
-    jobs = [(ks[i % len(ks)], 2000 + i, iters2) for i in range(workers)]
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(workers) as pool:
-        res = pool.map(_cpu_worker, jobs, chunksize=1)
-    dt2 = time.perf_counter() - t0
-    it2 = sum(r[0] for r in res)
-    busy2 = max(r[1] for r in res)              # the slowest worker's own clock: excludes fork/teardown
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-workers-child", npy_path, "--cpu-iters", "3"],
+                           capture_output=True, text=True, timeout=120, env=env)
+        if p.returncode == 0:
+            mode2 = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        else:
+            mode2 = {"error": p.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        mode2 = {"error": "timed out after 120 s"}
     cpu_model = "unknown"
     try:
         cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
@@ -122,10 +154,8 @@ def cpu_baseline_child(npy_path, max_iter):
     print(json.dumps({
         "one_worker_all_threads": {"restart_iterations_per_s": it1 / dt1, "threads": int(blas_threads),
                                    "iterations": it1, "seconds": dt1},
-        "workers_single_thread": {"restart_iterations_per_s": it2 / busy2, "workers": workers,
-                                  "iterations": it2, "seconds": busy2, "wall_seconds_incl_fork": dt2,
-                                  "iterations_per_worker": iters2},
-        "cpu_count": ncpu, "cpu_model": cpu_model, "blas": blas, "ks": list(ks)}))
+        "workers_single_thread": mode2,
+        "cpu_count": os.cpu_count(), "cpu_model": cpu_model, "blas": blas, "ks": list(ks)}))
 
 
 def cpu_baseline(X32, mean_iters_per_restart, max_iter):
@@ -153,7 +183,8 @@ def cpu_baseline(X32, mean_iters_per_restart, max_iter):
         raise RuntimeError("cpu baseline child failed: %s" % p.stderr[-2000:])
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     a, b = d["one_worker_all_threads"], d["workers_single_thread"]
-    best_is_workers = b["restart_iterations_per_s"] >= a["restart_iterations_per_s"]
+    ok2 = isinstance(b, dict) and "restart_iterations_per_s" in b
+    best_is_workers = ok2 and b["restart_iterations_per_s"] >= a["restart_iterations_per_s"]
     best = b if best_is_workers else a
     it_per_s = best["restart_iterations_per_s"]
     return {
@@ -167,11 +198,12 @@ def cpu_baseline(X32, mean_iters_per_restart, max_iter):
         "modes": d,
         "sample": ("sklearn.decomposition.non_negative_factorization (solver=cd, float64, init=random) on the same X, "
                    "k in (5, 9, 13): mode 1 = one worker with all BLAS threads, %d outer iterations per k (%d iterations "
-                   "in %.1f s); mode 2 = %d single-thread processes, one restart each capped at %d outer iterations "
-                   "(%d iterations, slowest worker %.1f s); the better mode is `value`; "
-                   "restarts_per_s_extrapolated = value / mean iterations per restart of the GPU run (%.1f)"
-                   % (max_iter, a["iterations"], a["seconds"], b["workers"], b["iterations_per_worker"],
-                      b["iterations"], b["seconds"], mean_iters_per_restart)),
+                   "in %.1f s); mode 2 = one single-thread process per core, one restart each capped at 3 outer iterations "
+                   "(%s); the better mode is `value`; restarts_per_s_extrapolated = value / mean iterations per restart of "
+                   "the GPU run (%.1f)"
+                   % (max_iter, a["iterations"], a["seconds"],
+                      ("%d workers, %d iterations, slowest worker %.1f s" % (b["workers"], b["iterations"], b["seconds"]))
+                      if ok2 else "failed: %s" % (b or {}).get("error", "?"), mean_iters_per_restart)),
     }
 
 
@@ -225,6 +257,9 @@ def main():
     args = parse()
     if args.cpu_baseline_child:
         cpu_baseline_child(args.cpu_baseline_child, args.cpu_iters)
+        return
+    if args.cpu_workers_child:
+        cpu_workers_child(args.cpu_workers_child, args.cpu_iters)
         return
     # stdout must carry exactly ONE JSON line, but RCCL prints a version banner to the C-level
     # stdout (flushed at exit): keep the real stdout aside and point fd 1 at stderr meanwhile

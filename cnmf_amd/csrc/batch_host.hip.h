@@ -260,7 +260,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     const int jwA = usec ? G3C_JW : G3_JW;         // width of a pass-A / pass-B tile
     const int nsplit3 = use3 ? pick_nsplit3(ctx, KC, jwA) : 1;
     const int fin_y = (max_k * max_k + 255) / 256;       // finalize blocks per slot
-    const int lag = std::max(1, std::min(RING - 2, prm->lag > 0 ? prm->lag : 2));
+    const int lag_env = getenv("CNMF_LAG") ? atoi(getenv("CNMF_LAG")) : 0;
+    const int lag = std::max(1, std::min(RING - 2, prm->lag > 0 ? prm->lag : (lag_env > 0 ? lag_env : 2)));
     hipStream_t st = ctx->stream;
 
     // device result buffers

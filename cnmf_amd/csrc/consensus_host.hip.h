@@ -180,7 +180,17 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     CONS_TRY(hipMemcpyAsync(dkeep, keep_idx.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
     CONS_TRY(hipMemcpyAsync(du, uniforms, nu * sizeof(double), hipMemcpyHostToDevice, st));
     gather_rows_kernel<<<dim3((G + 255) / 256, Rk), 256, 0, st>>>(dL2, ld, dkeep, Rk, G, dX, ld);
-    col_stats_kernel<<<(G + 63) / 64, 256, 0, st>>>(dX, ld, Rk, G, dmean, dvar);
+    {   // column mean / population variance of the kept rows (sklearn _kmeans.py:1477-1484, 279-288), rows spread
+        // over 64-row chunks, chunk partials added in order
+        const int rpc = 64, chunks = (Rk + rpc - 1) / rpc;
+        double* dcpart = pool.get<double>((size_t)chunks * G);
+        if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+        dim3 gp((G + 255) / 256, chunks);
+        col_partial_f64_kernel<<<gp, 256, 0, st>>>(dX, ld, Rk, G, rpc, nullptr, dcpart);
+        col_combine_f64_kernel<<<(G + 255) / 256, 256, 0, st>>>(dcpart, chunks, G, 1.0 / Rk, dmean);
+        col_partial_f64_kernel<<<gp, 256, 0, st>>>(dX, ld, Rk, G, rpc, dmean, dcpart);
+        col_combine_f64_kernel<<<(G + 255) / 256, 256, 0, st>>>(dcpart, chunks, G, 1.0 / Rk, dvar);
+    }
     center_rows_kernel<<<Rk, 256, 0, st>>>(dX, ld, G, dmean, dxsq);
     std::vector<double> hvar(G);
     CONS_TRY(hipMemcpyAsync(hvar.data(), dvar, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -421,11 +421,14 @@ static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, cons
     return launch_gemm2h_streamk_t<1, false>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
 }
 
-// column groups of the split launch: every workgroup (64 rows) walks its k tiles with stride `groups`, so that all
-// workgroups are resident at once (<= 8 per CU) and the row scale is reduced once per workgroup
+// geometry of the split launch: tiles of 16 rows x 256 k when K % 256 == 0 (1 KB contiguous per row), else 64 x 64;
+// every workgroup walks its k tiles with stride `groups`, so that all workgroups are resident at once (<= 7 per CU)
+// and the row scale is reduced once per workgroup
+static bool split2h_wide(int K) { return K % 256 == 0; }
 static int split2h_col_groups(int K, int rows)
 {
-    const int tiles = K / 64, rg = std::max(1, rows / 64);
+    const int tk = split2h_wide(K) ? 256 : 64, trows = split2h_wide(K) ? 16 : 64;
+    const int tiles = K / tk, rg = std::max(1, rows / trows);
     const int cap = std::max(1, (256 * 7) / rg);
     int per = (tiles + cap - 1) / cap;                     // k tiles per workgroup
     return (tiles + per - 1) / per;
@@ -435,8 +438,13 @@ static int split2h_col_groups(int K, int rows)
 static hipError_t launch_split2h(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst, int TR,
                                  const double* kscale, const float* rmax_part, int parts, float* inv_scale)
 {
-    dim3 grid(split2h_col_groups(K, rows), rows / 64);
-    split2h_tiled_kernel<<<grid, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale, rmax_part, parts, inv_scale);
+    if (split2h_wide(K)) {
+        dim3 grid(split2h_col_groups(K, rows), rows / 16);
+        split2h_tiled_kernel<16, 16><<<grid, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale, rmax_part, parts, inv_scale);
+    } else {
+        dim3 grid(split2h_col_groups(K, rows), rows / 64);
+        split2h_tiled_kernel<64, 4><<<grid, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale, rmax_part, parts, inv_scale);
+    }
     return hipGetLastError();
 }
 
@@ -564,8 +572,15 @@ static hipError_t launch_split2h_finalize(hipStream_t st, const float* src, int 
                                           int TR, const double* kscale, const float* rmax_part, int parts,
                                           float* inv_scale, const FinalizeArgs& fa, int nslots, int fin_y)
 {
-    const int bx = split2h_col_groups(K, rows), by = rows / 64;
-    split2h_finalize_kernel<<<bx * by + nslots * fin_y, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale,
-                                                                    rmax_part, parts, inv_scale, bx, by, fa, fin_y);
+    const int bx = split2h_col_groups(K, rows);
+    if (split2h_wide(K)) {
+        const int by = rows / 16;
+        split2h_finalize_kernel<16, 16><<<bx * by + nslots * fin_y, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale,
+                                                                                rmax_part, parts, inv_scale, bx, by, fa, fin_y);
+    } else {
+        const int by = rows / 64;
+        split2h_finalize_kernel<64, 4><<<bx * by + nslots * fin_y, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale,
+                                                                               rmax_part, parts, inv_scale, bx, by, fa, fin_y);
+    }
     return hipGetLastError();
 }

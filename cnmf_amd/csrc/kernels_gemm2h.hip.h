@@ -64,41 +64,52 @@ __device__ __forceinline__ void split2h(float y, unsigned short& h, unsigned sho
     m = f16_bits(y - f16_to_f32(h));
 }
 
-// ---- planes of the packed factor, through LDS (64 rows x 64 k per workgroup, as split3_tiled_body).
+// ---- planes of the packed factor, through LDS.  A workgroup converts tiles of TROWS rows x TKB 16-k blocks
+// (TROWS * TKB = 256: 16 rows x 256 k -- 1 KB contiguous per row read and per block written -- when K % 256 == 0,
+// else 64 rows x 64 k) and walks the k tiles bx, bx + nbx, ... of its rows (the row scale is reduced once).
 //   rmax_part [rows][parts] : per-row maxima of the values to convert (after kscale), one per sweep workgroup
 //   inv_scale [rows]        : 2^-s_c, written by the workgroups of the first k column (bx == 0)
-// `tile` = unsigned short [4][64][32] (16 KB), `red` = float [4][64]
+// `tile` = unsigned short [TKB][TROWS][32] (16 KB), `red` = float [256 / TROWS][TROWS] (1 KB)
+template <int TROWS, int TKB>
 __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src, int ld, int K, int TR,
                                                    unsigned short* __restrict__ dst, const double* __restrict__ kscale,
                                                    const float* __restrict__ rmax_part, int parts,
                                                    float* __restrict__ inv_scale, int bx, int nbx, int by,
-                                                   unsigned short (*tile)[64][32], float (*red)[64])
+                                                   unsigned short* tile_, float* red_)
 {
+    static_assert(TROWS * TKB == 256, "tile = 256 (row, block) pairs");
+    constexpr int NQ = 256 / TROWS;                      // threads per row in the maximum reduction
+    constexpr int KQ = TKB * 4;                          // float4 per row of a tile
+    constexpr int RPP = 256 / KQ;                        // rows per pass of the conversion
+    unsigned short (*tile)[TROWS][32] = reinterpret_cast<unsigned short (*)[TROWS][32]>(tile_);
+    float (*red)[TROWS] = reinterpret_cast<float (*)[TROWS]>(red_);
     const int t = threadIdx.x;
-    const int r0 = by * 64;
+    const int r0 = by * TROWS;
     {
-        const int row = t & 63, qt = t >> 6;
+        const int row = t % TROWS, qt = t / TROWS;
         float mx = 0.f;
-        for (int p = qt; p < parts; p += 4) mx = fmaxf(mx, rmax_part[(size_t)(r0 + row) * parts + p]);
+        for (int p = qt; p < parts; p += NQ) mx = fmaxf(mx, rmax_part[(size_t)(r0 + row) * parts + p]);
         red[qt][row] = mx;
     }
     __syncthreads();
-    const int kq = t & 15, rr = t >> 4;                  // float4 index along k, row within a pass of 16
+    const int kq = t % KQ, rr = t / KQ;                  // float4 index along k, row within a pass
     int sh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = rr + 16 * i;
-        sh[i] = g2_row_shift(fmaxf(fmaxf(red[0][row], red[1][row]), fmaxf(red[2][row], red[3][row])));
+        const int row = rr + RPP * i;
+        float mx = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) mx = fmaxf(mx, red[q][row]);
+        sh[i] = g2_row_shift(mx);
         if (bx == 0 && kq == 0) inv_scale[r0 + row] = ldexpf(1.0f, -sh[i]);
     }
     const int Kb = K / 16;
     const int tr = r0 / TR, rin = r0 % TR;
-    // the workgroup converts the k tiles bx, bx + nbx, ... of its 64 rows (the row scale is computed once)
-    for (int kt = bx; kt < K / 64; kt += nbx) {
-        const int k0 = kt * 64;
+    for (int kt = bx; kt < K / (16 * TKB); kt += nbx) {
+        const int k0 = kt * 16 * TKB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = rr + 16 * i;
+            const int row = rr + RPP * i;
             const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * ld + k0 + kq * 4);
             float x[4] = {v.x, v.y, v.z, v.w};
             if (kscale) {                                 // count-structured data: the per-gene scale rides on the factor
@@ -108,8 +119,9 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
             unsigned short p[2][4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) split2h(ldexpf(x[e], sh[i]), p[0][e], p[1][e]);
-            // 16-k block kq >> 2, 8-k half (kq >> 1) & 1, element offset (kq & 1) * 4 inside the slot
-            const int hf = (kq >> 1) & 1, swz = (row >> 2) & 3;   // (r0, TR multiples of 64: row bits 2..3 are local)
+            // 16-k block kq >> 2, 8-k half (kq >> 1) & 1, element offset (kq & 1) * 4 inside the slot;
+            // (r0, TR multiples of 16: bits 2..3 of the in-tile row are bits 2..3 of the local row)
+            const int hf = (kq >> 1) & 1, swz = (row >> 2) & 3;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 uint2 w;
@@ -119,24 +131,28 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
         }
         __syncthreads();
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int pass = 0; pass < 4; ++pass) {
+            const int c = pass * 256 + t;                 // 16-byte chunk of the tile: [block][row][4 chunks]
+            const int b = c / (TROWS * 4), within = c % (TROWS * 4);
             unsigned short* g = dst + (((size_t)tr * Kb + (k0 / 16 + b)) * TR + rin) * 32;
-            const u32x4* s4 = reinterpret_cast<const u32x4*>(&tile[b][0][0]);      // 64 rows x 64 B = 256 chunks
-            reinterpret_cast<u32x4*>(g)[t] = s4[t];
+            reinterpret_cast<u32x4*>(g)[within] = reinterpret_cast<const u32x4*>(&tile[b][0][0])[within];
         }
         __syncthreads();
     }
 }
 
+// grid = (column groups, rows / TROWS)
+template <int TROWS, int TKB>
 __global__ __launch_bounds__(256) void split2h_tiled_kernel(const float* __restrict__ src, int ld, int K, int TR,
                                                             unsigned short* __restrict__ dst,
                                                             const double* __restrict__ kscale,
                                                             const float* __restrict__ rmax_part, int parts,
                                                             float* __restrict__ inv_scale)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short tile[4][64][32];
-    __shared__ float red[4][64];
-    split2h_tiled_body(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, blockIdx.x, gridDim.x, blockIdx.y, tile, red);
+    __shared__ __attribute__((aligned(16))) unsigned short tile[256 * 32];
+    __shared__ float red[256];
+    split2h_tiled_body<TROWS, TKB>(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, blockIdx.x, gridDim.x,
+                                   blockIdx.y, tile, red);
 }
 
 // per-row maxima of a packed factor in the partials layout the sweep writes ([rows][parts], part p = rows' columns

@@ -519,6 +519,7 @@ __global__ __launch_bounds__(256) void split3_finalize_kernel(const float* __res
 }
 
 // The same for the f16 two-plane split (kernels_gemm2h.hip.h).
+template <int TROWS, int TKB>
 __global__ __launch_bounds__(256) void split2h_finalize_kernel(const float* __restrict__ src, int ld, int K, int TR,
                                                                unsigned short* __restrict__ dst,
                                                                const double* __restrict__ kscale,
@@ -526,12 +527,12 @@ __global__ __launch_bounds__(256) void split2h_finalize_kernel(const float* __re
                                                                float* __restrict__ inv_scale, int split_bx,
                                                                int split_by, FinalizeArgs fa, int fin_y)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 64 * 32 * 2 + 4 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[256 * 32 * 2 + 256 * 4];
     const int b = blockIdx.x, nsplit = split_bx * split_by;
     if (b < nsplit) {
-        split2h_tiled_body(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, b % split_bx, split_bx, b / split_bx,
-                           reinterpret_cast<unsigned short (*)[64][32]>(lds),
-                           reinterpret_cast<float (*)[64]>(lds + 4 * 64 * 32 * 2));
+        split2h_tiled_body<TROWS, TKB>(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, b % split_bx, split_bx,
+                                       b / split_bx, reinterpret_cast<unsigned short*>(lds),
+                                       reinterpret_cast<float*>(lds + 256 * 32 * 2));
     } else {
         const int f = b - nsplit;
         finalize_body(fa, f / fin_y, f % fin_y, reinterpret_cast<double*>(lds));
