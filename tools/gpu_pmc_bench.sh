@@ -1,5 +1,6 @@
 #!/bin/bash
-# HBM traffic of the two GEMM passes inside the real bench loop (separate --pmc passes, no trace domains)
+# HBM traffic + MFMA-busy of the GEMM passes inside the real bench loop: separate `rocprofv3 --pmc` passes (kernel trace
+# only, no other trace domain), then profiles-style summary -> gpurun_out/pmc_traffic.json
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmcb; mkdir -p $R/gpurun_out/pmcb
@@ -9,21 +10,34 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
   rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmcb/$stag -o pmc --output-format csv -- \
      python $R/bench.py --steps 1 --warmup 0 --restarts-per-k 3 --no-cpu-baseline > $R/gpurun_out/pmcb/$stag.log 2>&1
 done
+cd $R
 python - <<PY
 import csv, glob, collections, os, json
 R=os.environ['GRAFT_REPO_ROOT']
-out={}
-for d in sorted(glob.glob(R+'/gpurun_out/pmcb/*/')):
-    f=os.path.join(d,'pmc_counter_collection.csv')
-    if not os.path.exists(f): continue
-    acc=collections.defaultdict(lambda: collections.defaultdict(list))
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(R+'/gpurun_out/pmcb/*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        name=r['Kernel_Name'].split('(')[0]
+        name=r['Kernel_Name'].split('(')[0].replace('void ','')
         acc[name][r['Counter_Name']].append(float(r['Counter_Value']))
-    for name,cs in acc.items():
-        for c,v in cs.items():
-            out.setdefault(name,{})[c]={'mean':sum(v)/len(v),'n':len(v),'max':max(v)}
-json.dump(out, open(R+'/gpurun_out/pmcb/summary.json','w'), indent=1)
-for k,v in out.items():
-    if 'gemm' in k or 'sweep' in k: print(k, {c:round(x['mean'],1) for c,x in v.items()})
+def mean(name_part, c):
+    v=[x for n,cs in acc.items() if name_part in n for x in cs.get(c,[])]
+    return (sum(v)/len(v), len(v)) if v else (None, 0)
+N_pad, G_pad, KC = 50176, 2048, 256
+out={"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES (separate passes, --kernel-trace only) around \`bench.py --steps 1 --warmup 0 --restarts-per-k 3 --no-cpu-baseline\` on the default path (CNMF_GEMM3=4: count structure detected -> f16 two-plane kernels), tools/gpu_pmc_bench.sh; mean over all launches of the kernel. FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B/lane reads, LDS-DMA included; Infinity-Cache hits are counted). mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs)."}
+for key, part in (("passA","gemm2h_streamk_kernel"),("passB","gemm2h_kernel"),("sweepW","sweep_kernel<0, false, false>"),("split","split2h_finalize_kernel")):
+    e={"kernel": part}
+    for c in ("FETCH_SIZE","WRITE_SIZE","SQ_VALU_MFMA_BUSY_CYCLES","GRBM_GUI_ACTIVE"):
+        m,n=mean(part,c); e[c]=m; e["launches"]=n or e.get("launches",0)
+    if e["FETCH_SIZE"] is not None and e["WRITE_SIZE"] is not None:
+        e["hbm_bytes_per_launch"]=(2*e["FETCH_SIZE"]+e["WRITE_SIZE"])*1024
+    if e["SQ_VALU_MFMA_BUSY_CYCLES"] and e["GRBM_GUI_ACTIVE"]:
+        e["mfma_busy_frac"]=e["SQ_VALU_MFMA_BUSY_CYCLES"]/(1024*e["GRBM_GUI_ACTIVE"]/8)
+    out[key]=e
+xplane = N_pad*G_pad*2
+out["algorithmic_bytes_per_launch"]={
+  "passA": xplane + KC*G_pad*4 + KC*N_pad*4,
+  "passB": xplane + KC*N_pad*4 + 32*KC*G_pad*4,
+  "note": "count plane of X (or X^T) once (2 B per element, f16) + the factor's two f16 planes once (4 B per element) + the product written once (pass A: one XHt plane of 51 MB -- the stream-K partial planes of cut tiles come on top; pass B: 32 split-K partial planes of 2 MB)"}
+json.dump(out, open(R+'/gpurun_out/pmc_traffic.json','w'), indent=1)
+print(json.dumps({k:(v if not isinstance(v,dict) else {kk:vv for kk,vv in v.items() if kk in('hbm_bytes_per_launch','mfma_busy_frac','launches')}) for k,v in out.items() if k!='_source'}, indent=1))
 PY
