@@ -246,6 +246,8 @@ extern "C" int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn,
         else if (ns == 2 && var == 3) e = launch_gemm2h_t<2, false, 3>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
         else if (ns == 2 && var == 4) e = launch_gemm2h_t<2, false, 4>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
         else if (ns == 2 && var == 5) e = launch_gemm2h_t<2, false, 5>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
+        else if (ns == 2 && var == 6) e = launch_gemm2h_t<2, false, 6>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
+        else if (ns == 2 && var == 7) e = launch_gemm2h_t<2, false, 7>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
         else if (ns == 2) e = launch_gemm2h_t<2, false, 0>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
         else e = launch_gemm2h_t<1, false>(st, dA2, dB1, nullptr, nullptr, dInv, Kb, dC, Jp, (long long)KC * Jp, KC, Jp, nsplit);
         HIP_TRY(ctx, e);

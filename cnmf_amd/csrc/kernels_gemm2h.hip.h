@@ -85,6 +85,16 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
     float (*red)[TROWS] = reinterpret_cast<float (*)[TROWS]>(red_);
     const int t = threadIdx.x;
     const int r0 = by * TROWS;
+    const int kq = t % KQ, rr = t / KQ;                  // float4 index along k, row within a pass
+    const int ntiles = K / (16 * TKB);
+    // the data of the first k tile and the row maxima are requested together (one memory latency, not two)
+    float4 v[4];
+    {
+        const int k0 = bx * 16 * TKB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[i] = *reinterpret_cast<const float4*>(src + (size_t)(r0 + rr + RPP * i) * ld + k0 + kq * 4);
+    }
     {
         const int row = t % TROWS, qt = t / TROWS;
         float mx = 0.f;
@@ -92,7 +102,6 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
         red[qt][row] = mx;
     }
     __syncthreads();
-    const int kq = t % KQ, rr = t / KQ;                  // float4 index along k, row within a pass
     int sh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -105,13 +114,20 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
     }
     const int Kb = K / 16;
     const int tr = r0 / TR, rin = r0 % TR;
-    for (int kt = bx; kt < K / (16 * TKB); kt += nbx) {
+    for (int kt = bx; kt < ntiles; kt += nbx) {
         const int k0 = kt * 16 * TKB;
+        // request the NEXT tile before converting this one
+        float4 vn[4];
+        const bool has_next = kt + nbx < ntiles;
+        if (has_next) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                vn[i] = *reinterpret_cast<const float4*>(src + (size_t)(r0 + rr + RPP * i) * ld + (k0 + nbx * 16 * TKB) + kq * 4);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = rr + RPP * i;
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * ld + k0 + kq * 4);
-            float x[4] = {v.x, v.y, v.z, v.w};
+            float x[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
             if (kscale) {                                 // count-structured data: the per-gene scale rides on the factor
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = (float)((double)x[e] * kscale[k0 + kq * 4 + e]);
@@ -138,6 +154,10 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
             reinterpret_cast<u32x4*>(g)[within] = reinterpret_cast<const u32x4*>(&tile[b][0][0])[within];
         }
         __syncthreads();
+        if (has_next) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = vn[i];
+        }
     }
 }
 
@@ -417,7 +437,9 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
     constexpr int AHEAD = IMGS - 1;                      // steps requested ahead of the one being multiplied
     constexpr bool SPREAD = VAR >= 1 && NSUB == 2 && !HI;
     constexpr bool PRIO = false;
-    constexpr bool NOMFMA = VAR == 2, NODMA = VAR == 3, SPLITRD = VAR >= 4, ASMDMA = VAR == 5;
+    constexpr bool NOMFMA = VAR == 2, NODMA = VAR == 3 || VAR == 6 || VAR == 7, SPLITRD = VAR >= 4, ASMDMA = VAR == 5;
+    constexpr bool NOREAD = VAR == 6 || VAR == 7;         // timing ablations: fragments read once / ... and no barriers
+    constexpr bool NOBAR = VAR == 7;
     G3_WAIT_VM(0);                                          // stores of a previous segment
     G2_ISSUE(0)
     if (nst > 1) G2_ISSUE(1)
@@ -494,12 +516,13 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
     }
 #define G2_STEP(MORE_)                                                                             \
         {                                                                                          \
-            G3_RAW_BARRIER()                                        /* X_s */                      \
-            if constexpr (SPLITRD) { G2_READ_A(s) } else { G2_READ(s) }                            \
+            if constexpr (!NOBAR) G3_RAW_BARRIER()                  /* X_s */                      \
+            if constexpr (NOREAD) { if (s == 0) { G2_READ(s) } }                                   \
+            else if constexpr (SPLITRD) { G2_READ_A(s) } else { G2_READ(s) }                       \
             G2_MF(0, 0, 1) G2_MF(0, 1, 1)                                                          \
             if (MORE_) G2_PIECE(s + AHEAD, 0)                                                      \
             G2_MF(0, 0, 0) G2_MF(0, 1, 0)                                                          \
-            if constexpr (SPLITRD) { G2_READ_B(s) }                                                \
+            if constexpr (SPLITRD && !NOREAD) { G2_READ_B(s) }                                     \
             if (MORE_) G2_PIECE(s + AHEAD, 1)                                                      \
             G2_MF(1, 0, 1) G2_MF(1, 1, 1)                                                          \
             if (MORE_) G2_PIECE(s + AHEAD, 2)                                                      \
@@ -507,7 +530,7 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
             /* step s+1 must have landed before Y_s; the three pieces of step s+2 just issued may stay in flight */ \
             if (s + 1 < nst) { if (MORE_) G3_WAIT_VM(3); else G3_WAIT_VM(0); }                     \
-            G3_RAW_BARRIER()                                        /* Y_s */                      \
+            if constexpr (!NOBAR) G3_RAW_BARRIER()                  /* Y_s */                      \
             G2_MF(0, 2, 1) G2_MF(0, 3, 1)                                                          \
             if (MORE_) G2_PIECE(s + AHEAD, 3)                                                      \
             G2_MF(0, 2, 0) G2_MF(0, 3, 0)                                                          \

@@ -142,7 +142,7 @@ __device__ __forceinline__ void sweep_body(
                 const size_t stride = (size_t)sp.tile_rows * (1u << 20) + (size_t)sp.tile_cols;
                 // U planes' loads in flight at a time; the additions keep the split order (bit-identical to
                 // reduce_splits_kernel)
-                constexpr int U = KP <= 16 ? 4 : (KP <= 32 ? 2 : 1);
+                constexpr int U = KP <= 16 ? 8 : (KP <= 32 ? 2 : 1);
                 int s = 1;
                 for (; s + U <= nsplit; s += U) {
                     float q[U][KP];
