@@ -449,6 +449,19 @@ def main():
                              "peak": HBM_PEAK_GBS},
             "gemm_share_of_gpu_time": (avgA + avgB) * launches / max(agg["gpu_ms"], 1e-9),
         }
+        tr = roof["traffic_detail"]
+        if tr:
+            # the pass is nearly balanced between the two roofs: also quote the HBM side (PMC bytes / measured time)
+            dur = (avgA if dom == "A" else avgB) * 1e-3
+            roof["hbm"] = {"achieved_GBs": tr["hbm_bytes_per_launch"] / dur / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                           "frac": tr["hbm_bytes_per_launch"] / dur / 1e9 / HBM_PEAK_GBS,
+                           "traffic_over_algorithmic": tr["hbm_bytes_per_launch"] / tr["algorithmic_bytes_per_launch"]}
+        if agg["gemm_mode"] == 4:
+            # measured ceiling of THIS instruction stream with everything but the MFMAs removed (tools/
+            # probe_gemm2h_ablate.py var 7, profiles/r2_probe_gemm2h_variants.txt): the matrix pipe on non-zero data at
+            # the clock the power budget allows -- not a roofline, but the reason `frac` cannot approach 1
+            roof["mfma_only_ablation"] = {"tflops_issued": 1460.0, "source": "profiles/r2_probe_gemm2h_variants.txt",
+                                          "issued_over_mfma_only": ach * per_product * agg["col_iters"] / max(agg["rc_iters"], 1) / 1460.0}
         if split:
             roof["matrix_pipe"] = {
                 "scheme": ("X = n * d detected (n integer <= 2048: one exact f16 plane; d per gene, folded into the factor); "
