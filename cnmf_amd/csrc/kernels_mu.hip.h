@@ -32,13 +32,16 @@ __device__ __forceinline__ void mu_ratio(float x, float wh, float& r, float& d)
 // block = 256 threads = 64 cells x 4 gene quarters; grid.x = ceil(N/64).  X goes through an LDS
 // tile [64 cells][64 genes] (loaded coalesced, 256 B per row; read back one row per lane, stride 65
 // -> conflict-free) and the matching Ht tile [64 genes][KP] is read back as wave-wide broadcasts.
-template <int KP, bool BETA1>
-__global__ __launch_bounds__(256) void mu_w_kernel(const float* __restrict__ X, int ldx, int N, int G,
-                                                   float* __restrict__ W, const float* __restrict__ Ht,
-                                                   const float* __restrict__ Hsum, float l1, float l2)
+// NQ waves per workgroup share the 64 cells (each takes 64 / NQ genes of every gene tile): NQ = 8 (512 threads) doubles
+// the waves per SIMD of this latency-bound kernel (PMC, round 2: 3 waves per SIMD, 49 % of the wave cycles waiting).
+template <int KP, bool BETA1, int NQ = 8>
+__global__ __launch_bounds__(64 * NQ) void mu_w_kernel(const float* __restrict__ X, int ldx, int N, int G,
+                                                       float* __restrict__ W, const float* __restrict__ Ht,
+                                                       const float* __restrict__ Hsum, float l1, float l2)
 {
+    constexpr int NT = 64 * NQ, GPW = 64 / NQ;           // threads; genes per wave and tile
     constexpr int XS = 64 * 65, HS = 64 * KP;
-    constexpr int RED = (BETA1 ? 1 : 2) * 3 * 64 * (KP + 1);
+    constexpr int RED = (BETA1 ? 1 : 2) * (NQ - 1) * 64 * (KP + 1);
     __shared__ __attribute__((aligned(16))) float lds[(XS + HS) > RED ? (XS + HS) : RED];
     float* xs = lds;                 // [64][65]
     float* hs = lds + XS;            // [64][KP]
@@ -54,15 +57,15 @@ __global__ __launch_bounds__(256) void mu_w_kernel(const float* __restrict__ X, 
     for (int g0 = 0; g0 < ldx; g0 += 64) {
         // X and Ht are zero padded to ldx (a multiple of 32) columns / rows; a padded gene adds 0
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = lrow + 16 * j;
+        for (int j = 0; j < 64 / (NT / 16); ++j) {
+            const int r = lrow + (NT / 16) * j;
             const int row = min(i0 + r, N - 1);
             v4f v = v4f{0.f, 0.f, 0.f, 0.f};
             if (g0 + lc4 < ldx) v = *reinterpret_cast<const v4f*>(X + (size_t)row * ldx + g0 + lc4);
             float* d = xs + r * 65 + lc4;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
-        for (int e = tid * 4; e < HS; e += 1024) {
+        for (int e = tid * 4; e < HS; e += NT * 4) {
             const int g = g0 + e / KP;
             v4f v = v4f{0.f, 0.f, 0.f, 0.f};
             if (g < ldx) v = *reinterpret_cast<const v4f*>(Ht + (size_t)g0 * KP + e);
@@ -70,8 +73,8 @@ __global__ __launch_bounds__(256) void mu_w_kernel(const float* __restrict__ X, 
         }
         __syncthreads();
 #pragma unroll 4
-        for (int u = 0; u < 16; ++u) {
-            const int gl = q * 16 + u;
+        for (int u = 0; u < GPW; ++u) {
+            const int gl = q * GPW + u;
             const float x = xs[ci * 65 + gl];
             const float* h = hs + gl * KP;                        // same address for the whole wave
             float wh = 0.f;
@@ -84,7 +87,8 @@ __global__ __launch_bounds__(256) void mu_w_kernel(const float* __restrict__ X, 
         }
         __syncthreads();
     }
-    float (*red)[3][64][KP + 1] = reinterpret_cast<float (*)[3][64][KP + 1]>(lds);   // quarters 1..3 -> quarter 0
+    // waves 1..NQ-1 -> wave 0, added in wave order
+    float (*red)[NQ - 1][64][KP + 1] = reinterpret_cast<float (*)[NQ - 1][64][KP + 1]>(lds);
     if (q > 0) {
 #pragma unroll
         for (int c = 0; c < KP; ++c) { red[0][q - 1][ci][c] = num[c]; if (!BETA1) red[BETA1 ? 0 : 1][q - 1][ci][c] = den[c]; }
@@ -93,9 +97,10 @@ __global__ __launch_bounds__(256) void mu_w_kernel(const float* __restrict__ X, 
     if (q == 0 && live) {
 #pragma unroll
         for (int c = 0; c < KP; ++c) {
-            const float n = num[c] + red[0][0][ci][c] + red[0][1][ci][c] + red[0][2][ci][c];
-            float dn = BETA1 ? Hsum[c]
-                             : (den[c] + red[BETA1 ? 0 : 1][0][ci][c] + red[BETA1 ? 0 : 1][1][ci][c] + red[BETA1 ? 0 : 1][2][ci][c]);
+            float n = num[c], dsum = den[c];
+#pragma unroll
+            for (int z = 0; z < NQ - 1; ++z) { n += red[0][z][ci][c]; if (!BETA1) dsum += red[BETA1 ? 0 : 1][z][ci][c]; }
+            float dn = BETA1 ? Hsum[c] : dsum;
             if (l1 > 0.f) dn += l1;
             if (l2 > 0.f) dn += l2 * w[c];
             if (dn == 0.f) dn = MU_EPS;

@@ -52,7 +52,7 @@ static int mu_run_one(cnmf_ctx* ctx, hipStream_t st, int N, int G, int k, float*
     bool hsum_valid = false;
     for (it = 1; it <= prm->max_iter; ++it) {
         if (BETA1 && !hsum_valid) { colsum(dHt, G, dHsum); hsum_valid = true; }
-        mu_w_kernel<KP, BETA1><<<gW, 256, 0, st>>>(ctx->X, ldx, N, G, dW, dHt, dHsum, l1W, l2W);
+        mu_w_kernel<KP, BETA1, (KP <= 32 ? 8 : 4)><<<gW, 64 * (KP <= 32 ? 8 : 4), 0, st>>>(ctx->X, ldx, N, G, dW, dHt, dHsum, l1W, l2W);
         if (update_H) {
             if (BETA1) colsum(dW, N, dWsum);
             mu_h_partial_kernel<KP, BETA1><<<gH, 256, 0, st>>>(ctx->X, ldx, N, G, dW, dHt, rpc, pnum, pden);
@@ -102,7 +102,8 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
         if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
         if (k > 32 && beta != 1) { SET_ERR(ctx, "itakura-saito with n_components > 32 is not supported on the device"); return CNMF_EUNSUPPORTED; }
         const int KP = k <= 8 ? 8 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
-        const int nchunks = std::max(1, std::min(64, N / 256));
+        // row chunks of the H half-step / divergence kernels: ~8 waves per SIMD (2048 workgroups), >= 64 rows each
+        const int nchunks = std::max(1, std::min(std::max(64, 2048 / std::max(1, (G + 255) / 256)), N / 64));
         const int rpc = (N + nchunks - 1) / nchunks;
         DevPool rp;                                   // per-restart scratch
         float* dW = rp.get<float>((size_t)N * KP);
