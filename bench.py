@@ -278,6 +278,7 @@ def main():
     gather_mode = "none"
     if multi:
         gather_mode = os.environ.get("CNMF_GATHER", "torch" if os.environ.get("CNMF_BENCH_BACKEND") else "rccl")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the HIP runtime starts (dmabuf IPC only)
     dist = None
     if gather_mode == "torch":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
