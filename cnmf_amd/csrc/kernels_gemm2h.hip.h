@@ -69,7 +69,7 @@ __device__ __forceinline__ void split2h(float y, unsigned short& h, unsigned sho
 // else 64 rows x 64 k) and walks the k tiles bx, bx + nbx, ... of its rows (the row scale is reduced once).
 //   rmax_part [rows][parts] : per-row maxima of the values to convert (after kscale), one per sweep workgroup
 //   inv_scale [rows]        : 2^-s_c, written by the workgroups of the first k column (bx == 0)
-// `tile` = unsigned short [TKB][TROWS][32] (16 KB), `red` = float [256 / TROWS][TROWS] (1 KB)
+// `tile` = unsigned short [TKB][TROWS][32] (16 KB), `red` = float [256 / TROWS][TROWS] (1 KB, may alias the tile)
 template <int TROWS, int TKB>
 __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src, int ld, int K, int TR,
                                                    unsigned short* __restrict__ dst, const double* __restrict__ kscale,
@@ -112,6 +112,7 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
         sh[i] = g2_row_shift(mx);
         if (bx == 0 && kq == 0) inv_scale[r0 + row] = ldexpf(1.0f, -sh[i]);
     }
+    __syncthreads();                                     // `red` may alias the tile
     const int Kb = K / 16;
     const int tr = r0 / TR, rin = r0 % TR;
     for (int kt = bx; kt < ntiles; kt += nbx) {
@@ -169,8 +170,10 @@ __global__ __launch_bounds__(256) void split2h_tiled_kernel(const float* __restr
                                                             const float* __restrict__ rmax_part, int parts,
                                                             float* __restrict__ inv_scale)
 {
+    // 16 KB in all: the maxima scratch lives in the tile (it is consumed before the first tile is written), so that a
+    // split workgroup fits beside a GEMM workgroup (144 of the 160 KB) when two batches share the GPU
     __shared__ __attribute__((aligned(16))) unsigned short tile[256 * 32];
-    __shared__ float red[256];
+    float* red = reinterpret_cast<float*>(tile);
     split2h_tiled_body<TROWS, TKB>(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, blockIdx.x, gridDim.x,
                                    blockIdx.y, tile, red);
 }

@@ -32,7 +32,9 @@ static inline int sweep_wstride(int kmax) { return sweep_kg(kmax) + 1; }
 static inline size_t sweep_lds_bytes(int kmax)
 {
     const int kg = sweep_kg(kmax);
-    return sizeof(float) * (size_t)(kg * (kg + 4) + 8 + 256 + 4 * 64 * sweep_wstride(kmax));
+    // ranks <= 16 stage the Gram operand 32 rows at a time: 11 KB per workgroup, so that a sweep workgroup fits beside
+    // a GEMM workgroup (144 KB of the 160 KB) when two batches share the GPU
+    return sizeof(float) * (size_t)(kg * (kg + 4) + 8 + 256 + 4 * (kg == 16 ? 32 : 64) * sweep_wstride(kmax));
 }
 
 struct SlotDesc {                   // one restart in flight (device + host mirror)
@@ -86,7 +88,8 @@ __device__ __forceinline__ void sweep_body(
     float* rmx = lds + kg * gs + 8;                                       // [4][64] per-wave row maxima
     float* Wsb = rmx + 256;
 #define GS(t_, r_) Gsb[(t_) * gs + (r_)]
-#define WS(wv_, r_, c_) Wsb[((wv_) * 64 + (r_)) * wstride + (c_)]
+    constexpr int SR = (GMODE == 0) ? 32 : 64;                            // rows of a wave staged at a time
+#define WS(wv_, r_, c_) Wsb[((wv_) * SR + (r_)) * wstride + (c_)]
     const int k = sd.k, off = sd.off;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < KP * KP; e += 256) {
@@ -224,17 +227,26 @@ __device__ __forceinline__ void sweep_body(
         }
         if (want_gram) {
             // Gram of the updated rows on the (otherwise idle) matrix pipe: acc += Wrows^T . Wrows
-#pragma unroll
-            for (int c = 0; c < GR; ++c) WS(wave, lane, c) = (c < KP) ? w[c < KP ? c : 0] : 0.f;
-            __builtin_amdgcn_wave_barrier();       // wave-private tile: LDS ops of one wave are in order
             if constexpr (GMODE == 0) {
                 const int li = lane & 15, q = lane >> 4;
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float a = WS(wave, 4 * s + q, li);
-                    gacc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, gacc4, 0, 0, 0);
+                for (int hf = 0; hf < 2; ++hf) {   // rows 0..31, then 32..63 of the wave (same order of the additions)
+                    if ((lane >> 5) == hf) {
+#pragma unroll
+                        for (int c = 0; c < GR; ++c) WS(wave, lane & 31, c) = (c < KP) ? w[c < KP ? c : 0] : 0.f;
+                    }
+                    __builtin_amdgcn_wave_barrier();   // wave-private tile: LDS ops of one wave are in order
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const float a = WS(wave, 4 * s + q, li);
+                        gacc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, gacc4, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
             } else if constexpr (GMODE == 1) {
+#pragma unroll
+                for (int c = 0; c < GR; ++c) WS(wave, lane, c) = (c < KP) ? w[c < KP ? c : 0] : 0.f;
+                __builtin_amdgcn_wave_barrier();
                 const int li = lane & 31, h = lane >> 5;
 #pragma unroll 8
                 for (int s = 0; s < 32; ++s) {
@@ -242,6 +254,9 @@ __device__ __forceinline__ void sweep_body(
                     gacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, gacc[0], 0, 0, 0);
                 }
             } else {
+#pragma unroll
+                for (int c = 0; c < GR; ++c) WS(wave, lane, c) = (c < KP) ? w[c < KP ? c : 0] : 0.f;
+                __builtin_amdgcn_wave_barrier();
                 const int li = lane & 31, h = lane >> 5;
 #pragma unroll 4
                 for (int s = 0; s < 32; ++s) {
@@ -527,12 +542,12 @@ __global__ __launch_bounds__(256) void split2h_finalize_kernel(const float* __re
                                                                float* __restrict__ inv_scale, int split_bx,
                                                                int split_by, FinalizeArgs fa, int fin_y)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[256 * 32 * 2 + 256 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[256 * 32 * 2];      // 16 KB (see split2h_tiled_kernel)
     const int b = blockIdx.x, nsplit = split_bx * split_by;
     if (b < nsplit) {
         split2h_tiled_body<TROWS, TKB>(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, b % split_bx, split_bx,
                                        b / split_bx, reinterpret_cast<unsigned short*>(lds),
-                                       reinterpret_cast<float*>(lds + 256 * 32 * 2));
+                                       reinterpret_cast<float*>(lds));
     } else {
         const int f = b - nsplit;
         finalize_body(fa, f / fin_y, f % fin_y, reinterpret_cast<double*>(lds));
