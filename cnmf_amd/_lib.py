@@ -77,6 +77,9 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-unused-value", "-Wno-unused-result",
+           # MFMA accumulators in plain VGPRs (gfx950 has one unified file): no v_accvgpr moves around the
+           # elementwise work between chained MFMAs (kernels_mu_mfma.hip.h)
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1",
            os.path.join(SRC_DIR, "cnmf_hip.hip"), "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))

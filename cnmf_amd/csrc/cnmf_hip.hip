@@ -109,7 +109,7 @@ extern "C" void cnmf_destroy(cnmf_ctx* ctx)
     hipStreamSynchronize(ctx->stream);
     free_batch(ctx);
     cnmf_comm_finalize(ctx);
-    hipFree(ctx->X); hipFree(ctx->X3); hipFree(ctx->Xt3);
+    hipFree(ctx->X); hipFree(ctx->X3); hipFree(ctx->Xt3); hipFree(ctx->XtF);
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     hipFree(ctx->stageW); hipFree(ctx->stageH); hipFree(ctx->spectra);
@@ -127,6 +127,7 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     free_batch(ctx);
     hipFree(ctx->X); ctx->X = nullptr;
+    hipFree(ctx->XtF); ctx->XtF = nullptr;
     hipFree(ctx->X3); hipFree(ctx->Xt3); ctx->X3 = ctx->Xt3 = nullptr;
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);

@@ -6,6 +6,7 @@
 // (beta_loss='frobenius' -> CD is the default, cnmf.py:334,630).
 #pragma once
 #include "kernels_mu.hip.h"
+#include "kernels_mu_mfma.hip.h"
 
 namespace cnmf {
 
@@ -73,6 +74,217 @@ static int mu_run_one(cnmf_ctx* ctx, hipStream_t st, int N, int G, int k, float*
     return CNMF_OK;
 }
 
+// ---- Kullback-Leibler restarts on the matrix pipe, up to MU_MAXSLOTS in flight (kernels_mu_mfma.hip.h).
+// All live restarts advance one iteration per round of launches; the divergence is evaluated (and slots are retired /
+// refilled) only at rounds where every live restart sits at a multiple of 10 iterations, so one host synchronisation
+// per 10 iterations serves the whole batch (sklearn evaluates it every 10 iterations, _nmf.py:871-884).
+static int mu_ensure_xt(cnmf_ctx* ctx, int Gs)
+{
+    if (ctx->XtF) return CNMF_OK;
+    const size_t n = (size_t)Gs * ctx->N_pad;
+    HIP_TRY(ctx, hipMalloc(&ctx->XtF, n * sizeof(float)));
+    dim3 grid(Gs / 32, ctx->N_pad / 32), block(32, 8);
+    mu_transpose_kernel<<<grid, block, 0, ctx->stream>>>(ctx->X, ctx->G_pad, (int)ctx->N, (int)ctx->G, ctx->XtF, ctx->N_pad, Gs);
+    HIP_TRY(ctx, hipGetLastError());
+    return CNMF_OK;
+}
+
+struct MuJob { int restart; int k; size_t hoff, woff; };
+
+template <int KP>
+static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init_mode, const uint32_t* seeds,
+                         const double* avg, const float* W0, const float* H0, int update_H,
+                         const cnmf_cd_params* prm, float* H_out, float* W_out, int32_t* n_iter_out, double* err_out)
+{
+    hipStream_t st = ctx->stream;
+    const int N = (int)ctx->N, G = (int)ctx->G, ldx = ctx->G_pad, Np = ctx->N_pad;
+    const int Gs = round_up(ctx->G_pad, 64);
+    int rc = mu_ensure_xt(ctx, Gs);
+    if (rc) return rc;
+    const int nstrips = (N + 63) / 64, ntiles = Np / 32;
+    const int nchunks = std::min(32, ntiles), tpc = (ntiles + nchunks - 1) / nchunks;
+    const int R = (int)std::min<size_t>(MU_MAXSLOTS, jobs.size());
+    const float l1W = (float)prm->l1_reg_W, l2W = (float)prm->l2_reg_W;
+    const float l1H = (float)prm->l1_reg_H, l2H = (float)prm->l2_reg_H;
+
+    struct Slot { MuSlotDev d; int job = -1; int it = 0; double err0 = 0, prev = 0, err = 0; bool fresh = false; };
+    std::vector<Slot> slots(R);
+    DevPool pool;
+    int kmax = 1;
+    for (const MuJob& j : jobs) kmax = std::max(kmax, j.k);
+    for (Slot& s : slots) {
+        MuSlotDev& d = s.d;
+        d.W = pool.get<float>((size_t)Np * KP, true, st);
+        d.Ht = pool.get<float>((size_t)Gs * KP, true, st);
+        d.Wp_hi = pool.get<mu_u16>((size_t)Np * KP, true, st); d.Wp_lo = pool.get<mu_u16>((size_t)Np * KP, true, st);
+        d.Wc_hi = pool.get<mu_u16>((size_t)2 * Np * KP, true, st); d.Wc_lo = d.Wc_hi ? d.Wc_hi + (size_t)Np * KP : nullptr;
+        d.Hp_hi = pool.get<mu_u16>((size_t)Gs * KP, true, st); d.Hp_lo = pool.get<mu_u16>((size_t)Gs * KP, true, st);
+        d.Hc_hi = pool.get<mu_u16>((size_t)2 * Gs * KP, true, st); d.Hc_lo = d.Hc_hi ? d.Hc_hi + (size_t)Gs * KP : nullptr;
+        d.Hsum = pool.get<float>(KP, true, st); d.Wsum = pool.get<float>(KP, true, st);
+        d.pnum = pool.get<float>((size_t)nchunks * Gs * KP);
+        d.divpart = pool.get<double>(nstrips);
+        d.cspart = pool.get<double>((size_t)256 * KP);
+    }
+    // component-major staging of the initial / final factors, one kmax-row band per slot (the seeded initialisation of
+    // all fresh slots is ONE launch: a workgroup per restart, the Mersenne twister is serial inside it)
+    float* cmH = pool.get<float>((size_t)R * kmax * G);
+    float* cmW = pool.get<float>((size_t)R * kmax * N);
+    RngJob* dj = pool.get<RngJob>(R);
+    if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+    std::vector<double> hdiv((size_t)R * nstrips);
+    std::vector<float> hsums((size_t)R * 2 * KP);
+
+    auto batch_of = [&](const std::vector<int>& ids) { MuBatch mb; mb.n = (int)ids.size(); for (int i = 0; i < mb.n; ++i) mb.s[i] = slots[ids[i]].d; return mb; };
+    auto sw_of = [](int n) { return n >= 4 ? 4 : (n >= 2 ? 2 : 1); };
+    auto colsum = [&](const MuBatch& mb, int which) {
+        const int Rr = which ? G : N;
+        const int nb = std::max(1, std::min(256, Rr / 256));
+        mu_colsum_batch_part_kernel<KP><<<dim3(nb, mb.n), 256, 0, st>>>(mb, which, Rr);
+        mu_colsum_batch_final_kernel<KP><<<dim3(1, mb.n), 1024, 0, st>>>(mb, which, nb);
+    };
+    auto install = [&](const std::vector<int>& sis, const std::vector<int>& jis) -> int {
+        const int gHt = (G * KP + 255) / 256, gWp = (int)(((size_t)N * KP + 255) / 256);
+        if (update_H && init_mode == 1) {
+            std::vector<RngJob> hj(sis.size());
+            for (size_t i = 0; i < sis.size(); ++i) {
+                const MuJob& jb = jobs[jis[i]];
+                hj[i] = RngJob{seeds[jb.restart], jb.k, sis[i] * kmax, avg[jb.restart], (long long)jb.k * ((long long)G + N)};
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(dj, hj.data(), hj.size() * sizeof(RngJob), hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));                      // `hj` is a stack temporary
+            rng_kernel<1><<<(int)sis.size(), 256, 0, st>>>(dj, nullptr, cmH, G, G, cmW, N, N);
+        }
+        for (size_t i = 0; i < sis.size(); ++i) {
+            Slot& s = slots[sis[i]];
+            const MuJob& jb = jobs[jis[i]];
+            const int k = jb.k, r = jb.restart;
+            float* cH = cmH + (size_t)sis[i] * kmax * G;
+            float* cW = cmW + (size_t)sis[i] * kmax * N;
+            if (!update_H) {
+                HIP_TRY(ctx, hipMemcpyAsync(cH, H0 + jb.hoff, (size_t)k * G * sizeof(float), hipMemcpyHostToDevice, st));
+                mu_pack_kernel<<<gHt, 256, 0, st>>>(cH, k, G, s.d.Ht, KP);
+                mu_fill_kernel<<<gWp, 256, 0, st>>>(s.d.W, k, N, KP, (float)avg[r]);       // sklearn _nmf.py:1229-1231
+            } else if (init_mode == 0) {
+                HIP_TRY(ctx, hipMemcpyAsync(cH, H0 + jb.hoff, (size_t)k * G * sizeof(float), hipMemcpyHostToDevice, st));
+                HIP_TRY(ctx, hipMemcpyAsync(cW, W0 + jb.woff, (size_t)k * N * sizeof(float), hipMemcpyHostToDevice, st));
+                mu_pack_kernel<<<gHt, 256, 0, st>>>(cH, k, G, s.d.Ht, KP);
+                mu_pack_rm_kernel<<<gWp, 256, 0, st>>>(cW, k, N, s.d.W, KP);
+            } else {
+                mu_pack_kernel<<<gHt, 256, 0, st>>>(cH, k, G, s.d.Ht, KP);
+                mu_pack_kernel<<<gWp, 256, 0, st>>>(cW, k, N, s.d.W, KP);
+            }
+            mu_planes_kernel<KP><<<(int)(((size_t)Np * KP + 255) / 256), 256, 0, st>>>(s.d.W, Np, s.d.Wp_hi, s.d.Wp_lo, s.d.Wc_hi, s.d.Wc_lo);
+            mu_planes_kernel<KP><<<(Gs * KP + 255) / 256, 256, 0, st>>>(s.d.Ht, Gs, s.d.Hp_hi, s.d.Hp_lo, s.d.Hc_hi, s.d.Hc_lo);
+            s.job = jis[i]; s.it = 0; s.fresh = true; s.err0 = s.prev = s.err = 0.0;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return CNMF_OK;
+    };
+    auto retire = [&](int si) -> int {
+        Slot& s = slots[si];
+        const MuJob& jb = jobs[s.job];
+        const int k = jb.k;
+        float* cH = cmH + (size_t)si * kmax * G;
+        float* cW = cmW + (size_t)si * kmax * N;
+        if (H_out && update_H) {
+            mu_unpack_kernel<<<(G * k + 255) / 256, 256, 0, st>>>(s.d.Ht, k, G, KP, cH, 1);
+            HIP_TRY(ctx, hipMemcpyAsync(H_out + jb.hoff, cH, (size_t)k * G * sizeof(float), hipMemcpyDeviceToHost, st));
+        }
+        if (W_out) {
+            mu_unpack_kernel<<<(int)(((size_t)N * k + 255) / 256), 256, 0, st>>>(s.d.W, k, N, KP, cW, 0);
+            HIP_TRY(ctx, hipMemcpyAsync(W_out + jb.woff, cW, (size_t)k * N * sizeof(float), hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (n_iter_out) n_iter_out[jb.restart] = s.it;
+        if (err_out) err_out[jb.restart] = s.err;
+        s.job = -1;
+        return CNMF_OK;
+    };
+    // divergence of the current factors of the slots `ids` -> err[] (host)
+    auto divergence = [&](const std::vector<int>& ids, std::vector<double>& err) -> int {
+        const MuBatch mb = batch_of(ids);
+        if (!update_H) colsum(mb, 0);                 // refit: the iterations do not need the column sums of W
+        const int sw = sw_of(mb.n), nsub = 4 / sw;
+        dim3 grid((nstrips + nsub - 1) / nsub, 1, (mb.n + sw - 1) / sw);
+        mu_w_mfma_kernel<KP, 1><<<grid, 256, 0, st>>>(ctx->XtF, Np, N, Gs, mb, sw, 0.f, 0.f);
+        HIP_TRY(ctx, hipGetLastError());
+        for (int i = 0; i < mb.n; ++i) {
+            HIP_TRY(ctx, hipMemcpyAsync(hdiv.data() + (size_t)i * nstrips, mb.s[i].divpart, (size_t)nstrips * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(hsums.data() + (size_t)i * 2 * KP, mb.s[i].Hsum, KP * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(hsums.data() + (size_t)i * 2 * KP + KP, mb.s[i].Wsum, KP * sizeof(float), hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        err.resize(mb.n);
+        for (int i = 0; i < mb.n; ++i) {
+            double res = 0.0;
+            for (int q = 0; q < nstrips; ++q) res += hdiv[(size_t)i * nstrips + q];
+            double swh = 0.0;
+            for (int c = 0; c < KP; ++c) swh += (double)hsums[(size_t)i * 2 * KP + c] * (double)hsums[(size_t)i * 2 * KP + KP + c];
+            res += swh;
+            err[i] = std::sqrt(2.0 * std::max(res, 0.0));
+        }
+        return CNMF_OK;
+    };
+
+    size_t next = 0;
+    std::vector<int> ids;
+    std::vector<double> errs;
+    for (;;) {
+        // ---- aligned point: every live slot sits at a multiple of 10 iterations (or nothing is live)
+        bool aligned = true;
+        for (const Slot& s : slots) if (s.job >= 0 && s.it % 10 != 0 && s.it < prm->max_iter) aligned = false;
+        if (aligned) {
+            // refill
+            std::vector<int> fresh, fjobs;
+            for (int si = 0; si < R && next < jobs.size(); ++si)
+                if (slots[si].job < 0) { fresh.push_back(si); fjobs.push_back((int)next++); }
+            if (!fresh.empty()) {
+                rc = install(fresh, fjobs);
+                if (rc) return rc;
+                const MuBatch mb = batch_of(fresh); colsum(mb, 0); colsum(mb, 1);
+            }
+            // divergence of the fresh slots (error at init) and of the slots due for the convergence test
+            ids.clear();
+            for (int si = 0; si < R; ++si) {
+                const Slot& s = slots[si];
+                if (s.job < 0) continue;
+                if (s.fresh || (prm->tol > 0 && s.it > 0 && s.it % 10 == 0)) ids.push_back(si);
+            }
+            if (!ids.empty()) {
+                rc = divergence(ids, errs);
+                if (rc) return rc;
+                for (size_t i = 0; i < ids.size(); ++i) {
+                    Slot& s = slots[ids[i]];
+                    if (s.fresh) { s.err0 = s.prev = s.err = errs[i]; s.fresh = false; continue; }
+                    s.err = errs[i];
+                    if ((s.prev - s.err) / s.err0 < prm->tol) { rc = retire(ids[i]); if (rc) return rc; }
+                    else s.prev = s.err;
+                }
+            }
+        }
+        // slots that have used up their iterations
+        for (int si = 0; si < R; ++si)
+            if (slots[si].job >= 0 && slots[si].it >= prm->max_iter) { rc = retire(si); if (rc) return rc; }
+        ids.clear();
+        for (int si = 0; si < R; ++si) if (slots[si].job >= 0) ids.push_back(si);
+        if (ids.empty()) { if (next >= jobs.size()) break; else continue; }
+        // ---- one iteration of every live slot
+        const MuBatch mb = batch_of(ids);
+        const int sw = sw_of(mb.n), nsub = 4 / sw;
+        const int gz = (mb.n + sw - 1) / sw;
+        mu_w_mfma_kernel<KP, 0><<<dim3((nstrips + nsub - 1) / nsub, 1, gz), 256, 0, st>>>(ctx->XtF, Np, N, Gs, mb, sw, l1W, l2W);
+        if (update_H) {
+            colsum(mb, 0);
+            mu_h_mfma_kernel<KP><<<dim3(Gs / 64, (nchunks + nsub - 1) / nsub, gz), 256, 0, st>>>(ctx->X, ldx, Np, Gs, mb, tpc, nchunks, sw);
+            mu_h_finish_mfma_kernel<KP><<<dim3((Gs * KP + 255) / 256, mb.n), 256, 0, st>>>(mb, G, Gs, nchunks, l1H, l2H);
+            colsum(mb, 1);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        for (int si : ids) slots[si].it++;
+    }
+    return CNMF_OK;
+}
+
 }  // namespace cnmf
 
 extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode,
@@ -95,12 +307,34 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
     hipStream_t st = ctx->stream;
     const int N = (int)ctx->N, G = (int)ctx->G, Gp = ctx->G_pad;
     DevPool pool;
-    size_t hoff = 0, woff = 0;
     for (int r = 0; r < n; ++r) {
         const int k = kk[r];
         if (k < 1) { SET_ERR(ctx, "n_components must be >= 1"); return CNMF_EINVAL; }
         if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
         if (k > 32 && beta != 1) { SET_ERR(ctx, "itakura-saito with n_components > 32 is not supported on the device"); return CNMF_EUNSUPPORTED; }
+    }
+    // Kullback-Leibler with rank <= 32: batched on the matrix pipe (kernels_mu_mfma.hip.h); the rest below, one by one
+    std::vector<char> done(n, 0);
+    {
+        const char* e = getenv("CNMF_MU_VALU");
+        if (beta == 1 && !(e && atoi(e) != 0)) {
+            std::vector<MuJob> j16, j32;
+            size_t ho = 0, wo = 0;
+            for (int r = 0; r < n; ++r) {
+                const int k = kk[r];
+                if (k <= 16) j16.push_back(MuJob{r, k, ho, wo});
+                else if (k <= 32) j32.push_back(MuJob{r, k, ho, wo});
+                if (k <= 32) done[r] = 1;
+                ho += (size_t)k * G; wo += (size_t)k * N;
+            }
+            if (!j16.empty()) { rc = mu_batch_mfma<16>(ctx, j16, init_mode, seeds, avg, W0, H0, update_H, prm, H_out, W_out, n_iter_out, err_out); if (rc) return rc; }
+            if (!j32.empty()) { rc = mu_batch_mfma<32>(ctx, j32, init_mode, seeds, avg, W0, H0, update_H, prm, H_out, W_out, n_iter_out, err_out); if (rc) return rc; }
+        }
+    }
+    size_t hoff = 0, woff = 0;
+    for (int r = 0; r < n; ++r) {
+        const int k = kk[r];
+        if (done[r]) { hoff += (size_t)k * G; woff += (size_t)k * N; continue; }
         const int KP = k <= 8 ? 8 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
         // row chunks of the H half-step / divergence kernels: ~8 waves per SIMD (2048 workgroups), >= 64 rows each
         const int nchunks = std::max(1, std::min(std::max(64, 2048 / std::max(1, (G + 255) / 256)), N / 64));

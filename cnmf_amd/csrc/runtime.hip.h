@@ -24,6 +24,8 @@ struct cnmf_ctx {
     unsigned int *hiA = nullptr, *hiB = nullptr;   // their flags: one bit per (tile row, block)
     double* d_scale = nullptr;                     // per-gene scale d [G_pad]
     int count_fmt = 0;                             // 3 = bf16 planes (base 256), 4 = f16 planes (base 2048, swizzled slots)
+    float* XtF = nullptr;                          // X^T [round_up(G_pad, 64)][N_pad] float32, built on first use by the
+                                                   // Kullback-Leibler solver (kernels_mu_mfma.hip.h)
 
     // batch buffers (sized for kc_alloc columns)
     int kc_alloc = 0, nsplit_alloc = 0, nsplitA_alloc = 0, parts_alloc = 0;

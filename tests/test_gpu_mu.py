@@ -78,3 +78,32 @@ def test_mu_through_cnmf_callsite(engine, X, tmp_path):
     _, H_ref, _ = nmf_mu.nmf_mu(X, 4, seed=led[0][2], max_iter=120)
     maxabs, relfro = nmf_cd.spectra_error(H_ref, merged.values[:4])
     assert maxabs <= 1e-4 and relfro <= 1e-3
+
+
+def test_mu_batch_matches_single_and_valu_path(engine, X, monkeypatch):
+    """Kullback-Leibler restarts run batched on the matrix pipe (kernels_mu_mfma.hip.h): a restart's result must not
+    depend on what else is in the batch (bit for bit), and must agree with the vector-ALU path and the oracle."""
+    engine.set_matrix(X)
+    ks = [5, 7, 12, 20, 9, 16, 17, 3, 8, 13, 6, 11, 10, 4, 15, 14, 19, 2]          # more than one round of 16 slots
+    seeds = [100 + i for i in range(len(ks))]
+    H, W, n_iter, err = engine.nmf_mu_batch(ks, seeds=seeds, max_iter=200, return_W=True, warn=False)
+    for i in (0, 3, 6, 17):
+        H1, W1, n1, e1 = engine.nmf_mu_batch([ks[i]], seeds=[seeds[i]], max_iter=200, return_W=True, warn=False)
+        assert int(n1[0]) == int(n_iter[i])
+        np.testing.assert_array_equal(H1[0], H[i])
+        np.testing.assert_array_equal(W1[0], W[i])
+    for i in (1, 2, 16):
+        W_ref, H_ref, _ = nmf_mu.nmf_mu(X, ks[i], seed=seeds[i], max_iter=int(n_iter[i]), tol=0.0)
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, H[i])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (i, maxabs, relfro)
+        ref_err = nmf_mu.beta_divergence(X, W_ref, H_ref, 1, square_root=True)
+        assert abs(err[i] - ref_err) <= 2e-3 * ref_err
+    # the vector-ALU path (float32 FMAs in another order): two float32 trajectories, held to a looser bound
+    monkeypatch.setenv("CNMF_MU_VALU", "1")
+    Hv, Wv, nv, ev = engine.nmf_mu_batch(ks[:6], seeds=seeds[:6], max_iter=200, return_W=True, warn=False)
+    monkeypatch.delenv("CNMF_MU_VALU")
+    for i in range(6):
+        assert abs(int(nv[i]) - int(n_iter[i])) <= 10
+        if int(nv[i]) == int(n_iter[i]):
+            maxabs, relfro = nmf_cd.spectra_error(Hv[i], H[i])
+            assert maxabs <= 2e-3 and relfro <= 2e-3, (i, maxabs, relfro)
