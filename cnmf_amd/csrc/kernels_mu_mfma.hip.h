@@ -19,9 +19,11 @@
 // For ranks <= 16 the hi and lo planes of the second product's A operand are stacked in the M dimension
 // (rows 0..15 = hi, 16..31 = lo of the same 16 components): one MFMA per Q plane covers both.
 //
-// Restarts share each X tile: the waves of a workgroup are different restarts on the SAME tile (the L1 serves the
-// repeats), further restart groups sit in gridDim.z.  Each wave owns two tiles along the non-reduced dimension, so a
-// streamed factor fragment is used twice.
+// Restarts share each X tile: a workgroup is 4 restarts on the SAME block of X (staged once through LDS), further
+// restart groups sit in gridDim.z.  Each wave owns two 32 x 32 tiles along the non-reduced dimension.
+// Measured (PMC, 16 restarts of rank 9 at 50000 x 2000): vector ALU 60 % busy (the quotient: clamp, reciprocal, two
+// bf16 planes = about 8 issue slots per element), matrix pipe 24 % -- they do not overlap inside a SIMD here, so the step is
+// bound by their sum.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels_gemm3.hip.h"
@@ -75,35 +77,13 @@ __device__ __forceinline__ mu_bf16x8 mu_ld8(const mu_u16* p)
     return __builtin_bit_cast(mu_bf16x8, *reinterpret_cast<const u32x4*>(p));
 }
 
-// max(s, eps) as ONE instruction: v_med3_f32(s, eps, +inf)  (fmaxf adds a canonicalising v_max for signalling NaNs
-// an MFMA result cannot be; inline assembly is not an option -- the hazard recogniser does not see an asm statement
-// reading MFMA results and omits the wait states)
+// max(s, eps) as ONE instruction: a signed integer maximum of the bit patterns (the order of non-negative floats is the
+// order of their bits; a negative s -- impossible for a product of non-negative factors -- would also clamp to eps).
+// fmaxf / v_med3_f32 cost a second, canonicalising v_max; inline assembly is not an option -- the hazard recogniser
+// does not see an asm statement reading MFMA results and omits the wait states.
 __device__ __forceinline__ float mu_clamp_eps(float s)
 {
-    return __builtin_amdgcn_fmed3f(s, MU_EPS, __builtin_inff());
-}
-
-// quotient planes of one tile: q[r] = x[r] / max(s[r], eps) as bf16 hi / lo, packed in register order
-// (registers 0..7 -> first B operand, 8..15 -> second).  v_rcp_f32 is a quarter-rate instruction: one reciprocal
-// serves two elements, q0 = x0 s1 / (s0 s1), q1 = x1 s0 / (s0 s1)  (s >= eps = 1.2e-7: the product cannot underflow).
-__device__ __forceinline__ void mu_quotient_planes(const f32x16& s, const float* x, u32x4 (&qh)[2], u32x4 (&ql)[2])
-{
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        unsigned ph[4], pl[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int r = 8 * c + 2 * d;
-            const float s0 = mu_clamp_eps(s[r]), s1 = mu_clamp_eps(s[r + 1]);
-            const float rc = __builtin_amdgcn_rcpf(s0 * s1);
-            const float q0 = (x[r] * s1) * rc, q1 = (x[r + 1] * s0) * rc;
-            ph[d] = mu_pack_bf16(q0, q1);
-            const float h0 = __uint_as_float(ph[d] << 16), h1 = __uint_as_float(ph[d] & 0xffff0000u);
-            pl[d] = mu_pack_bf16(q0 - h0, q1 - h1);
-        }
-        qh[c] = u32x4{ph[0], ph[1], ph[2], ph[3]};
-        ql[c] = u32x4{pl[0], pl[1], pl[2], pl[3]};
-    }
+    return __int_as_float(max(__float_as_int(s), __float_as_int(MU_EPS)));
 }
 
 #define MU_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0)
@@ -127,185 +107,32 @@ __device__ __forceinline__ f32x16 mu_product(const mu_bf16x8 (&a)[KS][2], const 
     return s;
 }
 
-// numerator += A2 . Q  (A2: component planes in pos16 order, Q: the quotient planes)
-//   KP = 16: a2[c][0] holds hi (rows 0..15) and lo (rows 16..31) stacked; KP = 32: a2[c][0] = hi, a2[c][1] = lo
+// one 16-deep chunk c of a tile: quotient planes of registers 8c .. 8c+7, then the MFMAs that consume them
 template <int KP>
-__device__ __forceinline__ void mu_accumulate(f32x16& acc, const mu_bf16x8 (&a2)[2][KP == 16 ? 1 : 2],
-                                              const u32x4 (&qh)[2], const u32x4 (&ql)[2])
+__device__ __forceinline__ void mu_quotient_accumulate_chunk(f32x16& acc, const f32x16& s, const float (&x)[16], int c,
+                                                             const mu_bf16x8 (&a2c)[KP == 16 ? 1 : 2])
 {
+    unsigned ph[4], pl[4];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const mu_bf16x8 bh = __builtin_bit_cast(mu_bf16x8, qh[c]), bl = __builtin_bit_cast(mu_bf16x8, ql[c]);
-        if constexpr (KP == 16) {
-            acc = MU_MFMA(a2[c][0], bl, acc);
-            acc = MU_MFMA(a2[c][0], bh, acc);
-        } else {
-            acc = MU_MFMA(a2[c][1], bl, acc);
-            acc = MU_MFMA(a2[c][1], bh, acc);
-            acc = MU_MFMA(a2[c][0], bl, acc);
-            acc = MU_MFMA(a2[c][0], bh, acc);
-        }
+    for (int d = 0; d < 4; ++d) {
+        const int r = 8 * c + 2 * d;
+        const float s0 = mu_clamp_eps(s[r]), s1 = mu_clamp_eps(s[r + 1]);
+        const float rc = __builtin_amdgcn_rcpf(s0 * s1);
+        const float q0 = (x[r] * s1) * rc, q1 = (x[r + 1] * s0) * rc;
+        ph[d] = mu_pack_bf16(q0, q1);
+        const float h0 = __uint_as_float(ph[d] << 16), h1 = __uint_as_float(ph[d] & 0xffff0000u);
+        pl[d] = mu_pack_bf16(q0 - h0, q1 - h1);
     }
-}
-
-// wave -> (slot, sub): `sw` (1, 2 or 4) waves of a workgroup are different restarts, the other 4 / sw are further tiles
-__device__ __forceinline__ bool mu_wave_role(const MuBatch& mb, int sw, int& slot, int& sub)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    slot = blockIdx.z * sw + (wave % sw);
-    sub = wave / sw;
-    return slot < mb.n;
-}
-
-// Streamed operands come in through buffer loads: resource descriptor (wave-uniform base) + per-lane 32-bit byte
-// offset + scalar offset -- no 64-bit per-lane address arithmetic in the tile loop.
-typedef __amdgpu_buffer_rsrc_t mu_rsrc;
-__device__ __forceinline__ mu_rsrc mu_make_rsrc(const void* base)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ float mu_bld(mu_rsrc rs, unsigned voff, unsigned soff)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
-}
-__device__ __forceinline__ mu_bf16x8 mu_bld8(mu_rsrc rs, unsigned voff, unsigned soff)
-{
-    return __builtin_bit_cast(mu_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
-}
-
-// The tile loop shared by both half-steps.  Streams, per 32-deep step t of the reduced dimension:
-//   x      : X values of the wave's two 32 x 32 tiles in the C layout -- row (8 (r / 4) + 4 h + r % 4) of the step,
-//            column l32 (+32 for the second tile); `xs` = bytes between consecutive rows of the stepped dimension
-//   a1     : first product's A fragments (row-major planes of the streamed factor, KP bf16 per row)
-//   a2     : second product's A fragments (component-major planes, `cs` elements per component row, lo plane after hi)
-// Every fragment is re-requested for step t + 1 as soon as its last use in step t has been issued (same registers:
-// the loads travel under the rest of the step), pinned by scheduling barriers so that the compiler does not sink them
-// back to their next use.
-template <int KP, bool SECOND>
-struct MuStream {
-    mu_rsrc rs_a1h, rs_a1l, rs_a2;
-    const float* xbase;            // X (H half-step) or X^T (W half-step)
-    size_t xstep;                  // floats per 32-step of the reduced dimension
-    unsigned xv;                   // per-lane byte offset inside a step
-    unsigned xs;                   // bytes per row of the reduced dimension
-    unsigned a1o, a2o, plane_b;
-    float x[2][16];
-    mu_bf16x8 a1[KP / 16][2];
-    mu_bf16x8 a2[2][KP == 16 ? 1 : 2];
-
-    __device__ __forceinline__ void load_x(int jt, int t)
-    {
-        const mu_rsrc rs = mu_make_rsrc(xbase + (size_t)t * xstep);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[jt][r] = mu_bld(rs, xv, (unsigned)(8 * (r >> 2) + (r & 3)) * xs + 128u * jt);
-    }
-    __device__ __forceinline__ void load_a1(int t)
-    {
-        const unsigned so = 2u * (unsigned)(t * 32 * KP);
-#pragma unroll
-        for (int ks = 0; ks < KP / 16; ++ks) {
-            a1[ks][0] = mu_bld8(rs_a1h, a1o, so + 32u * ks);
-            a1[ks][1] = mu_bld8(rs_a1l, a1o, so + 32u * ks);
-        }
-    }
-    __device__ __forceinline__ void load_a2(int t)
-    {
-        if constexpr (SECOND) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int p = 0; p < (KP == 16 ? 1 : 2); ++p)
-                    a2[c][p] = mu_bld8(rs_a2, a2o, 2u * (unsigned)(t * 32 + 16 * c) + p * plane_b);
-        }
-    }
-};
-
-#define MU_PIN() __builtin_amdgcn_sched_barrier(0)
-
-// numerators of steps [t0, t1) into acc[2]
-template <int KP>
-__device__ __forceinline__ void mu_tile_loop(MuStream<KP, true>& st, const mu_bf16x8 (&b1)[2][KP / 16][2],
-                                             f32x16 (&acc)[2], int t0, int t1)
-{
-    if (t0 >= t1) return;
-    st.load_x(0, t0); st.load_x(1, t0); st.load_a1(t0); st.load_a2(t0);
-    for (int t = t0; t < t1; ++t) {
-        const int tn = min(t + 1, t1 - 1);
-        u32x4 qh[2], ql[2];
-        f32x16 s = mu_product<KP / 16>(st.a1, b1[0]);
-        mu_quotient_planes(s, st.x[0], qh, ql);
-        MU_PIN(); st.load_x(0, tn); MU_PIN();
-        mu_accumulate<KP>(acc[0], st.a2, qh, ql);
-        s = mu_product<KP / 16>(st.a1, b1[1]);
-        MU_PIN(); st.load_a1(tn); MU_PIN();
-        mu_quotient_planes(s, st.x[1], qh, ql);
-        MU_PIN(); st.load_x(1, tn); MU_PIN();
-        mu_accumulate<KP>(acc[1], st.a2, qh, ql);
-        MU_PIN(); st.load_a2(tn); MU_PIN();
-    }
-}
-
-// ---- H half-step partials.  grid = (gene strips of 64, row chunks / (4 / sw), restart groups), block = 256
-//   pnum[chunk][g][c] = sum_{i in chunk} W[i][c] Q[i][g]
-template <int KP>
-__global__ __launch_bounds__(256) void mu_h_mfma_kernel(const float* __restrict__ X, int ldx, int Np, int Gs,
-                                                        MuBatch mb, int tiles_per_chunk, int nchunks, int sw)
-{
-    constexpr int KS = KP / 16;
-    int slot, sub;
-    if (!mu_wave_role(mb, sw, slot, sub)) return;
-    const MuSlotDev& sd = mb.s[slot];
-    const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5;
-    const int g0 = blockIdx.x * 64;
-    const int chunk = blockIdx.y * (4 / sw) + sub;
-    if (chunk >= nchunks) return;
-    const int ntiles = Np / 32;
-    const int rt0 = chunk * tiles_per_chunk, rt1 = min(ntiles, rt0 + tiles_per_chunk);
-
-    mu_bf16x8 b1[2][KS][2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const size_t o = (size_t)(g0 + 32 * jt + l32) * KP + 16 * ks + 8 * h;
-            b1[jt][ks][0] = mu_ld8(sd.Hp_hi + o);
-            b1[jt][ks][1] = mu_ld8(sd.Hp_lo + o);
-        }
-    f32x16 acc[2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
-    // second product's A operand: row m of the 32 = (plane, component); Wc_lo follows Wc_hi in memory.
-    // (a last gene strip beyond ldx reads into the next row -- X has a slack row -- and only feeds padded genes)
-    MuStream<KP, true> st;
-    st.rs_a1h = mu_make_rsrc(sd.Wp_hi); st.rs_a1l = mu_make_rsrc(sd.Wp_lo); st.rs_a2 = mu_make_rsrc(sd.Wc_hi);
-    st.xbase = X; st.xstep = (size_t)32 * ldx; st.xs = 4u * (unsigned)ldx;
-    st.xv = 4u * (unsigned)(4 * h * ldx + g0 + l32);
-    st.a1o = 2u * (unsigned)(l32 * KP + 8 * h);
-    st.plane_b = 2u * (unsigned)KP * (unsigned)Np;
-    st.a2o = (KP == 16) ? (2u * (unsigned)((l32 & 15) * Np + 8 * h) + (l32 >> 4) * st.plane_b)
-                        : 2u * (unsigned)(l32 * Np + 8 * h);
-    mu_tile_loop<KP>(st, b1, acc, rt0, rt1);
-    // C layout: register r <-> row m = 8 (r / 4) + 4 h + r % 4, column (gene) l32
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-        float* pn = sd.pnum + ((size_t)chunk * Gs + g0 + 32 * jt + l32) * KP;
-        if constexpr (KP == 16) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                v4f v;
-                v.x = acc[jt][4 * q + 0] + acc[jt][4 * q + 8]; v.y = acc[jt][4 * q + 1] + acc[jt][4 * q + 9];
-                v.z = acc[jt][4 * q + 2] + acc[jt][4 * q + 10]; v.w = acc[jt][4 * q + 3] + acc[jt][4 * q + 11];
-                *reinterpret_cast<v4f*>(pn + 8 * q + 4 * h) = v;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v4f v = {acc[jt][4 * q], acc[jt][4 * q + 1], acc[jt][4 * q + 2], acc[jt][4 * q + 3]};
-                *reinterpret_cast<v4f*>(pn + 8 * q + 4 * h) = v;
-            }
-        }
+    const mu_bf16x8 bh = __builtin_bit_cast(mu_bf16x8, u32x4{ph[0], ph[1], ph[2], ph[3]});
+    const mu_bf16x8 bl = __builtin_bit_cast(mu_bf16x8, u32x4{pl[0], pl[1], pl[2], pl[3]});
+    if constexpr (KP == 16) {
+        acc = MU_MFMA(a2c[0], bl, acc);
+        acc = MU_MFMA(a2c[0], bh, acc);
+    } else {
+        acc = MU_MFMA(a2c[1], bl, acc);
+        acc = MU_MFMA(a2c[1], bh, acc);
+        acc = MU_MFMA(a2c[0], bl, acc);
+        acc = MU_MFMA(a2c[0], bh, acc);
     }
 }
 
@@ -354,21 +181,309 @@ __global__ __launch_bounds__(256) void mu_planes_kernel(const float* __restrict_
     c_hi[o] = hi; c_lo[o] = lo;
 }
 
-// ---- W half-step (MODE 0) / divergence of the current factors (MODE 1).
-// grid = (row strips of 64 / (4 / sw), 1, restart groups), block = 256.  A wave owns 64 cells and walks all genes.
-template <int KP, int MODE>
-__global__ __launch_bounds__(256) void mu_w_mfma_kernel(const float* __restrict__ Xt, int ldxt, int N, int Gs,
-                                                        MuBatch mb, int sw, float l1, float l2)
+// W half-step epilogue: W[row][c] *= numerator / denominator for the wave's 64 cells, planes refreshed.
+// C layout: register r <-> component m = 8 (r / 4) + 4 h + r % 4, column (cell) l32
+template <int KP>
+__device__ __forceinline__ void mu_w_epilogue(const MuSlotDev& sd, const f32x16 (&acc)[2], int r0, int l32, int h, int N,
+                                              int ldxt, float l1, float l2)
 {
-    constexpr int KS = KP / 16;
-    int slot, sub;
-    if (!mu_wave_role(mb, sw, slot, sub)) return;
-    const MuSlotDev& sd = mb.s[slot];
-    const int lane = threadIdx.x & 63, l32 = lane & 31, h = lane >> 5;
-    const int strip = blockIdx.x * (4 / sw) + sub;
-    const int r0 = strip * 64;
-    if (r0 >= N) return;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const int row = r0 + 32 * jt + l32;
+        if (row >= N) continue;
+        constexpr int NQ = KP / 8;                     // groups of 4 components held by this lane
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c0 = 8 * q + 4 * h;
+            float num[4];
+            if constexpr (KP == 16) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) num[t] = acc[jt][4 * q + t] + acc[jt][4 * q + t + 8];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) num[t] = acc[jt][4 * q + t];
+            }
+            float* wp = sd.W + (size_t)row * KP + c0;
+            const v4f wv = *reinterpret_cast<const v4f*>(wp);
+            const float w[4] = {wv.x, wv.y, wv.z, wv.w};
+            float o[4];
+            mu_u16 hi[4], lo[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float dn = sd.Hsum[c0 + t];
+                if (l1 > 0.f) dn += l1;
+                if (l2 > 0.f) dn += l2 * w[t];
+                if (dn == 0.f) dn = MU_EPS;
+                o[t] = w[t] * (num[t] / dn);
+                mu_split_bf16(o[t], hi[t], lo[t]);
+                const size_t co = (size_t)(c0 + t) * ldxt + (row & ~15) + mu_pos16(row & 15);
+                sd.Wc_hi[co] = hi[t]; sd.Wc_lo[co] = lo[t];
+            }
+            *reinterpret_cast<v4f*>(wp) = v4f{o[0], o[1], o[2], o[3]};
+            uint2 ph, pl;
+            ph.x = hi[0] | ((unsigned)hi[1] << 16); ph.y = hi[2] | ((unsigned)hi[3] << 16);
+            pl.x = lo[0] | ((unsigned)lo[1] << 16); pl.y = lo[2] | ((unsigned)lo[3] << 16);
+            *reinterpret_cast<uint2*>(sd.Wp_hi + (size_t)row * KP + c0) = ph;
+            *reinterpret_cast<uint2*>(sd.Wp_lo + (size_t)row * KP + c0) = pl;
+        }
+    }
+}
 
+// ---- the workgroup: 8 waves = 4 restarts x 2 halves of a 128-wide block of the non-reduced dimension.  Per 32-deep
+// step it brings in ONE copy of the X block (32 x 128 floats) and one copy of each restart's factor fragments through
+// LDS (double buffered, one barrier per step); every wave then reads its operands from LDS in the fragment layouts
+// (2 KB of L2 -> CU traffic per tile and restart).
+typedef __amdgpu_buffer_rsrc_t mu_rsrc;
+template <int KP>
+struct MuLds {
+    static constexpr int XS = 136;                                   // floats per X row: 4 rows apart = 32 banks apart
+    static constexpr int A1ROW = KP * 2 + (KP == 32 ? 16 : 0);       // bytes per row of the row-major planes
+    static constexpr int A2ROW = 80;                                 // bytes per (plane, component): 32 positions + pad
+    static constexpr int X_BYTES = 32 * XS * 4;
+    static constexpr int A1_BYTES = 4 * 2 * 32 * A1ROW;              // [restart][plane][row]
+    static constexpr int A2_BYTES = 4 * 2 * KP * A2ROW;              // [restart][plane][component]
+    static constexpr int BUF = X_BYTES + A1_BYTES + A2_BYTES;
+    static constexpr int NA1 = (2 * 32 * KP * 2 / 16) / 128;         // 16-byte chunks per thread and restart
+    static constexpr int NA2 = (2 * KP * 4) / 128;
+};
+
+struct MuCoopSrc {                   // what one restart streams (the H half-step streams W, the W half-step H)
+    const mu_u16 *a1h, *a1l;         // row-major planes [L][KP]
+    const mu_u16* a2;                // component-major planes: hi [KP][cs], lo after it
+    int cs;
+};
+
+// SECOND = false: only the first product's operands (divergence pass)
+template <int KP, bool SECOND>
+struct MuCoop {
+    using L = MuLds<KP>;
+    unsigned char* lds;
+    // loader role
+    const float* xbase; size_t xld; unsigned long long xbytes;       // X / X^T, floats per reduced row, bytes in all
+    int c0;                                                          // first non-reduced column of the workgroup
+    MuCoopSrc src; bool src_live;
+    int tid;
+    u32x4 rx[2], ra1[L::NA1], ra2[L::NA2];
+
+    __device__ __forceinline__ void gload(int t)
+    {
+        const unsigned long long off = (unsigned long long)t * 32ull * xld * 4ull;
+        const unsigned long long rem = xbytes - off;
+        const mu_rsrc rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(xbase) + off), 0,
+                                                             (int)(rem > 0x7fffffffull ? 0x7fffffffull : rem), 0x00020000);
+        const unsigned vo = 4u * (unsigned)((tid >> 5) * xld + c0 + (tid & 31) * 4);
+        rx[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
+        rx[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (unsigned)(64ull * xld), 0);          // row + 16
+        if (src_live) {
+            const int tt = tid & 127;
+#pragma unroll
+            for (int i = 0; i < L::NA1; ++i) {
+                const int q = tt + 128 * i, plane = q / (2 * KP * 2), within = q % (2 * KP * 2);
+                const mu_u16* pp = (plane ? src.a1l : src.a1h) + (size_t)t * 32 * KP;
+                ra1[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(pp) + within * 16);
+            }
+            if constexpr (SECOND) {
+#pragma unroll
+                for (int i = 0; i < L::NA2; ++i) {
+                    const int q = tt + 128 * i, plane = q / (4 * KP), rem2 = q % (4 * KP), comp = rem2 >> 2, part = rem2 & 3;
+                    ra2[i] = *reinterpret_cast<const u32x4*>(src.a2 + ((size_t)plane * KP + comp) * src.cs + (size_t)t * 32 + part * 8);
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void lstore(int buf)
+    {
+        unsigned char* b = lds + buf * L::BUF;
+        float* xs = reinterpret_cast<float*>(b);
+        *reinterpret_cast<u32x4*>(xs + (tid >> 5) * L::XS + (tid & 31) * 4) = rx[0];
+        *reinterpret_cast<u32x4*>(xs + ((tid >> 5) + 16) * L::XS + (tid & 31) * 4) = rx[1];
+        if (src_live) {
+            const int tt = tid & 127, rsi = tid >> 7;
+#pragma unroll
+            for (int i = 0; i < L::NA1; ++i) {
+                const int q = tt + 128 * i, plane = q / (2 * KP * 2), within = q % (2 * KP * 2);
+                const int row = within / (KP / 8), part = within % (KP / 8);
+                *reinterpret_cast<u32x4*>(b + L::X_BYTES + ((rsi * 2 + plane) * 32 + row) * L::A1ROW + part * 16) = ra1[i];
+            }
+            if constexpr (SECOND) {
+#pragma unroll
+                for (int i = 0; i < L::NA2; ++i) {
+                    const int q = tt + 128 * i, plane = q / (4 * KP), rem2 = q % (4 * KP), comp = rem2 >> 2, part = rem2 & 3;
+                    *reinterpret_cast<u32x4*>(b + L::X_BYTES + L::A1_BYTES + ((rsi * 2 + plane) * KP + comp) * L::A2ROW + part * 16) = ra2[i];
+                }
+            }
+        }
+    }
+    // fragment reads of the computing wave (restart rs, half gs)
+    __device__ __forceinline__ void read_x(int buf, int gs, int jt, int l32, int h, float (&x)[16]) const
+    {
+        const float* xs = reinterpret_cast<const float*>(lds + buf * L::BUF) + 4 * h * L::XS + gs * 64 + jt * 32 + l32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = xs[(8 * (r >> 2) + (r & 3)) * L::XS];
+    }
+    __device__ __forceinline__ void read_a1(int buf, int rs, int l32, int h, mu_bf16x8 (&a1)[KP / 16][2]) const
+    {
+        const unsigned char* b = lds + buf * L::BUF + L::X_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < KP / 16; ++ks)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                a1[ks][p] = __builtin_bit_cast(mu_bf16x8, *reinterpret_cast<const u32x4*>(b + ((rs * 2 + p) * 32 + l32) * L::A1ROW + (16 * ks + 8 * h) * 2));
+    }
+    __device__ __forceinline__ void read_a2(int buf, int rs, int l32, int h, int c, mu_bf16x8 (&a2c)[KP == 16 ? 1 : 2]) const
+    {
+        const unsigned char* b = lds + buf * L::BUF + L::X_BYTES + L::A1_BYTES;
+        if constexpr (KP == 16)
+            a2c[0] = __builtin_bit_cast(mu_bf16x8, *reinterpret_cast<const u32x4*>(b + ((rs * 2 + (l32 >> 4)) * 16 + (l32 & 15)) * L::A2ROW + (16 * c + 8 * h) * 2));
+        else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                a2c[p] = __builtin_bit_cast(mu_bf16x8, *reinterpret_cast<const u32x4*>(b + ((rs * 2 + p) * 32 + l32) * L::A2ROW + (16 * c + 8 * h) * 2));
+        }
+    }
+};
+
+// steps [t0, t1): numerators of the wave's two tiles into acc (MODE 0) or the divergence partial into dv (MODE 1)
+template <int KP, int MODE>
+__device__ __forceinline__ void mu_coop_loop(MuCoop<KP, MODE == 0>& co, bool active, int rs, int gs, int l32, int h,
+                                             const mu_bf16x8 (&b1)[2][KP / 16][2], f32x16 (&acc)[2], double& dv,
+                                             int t0, int t1)
+{
+    if (t0 >= t1) return;
+    co.gload(t0);
+    co.lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int t = t0; t < t1; ++t, buf ^= 1) {
+        const bool more = t + 1 < t1;
+        if (more) co.gload(t + 1);
+        if (active) {
+            mu_bf16x8 a1[KP / 16][2];
+            co.read_a1(buf, rs, l32, h, a1);
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    float x[16];
+                    co.read_x(buf, gs, jt, l32, h, x);
+                    const f32x16 s = mu_product<KP / 16>(a1, b1[jt]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        mu_bf16x8 a2c[KP == 16 ? 1 : 2];
+                        co.read_a2(buf, rs, l32, h, c, a2c);
+                        mu_quotient_accumulate_chunk<KP>(acc[jt], s, x, c, a2c);
+                    }
+                }
+            } else {
+                float part = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    float x[16];
+                    co.read_x(buf, gs, jt, l32, h, x);
+                    const f32x16 s = mu_product<KP / 16>(a1, b1[jt]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (x[r] > MU_EPS) part += x[r] * logf(x[r] / fmaxf(s[r], MU_EPS)) - x[r];
+                }
+                dv += (double)part;
+            }
+        }
+        if (more) co.lstore(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// ---- H half-step partials, cooperative.  grid = (gene blocks of 128, row chunks, restart groups of 4), block = 512
+template <int KP>
+__global__ __launch_bounds__(512) void mu_h_coop_kernel(const float* __restrict__ X, int ldx, int Np, int Gs,
+                                                        MuBatch mb, int tiles_per_chunk, int nchunks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char mu_lds[];
+    constexpr int KS = KP / 16;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rs = wave & 3, gs = wave >> 2;
+    const int slot = blockIdx.z * 4 + rs;
+    const bool active = slot < mb.n;
+    const MuSlotDev& sd = mb.s[active ? slot : 0];
+    const int g0 = blockIdx.x * 128 + gs * 64;
+    const int chunk = blockIdx.y;
+    const int ntiles = Np / 32;
+    const int rt0 = chunk * tiles_per_chunk, rt1 = min(ntiles, rt0 + tiles_per_chunk);
+
+    MuCoop<KP, true> co;
+    co.lds = mu_lds; co.tid = tid;
+    co.xbase = X; co.xld = (size_t)ldx; co.xbytes = (unsigned long long)(Np + 1) * ldx * 4ull;     // the slack row included
+    co.c0 = blockIdx.x * 128;
+    {
+        const int ls = blockIdx.z * 4 + (tid >> 7);                  // the restart this thread loads for
+        co.src_live = ls < mb.n;
+        const MuSlotDev& sl = mb.s[co.src_live ? ls : 0];
+        co.src = MuCoopSrc{sl.Wp_hi, sl.Wp_lo, sl.Wc_hi, Np};
+    }
+    mu_bf16x8 b1[2][KS][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const size_t o = (size_t)(g0 + 32 * jt + l32) * KP + 16 * ks + 8 * h;
+            b1[jt][ks][0] = mu_ld8(sd.Hp_hi + o);
+            b1[jt][ks][1] = mu_ld8(sd.Hp_lo + o);
+        }
+    f32x16 acc[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+    double dv = 0.0;
+    mu_coop_loop<KP, 0>(co, active, rs, gs, l32, h, b1, acc, dv, rt0, rt1);
+    if (!active) return;
+    // C layout: register r <-> row m = 8 (r / 4) + 4 h + r % 4, column (gene) l32
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        float* pn = sd.pnum + ((size_t)chunk * Gs + g0 + 32 * jt + l32) * KP;
+        if constexpr (KP == 16) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                v4f v;
+                v.x = acc[jt][4 * q + 0] + acc[jt][4 * q + 8]; v.y = acc[jt][4 * q + 1] + acc[jt][4 * q + 9];
+                v.z = acc[jt][4 * q + 2] + acc[jt][4 * q + 10]; v.w = acc[jt][4 * q + 3] + acc[jt][4 * q + 11];
+                *reinterpret_cast<v4f*>(pn + 8 * q + 4 * h) = v;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v4f v = {acc[jt][4 * q], acc[jt][4 * q + 1], acc[jt][4 * q + 2], acc[jt][4 * q + 3]};
+                *reinterpret_cast<v4f*>(pn + 8 * q + 4 * h) = v;
+            }
+        }
+    }
+}
+
+// ---- W half-step (MODE 0) / divergence (MODE 1), cooperative.  grid = (cell blocks of 128, 1, restart groups of 4)
+template <int KP, int MODE>
+__global__ __launch_bounds__(512) void mu_w_coop_kernel(const float* __restrict__ Xt, int ldxt, int N, int Gs,
+                                                        MuBatch mb, float l1, float l2)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char mu_lds[];
+    constexpr int KS = KP / 16;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rs = wave & 3, gs = wave >> 2;
+    const int slot = blockIdx.z * 4 + rs;
+    const bool active = slot < mb.n;
+    const MuSlotDev& sd = mb.s[active ? slot : 0];
+    const int r0 = blockIdx.x * 128 + gs * 64;                       // (ldxt = N_pad is a multiple of 128)
+
+    MuCoop<KP, MODE == 0> co;
+    co.lds = mu_lds; co.tid = tid;
+    co.xbase = Xt; co.xld = (size_t)ldxt; co.xbytes = (unsigned long long)Gs * ldxt * 4ull;
+    co.c0 = blockIdx.x * 128;
+    {
+        const int ls = blockIdx.z * 4 + (tid >> 7);
+        co.src_live = ls < mb.n;
+        const MuSlotDev& sl = mb.s[co.src_live ? ls : 0];
+        co.src = MuCoopSrc{sl.Hp_hi, sl.Hp_lo, sl.Hc_hi, Gs};
+    }
     mu_bf16x8 b1[2][KS][2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
@@ -384,86 +499,15 @@ __global__ __launch_bounds__(256) void mu_w_mfma_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
     double dv = 0.0;
-    const int ngt = Gs / 32;
-    if constexpr (MODE == 0) {
-        MuStream<KP, true> st;                                                  // Hc_lo follows Hc_hi in memory
-        st.rs_a1h = mu_make_rsrc(sd.Hp_hi); st.rs_a1l = mu_make_rsrc(sd.Hp_lo); st.rs_a2 = mu_make_rsrc(sd.Hc_hi);
-        st.xbase = Xt; st.xstep = (size_t)32 * ldxt; st.xs = 4u * (unsigned)ldxt;
-        st.xv = 4u * (unsigned)(4 * h * ldxt + r0 + l32);
-        st.a1o = 2u * (unsigned)(l32 * KP + 8 * h);
-        st.plane_b = 2u * (unsigned)KP * (unsigned)Gs;
-        st.a2o = (KP == 16) ? (2u * (unsigned)((l32 & 15) * Gs + 8 * h) + (l32 >> 4) * st.plane_b)
-                            : 2u * (unsigned)(l32 * Gs + 8 * h);
-        mu_tile_loop<KP>(st, b1, acc, 0, ngt);
-    } else {
-        // sum over X > eps of  X log(X / WH) - X   (sklearn _nmf.py:125-141; + sum WH added by the host)
-        MuStream<KP, false> st;
-        st.rs_a1h = mu_make_rsrc(sd.Hp_hi); st.rs_a1l = mu_make_rsrc(sd.Hp_lo);
-        st.xbase = Xt; st.xstep = (size_t)32 * ldxt; st.xs = 4u * (unsigned)ldxt;
-        st.xv = 4u * (unsigned)(4 * h * ldxt + r0 + l32);
-        st.a1o = 2u * (unsigned)(l32 * KP + 8 * h);
-        for (int gt = 0; gt < ngt; ++gt) {
-            st.load_x(0, gt); st.load_x(1, gt); st.load_a1(gt);
-            float part = 0.f;
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
-                const f32x16 s = mu_product<KS>(st.a1, b1[jt]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float xv = st.x[jt][r];
-                    if (xv > MU_EPS) part += xv * logf(xv / fmaxf(s[r], MU_EPS)) - xv;
-                }
-            }
-            dv += (double)part;
-        }
-    }
+    mu_coop_loop<KP, MODE>(co, active, rs, gs, l32, h, b1, acc, dv, 0, Gs / 32);
+    if (!active) return;
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dv += __shfl_xor(dv, o, 64);
-        if (lane == 0) sd.divpart[strip] = dv;
+        if (lane == 0 && r0 < N) sd.divpart[blockIdx.x * 2 + gs] = dv;          // one partial per 64-cell strip
         return;
     } else {
-        // C layout: register r <-> component m = 8 (r / 4) + 4 h + r % 4, column (cell) l32
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-            const int row = r0 + 32 * jt + l32;
-            if (row >= N) continue;
-            constexpr int NQ = KP / 8;                     // groups of 4 components held by this lane
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int c0 = 8 * q + 4 * h;
-                float num[4];
-                if constexpr (KP == 16) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) num[t] = acc[jt][4 * q + t] + acc[jt][4 * q + t + 8];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) num[t] = acc[jt][4 * q + t];
-                }
-                float* wp = sd.W + (size_t)row * KP + c0;
-                const v4f wv = *reinterpret_cast<const v4f*>(wp);
-                const float w[4] = {wv.x, wv.y, wv.z, wv.w};
-                float o[4];
-                mu_u16 hi[4], lo[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float dn = sd.Hsum[c0 + t];
-                    if (l1 > 0.f) dn += l1;
-                    if (l2 > 0.f) dn += l2 * w[t];
-                    if (dn == 0.f) dn = MU_EPS;
-                    o[t] = w[t] * (num[t] / dn);
-                    mu_split_bf16(o[t], hi[t], lo[t]);
-                    const size_t co = (size_t)(c0 + t) * ldxt + (row & ~15) + mu_pos16(row & 15);
-                    sd.Wc_hi[co] = hi[t]; sd.Wc_lo[co] = lo[t];
-                }
-                *reinterpret_cast<v4f*>(wp) = v4f{o[0], o[1], o[2], o[3]};
-                uint2 ph, pl;
-                ph.x = hi[0] | ((unsigned)hi[1] << 16); ph.y = hi[2] | ((unsigned)hi[3] << 16);
-                pl.x = lo[0] | ((unsigned)lo[1] << 16); pl.y = lo[2] | ((unsigned)lo[3] << 16);
-                *reinterpret_cast<uint2*>(sd.Wp_hi + (size_t)row * KP + c0) = ph;
-                *reinterpret_cast<uint2*>(sd.Wp_lo + (size_t)row * KP + c0) = pl;
-            }
-        }
+        mu_w_epilogue<KP>(sd, acc, r0, l32, h, N, ldxt, l1, l2);
     }
 }
 

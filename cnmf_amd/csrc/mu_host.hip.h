@@ -98,7 +98,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
 {
     hipStream_t st = ctx->stream;
     const int N = (int)ctx->N, G = (int)ctx->G, ldx = ctx->G_pad, Np = ctx->N_pad;
-    const int Gs = round_up(ctx->G_pad, 64);
+    const int Gs = round_up(ctx->G_pad, 128);
     int rc = mu_ensure_xt(ctx, Gs);
     if (rc) return rc;
     const int nstrips = (N + 63) / 64, ntiles = Np / 32;
@@ -134,8 +134,17 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
     std::vector<double> hdiv((size_t)R * nstrips);
     std::vector<float> hsums((size_t)R * 2 * KP);
 
+    constexpr int coop_lds = 2 * MuLds<KP>::BUF;
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)mu_h_coop_kernel<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
+            hipFuncSetAttribute((const void*)mu_w_coop_kernel<KP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
+            hipFuncSetAttribute((const void*)mu_w_coop_kernel<KP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
+            attr_set = true;
+        }
+    }
     auto batch_of = [&](const std::vector<int>& ids) { MuBatch mb; mb.n = (int)ids.size(); for (int i = 0; i < mb.n; ++i) mb.s[i] = slots[ids[i]].d; return mb; };
-    auto sw_of = [](int n) { return n >= 4 ? 4 : (n >= 2 ? 2 : 1); };
     auto colsum = [&](const MuBatch& mb, int which) {
         const int Rr = which ? G : N;
         const int nb = std::max(1, std::min(256, Rr / 256));
@@ -204,9 +213,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
     auto divergence = [&](const std::vector<int>& ids, std::vector<double>& err) -> int {
         const MuBatch mb = batch_of(ids);
         if (!update_H) colsum(mb, 0);                 // refit: the iterations do not need the column sums of W
-        const int sw = sw_of(mb.n), nsub = 4 / sw;
-        dim3 grid((nstrips + nsub - 1) / nsub, 1, (mb.n + sw - 1) / sw);
-        mu_w_mfma_kernel<KP, 1><<<grid, 256, 0, st>>>(ctx->XtF, Np, N, Gs, mb, sw, 0.f, 0.f);
+        mu_w_coop_kernel<KP, 1><<<dim3((N + 127) / 128, 1, (mb.n + 3) / 4), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, 0.f, 0.f);
         HIP_TRY(ctx, hipGetLastError());
         for (int i = 0; i < mb.n; ++i) {
             HIP_TRY(ctx, hipMemcpyAsync(hdiv.data() + (size_t)i * nstrips, mb.s[i].divpart, (size_t)nstrips * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -270,12 +277,11 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         if (ids.empty()) { if (next >= jobs.size()) break; else continue; }
         // ---- one iteration of every live slot
         const MuBatch mb = batch_of(ids);
-        const int sw = sw_of(mb.n), nsub = 4 / sw;
-        const int gz = (mb.n + sw - 1) / sw;
-        mu_w_mfma_kernel<KP, 0><<<dim3((nstrips + nsub - 1) / nsub, 1, gz), 256, 0, st>>>(ctx->XtF, Np, N, Gs, mb, sw, l1W, l2W);
+        const int gz4 = (mb.n + 3) / 4;
+        mu_w_coop_kernel<KP, 0><<<dim3((N + 127) / 128, 1, gz4), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, l1W, l2W);
         if (update_H) {
             colsum(mb, 0);
-            mu_h_mfma_kernel<KP><<<dim3(Gs / 64, (nchunks + nsub - 1) / nsub, gz), 256, 0, st>>>(ctx->X, ldx, Np, Gs, mb, tpc, nchunks, sw);
+            mu_h_coop_kernel<KP><<<dim3(Gs / 128, nchunks, gz4), 512, coop_lds, st>>>(ctx->X, ldx, Np, Gs, mb, tpc, nchunks);
             mu_h_finish_mfma_kernel<KP><<<dim3((Gs * KP + 255) / 256, mb.n), 256, 0, st>>>(mb, G, Gs, nchunks, l1H, l2H);
             colsum(mb, 1);
         }
