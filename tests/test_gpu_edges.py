@@ -98,3 +98,49 @@ def test_large_rank_refit_and_mu(engine):
     assert np.abs(R - R_ref).max() <= 2e-3 * np.abs(R_ref).max()
     with pytest.raises(NotImplementedError):
         engine.nmf_mu_batch([40], seeds=[1], beta_loss="itakura-saito", max_iter=5)
+
+
+@pytest.mark.parametrize("n,g,k", [(7, 5, 2), (33, 31, 3), (129, 33, 5), (257, 65, 1), (200, 140, 32), (64, 128, 16),
+                                   (300, 150, 17), (131, 257, 9)])
+def test_kl_small_and_ragged_shapes(engine, n, g, k):
+    """The Kullback-Leibler solver's matrix-pipe kernels work on 128-wide blocks and 32-deep steps: shapes below and
+    across every one of those sizes, ranks 1 / 16 / 17 / 32 (both register layouts), against the float64 oracle."""
+    from oracle import nmf_mu
+    X = _x(n, g, seed=n + g)
+    engine.set_matrix(X)
+    W_ref, H_ref, n_ref = nmf_mu.nmf_mu(X, k, seed=5, max_iter=60)
+    H, W, n_iter, err = engine.nmf_mu_batch([k], seeds=[5], max_iter=60, return_W=True, warn=False)
+    assert H[0].shape == (k, g) and W[0].shape == (n, k)
+    assert abs(int(n_iter[0]) - n_ref) <= 10
+    if int(n_iter[0]) != n_ref:
+        W_ref, H_ref, _ = nmf_mu.nmf_mu(X, k, seed=5, max_iter=int(n_iter[0]), tol=0.0)
+    R, R_ref = W[0].astype(np.float64) @ H[0], W_ref @ H_ref
+    assert np.abs(R - R_ref).max() <= 2e-3 * max(1.0, np.abs(R_ref).max())
+    ref_err = nmf_mu.beta_divergence(X, W_ref, H_ref, 1, square_root=True)
+    assert abs(err[0] - ref_err) <= 2e-3 * max(ref_err, 1e-6)
+
+
+def test_kl_refit_regularised_and_zero_rows(engine):
+    """update_H = False (the refit of cnmf.py:776-802 under beta_loss='kullback-leibler'), l1 / l2 penalties, and a
+    matrix with all-zero cells and genes (denominators of zero: sklearn's EPSILON / 1.0 substitutions)."""
+    from oracle import nmf_mu
+    X = _x(180, 90, seed=3)
+    X[[0, 17, 179]] = 0.0
+    X[:, [2, 89]] = 0.0
+    engine.set_matrix(X)
+    W_ref, H_ref, n_ref = nmf_mu.nmf_mu(X, 6, seed=8, max_iter=40, alpha_W=0.002, alpha_H=0.001, l1_ratio=0.3)
+    H, W, n_iter, _ = engine.nmf_mu_batch([6], seeds=[8], max_iter=40, alpha_W=0.002, alpha_H=0.001, l1_ratio=0.3,
+                                          return_W=True, warn=False)
+    assert abs(int(n_iter[0]) - n_ref) <= 10
+    if int(n_iter[0]) != n_ref:
+        W_ref, H_ref, _ = nmf_mu.nmf_mu(X, 6, seed=8, max_iter=int(n_iter[0]), tol=0.0, alpha_W=0.002, alpha_H=0.001, l1_ratio=0.3)
+    assert np.isfinite(H[0]).all() and np.isfinite(W[0]).all()
+    R, R_ref = W[0].astype(np.float64) @ H[0], W_ref @ H_ref
+    assert np.abs(R - R_ref).max() <= 2e-3 * max(1.0, np.abs(R_ref).max())
+    Hn = H_ref / np.maximum(H_ref.sum(axis=1, keepdims=True), 1e-12)
+    Wr_ref, nr_ref = nmf_mu.nnls_mu(X, Hn, max_iter=80)
+    Wr, nr = engine.nnls_mu(Hn, max_iter=80, warn=False)
+    assert abs(nr - nr_ref) <= 10
+    if nr != nr_ref:
+        Wr_ref, _ = nmf_mu.nnls_mu(X, Hn, max_iter=int(nr), tol=0.0)
+    assert np.abs(Wr - Wr_ref).max() <= 2e-3 * max(1e-6, np.abs(Wr_ref).max())
