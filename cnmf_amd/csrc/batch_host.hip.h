@@ -156,21 +156,31 @@ struct HostSlot { int state = 0; int restart = -1; int off = 0; int k = 0; int64
 // `stamp`.  The snapshot is `lag` iterations old when it is needed, so this normally returns at once.
 static int wait_snapshot(cnmf_ctx* ctx, const SlotDesc* sp, int n, int stamp)
 {
+    // Pure spinning on the host-mapped stamp.  The stream is queried (to notice a dead stream instead of spinning for
+    // ever) only after 20 ms without progress: hipStreamQuery on a busy stream makes the runtime append a completion
+    // marker behind the last enqueued kernel -- here always the H finalize -- and the GPU then pays ~6 us for that
+    // barrier packet in front of every pass A (measured: the finalize -> pass A gap of round 2's kernel traces).
+    using clk = std::chrono::steady_clock;
+    static const bool eager_query = getenv("CNMF_SPIN_QUERY") != nullptr;       // A/B: the round-1 behaviour
     for (int s = 0; s < n; ++s) {
         const volatile int* flag = &sp[s].pad_;
         long spins = 0;
+        clk::time_point t0;
+        bool timing = false;
         while (*flag != stamp) {
-            if (++spins % 4096 == 0) {
-                const hipError_t q = hipStreamQuery(ctx->stream);
-                if (q == hipSuccess) {                       // stream drained: the stamp must be there
-                    if (*flag == stamp) break;
-                    SET_ERR(ctx, "slot snapshot %d was never published (slot %d)", stamp, s);
-                    return CNMF_EHIP;
-                }
-                if (q != hipErrorNotReady) {
-                    SET_ERR(ctx, "stream failed while waiting for a slot snapshot: %s", hipGetErrorString(q));
-                    return CNMF_EHIP;
-                }
+            if (++spins % 4096 != 0) continue;
+            if (!timing) { t0 = clk::now(); timing = true; continue; }
+            if (!eager_query && std::chrono::duration_cast<std::chrono::milliseconds>(clk::now() - t0).count() < 20) continue;
+            t0 = clk::now();
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {                       // stream drained: the stamp must be there
+                if (*flag == stamp) break;
+                SET_ERR(ctx, "slot snapshot %d was never published (slot %d)", stamp, s);
+                return CNMF_EHIP;
+            }
+            if (q != hipErrorNotReady) {
+                SET_ERR(ctx, "stream failed while waiting for a slot snapshot: %s", hipGetErrorString(q));
+                return CNMF_EHIP;
             }
         }
     }
