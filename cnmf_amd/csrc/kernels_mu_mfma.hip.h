@@ -1,8 +1,9 @@
-// Kullback-Leibler multiplicative updates on the matrix pipe, batched over restarts.
+// Multiplicative updates (Kullback-Leibler, Itakura-Saito) on the matrix pipe, batched over restarts.
 // Restates sklearn/decomposition/_nmf.py:526-631 (_multiplicative_update_w), :634-728 (_multiplicative_update_h)
-// and :84-194 (_beta_divergence) for beta = 1 and dense X -- the solver the reference keeps for
-// beta_loss='kullback-leibler' (cnmf.py:618-631).  kernels_mu.hip.h holds the vector-ALU version (Itakura-Saito,
-// ranks above 32, and the A/B fallback CNMF_MU_VALU=1).
+// and :84-194 (_beta_divergence) for beta = 1 / 0 and dense X -- the solver the reference keeps for
+// beta_loss != 'frobenius' (cnmf.py:618-631).  kernels_mu.hip.h holds the vector-ALU version (ranks above 32 and
+// the A/B fallback CNMF_MU_VALU=1).  Below the text describes beta = 1; Itakura-Saito carries a second ratio
+// (1 / S for the denominator next to X / S^2 for the numerator) through a second set of accumulators.
 //
 // Per 32 x 32 tile of X and per restart, two chained MFMA products with the elementwise quotient in between:
 //   S = W.H        (v_mfma_f32_32x32x16_bf16, the rank is the k dimension; factors as two bf16 planes hi + lo,
@@ -47,6 +48,7 @@ struct MuSlotDev {                     // one restart in flight (all pointers de
     mu_u16 *Hc_hi, *Hc_lo;             // [KP][Gs]; ONE allocation, lo follows hi
     float *Hsum, *Wsum;                // [KP] column sums
     float* pnum;                       // [nchunks][Gs][KP] partial numerators of the H half-step
+    float* pden;                       // ... and denominators (Itakura-Saito only)
     double* divpart;                   // [nstrips] partial divergences
     double* cspart;                    // [256][KP] column-sum partials
 };
@@ -107,24 +109,22 @@ __device__ __forceinline__ f32x16 mu_product(const mu_bf16x8 (&a)[KS][2], const 
     return s;
 }
 
-// one 16-deep chunk c of a tile: quotient planes of registers 8c .. 8c+7, then the MFMAs that consume them
-template <int KP>
-__device__ __forceinline__ void mu_quotient_accumulate_chunk(f32x16& acc, const f32x16& s, const float (&x)[16], int c,
-                                                             const mu_bf16x8 (&a2c)[KP == 16 ? 1 : 2])
+// bf16 hi / lo planes of 8 values (register order), as MFMA B operands
+__device__ __forceinline__ void mu_planes8(const float (&q)[8], mu_bf16x8& bh, mu_bf16x8& bl)
 {
     unsigned ph[4], pl[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const int r = 8 * c + 2 * d;
-        const float s0 = mu_clamp_eps(s[r]), s1 = mu_clamp_eps(s[r + 1]);
-        const float rc = __builtin_amdgcn_rcpf(s0 * s1);
-        const float q0 = (x[r] * s1) * rc, q1 = (x[r + 1] * s0) * rc;
-        ph[d] = mu_pack_bf16(q0, q1);
+        ph[d] = mu_pack_bf16(q[2 * d], q[2 * d + 1]);
         const float h0 = __uint_as_float(ph[d] << 16), h1 = __uint_as_float(ph[d] & 0xffff0000u);
-        pl[d] = mu_pack_bf16(q0 - h0, q1 - h1);
+        pl[d] = mu_pack_bf16(q[2 * d] - h0, q[2 * d + 1] - h1);
     }
-    const mu_bf16x8 bh = __builtin_bit_cast(mu_bf16x8, u32x4{ph[0], ph[1], ph[2], ph[3]});
-    const mu_bf16x8 bl = __builtin_bit_cast(mu_bf16x8, u32x4{pl[0], pl[1], pl[2], pl[3]});
+    bh = __builtin_bit_cast(mu_bf16x8, u32x4{ph[0], ph[1], ph[2], ph[3]});
+    bl = __builtin_bit_cast(mu_bf16x8, u32x4{pl[0], pl[1], pl[2], pl[3]});
+}
+template <int KP>
+__device__ __forceinline__ void mu_accumulate8(f32x16& acc, const mu_bf16x8 (&a2c)[KP == 16 ? 1 : 2], mu_bf16x8 bh, mu_bf16x8 bl)
+{
     if constexpr (KP == 16) {
         acc = MU_MFMA(a2c[0], bl, acc);
         acc = MU_MFMA(a2c[0], bh, acc);
@@ -136,8 +136,40 @@ __device__ __forceinline__ void mu_quotient_accumulate_chunk(f32x16& acc, const 
     }
 }
 
-// ---- H half-step finish: Ht[g][c] *= num / den, planes refreshed.  grid = (ceil(Gs * KP / 256), slots)
-template <int KP>
+// one 16-deep chunk c of a tile: the ratio planes of registers 8c .. 8c+7, then the MFMAs that consume them.
+//   Kullback-Leibler (BETA1): numerator ratio X / S.
+//   Itakura-Saito: numerator ratio X / S^2 into acc, denominator ratio 1 / S into accd (sklearn _nmf.py:580-604).
+// v_rcp_f32 is a quarter-rate instruction: one reciprocal serves two elements, 1/s0 = s1 / (s0 s1)
+// (s >= eps = 1.2e-7: the product cannot underflow).
+template <int KP, bool BETA1>
+__device__ __forceinline__ void mu_quotient_accumulate_chunk(f32x16& acc, f32x16& accd, const f32x16& s, const float (&x)[16],
+                                                             int c, const mu_bf16x8 (&a2c)[KP == 16 ? 1 : 2])
+{
+    float qn[8], qd[BETA1 ? 1 : 8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int r = 8 * c + 2 * d;
+        const float s0 = mu_clamp_eps(s[r]), s1 = mu_clamp_eps(s[r + 1]);
+        const float rc = __builtin_amdgcn_rcpf(s0 * s1);
+        if constexpr (BETA1) {
+            qn[2 * d] = (x[r] * s1) * rc; qn[2 * d + 1] = (x[r + 1] * s0) * rc;
+        } else {
+            const float i0 = s1 * rc, i1 = s0 * rc;
+            qd[2 * d] = i0; qd[2 * d + 1] = i1;
+            qn[2 * d] = (x[r] * i0) * i0; qn[2 * d + 1] = (x[r + 1] * i1) * i1;
+        }
+    }
+    mu_bf16x8 bh, bl;
+    mu_planes8(qn, bh, bl);
+    mu_accumulate8<KP>(acc, a2c, bh, bl);
+    if constexpr (!BETA1) {
+        mu_planes8(qd, bh, bl);
+        mu_accumulate8<KP>(accd, a2c, bh, bl);
+    }
+}
+
+// ---- H half-step finish: Ht[g][c] *= (num / den)^gamma, planes refreshed.  grid = (ceil(Gs * KP / 256), slots)
+template <int KP, bool BETA1>
 __global__ __launch_bounds__(256) void mu_h_finish_mfma_kernel(MuBatch mb, int G, int Gs, int nchunks, float l1, float l2)
 {
     const MuSlotDev& sd = mb.s[blockIdx.y];
@@ -146,16 +178,22 @@ __global__ __launch_bounds__(256) void mu_h_finish_mfma_kernel(MuBatch mb, int G
     const int g = e / KP, c = e % KP;
     float v = 0.f;
     if (g < G) {
-        float n = 0.f;
+        float n = 0.f, dn = 0.f;
         for (int q = 0; q < nchunks; ++q) n += sd.pnum[(size_t)q * Gs * KP + e];
-        float dn = sd.Wsum[c];
-        if (dn == 0.f) dn = 1.0f;                              // sklearn _nmf.py:684-686
+        if constexpr (BETA1) {
+            dn = sd.Wsum[c];
+            if (dn == 0.f) dn = 1.0f;                          // sklearn _nmf.py:684-686
+        } else {
+            for (int q = 0; q < nchunks; ++q) dn += sd.pden[(size_t)q * Gs * KP + e];
+        }
         const float hv = sd.Ht[e];
         if (l1 > 0.f) dn += l1;
         if (l2 > 0.f) dn += l2 * hv;
         if (dn == 0.f) dn = MU_EPS;
-        v = hv * (n / dn);
-        if (v < F64_EPS_AS_F32) v = 0.f;                       // sklearn _nmf.py:868-869
+        float delta = n / dn;
+        if (!BETA1) delta = sqrtf(delta);                      // gamma = 1 / (2 - beta) = 1/2
+        v = hv * delta;
+        if (v < F64_EPS_AS_F32) v = 0.f;                       // sklearn _nmf.py:868-869 (beta <= 1)
     }
     sd.Ht[e] = v;
     mu_u16 hi, lo;
@@ -183,9 +221,9 @@ __global__ __launch_bounds__(256) void mu_planes_kernel(const float* __restrict_
 
 // W half-step epilogue: W[row][c] *= numerator / denominator for the wave's 64 cells, planes refreshed.
 // C layout: register r <-> component m = 8 (r / 4) + 4 h + r % 4, column (cell) l32
-template <int KP>
-__device__ __forceinline__ void mu_w_epilogue(const MuSlotDev& sd, const f32x16 (&acc)[2], int r0, int l32, int h, int N,
-                                              int ldxt, float l1, float l2)
+template <int KP, bool BETA1>
+__device__ __forceinline__ void mu_w_epilogue(const MuSlotDev& sd, const f32x16 (&acc)[2], const f32x16 (&accd)[2], int r0,
+                                              int l32, int h, int N, int ldxt, float l1, float l2)
 {
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
@@ -195,13 +233,21 @@ __device__ __forceinline__ void mu_w_epilogue(const MuSlotDev& sd, const f32x16 
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int c0 = 8 * q + 4 * h;
-            float num[4];
+            float num[4], den[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (KP == 16) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) num[t] = acc[jt][4 * q + t] + acc[jt][4 * q + t + 8];
+                if constexpr (!BETA1) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) den[t] = accd[jt][4 * q + t] + accd[jt][4 * q + t + 8];
+                }
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) num[t] = acc[jt][4 * q + t];
+                if constexpr (!BETA1) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) den[t] = accd[jt][4 * q + t];
+                }
             }
             float* wp = sd.W + (size_t)row * KP + c0;
             const v4f wv = *reinterpret_cast<const v4f*>(wp);
@@ -210,11 +256,14 @@ __device__ __forceinline__ void mu_w_epilogue(const MuSlotDev& sd, const f32x16 
             mu_u16 hi[4], lo[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                float dn = sd.Hsum[c0 + t];
+                float dn = BETA1 ? sd.Hsum[c0 + t] : den[t];
                 if (l1 > 0.f) dn += l1;
                 if (l2 > 0.f) dn += l2 * w[t];
                 if (dn == 0.f) dn = MU_EPS;
-                o[t] = w[t] * (num[t] / dn);
+                float delta = num[t] / dn;
+                if (!BETA1) delta = sqrtf(delta);              // gamma = 1/2
+                o[t] = w[t] * delta;
+                if (!BETA1 && o[t] < F64_EPS_AS_F32) o[t] = 0.f;      // sklearn _nmf.py:849-850 (beta < 1 only)
                 mu_split_bf16(o[t], hi[t], lo[t]);
                 const size_t co = (size_t)(c0 + t) * ldxt + (row & ~15) + mu_pos16(row & 15);
                 sd.Wc_hi[co] = hi[t]; sd.Wc_lo[co] = lo[t];
@@ -344,10 +393,10 @@ struct MuCoop {
 };
 
 // steps [t0, t1): numerators of the wave's two tiles into acc (MODE 0) or the divergence partial into dv (MODE 1)
-template <int KP, int MODE>
+template <int KP, int MODE, bool BETA1>
 __device__ __forceinline__ void mu_coop_loop(MuCoop<KP, MODE == 0>& co, bool active, int rs, int gs, int l32, int h,
-                                             const mu_bf16x8 (&b1)[2][KP / 16][2], f32x16 (&acc)[2], double& dv,
-                                             int t0, int t1)
+                                             const mu_bf16x8 (&b1)[2][KP / 16][2], f32x16 (&acc)[2], f32x16 (&accd)[2],
+                                             double& dv, int t0, int t1)
 {
     if (t0 >= t1) return;
     co.gload(t0);
@@ -370,7 +419,7 @@ __device__ __forceinline__ void mu_coop_loop(MuCoop<KP, MODE == 0>& co, bool act
                     for (int c = 0; c < 2; ++c) {
                         mu_bf16x8 a2c[KP == 16 ? 1 : 2];
                         co.read_a2(buf, rs, l32, h, c, a2c);
-                        mu_quotient_accumulate_chunk<KP>(acc[jt], s, x, c, a2c);
+                        mu_quotient_accumulate_chunk<KP, BETA1>(acc[jt], accd[jt], s, x, c, a2c);
                     }
                 }
             } else {
@@ -384,7 +433,9 @@ __device__ __forceinline__ void mu_coop_loop(MuCoop<KP, MODE == 0>& co, bool act
                     for (int r = 0; r < 16; ++r) {
                         // hardware reciprocal and logarithm (1 ulp each): the sum below carries ~1e8 terms of mixed
                         // sign, a relative 1e-7 per term is far inside the 1e-4 convergence test it feeds
-                        const float t = x[r] * __logf(x[r] * __builtin_amdgcn_rcpf(mu_clamp_eps(s[r]))) - x[r];
+                        // KL: X log(X / S) - X;  IS: X / S - log(X / S)   (sklearn _nmf.py:125-141, 143-147)
+                        const float dq = x[r] * __builtin_amdgcn_rcpf(mu_clamp_eps(s[r]));
+                        const float t = BETA1 ? (x[r] * __logf(dq) - x[r]) : (dq - __logf(dq));
                         part += (x[r] > MU_EPS) ? t : 0.f;
                     }
                 }
@@ -397,7 +448,7 @@ __device__ __forceinline__ void mu_coop_loop(MuCoop<KP, MODE == 0>& co, bool act
 }
 
 // ---- H half-step partials, cooperative.  grid = (gene blocks of 128, row chunks, restart groups of 4), block = 512
-template <int KP>
+template <int KP, bool BETA1>
 __global__ __launch_bounds__(512) void mu_h_coop_kernel(const float* __restrict__ X, int ldx, int Np, int Gs,
                                                         MuBatch mb, int tiles_per_chunk, int nchunks)
 {
@@ -438,33 +489,42 @@ __global__ __launch_bounds__(512) void mu_h_coop_kernel(const float* __restrict_
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+    f32x16 accd[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accd[jt][r] = 0.f;
     double dv = 0.0;
-    mu_coop_loop<KP, 0>(co, active, rs, gs, l32, h, b1, acc, dv, rt0, rt1);
+    mu_coop_loop<KP, 0, BETA1>(co, active, rs, gs, l32, h, b1, acc, accd, dv, rt0, rt1);
     if (!active) return;
     // C layout: register r <-> row m = 8 (r / 4) + 4 h + r % 4, column (gene) l32
+    auto store = [&](float* base, const f32x16 (&a)[2]) {
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-        float* pn = sd.pnum + ((size_t)chunk * Gs + g0 + 32 * jt + l32) * KP;
-        if constexpr (KP == 16) {
+        for (int jt = 0; jt < 2; ++jt) {
+            float* pn = base + ((size_t)chunk * Gs + g0 + 32 * jt + l32) * KP;
+            if constexpr (KP == 16) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                v4f v;
-                v.x = acc[jt][4 * q + 0] + acc[jt][4 * q + 8]; v.y = acc[jt][4 * q + 1] + acc[jt][4 * q + 9];
-                v.z = acc[jt][4 * q + 2] + acc[jt][4 * q + 10]; v.w = acc[jt][4 * q + 3] + acc[jt][4 * q + 11];
-                *reinterpret_cast<v4f*>(pn + 8 * q + 4 * h) = v;
-            }
-        } else {
+                for (int q = 0; q < 2; ++q) {
+                    v4f v;
+                    v.x = a[jt][4 * q + 0] + a[jt][4 * q + 8]; v.y = a[jt][4 * q + 1] + a[jt][4 * q + 9];
+                    v.z = a[jt][4 * q + 2] + a[jt][4 * q + 10]; v.w = a[jt][4 * q + 3] + a[jt][4 * q + 11];
+                    *reinterpret_cast<v4f*>(pn + 8 * q + 4 * h) = v;
+                }
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v4f v = {acc[jt][4 * q], acc[jt][4 * q + 1], acc[jt][4 * q + 2], acc[jt][4 * q + 3]};
-                *reinterpret_cast<v4f*>(pn + 8 * q + 4 * h) = v;
+                for (int q = 0; q < 4; ++q) {
+                    v4f v = {a[jt][4 * q], a[jt][4 * q + 1], a[jt][4 * q + 2], a[jt][4 * q + 3]};
+                    *reinterpret_cast<v4f*>(pn + 8 * q + 4 * h) = v;
+                }
             }
         }
-    }
+    };
+    store(sd.pnum, acc);
+    if constexpr (!BETA1) store(sd.pden, accd);
 }
 
 // ---- W half-step (MODE 0) / divergence (MODE 1), cooperative.  grid = (cell blocks of 128, 1, restart groups of 4)
-template <int KP, int MODE>
+template <int KP, int MODE, bool BETA1>
 __global__ __launch_bounds__(512) void mu_w_coop_kernel(const float* __restrict__ Xt, int ldxt, int N, int Gs,
                                                         MuBatch mb, float l1, float l2)
 {
@@ -502,8 +562,13 @@ __global__ __launch_bounds__(512) void mu_w_coop_kernel(const float* __restrict_
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+    f32x16 accd[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accd[jt][r] = 0.f;
     double dv = 0.0;
-    mu_coop_loop<KP, MODE>(co, active, rs, gs, l32, h, b1, acc, dv, 0, Gs / 32);
+    mu_coop_loop<KP, MODE, BETA1>(co, active, rs, gs, l32, h, b1, acc, accd, dv, 0, Gs / 32);
     if (!active) return;
     if constexpr (MODE == 1) {
 #pragma unroll
@@ -511,7 +576,7 @@ __global__ __launch_bounds__(512) void mu_w_coop_kernel(const float* __restrict_
         if (lane == 0 && r0 < N) sd.divpart[blockIdx.x * 2 + gs] = dv;          // one partial per 64-cell strip
         return;
     } else {
-        mu_w_epilogue<KP>(sd, acc, r0, l32, h, N, ldxt, l1, l2);
+        mu_w_epilogue<KP, BETA1>(sd, acc, accd, r0, l32, h, N, ldxt, l1, l2);
     }
 }
 

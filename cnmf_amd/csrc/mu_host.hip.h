@@ -91,7 +91,7 @@ static int mu_ensure_xt(cnmf_ctx* ctx, int Gs)
 
 struct MuJob { int restart; int k; size_t hoff, woff; };
 
-template <int KP>
+template <int KP, bool BETA1>
 static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init_mode, const uint32_t* seeds,
                          const double* avg, const float* W0, const float* H0, int update_H,
                          const cnmf_cd_params* prm, float* H_out, float* W_out, int32_t* n_iter_out, double* err_out)
@@ -122,6 +122,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         d.Hc_hi = pool.get<mu_u16>((size_t)2 * Gs * KP, true, st); d.Hc_lo = d.Hc_hi ? d.Hc_hi + (size_t)Gs * KP : nullptr;
         d.Hsum = pool.get<float>(KP, true, st); d.Wsum = pool.get<float>(KP, true, st);
         d.pnum = pool.get<float>((size_t)nchunks * Gs * KP);
+        d.pden = BETA1 ? nullptr : pool.get<float>((size_t)nchunks * Gs * KP);
         d.divpart = pool.get<double>(nstrips);
         d.cspart = pool.get<double>((size_t)256 * KP);
     }
@@ -138,9 +139,9 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
     {
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute((const void*)mu_h_coop_kernel<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
-            hipFuncSetAttribute((const void*)mu_w_coop_kernel<KP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
-            hipFuncSetAttribute((const void*)mu_w_coop_kernel<KP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
+            hipFuncSetAttribute((const void*)mu_h_coop_kernel<KP, BETA1>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
+            hipFuncSetAttribute((const void*)mu_w_coop_kernel<KP, 0, BETA1>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
+            hipFuncSetAttribute((const void*)mu_w_coop_kernel<KP, 1, BETA1>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
             attr_set = true;
         }
     }
@@ -213,7 +214,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
     auto divergence = [&](const std::vector<int>& ids, std::vector<double>& err) -> int {
         const MuBatch mb = batch_of(ids);
         if (!update_H) colsum(mb, 0);                 // refit: the iterations do not need the column sums of W
-        mu_w_coop_kernel<KP, 1><<<dim3((N + 127) / 128, 1, (mb.n + 3) / 4), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, 0.f, 0.f);
+        mu_w_coop_kernel<KP, 1, BETA1><<<dim3((N + 127) / 128, 1, (mb.n + 3) / 4), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, 0.f, 0.f);
         HIP_TRY(ctx, hipGetLastError());
         for (int i = 0; i < mb.n; ++i) {
             HIP_TRY(ctx, hipMemcpyAsync(hdiv.data() + (size_t)i * nstrips, mb.s[i].divpart, (size_t)nstrips * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -225,9 +226,11 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         for (int i = 0; i < mb.n; ++i) {
             double res = 0.0;
             for (int q = 0; q < nstrips; ++q) res += hdiv[(size_t)i * nstrips + q];
-            double swh = 0.0;
-            for (int c = 0; c < KP; ++c) swh += (double)hsums[(size_t)i * 2 * KP + c] * (double)hsums[(size_t)i * 2 * KP + KP + c];
-            res += swh;
+            if (BETA1) {                                   // + sum(WH) from the column sums
+                double swh = 0.0;
+                for (int c = 0; c < KP; ++c) swh += (double)hsums[(size_t)i * 2 * KP + c] * (double)hsums[(size_t)i * 2 * KP + KP + c];
+                res += swh;
+            } else res -= (double)N * (double)G;           // Itakura-Saito: sum(X/WH) - N G - sum log(X/WH)
             err[i] = std::sqrt(2.0 * std::max(res, 0.0));
         }
         return CNMF_OK;
@@ -278,11 +281,11 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         // ---- one iteration of every live slot
         const MuBatch mb = batch_of(ids);
         const int gz4 = (mb.n + 3) / 4;
-        mu_w_coop_kernel<KP, 0><<<dim3((N + 127) / 128, 1, gz4), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, l1W, l2W);
+        mu_w_coop_kernel<KP, 0, BETA1><<<dim3((N + 127) / 128, 1, gz4), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, l1W, l2W);
         if (update_H) {
             colsum(mb, 0);
-            mu_h_coop_kernel<KP><<<dim3(Gs / 128, nchunks, gz4), 512, coop_lds, st>>>(ctx->X, ldx, Np, Gs, mb, tpc, nchunks);
-            mu_h_finish_mfma_kernel<KP><<<dim3((Gs * KP + 255) / 256, mb.n), 256, 0, st>>>(mb, G, Gs, nchunks, l1H, l2H);
+            mu_h_coop_kernel<KP, BETA1><<<dim3(Gs / 128, nchunks, gz4), 512, coop_lds, st>>>(ctx->X, ldx, Np, Gs, mb, tpc, nchunks);
+            mu_h_finish_mfma_kernel<KP, BETA1><<<dim3((Gs * KP + 255) / 256, mb.n), 256, 0, st>>>(mb, G, Gs, nchunks, l1H, l2H);
             colsum(mb, 1);
         }
         HIP_TRY(ctx, hipGetLastError());
@@ -319,11 +322,11 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
         if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
         if (k > 32 && beta != 1) { SET_ERR(ctx, "itakura-saito with n_components > 32 is not supported on the device"); return CNMF_EUNSUPPORTED; }
     }
-    // Kullback-Leibler with rank <= 32: batched on the matrix pipe (kernels_mu_mfma.hip.h); the rest below, one by one
+    // rank <= 32: batched on the matrix pipe (kernels_mu_mfma.hip.h); the rest below, one by one
     std::vector<char> done(n, 0);
     {
         const char* e = getenv("CNMF_MU_VALU");
-        if (beta == 1 && !(e && atoi(e) != 0)) {
+        if (!(e && atoi(e) != 0)) {
             std::vector<MuJob> j16, j32;
             size_t ho = 0, wo = 0;
             for (int r = 0; r < n; ++r) {
@@ -333,8 +336,10 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
                 if (k <= 32) done[r] = 1;
                 ho += (size_t)k * G; wo += (size_t)k * N;
             }
-            if (!j16.empty()) { rc = mu_batch_mfma<16>(ctx, j16, init_mode, seeds, avg, W0, H0, update_H, prm, H_out, W_out, n_iter_out, err_out); if (rc) return rc; }
-            if (!j32.empty()) { rc = mu_batch_mfma<32>(ctx, j32, init_mode, seeds, avg, W0, H0, update_H, prm, H_out, W_out, n_iter_out, err_out); if (rc) return rc; }
+#define MU_BATCH(KP_, B1_, jobs_) mu_batch_mfma<KP_, B1_>(ctx, jobs_, init_mode, seeds, avg, W0, H0, update_H, prm, H_out, W_out, n_iter_out, err_out)
+            if (!j16.empty()) { rc = beta == 1 ? MU_BATCH(16, true, j16) : MU_BATCH(16, false, j16); if (rc) return rc; }
+            if (!j32.empty()) { rc = beta == 1 ? MU_BATCH(32, true, j32) : MU_BATCH(32, false, j32); if (rc) return rc; }
+#undef MU_BATCH
         }
     }
     size_t hoff = 0, woff = 0;

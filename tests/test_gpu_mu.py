@@ -107,3 +107,28 @@ def test_mu_batch_matches_single_and_valu_path(engine, X, monkeypatch):
         if int(nv[i]) == int(n_iter[i]):
             maxabs, relfro = nmf_cd.spectra_error(Hv[i], H[i])
             assert maxabs <= 2e-3 and relfro <= 2e-3, (i, maxabs, relfro)
+
+
+def test_itakura_saito_batch_vs_oracle(engine, X):
+    """Itakura-Saito restarts run on the same batched matrix-pipe kernels (a second ratio and a second set of
+    accumulators for the denominator): ranks on both register layouts, more restarts than one round of launches
+    needs, each against the float64 oracle; and batch independence bit for bit."""
+    Xp = X + 1e-3
+    engine.set_matrix(Xp)
+    ks = [5, 3, 16, 17, 9, 24, 7]
+    seeds = [40 + i for i in range(len(ks))]
+    H, W, n_iter, err = engine.nmf_mu_batch(ks, seeds=seeds, beta_loss="itakura-saito", max_iter=120, return_W=True, warn=False)
+    for i in (0, 2, 3, 5):
+        W_ref, H_ref, n_ref = nmf_mu.nmf_mu(Xp, ks[i], seed=seeds[i], beta_loss="itakura-saito", max_iter=120)
+        assert abs(int(n_iter[i]) - n_ref) <= 10, (i, n_iter[i], n_ref)
+        if int(n_iter[i]) != n_ref:
+            W_ref, H_ref, _ = nmf_mu.nmf_mu(Xp, ks[i], seed=seeds[i], beta_loss="itakura-saito", max_iter=int(n_iter[i]), tol=0.0)
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, H[i])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (i, maxabs, relfro)
+        assert np.abs(W[i] - W_ref).max() <= 2e-3 * np.abs(W_ref).max()
+        ref_err = nmf_mu.beta_divergence(Xp, W_ref, H_ref, 0, square_root=True)
+        assert abs(err[i] - ref_err) <= 2e-3 * ref_err
+    H1, W1, n1, _ = engine.nmf_mu_batch([ks[3]], seeds=[seeds[3]], beta_loss="itakura-saito", max_iter=120, return_W=True, warn=False)
+    assert int(n1[0]) == int(n_iter[3])
+    np.testing.assert_array_equal(H1[0], H[3])
+    np.testing.assert_array_equal(W1[0], W[3])

@@ -10,6 +10,7 @@ from cnmf_amd import synth
 from cnmf_amd.cnmf import cNMF
 
 n_iter = int(os.environ.get("N_ITER", 100))
+beta_loss = os.environ.get("BETA_LOSS", "frobenius")          # kullback-leibler: the multiplicative-update solver
 t = {}
 t0 = time.perf_counter(); X = synth.make_config("C3", dtype=np.float32); t["synthesize_input_s"] = time.perf_counter() - t0
 df = pd.DataFrame(X, index=["c%d" % i for i in range(X.shape[0])], columns=["g%d" % j for j in range(X.shape[1])])
@@ -25,7 +26,7 @@ if os.environ.get("WITH_TPM", "1") == "1":
     C = C[:, C.sum(axis=0) > 0]
     tpm = (sp.csr_matrix((C / C.sum(axis=1, keepdims=True) * 1e6).astype(np.float32)), list(df.columns))
     t["synthesize_tpm_s"] = time.perf_counter() - t0
-t0 = time.perf_counter(); obj.prepare_from_matrix(df, components=list(range(5, 14)), n_iter=n_iter, seed=14, beta_loss="frobenius", tpm=tpm); t["prepare_from_matrix_s"] = time.perf_counter() - t0
+t0 = time.perf_counter(); obj.prepare_from_matrix(df, components=list(range(5, 14)), n_iter=n_iter, seed=14, beta_loss=beta_loss, tpm=tpm); t["prepare_from_matrix_s"] = time.perf_counter() - t0
 import io, contextlib
 buf = io.StringIO()
 t0 = time.perf_counter()
@@ -40,7 +41,7 @@ t["combine_s"] = time.perf_counter() - t0
 t0 = time.perf_counter(); stats = obj.k_selection_stats(); t["k_selection_stats_s"] = time.perf_counter() - t0
 t0 = time.perf_counter(); obj.k_selection_stats(batched=False); t_loop = time.perf_counter() - t0
 t0 = time.perf_counter(); med, usages = obj.consensus(9, density_threshold=0.5); t["consensus_k9_s"] = time.perf_counter() - t0
-res = dict(config="C3 north star: 50000 x 2000, K=5..13, n_iter=%d (%d restarts), 1x MI355X" % (n_iter, 9 * n_iter),
+res = dict(config="C3 north star: 50000 x 2000, K=5..13, n_iter=%d (%d restarts), beta_loss=%s, 1x MI355X" % (n_iter, 9 * n_iter, beta_loss),
            stages=t, total_prepare_to_consensus_s=sum(v for k, v in t.items() if not k.startswith("synthesize")),
            k_selection_per_k_loop_s=t_loop, consensus_includes_tpm_tail=tpm is not None,
            restarts=9 * n_iter, restarts_per_s=9 * n_iter / t["factorize_s"],
@@ -49,4 +50,4 @@ res = dict(config="C3 north star: 50000 x 2000, K=5..13, n_iter=%d (%d restarts)
            k_selection=stats.to_dict(orient="list"))
 print(json.dumps(res))
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(res, open("gpurun_out/e2e_c3.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/e2e_c3%s.json" % ("" if beta_loss == "frobenius" else "_kl"), "w"), indent=1)
