@@ -435,7 +435,8 @@ __device__ __forceinline__ void mu_coop_loop(MuCoop<KP, MODE == 0>& co, bool act
                         // sign, a relative 1e-7 per term is far inside the 1e-4 convergence test it feeds
                         // KL: X log(X / S) - X;  IS: X / S - log(X / S)   (sklearn _nmf.py:125-141, 143-147)
                         const float dq = x[r] * __builtin_amdgcn_rcpf(mu_clamp_eps(s[r]));
-                        const float t = BETA1 ? (x[r] * __logf(dq) - x[r]) : (dq - __logf(dq));
+                        const float lg = __builtin_amdgcn_logf(dq) * 0.69314718056f;     // v_log_f32 (log2); dq is never denormal
+                        const float t = BETA1 ? (x[r] * lg - x[r]) : (dq - lg);
                         part += (x[r] > MU_EPS) ? t : 0.f;
                     }
                 }

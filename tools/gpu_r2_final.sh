@@ -15,3 +15,8 @@ print(d.get("consensus"))
 PY
 tail -2 gpurun_out/bench.err
 bash tools/gpu_r2_prof.sh 2>&1 | grep -v "count_\|col_min\|fillBuffer\|copyBuffer\|rng_kernel" | tail -8
+# multiplicative-update solver: probe, kernel trace, PMC
+bash tools/gpu_r2_mu_final.sh > gpurun_out/mu_final.log 2>&1; grep "KL k" gpurun_out/mu_final.log | head -9
+# end to end, north-star job with the TPM tail; and the same job under beta_loss = kullback-leibler at n_iter = 10
+timeout 600 python tools/e2e_c3.py 2>/dev/null | tail -1 | cut -c1-600
+BETA_LOSS=kullback-leibler N_ITER=10 timeout 600 python tools/e2e_c3.py 2>/dev/null | tail -1 | cut -c1-600
