@@ -17,7 +17,7 @@ all-gather of the per-restart spectra at the end of the step (RCCL over xGMI).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
   roofline     -- the dominant kernel (MFMA GEMM passes): algorithmic flops / launch duration measured
-                  with HIP events inside the library (every 8th iteration), vs the roofline of the
+                  with HIP events inside the library (every --event-stride-th iteration, default 64), vs the roofline of the
                   f32-accurate split-operand scheme (bf16 dense MFMA peak / 6)
   cpu_baseline -- scikit-learn's non_negative_factorization (the call the reference makes,
                   cnmf.py:672) timed on this box's host cores on a bounded sample.
@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--restarts-per-k", type=int, default=100)
     ap.add_argument("--kmin", type=int, default=5)
     ap.add_argument("--kmax", type=int, default=13)
+    ap.add_argument("--event-stride", type=int, default=64,
+                    help="HIP events around the two GEMM passes of every n-th iteration (the roofline's launch durations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=30)
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
@@ -367,11 +369,11 @@ def main():
         ks, seeds = step_jobs(step)
         if gather_mode == "rccl":
             eng.spectra_reset()
-            _, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=8 if profile else 0, resident=True)
+            _, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=args.event_stride if profile else 0, resident=True)
             st = dict(eng.last_stats)
             gather(None, ks, step)
         else:
-            H, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=8 if profile else 0)
+            H, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=args.event_stride if profile else 0)
             st = dict(eng.last_stats)
             gather(H, ks, step)
         return ks, st
@@ -401,7 +403,7 @@ def main():
         # roofline of the dominant kernel (rank 0's launches): the MFMA GEMM pass
         flops_per_col_iter = 2.0 * N * G                        # one pass, one component column
         alg_flops_A = flops_per_col_iter * agg["rc_iters"]      # algorithmic (converged columns excluded)
-        # the passes of every 8th iteration are bracketed by HIP events (an event record costs ~6 us of
+        # the passes of every n-th iteration (--event-stride) are bracketed by HIP events (an event record costs ~6 us of
         # queue time): average duration of the sampled launches x all launches = time in the pass
         launches = max(agg["outer"], 1)
         avgA = agg["passA_ms"] / max(agg["nA"], 1)
