@@ -15,3 +15,10 @@ for ks in ([9], [13], [20], [9] * 16, [5, 6, 7, 8, 9, 10, 11, 12, 13] * 4, [20] 
     dt = time.perf_counter() - t
     print("KL k=%s x%d: %d iterations each in %.3f s -> %.1f us per restart-iteration"
           % (sorted(set(ks)), len(ks), n[0], dt, dt / n.sum() * 1e6), flush=True)
+if not os.environ.get("CNMF_MU_VALU"):
+    eng.set_matrix(X + np.float32(1e-3))                   # Itakura-Saito wants a positive matrix
+    ks = [9] * 16
+    t = time.perf_counter()
+    H, _, n, err = eng.nmf_mu_batch(ks, seeds=list(range(7, 7 + len(ks))), beta_loss="itakura-saito", max_iter=its, tol=0, warn=False)
+    dt = time.perf_counter() - t
+    print("IS k=[9] x16: %d iterations each in %.3f s -> %.1f us per restart-iteration" % (n[0], dt, dt / n.sum() * 1e6), flush=True)
