@@ -37,7 +37,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 mu_bf16x2;
 typedef float mu_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short mu_u16;
 
-constexpr int MU_MAXSLOTS = 16;
+constexpr int MU_MAXSLOTS = 32;       // (the batch travels as a kernel argument: 32 x 120 B < the 4 KB limit)
 
 struct MuSlotDev {                     // one restart in flight (all pointers device memory)
     float* W;                          // [Np][KP]

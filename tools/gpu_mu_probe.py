@@ -9,7 +9,7 @@ X = synth.make_config("C3", dtype=np.float32)
 eng = Engine(0); eng.set_matrix(X)
 its = int(os.environ.get("MU_ITERS", "50"))
 eng.nmf_mu_batch([5], seeds=[1], max_iter=3, tol=0, warn=False)          # warm up (X^T copy, code objects)
-for ks in ([9], [13], [20], [9] * 16, [5, 6, 7, 8, 9, 10, 11, 12, 13] * 4, [20] * 16):
+for ks in ([9], [13], [20], [9] * 16, [9] * 32, [5, 6, 7, 8, 9, 10, 11, 12, 13] * 4, [9] * 64, [20] * 16, [20] * 32):
     t = time.perf_counter()
     H, _, n, err = eng.nmf_mu_batch(ks, seeds=list(range(7, 7 + len(ks))), max_iter=its, tol=0, warn=False)
     dt = time.perf_counter() - t
