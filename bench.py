@@ -272,6 +272,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     multi = world > 1 or bool(os.environ.get("CNMF_BENCH_FORCE_DIST"))     # (the override exercises the N > 1 code at world 1)
+    if os.environ.get("CNMF_BENCH_ONE_GPU"):                               # test hook: every rank on GPU 0
+        local_rank = 0
     # Transport of everything that crosses ranks (the one data-path gather, the barrier, the max/sum over ranks):
     #   "rccl"  (default) -- ncclAllGather inside the C-ABI library (cnmf_comm_* / cnmf_allgather_*); NO torch:
     #                        the launcher only provides RANK / WORLD_SIZE / MASTER_PORT, the 128-byte RCCL id
