@@ -56,6 +56,7 @@ struct MuBatch {
     int n;
     MuSlotDev s[MU_MAXSLOTS];
 };
+static_assert(sizeof(MuBatch) <= 3968, "MuBatch travels by value: kernel arguments are limited to 4 KB");
 
 // position of row / gene `i` inside its 16 block in the component-major planes (swap bits 2 and 3)
 __device__ __host__ __forceinline__ int mu_pos16(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
