@@ -43,9 +43,9 @@ struct MuSlotDev {                     // one restart in flight (all pointers de
     float* W;                          // [Np][KP]
     float* Ht;                         // [Gs][KP]
     mu_u16 *Wp_hi, *Wp_lo;             // row-major bf16 planes of W   [Np][KP]
-    mu_u16 *Wc_hi, *Wc_lo;             // component-major, pos16 order [KP][Np]; ONE allocation, lo follows hi
+    mu_u16* Wc_hi;                     // component-major, pos16 order [2][KP][Np]: the lo plane follows the hi plane
     mu_u16 *Hp_hi, *Hp_lo;             // [Gs][KP]
-    mu_u16 *Hc_hi, *Hc_lo;             // [KP][Gs]; ONE allocation, lo follows hi
+    mu_u16* Hc_hi;                     // [2][KP][Gs], likewise
     float *Hsum, *Wsum;                // [KP] column sums
     float* pnum;                       // [nchunks][Gs][KP] partial numerators of the H half-step
     float* pden;                       // ... and denominators (Itakura-Saito only)
@@ -56,6 +56,7 @@ struct MuBatch {
     int n;
     MuSlotDev s[MU_MAXSLOTS];
 };
+static_assert(sizeof(MuBatch) <= 3968, "MuBatch travels by value: keep the kernel arguments below 4 KB");
 static_assert(sizeof(MuBatch) <= 3968, "MuBatch travels by value: kernel arguments are limited to 4 KB");
 
 // position of row / gene `i` inside its 16 block in the component-major planes (swap bits 2 and 3)
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void mu_h_finish_mfma_kernel(MuBatch mb, int G
     mu_split_bf16(v, hi, lo);
     sd.Hp_hi[e] = hi; sd.Hp_lo[e] = lo;
     const size_t o = (size_t)c * Gs + (g & ~15) + mu_pos16(g & 15);
-    sd.Hc_hi[o] = hi; sd.Hc_lo[o] = lo;
+    sd.Hc_hi[o] = hi; sd.Hc_hi[(size_t)KP * Gs + o] = lo;
 }
 
 // planes of a freshly installed factor M [L][KP] (L = Np or Gs; rows >= the live count must already be zero)
@@ -267,7 +268,7 @@ __device__ __forceinline__ void mu_w_epilogue(const MuSlotDev& sd, const f32x16 
                 if (!BETA1 && o[t] < F64_EPS_AS_F32) o[t] = 0.f;      // sklearn _nmf.py:849-850 (beta < 1 only)
                 mu_split_bf16(o[t], hi[t], lo[t]);
                 const size_t co = (size_t)(c0 + t) * ldxt + (row & ~15) + mu_pos16(row & 15);
-                sd.Wc_hi[co] = hi[t]; sd.Wc_lo[co] = lo[t];
+                sd.Wc_hi[co] = hi[t]; sd.Wc_hi[(size_t)KP * ldxt + co] = lo[t];
             }
             *reinterpret_cast<v4f*>(wp) = v4f{o[0], o[1], o[2], o[3]};
             uint2 ph, pl;

@@ -117,9 +117,9 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         d.W = pool.get<float>((size_t)Np * KP, true, st);
         d.Ht = pool.get<float>((size_t)Gs * KP, true, st);
         d.Wp_hi = pool.get<mu_u16>((size_t)Np * KP, true, st); d.Wp_lo = pool.get<mu_u16>((size_t)Np * KP, true, st);
-        d.Wc_hi = pool.get<mu_u16>((size_t)2 * Np * KP, true, st); d.Wc_lo = d.Wc_hi ? d.Wc_hi + (size_t)Np * KP : nullptr;
+        d.Wc_hi = pool.get<mu_u16>((size_t)2 * Np * KP, true, st);
         d.Hp_hi = pool.get<mu_u16>((size_t)Gs * KP, true, st); d.Hp_lo = pool.get<mu_u16>((size_t)Gs * KP, true, st);
-        d.Hc_hi = pool.get<mu_u16>((size_t)2 * Gs * KP, true, st); d.Hc_lo = d.Hc_hi ? d.Hc_hi + (size_t)Gs * KP : nullptr;
+        d.Hc_hi = pool.get<mu_u16>((size_t)2 * Gs * KP, true, st);
         d.Hsum = pool.get<float>(KP, true, st); d.Wsum = pool.get<float>(KP, true, st);
         d.pnum = pool.get<float>((size_t)nchunks * Gs * KP);
         d.pden = BETA1 ? nullptr : pool.get<float>((size_t)nchunks * Gs * KP);
@@ -183,8 +183,8 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
                 mu_pack_kernel<<<gHt, 256, 0, st>>>(cH, k, G, s.d.Ht, KP);
                 mu_pack_kernel<<<gWp, 256, 0, st>>>(cW, k, N, s.d.W, KP);
             }
-            mu_planes_kernel<KP><<<(int)(((size_t)Np * KP + 255) / 256), 256, 0, st>>>(s.d.W, Np, s.d.Wp_hi, s.d.Wp_lo, s.d.Wc_hi, s.d.Wc_lo);
-            mu_planes_kernel<KP><<<(Gs * KP + 255) / 256, 256, 0, st>>>(s.d.Ht, Gs, s.d.Hp_hi, s.d.Hp_lo, s.d.Hc_hi, s.d.Hc_lo);
+            mu_planes_kernel<KP><<<(int)(((size_t)Np * KP + 255) / 256), 256, 0, st>>>(s.d.W, Np, s.d.Wp_hi, s.d.Wp_lo, s.d.Wc_hi, s.d.Wc_hi + (size_t)Np * KP);
+            mu_planes_kernel<KP><<<(Gs * KP + 255) / 256, 256, 0, st>>>(s.d.Ht, Gs, s.d.Hp_hi, s.d.Hp_lo, s.d.Hc_hi, s.d.Hc_hi + (size_t)Gs * KP);
             s.job = jis[i]; s.it = 0; s.fresh = true; s.err0 = s.prev = s.err = 0.0;
         }
         HIP_TRY(ctx, hipGetLastError());
