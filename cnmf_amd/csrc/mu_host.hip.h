@@ -326,8 +326,9 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
     std::vector<char> done(n, 0);
     {
         const char* e = getenv("CNMF_MU_VALU");
-        // (the matrix-pipe kernels address X / X^T rows with 32-bit byte offsets: up to 2^25 cells or genes)
-        if (!(e && atoi(e) != 0) && ctx->N_pad <= (1 << 25) && ctx->G_pad <= (1 << 25)) {
+        // (the matrix-pipe kernels address a 32-row step of X / X^T with 32-bit byte offsets below 2^31 -- the buffer
+        //  descriptor's range: 4 * 32 * row length -> up to 2^24 cells or genes)
+        if (!(e && atoi(e) != 0) && ctx->N_pad <= (1 << 24) && ctx->G_pad <= (1 << 24)) {
             std::vector<MuJob> j16, j32;
             size_t ho = 0, wo = 0;
             for (int r = 0; r < n; ++r) {
