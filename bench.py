@@ -5,26 +5,42 @@ Workload (default, ``config.workload``): the north-star headline shape -- 50 000
 2000 high-variance genes (synthetic gamma-Poisson counts, reference `prepare` scaling,
 cnmf_amd/synth.py "C3"), K in {5..13}.  One STEP = one pass of the hot path over one
 batch of restarts: ``--restarts-per-k`` restarts for every K (default 100 = the north star's
-n_iter -> one step is one whole factorize() job of 900 restarts per GPU, streamed through 256
+n_iter -> one step is one whole factorize() job of 900 restarts, streamed through 256
 packed component columns by the slot work-queue), run to sklearn's stopping rule (tol 1e-4, max_iter 1000)
 with sklearn's init='random' generated on the device from the cNMF ledger seeds
 (master seed 14).  X is resident in HBM before the timed region.
 
-Multi-GPU (weak scaling, one process per GPU via torch.distributed.run): every rank holds
-a replica of X and runs its own batch of restarts per step (ledger rows sharded
-round-robin like the reference's worker_filter, cnmf.py:52-53); the only exchange is one
-all-gather of the per-restart spectra at the end of the step (RCCL over xGMI).
+Multi-GPU, one process per GPU.  ``python bench.py --gpus N`` with N > 1 SPAWNS its N ranks itself (no launcher, no
+torch: RANK / LOCAL_RANK / WORLD_SIZE in the environment, the 128-byte RCCL id through a file); under an external
+launcher (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``: WORLD_SIZE already set) it runs
+as that launcher's rank.  Either way the world size must equal ``--gpus`` or the run fails.
+  --scaling strong (default): one step is the SAME fixed job at every N -- the north-star factorize() of
+      |K| x restarts-per-k restarts -- sharded over the ranks exactly like the reference's worker_filter (ledger row idx
+      -> rank idx % N, cnmf.py:52-53); the step ends when the ONE all-gather of the per-restart spectra (RCCL over
+      xGMI, inside the library) has completed on every rank; value = restarts of the job / max-over-ranks time.
+  --scaling weak: every rank runs its own |K| x restarts-per-k restarts per step (per-GPU work fixed).
+Every rank holds a replica of X; there is no collective inside the restart loop.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement), with extra objects:
   roofline     -- the dominant kernel (MFMA GEMM passes): algorithmic flops / launch duration measured
-                  with HIP events inside the library (every --event-stride-th iteration, default 64), vs the roofline of the
-                  f32-accurate split-operand scheme (bf16 dense MFMA peak / 6)
+                  with HIP events inside the library (every --event-stride-th iteration, default 64), vs the roofline of
+                  the scheme the pass runs (f16 / bf16 dense MFMA peak / MFMAs per f32-class product: 2 on the default
+                  count path, 3 or 6 on the others; f32 MFMA peak on the exact-f32 pipe)
   cpu_baseline -- scikit-learn's non_negative_factorization (the call the reference makes,
                   cnmf.py:672) timed on this box's host cores on a bounded sample.
+  consensus    -- BASELINE config 5 (consensus-only stress) wall-clock, GPU next to the sklearn/pandas calls
+  general_path -- the same step with count detection OFF (any-X split-operand kernels), bounded
+  e2e          -- prepare -> factorize -> combine -> k selection -> consensus(k=9) with the TPM tail, seconds per stage,
+                  next to the CPU reference path (measured stage by stage, factorize extrapolated from the measured
+                  restart-iterations/s)
+(the last four at N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,14 +50,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
-# bf16 MFMAs per f32-accurate product (kernels_gemm3.hip.h), by cnmf_batch_stats.gemm_mode:
-#   1/2: both operands as three planes, ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh)
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 / _f16, dense
+# MFMAs per f32-accurate product, by cnmf_batch_stats.gemm_mode:
+#   1/2: both operands as three bf16 planes, ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh)   (kernels_gemm3.hip.h)
 #   3  : count-structured X = (integers <= 256) x per-gene scale -> ONE integer plane, (ah + am + al)*n, all exact
 #   4  : the same on the f16 pipe (kernels_gemm2h.hip.h): counts <= 2048 in one f16 plane, the factor as TWO f16 planes
 #        with a per-row exponent (within 1 ulp_f32 of the f32 value, exact for 3 in 4), partial products exact
 SPLIT_MFMAS_PER_PRODUCT = {1: 6, 2: 6, 3: 3, 4: 2}
 HBM_PEAK_GBS = 8000.0
+# device sources whose text the committed PMC / ablation profiles describe: a profile taken from other sources is stale
+PROFILED_SOURCES = ("cnmf_amd/csrc/kernels_gemm2h.hip.h", "cnmf_amd/csrc/kernels_sweep.hip.h",
+                    "cnmf_amd/csrc/kernels_gemm3.hip.h", "cnmf_amd/csrc/gemm_host.hip.h")
 
 
 def parse():
@@ -49,6 +68,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--workload", default="C3", help="C1|C2|C3 (cnmf_amd/synth.py)")
     ap.add_argument("--n-cells", type=int, default=None, help="truncate the workload (debug only)")
     ap.add_argument("--restarts-per-k", type=int, default=100)
@@ -57,12 +77,96 @@ def parse():
     ap.add_argument("--event-stride", type=int, default=64,
                     help="HIP events around the two GEMM passes of every n-th iteration (the roofline's launch durations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip general_path and e2e (profiling runs)")
+    ap.add_argument("--emulate-rank", default=None, metavar="R/W",
+                    help="single GPU: run only the shard rank R of a world of W would run in --scaling strong "
+                         "(tools/shard_scaling.py: the projected strong-scaling curve from one GPU)")
     ap.add_argument("--cpu-iters", type=int, default=30)
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-workers-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--spawn-selftest", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------ self-launch (N > 1)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (this same command line, one per GPU), relay
+    rank 0's JSON line, fail if any rank fails.  No torch, no torch.distributed.run."""
+    port = _free_port()
+    id_file = os.path.join("/tmp", "cnmf_rccl_id.%d.%d" % (os.getpid(), port))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CNMF_RCCL_ID_FILE=id_file, CNMF_BENCH_SPAWNED="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0 = b""
+    failed = None
+    try:
+        # rank 0's stdout carries the one JSON line; poll all ranks so that one dead rank does not hang the others
+        # inside a collective for ever
+        import selectors
+        sel = selectors.DefaultSelector()
+        sel.register(procs[0].stdout, selectors.EVENT_READ)
+        open_out = True
+        while True:
+            if open_out:
+                for key, _ in sel.select(timeout=0.2):
+                    chunk = os.read(key.fileobj.fileno(), 65536)
+                    if chunk:
+                        out0 += chunk
+                    else:
+                        sel.unregister(key.fileobj)
+                        open_out = False
+            else:
+                time.sleep(0.1)
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = bad[0]
+                break
+            if all(c == 0 for c in codes) and not open_out:
+                break
+    finally:
+        if failed is not None:
+            time.sleep(1.0)                       # let the failing rank's message out first
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                      # exactly the PIDs started here
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        try:
+            os.remove(id_file)
+        except OSError:
+            pass
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d of %d exited with code %d -- no result\n" % (failed[0], n, failed[1]))
+        sys.exit(1)
+    lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: expected ONE JSON line from rank 0, got %d\n" % len(lines))
+        sys.exit(1)
+    d = json.loads(lines[0])
+    if d.get("n_gpus") != n:
+        sys.stderr.write("bench.py: the ranks report n_gpus=%r, asked for %d\n" % (d.get("n_gpus"), n))
+        sys.exit(1)
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
 def _cpu_worker(job):
     """One cNMF-style worker: a single-threaded scikit-learn restart capped at ``max_iter`` outer iterations."""
     k, seed, max_iter = job
@@ -77,25 +181,32 @@ def _cpu_worker(job):
 _CPU_X64 = None
 
 
-def cpu_workers_child(npy_path, iters):
-    """Mode 2 of SURVEY 8d, in its OWN interpreter started with OPENBLAS/OMP/MKL_NUM_THREADS=1 (set before numpy is
-    imported, so that every forked worker is single-threaded by construction): one process per available core, each
-    running ONE scikit-learn restart capped at ``iters`` outer iterations -- how cNMF is parallelised in practice
-    (Extras/run_parallel.py: total_workers independent processes)."""
-    global _CPU_X64
-    import multiprocessing as mp
-    _CPU_X64 = np.load(npy_path).astype(np.float64)
-    ks = (5, 9, 13)
+def granted_cpus():
+    """CPUs this process may use: affinity mask, capped by the cgroup v2 quota."""
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    try:                                                  # cgroup v2 CPU quota, if any
+    try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
         if q != "max":
             ncpu = max(1, min(ncpu, int(float(q) / float(per))))
     except Exception:
         pass
+    return ncpu
+
+
+def cpu_workers_child(npy_path, iters):
+    """Mode 2 of SURVEY 8d, in its OWN interpreter started with OPENBLAS/OMP/MKL_NUM_THREADS=1 (set before numpy is
+    imported, so that every forked worker is single-threaded by construction): one process per available core, each
+    running ONE scikit-learn restart capped at ``iters`` outer iterations -- how cNMF is parallelised in practice
+    (Extras/run_parallel.py: total_workers independent processes).  The clock of a worker starts AFTER it holds the
+    matrix; scikit-learn's own input checks and init are inside (they are inside the reference's call too)."""
+    global _CPU_X64
+    import multiprocessing as mp
+    _CPU_X64 = np.load(npy_path).astype(np.float64)
+    ks = (5, 9, 13)
+    ncpu = granted_cpus()
     try:
         avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
     except Exception:
@@ -115,49 +226,49 @@ def cpu_workers_child(npy_path, iters):
 
 def cpu_baseline_child(npy_path, max_iter):
     """Runs in a FRESH interpreter (no HIP context).  SURVEY.md section 8d: time (1) one worker with all BLAS threads
-    here and (2) cNMF-style single-thread worker processes (cpu_workers_child, its own interpreter) on a stratified k
-    sample; report both."""
-    import subprocess
+    here (capped at the CPUs this job is granted) and (2) cNMF-style single-thread worker processes
+    (cpu_workers_child, its own interpreter) on a stratified k sample; report both."""
     from oracle import sklearn_ref
     X64 = np.load(npy_path).astype(np.float64)
     ks = (5, 9, 13)
+    ncpu = granted_cpus()
+    blas = "unknown"
     try:
-        from threadpoolctl import threadpool_info
-        info = threadpool_info()
-        blas_threads = max([p.get("num_threads", 1) for p in info] + [1])
-        blas = ", ".join(sorted({"%s %s" % (p.get("internal_api"), p.get("version")) for p in info}))
+        from threadpoolctl import threadpool_info, threadpool_limits
+        blas = ", ".join(sorted({"%s %s" % (p.get("internal_api"), p.get("version")) for p in threadpool_info()}))
+        limiter = threadpool_limits(ncpu)                # BLAS threads = the CPUs actually granted (not the box's 256)
     except Exception:
-        blas_threads, blas = os.cpu_count(), "unknown"
-    # (1) one worker, all BLAS threads
+        limiter = None
+    # (1) one worker, BLAS threads = granted CPUs
     t0 = time.perf_counter()
     it1 = 0
     for k in ks:
         _, _, n_it = sklearn_ref.nmf(X64, k, seed=1000 + k, max_iter=max_iter)
         it1 += n_it
     dt1 = time.perf_counter() - t0
-    del X64
-    # (2) single-thread workers, bounded: 3 outer iterations each, 120 s at most
+    del X64, limiter
+    # (2) single-thread workers, bounded: 10 outer iterations each, 180 s at most
     env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
     mode2 = None
     try:
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-workers-child", npy_path, "--cpu-iters", "3"],
-                           capture_output=True, text=True, timeout=120, env=env)
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-workers-child", npy_path, "--cpu-iters", "10"],
+                           capture_output=True, text=True, timeout=180, env=env)
         if p.returncode == 0:
             mode2 = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
         else:
             mode2 = {"error": p.stderr[-400:]}
     except subprocess.TimeoutExpired:
-        mode2 = {"error": "timed out after 120 s"}
+        mode2 = {"error": "timed out after 180 s"}
     cpu_model = "unknown"
     try:
         cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         pass
     print(json.dumps({
-        "one_worker_all_threads": {"restart_iterations_per_s": it1 / dt1, "threads": int(blas_threads),
+        "one_worker_all_threads": {"restart_iterations_per_s": it1 / dt1, "threads": int(ncpu),
                                    "iterations": it1, "seconds": dt1},
         "workers_single_thread": mode2,
-        "cpu_count": os.cpu_count(), "cpu_model": cpu_model, "blas": blas, "ks": list(ks)}))
+        "cpu_count": os.cpu_count(), "cpus_granted": ncpu, "cpu_model": cpu_model, "blas": blas, "ks": list(ks)}))
 
 
 def cpu_baseline(X32, mean_iters_per_restart, max_iter):
@@ -165,7 +276,6 @@ def cpu_baseline(X32, mean_iters_per_restart, max_iter):
     reference makes (cnmf.py:672), in the better of SURVEY 8d's two modes.  The primary number is restart-
     ITERATIONS per second (measured, no extrapolation); restarts/s divides it by the GPU run's mean
     iteration count per restart."""
-    import subprocess
     import tempfile
     import shutil
     tmpdir = tempfile.gettempdir()
@@ -199,31 +309,66 @@ def cpu_baseline(X32, mean_iters_per_restart, max_iter):
         "restarts_per_s_extrapolated": it_per_s / max(mean_iters_per_restart, 1.0),
         "modes": d,
         "sample": ("sklearn.decomposition.non_negative_factorization (solver=cd, float64, init=random) on the same X, "
-                   "k in (5, 9, 13): mode 1 = one worker with all BLAS threads, %d outer iterations per k (%d iterations "
-                   "in %.1f s); mode 2 = one single-thread process per core, one restart each capped at 3 outer iterations "
-                   "(%s); the better mode is `value`; restarts_per_s_extrapolated = value / mean iterations per restart of "
-                   "the GPU run (%.1f)"
-                   % (max_iter, a["iterations"], a["seconds"],
+                   "k in (5, 9, 13): mode 1 = one worker with BLAS threads = the %d CPUs granted to this job, %d outer "
+                   "iterations per k (%d iterations in %.1f s); mode 2 = one single-thread process per granted CPU, one "
+                   "restart each capped at 10 outer iterations (%s); the better mode is `value`; "
+                   "restarts_per_s_extrapolated = value / mean iterations per restart of the GPU run (%.1f)"
+                   % (d.get("cpus_granted", a["threads"]), max_iter, a["iterations"], a["seconds"],
                       ("%d workers, %d iterations, slowest worker %.1f s" % (b["workers"], b["iterations"], b["seconds"]))
                       if ok2 else "failed: %s" % (b or {}).get("error", "?"), mean_iters_per_restart)),
     }
 
 
-def pmc_traffic(key, split_operand):
-    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE),
-    collected in separate rocprofv3 --pmc passes (tools/gpu_pmc_bench.sh) and committed under
-    profiles/ -- counters cannot be read from inside an un-profiled run.  None if absent."""
-    name = {0: "r1_pmc_traffic.json", 1: "r1_pmc_traffic_split.json", 2: "r1_pmc_traffic_split.json",
-            3: "r1_pmc_traffic_counts.json", 4: "r2_pmc_traffic_f16.json"}[split_operand]
+# ------------------------------------------------------------------------------------------ committed profiles
+def source_hashes():
+    out = {}
+    for rel in PROFILED_SOURCES:
+        try:
+            out[rel] = hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
+        except OSError:
+            out[rel] = None
+    return out
+
+
+def load_profile(name):
+    """A committed counter / ablation profile (profiles/<name>) together with a staleness verdict: the file records
+    the sha256 of the kernel sources it was measured on (tools/stamp_profile.py); if they differ from the tree's, the
+    numbers describe ANOTHER kernel and are not used."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
-        return {"hbm_bytes_per_launch": d[key]["hbm_bytes_per_launch"],
-                "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"][key],
-                "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)" % name}
     except Exception:
-        return None
+        return None, "absent"
+    rec = d.get("kernel_source_sha256")
+    if not isinstance(rec, dict):
+        return d, "unstamped (taken before round 3: kernel sources not recorded)"
+    now = source_hashes()
+    changed = sorted(k for k in rec if now.get(k) != rec[k])
+    if changed:
+        return d, "stale: %s changed since the profile was taken (git %s)" % (", ".join(changed), d.get("git_head", "?"))
+    return d, None
 
 
+def pmc_traffic(key, gemm_mode):
+    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE, WRITE_SIZE),
+    collected in separate rocprofv3 --pmc passes (tools/gpu_pmc_bench.sh) and committed under
+    profiles/ -- counters cannot be read from inside an un-profiled run.  (detail, usable)."""
+    name = {0: "r1_pmc_traffic.json", 1: "r1_pmc_traffic_split.json", 2: "r1_pmc_traffic_split.json",
+            3: "r1_pmc_traffic_counts.json", 4: "r3_pmc_traffic_f16.json"}[gemm_mode]
+    d, verdict = load_profile(name)
+    if d is None or key not in d:
+        return None, False
+    try:
+        det = {"hbm_bytes_per_launch": d[key]["hbm_bytes_per_launch"],
+               "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"][key],
+               "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH doubled per the "
+                         "gfx950 note of MI355X_MICROARCH.md)" % name,
+               "git_head": d.get("git_head"), "stale": verdict}
+    except Exception:
+        return None, False
+    return det, verdict is None
+
+
+# ------------------------------------------------------------------------------------------ extras (N = 1)
 def consensus_wallclock(eng, with_cpu=True):
     """BASELINE config 5 (consensus-only stress: 5000 stacked spectra x 2000 genes, k=20):
     wall-clock of the consensus core on the GPU (host call incl. transfers) next to the
@@ -250,11 +395,139 @@ def consensus_wallclock(eng, with_cpu=True):
         km = KMeans(n_clusters=20, n_init=10, random_state=1).fit(l2k)
         pd.DataFrame(l2k).groupby(pd.Series(km.labels_ + 1)).median()
         res["cpu_reference_ms"] = 1e3 * (time.perf_counter() - t0)
-        res["cpu_cores"] = os.cpu_count()
+        res["cpu_cores"] = granted_cpus()
         res["labels_match_cpu"] = bool(np.array_equal(out["labels"][out["density_filter"]], km.labels_))
     return res
 
 
+def general_path_step(X, ks_all, by_k, restarts_per_k, event_stride):
+    """The same step on a matrix that is NOT count-structured as far as the engine is concerned (count detection off:
+    what a Harmony-corrected or TPM-normalised input gets, reference preprocess.py:270-358): the any-X split-operand
+    kernels, 3 x 3 bf16 planes, 6 MFMAs per f32-class product.  Bounded (restarts_per_k restarts per K)."""
+    from cnmf_amd.engine import Engine
+    N, G = X.shape
+    eng = Engine(0, detect_counts=False)
+    try:
+        eng.set_matrix(X)
+        ks, seeds = [], []
+        for k in ks_all:
+            ks += [k] * restarts_per_k
+            seeds += by_k[k][:restarts_per_k]
+        eng.nmf_batch(ks[::9], seeds=seeds[::9], warn=False)                       # warm-up: planes of X, code objects
+        t0 = time.perf_counter()
+        _, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=event_stride)
+        dt = time.perf_counter() - t0
+        st = dict(eng.last_stats)
+    finally:
+        eng.close()
+    launches = max(int(st["outer_iterations"]), 1)
+    avgA = st["passA_ms"] / max(int(st["passA_launches"]), 1)
+    avgB = st["passB_ms"] / max(int(st["passB_launches"]), 1)
+    alg = 2.0 * N * G * int(st["restart_column_iterations"])
+    per = SPLIT_MFMAS_PER_PRODUCT.get(int(st["gemm_mode"]), 1)
+    peak = BF16_MFMA_PEAK_TFLOPS / per if int(st["gemm_mode"]) > 0 else FP32_MFMA_PEAK_TFLOPS
+    tfA = alg / max(avgA * launches, 1e-9) / 1e9
+    tfB = alg / max(avgB * launches, 1e-9) / 1e9
+    dom = "A" if avgA >= avgB else "B"
+    return {"workload": "the same matrix with count detection off (Engine(detect_counts=False)): %d restarts, K=%d..%d"
+                        % (len(ks), ks_all[0], ks_all[-1]),
+            "restarts_per_s": len(ks) / dt, "restart_iterations_per_s": float(np.sum(n_iter)) / dt,
+            "mean_iterations_per_restart": float(np.mean(n_iter)), "gemm_mode": int(st["gemm_mode"]),
+            "kernel": ("gemm3g_streamk_kernel (pass A, 3 x 3 bf16 planes)" if dom == "A" else "gemm3g_kernel (pass B, 3 x 3 bf16 planes)")
+                      if int(st["gemm_mode"]) in (1, 2) else "gemm_mode %d" % int(st["gemm_mode"]),
+            "avg_launch_ms": {"passA": avgA, "passB": avgB},
+            "achieved_TFLOPs": tfA if dom == "A" else tfB, "peak_TFLOPs": peak, "frac": (tfA if dom == "A" else tfB) / peak,
+            "flop_basis": "f32-equivalent flops; peak = bf16 dense MFMA peak / %d MFMAs per product" % per,
+            "column_utilisation": int(st["restart_column_iterations"]) / max(int(st["column_iterations"]), 1),
+            "gemm_share_of_gpu_time": (avgA + avgB) * launches / max(st["gpu_ms"], 1e-9)}
+
+
+def e2e_wallclock(eng, C, X, ks_all, restarts_per_k, cpu_it_per_s):
+    """prepare -> factorize -> combine -> k selection -> consensus(k = K_true) WITH the TPM tail through the host mirror
+    of the reference's cNMF object (what tools/e2e_c3.py does), seconds per stage; beside it the CPU reference path
+    stage by stage: the normalisation in numpy, factorize EXTRAPOLATED (sum of the GPU run's iteration counts / the
+    measured CPU restart-iterations/s -- running it takes hours), k selection and consensus by oracle/ (numpy / pandas
+    / scikit-learn restatement of cnmf.py:871-985), k selection on 3 of the 9 ranks and scaled."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    import pandas as pd
+    import scipy.sparse as sp
+    from cnmf_amd.cnmf import cNMF
+    keep = C.sum(axis=0) > 0
+    Ck = C[:, keep]
+    genes = ["g%d" % j for j in range(X.shape[1])]
+    cells = ["c%d" % i for i in range(X.shape[0])]
+    tpm_csr = sp.csr_matrix((Ck / Ck.sum(axis=1, keepdims=True) * 1e6).astype(np.float32))
+    out = tempfile.mkdtemp(prefix="cnmf_bench_e2e_")
+    t, buf = {}, io.StringIO()
+    try:
+        obj = cNMF(output_dir=out, name="c3", engine=eng, compress_merged=False)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(buf):
+            obj.prepare_from_counts(pd.DataFrame(Ck, index=cells, columns=genes), components=list(ks_all),
+                                    n_iter=restarts_per_k, seed=14, beta_loss="frobenius", tpm=(tpm_csr, genes))
+        t["prepare_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(buf):
+            obj.factorize(write_iter_files=False)
+        t["factorize_s"] = time.perf_counter() - t0
+        n_iter = np.asarray(obj.last_factorize_stats["n_iter"])
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(buf):
+            obj.combine()
+        t["combine_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        obj.k_selection_stats()
+        t["k_selection_s"] = time.perf_counter() - t0
+        k_cons = 9 if 9 in ks_all else ks_all[len(ks_all) // 2]
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(buf):
+            med, usages = obj.consensus(k_cons, density_threshold=0.5)
+        t["consensus_s"] = time.perf_counter() - t0
+        merged = {k: obj.merged_cache[k][1].values for k in ks_all}
+        gpu_med = med.values
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    res = {"workload": "prepare_from_counts (device normalisation) -> factorize (%d restarts) -> combine -> k selection "
+                       "(%d ranks, batched) -> consensus(k=%d, density 0.5) incl. TPM spectra / OLS z-scores / final "
+                       "usage refit from one CSR upload" % (len(ks_all) * restarts_per_k, len(ks_all), k_cons),
+           "stages_s": t, "total_s": sum(t.values()), "restarts": int(len(n_iter)),
+           "restart_iterations": int(n_iter.sum())}
+    # ---- the CPU reference path beside it
+    from oracle import consensus as oc
+    c = {}
+    t0 = time.perf_counter()
+    X64 = Ck.astype(np.float64)
+    X64 /= X64.std(axis=0, ddof=1)                                       # cnmf.py:540-548
+    c["prepare_s"] = time.perf_counter() - t0
+    c["factorize_s"] = float(n_iter.sum()) / cpu_it_per_s if cpu_it_per_s else None
+    sample = [k for k in (ks_all[0], k_cons, ks_all[-1])]
+    t0 = time.perf_counter()
+    for k in sample:
+        oc.consensus_core(merged[k].astype(np.float64), X64, k, stats_mode=True)     # incl. silhouette + prediction error
+    c["k_selection_s"] = (time.perf_counter() - t0) * len(ks_all) / len(sample)
+    t0 = time.perf_counter()
+    core = oc.consensus_core(merged[k_cons].astype(np.float64), X64, k_cons, density_threshold=0.5)
+    tpm64 = np.asarray(tpm_csr.todense(), dtype=np.float64)
+    tail = oc.consensus_tail(core, tpm64, tpm64.std(axis=0), np.arange(X64.shape[1]))
+    del tpm64
+    c["consensus_s"] = time.perf_counter() - t0
+    c["combine_s"] = t["combine_s"]                                      # file gather: the same host work either way
+    res["cpu_reference"] = {"stages_s": c, "total_s": (sum(v for v in c.values()) if c["factorize_s"] is not None else None),
+                            "cores": granted_cpus(), "kind": "reference (factorize: scikit-learn, extrapolated) + port "
+                            "(oracle/consensus.py for k selection, sampled on K = %s and scaled, and the consensus + tail)" % sample,
+                            "factorize_basis": "sum of the device run's iteration counts (%d) / measured CPU "
+                                               "restart-iterations/s (%.1f)" % (int(n_iter.sum()), cpu_it_per_s or 0.0)}
+    d = tail["median_spectra"] - gpu_med
+    res["consensus_spectra_sumsq_vs_cpu"] = float((d ** 2).sum())       # the reference's bar: < 1e-4
+    if res["cpu_reference"]["total_s"]:
+        res["speedup_vs_cpu"] = res["cpu_reference"]["total_s"] / res["total_s"]
+    return res
+
+
+# ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
     if args.cpu_baseline_child:
@@ -263,21 +536,42 @@ def main():
     if args.cpu_workers_child:
         cpu_workers_child(args.cpu_workers_child, args.cpu_iters)
         return
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                       # the parent: N ranks of this very command line, no launcher
+        return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started a world of %d ranks (WORLD_SIZE): refusing to "
+                         "report a number under the wrong n_gpus" % (args.gpus, world))
+    if args.spawn_selftest:                           # (tests/test_bench_spawn.py: the launch plumbing without a GPU)
+        if os.environ.get("CNMF_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rank": rank, "local_rank": local_rank,
+                              "id_file": os.environ.get("CNMF_RCCL_ID_FILE"), "spawned": os.environ.get("CNMF_BENCH_SPAWNED"),
+                              "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}))
+        return
     # stdout must carry exactly ONE JSON line, but RCCL prints a version banner to the C-level
     # stdout (flushed at exit): keep the real stdout aside and point fd 1 at stderr meanwhile
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     multi = world > 1 or bool(os.environ.get("CNMF_BENCH_FORCE_DIST"))     # (the override exercises the N > 1 code at world 1)
     if os.environ.get("CNMF_BENCH_ONE_GPU"):                               # test hook: every rank on GPU 0
         local_rank = 0
+    emu = None
+    if args.emulate_rank:
+        if multi:
+            raise SystemExit("--emulate-rank is a single-GPU projection")
+        emu = tuple(int(v) for v in args.emulate_rank.split("/"))
+        assert 0 <= emu[0] < emu[1]
     # Transport of everything that crosses ranks (the one data-path gather, the barrier, the max/sum over ranks):
     #   "rccl"  (default) -- ncclAllGather inside the C-ABI library (cnmf_comm_* / cnmf_allgather_*); NO torch:
-    #                        the launcher only provides RANK / WORLD_SIZE / MASTER_PORT, the 128-byte RCCL id
-    #                        travels through a file;
+    #                        the launcher only provides RANK / WORLD_SIZE, the 128-byte RCCL id travels through a file;
     #   "torch" -- torch.distributed (backend nccl = RCCL, or gloo for the one-GPU test hook).
     gather_mode = "none"
     if multi:
@@ -285,28 +579,26 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the HIP runtime starts (dmabuf IPC only)
     dist = None
     if gather_mode == "torch":
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
         # (test hook: CNMF_BENCH_BACKEND=gloo CNMF_BENCH_ONE_GPU=1 runs several ranks on ONE GPU to exercise the
         #  N > 1 bookkeeping -- ledger sharding, ragged gather, max-over-ranks -- where only one GPU exists)
         backend = os.environ.get("CNMF_BENCH_BACKEND", "nccl")
-        if os.environ.get("CNMF_BENCH_ONE_GPU"):
-            local_rank = 0
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend)
     tdev = "cpu" if os.environ.get("CNMF_BENCH_BACKEND", "nccl") == "gloo" else "cuda"
 
     from cnmf_amd import synth
-    from cnmf_amd.cnmf import ledger_seeds
+    from cnmf_amd.cnmf import ledger_seeds, worker_filter
     from cnmf_amd.engine import Engine
 
-    X = synth.make_config(args.workload, dtype=np.float32, n_cells=args.n_cells)
+    Ncfg, Gcfg, Kt, mu, sg, dseed = synth.CONFIGS[args.workload]
+    C, _ = synth.topic_counts(args.n_cells or Ncfg, Gcfg, Kt, mu, sg, dseed)      # raw counts (the e2e leg needs them too)
+    X = synth.normalise_like_prepare(C, dtype=np.float32)
     N, G = X.shape
     eng = Engine(local_rank)
     eng.set_matrix(X)
     if gather_mode == "rccl":
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         from cnmf_amd import dist as cd
         # all ranks of one node are children of the same launcher process: its pid + the rendezvous port
         # name the id file uniquely for this launch
@@ -316,17 +608,28 @@ def main():
 
     ks_all = list(range(args.kmin, args.kmax + 1))
     n_steps_total = args.warmup + args.steps
-    led = ledger_seeds(ks_all, args.restarts_per_k * n_steps_total * world, 14)      # the product's own ledger
-    by_k = {k: [s for (kk, _, s) in led if kk == k] for k in ks_all}
+    strong = args.scaling == "strong"
+    jobs_per_step = 1 if strong else world                   # whole jobs (|K| x restarts_per_k restarts) per step
+    led = ledger_seeds(ks_all, args.restarts_per_k * n_steps_total * jobs_per_step, 14)      # the product's own ledger
+    by_k = {k: [int(s) for (kk, _, s) in led if kk == k] for k in ks_all}
+    shard_rank, shard_world = emu if emu else (rank, world)
 
     def step_jobs(step):
+        """strong: the step's job = restarts_per_k ledger rows of every K, in ledger order (k-major); this rank runs the
+        rows idx with (idx - rank) % world == 0 (cnmf.py:52-53).  weak: every rank its own job."""
         ks, seeds = [], []
+        if strong:
+            for k in ks_all:
+                base = step * args.restarts_per_k
+                ks += [k] * args.restarts_per_k
+                seeds += by_k[k][base:base + args.restarts_per_k]
+            mine = list(worker_filter(range(len(ks)), shard_rank, shard_world))
+            return [ks[i] for i in mine], [seeds[i] for i in mine], len(ks) if not emu else len(mine)
         for k in ks_all:
             base = (step * world + rank) * args.restarts_per_k
-            for j in range(args.restarts_per_k):
-                ks.append(k)
-                seeds.append(by_k[k][base + j])
-        return ks, seeds
+            ks += [k] * args.restarts_per_k
+            seeds += by_k[k][base:base + args.restarts_per_k]
+        return ks, seeds, len(ks) * world
 
     def barrier():
         # every engine call returns with its stream drained, so a barrier over ranks is also a device barrier
@@ -337,58 +640,62 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def reduce_over_ranks(elapsed, restarts, riters):
-        """MAX of the elapsed time, SUM of the counters."""
+    def over_ranks(vec):
+        """[world, len(vec)] float64: every rank's row."""
+        v = np.asarray(vec, dtype=np.float64)
         if gather_mode == "rccl":
-            v = eng.allgather_array(np.array([elapsed, restarts, riters], dtype=np.float64))
-            return float(v[:, 0].max()), float(v[:, 1].sum()), float(v[:, 2].sum())
+            return eng.allgather_array(v)
         if dist is not None:
             import torch
-            t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            cnt = torch.tensor([restarts, riters], dtype=torch.float64, device=tdev)
-            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-            return float(t.item()), float(cnt[0].item()), float(cnt[1].item())
-        return elapsed, float(restarts), float(riters)
+            t = torch.tensor(v, dtype=torch.float64, device=tdev)
+            out = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            return np.stack([o.cpu().numpy() for o in out])
+        return v[None, :]
 
-    def gather(H_list, ks=None, step=0):
-        """The one data-path collective: all-gather of the packed per-restart spectra."""
+    def gather(H_list, ks, step):
+        """The one data-path collective: all-gather of the packed per-restart spectra.  Returns the restart count
+        every rank now holds."""
         if gather_mode == "none":
-            return
+            return len(ks)
         from cnmf_amd import dist as cd
         if gather_mode == "rccl":
-            hdr = np.array([(i, int(k), rank * len(ks) + i) for i, k in enumerate(ks)], dtype=np.int32).reshape(-1, 3)
+            hdr = np.array([(i, int(k), rank + world * i) for i, k in enumerate(ks)], dtype=np.int32).reshape(-1, 3)
             merged = cd.allgather_spectra_rccl(eng, hdr, None, G)      # blk=None: the device-resident spectra store
-            assert len(merged) == world * len(ks), (len(merged), world, len(ks))
-            return
+            return len(merged)
         import torch
-        rows = [(i, int(H.shape[0]), step) for i, H in enumerate(H_list)]
+        rows = [(i, int(H.shape[0]), rank + world * i) for i, H in enumerate(H_list)]
         hdr, blk = cd.pack_local(rows, H_list, G)
-        cd.allgather_spectra(hdr, blk, G, device=None if tdev == "cpu" else "cuda:%d" % local_rank)
+        merged = cd.allgather_spectra(hdr, blk, G, device=None if tdev == "cpu" else "cuda:%d" % local_rank)
         torch.cuda.synchronize()
+        return len(merged)
 
     def run_step(step, profile):
-        ks, seeds = step_jobs(step)
+        ks, seeds, job_restarts = step_jobs(step)
         if gather_mode == "rccl":
             eng.spectra_reset()
-            _, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=args.event_stride if profile else 0, resident=True)
+            eng.nmf_batch(ks, seeds=seeds, warn=False, profile=args.event_stride if profile else 0, resident=True)
             st = dict(eng.last_stats)
-            gather(None, ks, step)
+            got = gather(None, ks, step)
         else:
-            H, _, n_iter, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=args.event_stride if profile else 0)
+            H, _, _, _ = eng.nmf_batch(ks, seeds=seeds, warn=False, profile=args.event_stride if profile else 0)
             st = dict(eng.last_stats)
-            gather(H, ks, step)
-        return ks, st
+            got = gather(H, ks, step)
+        if multi and world > 1:
+            assert got == job_restarts, "gather returned %d restarts, the step's job has %d" % (got, job_restarts)
+        return ks, st, job_restarts
 
     agg = dict(restarts=0, restart_iters=0, rc_iters=0, outer=0, col_iters=0, passA_ms=0.0,
-               passB_ms=0.0, nA=0, nB=0, gpu_ms=0.0, kc=0, nsplit=0, gemm_mode=0)
+               passB_ms=0.0, nA=0, nB=0, gpu_ms=0.0, kc=0, nsplit=0, gemm_mode=0, tail_ms=0.0, tail_its=0, tail_live=0,
+               job_restarts=0)
     for step in range(args.warmup):
         run_step(step, False)
     barrier()
     t0 = time.perf_counter()
     for step in range(args.warmup, n_steps_total):
-        ks, st = run_step(step, True)
+        ks, st, job_restarts = run_step(step, True)
         agg["restarts"] += len(ks)
+        agg["job_restarts"] += job_restarts
         agg["restart_iters"] += int(st["restart_iterations"])
         agg["rc_iters"] += int(st["restart_column_iterations"])
         agg["outer"] += int(st["outer_iterations"])
@@ -397,9 +704,14 @@ def main():
         agg["nA"] += int(st["passA_launches"]); agg["nB"] += int(st["passB_launches"])
         agg["gpu_ms"] += st["gpu_ms"]; agg["kc"] = int(st["kc"]); agg["nsplit"] = int(st["nsplit"])
         agg["gemm_mode"] = int(st["gemm_mode"])
+        agg["tail_ms"] += st["tail_ms"]; agg["tail_its"] += int(st["tail_iterations"]); agg["tail_live"] += int(st["tail_live_columns"])
     barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed, total_restarts, total_riters = reduce_over_ranks(elapsed, agg["restarts"], agg["restart_iters"])
+    elapsed_local = time.perf_counter() - t0
+    per_rank = over_ranks([elapsed_local, agg["restarts"], agg["restart_iters"], agg["rc_iters"], agg["col_iters"],
+                           agg["gpu_ms"], agg["tail_ms"], agg["outer"]])
+    elapsed = float(per_rank[:, 0].max())                      # MAX over ranks
+    total_restarts = float(per_rank[:, 1].sum())
+    total_riters = float(per_rank[:, 2].sum())
 
     if rank == 0:
         # roofline of the dominant kernel (rank 0's launches): the MFMA GEMM pass
@@ -415,10 +727,10 @@ def main():
         dom = "A" if avgA >= avgB else "B"
         ach = tfA if dom == "A" else tfB
         split = agg["gemm_mode"] > 0
+        per_product = SPLIT_MFMAS_PER_PRODUCT.get(agg["gemm_mode"], 1)
         if split:
-            # f32-accurate products on the bf16 matrix pipe: 6 (3 for count-structured X) bf16 MFMAs per product,
-            # so the roofline of the scheme in f32-equivalent flops is the dense bf16 peak / 6 (/ 3)
-            per_product = SPLIT_MFMAS_PER_PRODUCT[agg["gemm_mode"]]
+            # f32-accurate products on the f16 / bf16 matrix pipe: 2 / 3 / 6 MFMAs per product, so the roofline of the
+            # scheme in f32-equivalent flops is the dense peak / that
             peak = BF16_MFMA_PEAK_TFLOPS / per_product
             if agg["gemm_mode"] == 4:
                 kern = ("gemm2h_streamk_kernel (pass A: X.Ht; X = one integer f16 plane x per-gene scale, factor = 2 f16 planes)"
@@ -435,15 +747,18 @@ def main():
             peak = FP32_MFMA_PEAK_TFLOPS
             kern = "gemm_streamk_kernel<NT> (pass A: X.Ht)" if dom == "A" else "gemm_kernel<NN> (pass B: Xt.W)"
         xbytes = {0: 4, 1: 6, 2: 6, 3: 2, 4: 2}[agg["gemm_mode"]]     # bytes per element of X as the GEMM reads it
+        tr, tr_ok = pmc_traffic("passA" if dom == "A" else "passB", agg["gemm_mode"])
         roof = {
             "bound": "mfma",
             "kernel": kern,
             "achieved": ach, "peak": peak, "unit": "TFLOP/s",
             "flop_basis": ("f32-equivalent flops (2.N.G per column and pass); peak = bf16/f16 dense MFMA peak / %d MFMAs per product"
-                           % SPLIT_MFMAS_PER_PRODUCT[agg["gemm_mode"]] if split else "f32 flops; peak = f32 MFMA peak"),
+                           % per_product if split else "f32 flops; peak = f32 MFMA peak"),
             "frac": ach / peak,
-            "traffic": (pmc_traffic("passA" if dom == "A" else "passB", agg["gemm_mode"]) or {}).get("hbm_bytes_per_launch"),
-            "traffic_detail": pmc_traffic("passA" if dom == "A" else "passB", agg["gemm_mode"]),
+            # HBM bytes per launch from the PMC counters -- only when the committed profile was taken on THESE kernel
+            # sources (load_profile); a stale or unstamped profile is reported in traffic_detail but not used
+            "traffic": tr["hbm_bytes_per_launch"] if (tr and tr_ok) else None,
+            "traffic_detail": tr,
             "avg_launch_ms": {"passA": avgA, "passB": avgB},
             "launches": {"per_pass": agg["outer"], "timed_with_hip_events": agg["nA"]},
             "achieved_passA": tfA, "achieved_passB": tfB,
@@ -453,9 +768,13 @@ def main():
                              "passB": N * G * xbytes / max(avgB, 1e-9) / 1e6,
                              "peak": HBM_PEAK_GBS},
             "gemm_share_of_gpu_time": (avgA + avgB) * launches / max(agg["gpu_ms"], 1e-9),
+            # both passes over the whole step: the end-to-end fraction of the scheme's roofline
+            "end_to_end": {"achieved": 2.0 * alg_flops_A / max(agg["gpu_ms"], 1e-9) / 1e9, "peak": peak,
+                           "frac": 2.0 * alg_flops_A / max(agg["gpu_ms"], 1e-9) / 1e9 / peak,
+                           "basis": "2 passes x algorithmic flops / device time of the whole call (all kernels)"},
+            "kernel_source_sha256": source_hashes(),
         }
-        tr = roof["traffic_detail"]
-        if tr:
+        if tr and tr_ok:
             # the pass is nearly balanced between the two roofs: also quote the HBM side (PMC bytes / measured time)
             dur = (avgA if dom == "A" else avgB) * 1e-3
             roof["hbm"] = {"achieved_GBs": tr["hbm_bytes_per_launch"] / dur / 1e9, "peak_GBs": HBM_PEAK_GBS,
@@ -463,10 +782,14 @@ def main():
                            "traffic_over_algorithmic": tr["hbm_bytes_per_launch"] / tr["algorithmic_bytes_per_launch"]}
         if agg["gemm_mode"] == 4:
             # measured ceiling of THIS instruction stream with everything but the MFMAs removed (tools/
-            # probe_gemm2h_ablate.py var 7, profiles/r2_probe_gemm2h_variants.txt): the matrix pipe on non-zero data at
-            # the clock the power budget allows -- not a roofline, but the reason `frac` cannot approach 1
-            roof["mfma_only_ablation"] = {"tflops_issued": 1460.0, "source": "profiles/r2_probe_gemm2h_variants.txt",
-                                          "issued_over_mfma_only": ach * per_product * agg["col_iters"] / max(agg["rc_iters"], 1) / 1460.0}
+            # probe_gemm2h_ablate.py var 7): the matrix pipe on non-zero data at the clock the power budget allows --
+            # not a roofline, but the reason `frac` cannot approach 1.  Read from a stamped profile, never a literal.
+            abl, verdict = load_profile("r3_gemm2h_ablation.json")
+            if abl and "mfma_only_tflops_issued" in abl:
+                issued = ach * per_product * agg["col_iters"] / max(agg["rc_iters"], 1)
+                roof["mfma_only_ablation"] = {"tflops_issued": abl["mfma_only_tflops_issued"],
+                                              "source": "profiles/r3_gemm2h_ablation.json", "stale": verdict,
+                                              "issued_over_mfma_only": (issued / abl["mfma_only_tflops_issued"]) if verdict is None else None}
         if split:
             roof["matrix_pipe"] = {
                 "scheme": ("X = n * d detected (n integer <= 2048: one exact f16 plane; d per gene, folded into the factor); "
@@ -482,33 +805,62 @@ def main():
                 "note": "launch averages include the tail launches (< 256 packed columns) that run on the exact-f32 pipe",
             }
         mean_it = total_riters / max(total_restarts, 1.0)
+        ranks = [{"rank": r, "seconds": float(per_rank[r, 0]), "restarts": int(per_rank[r, 1]),
+                  "column_utilisation": float(per_rank[r, 3] / max(per_rank[r, 4], 1.0)),
+                  "gpu_ms": float(per_rank[r, 5]), "tail_ms": float(per_rank[r, 6]),
+                  "tail_share_of_gpu_time": float(per_rank[r, 6] / max(per_rank[r, 5], 1e-9))} for r in range(per_rank.shape[0])]
         out = {
             "metric": "NMF restarts/sec (%dx%dxK%d..%d)" % (N, G, args.kmin, args.kmax),
             "value": total_restarts / elapsed,
             "unit": "restarts/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            # f32 results; the products run on the bf16 matrix pipe from exact operand planes
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            # f32 results; the products run on the f16 / bf16 matrix pipe from exact operand planes
             "dtype": ({1: "f32 (3x3 bf16 planes, f32 accumulate)", 2: "f32 (3x3 bf16 planes, f32 accumulate)",
                        3: "f32 (exact integer bf16 plane x 3 bf16 planes, f32 accumulate)",
                        4: "f32 (exact integer f16 plane x 2 f16 planes with per-row exponent, f32 accumulate)"}.get(agg["gemm_mode"], "f32")),
             "data": "synthetic",
-            "config": {"workload": "%s: %d cells x %d HVGs synthetic dense, K=%d..%d, %d restarts per K per step "
-                                   "per GPU, sklearn CD solver tol=1e-4 max_iter=1000, init=random from ledger seeds"
-                                   % (args.workload, N, G, args.kmin, args.kmax, args.restarts_per_k),
-                       "restarts_per_step_per_gpu": len(ks_all) * args.restarts_per_k,
+            "config": {"workload": "%s: %d cells x %d HVGs synthetic dense, K=%d..%d, %d restarts per K per step (%s), "
+                                   "sklearn CD solver tol=1e-4 max_iter=1000, init=random from ledger seeds"
+                                   % (args.workload, N, G, args.kmin, args.kmax, args.restarts_per_k,
+                                      "ONE job of %d restarts sharded idx %% %d over the GPUs" % (len(ks_all) * args.restarts_per_k, world)
+                                      if strong else "per GPU"),
+                       "restarts_per_step": int(total_restarts / max(args.steps, 1)),
+                       "restarts_per_step_per_gpu": int(agg["restarts"] / max(args.steps, 1)),
                        "packed_columns": agg["kc"], "splitk_passB": agg["nsplit"],
                        "mean_iterations_per_restart": mean_it,
                        "restart_iterations_per_s": total_riters / elapsed,
                        "column_utilisation": agg["rc_iters"] / max(agg["col_iters"], 1),
-                       "parallelism": "restart-sharded x%d" % world, "gather": gather_mode,
+                       "tail": {"ms_per_step": agg["tail_ms"] / max(args.steps, 1),
+                                "share_of_gpu_time": agg["tail_ms"] / max(agg["gpu_ms"], 1e-9),
+                                "iterations_per_step": agg["tail_its"] / max(args.steps, 1),
+                                "mean_live_columns": agg["tail_live"] / max(agg["tail_its"], 1),
+                                "meaning": "from the moment the queue of pending restarts ran dry to the end of the call"},
+                       "per_rank": ranks,
+                       "parallelism": "restart-sharded x%d (%s scaling)" % (world, args.scaling), "gather": gather_mode,
                        "torch_in_process": "torch" in sys.modules},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(X, mean_it, args.cpu_iters)
-            out["consensus"] = consensus_wallclock(eng)
+        if emu:
+            out["config"]["emulated_shard"] = {"rank": emu[0], "world": emu[1],
+                                               "note": "single GPU running only the shard that rank would own"}
+        if world == 1 and not emu:
+            cpu = None
+            if not args.no_cpu_baseline:
+                cpu = cpu_baseline(X, mean_it, args.cpu_iters)
+                out["cpu_baseline"] = cpu
+                out["consensus"] = consensus_wallclock(eng)
+            if not args.no_extras:
+                rpk = max(1, min(args.restarts_per_k, 20))
+                try:
+                    out["general_path"] = general_path_step(X, ks_all, by_k, rpk, args.event_stride)
+                except Exception as e:                    # an extra must never cost the headline line
+                    out["general_path"] = {"error": repr(e)}
+                try:
+                    out["e2e"] = e2e_wallclock(eng, C, X, ks_all, args.restarts_per_k, cpu["value"] if cpu else None)
+                except Exception as e:
+                    out["e2e"] = {"error": repr(e)}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
     barrier()

@@ -46,7 +46,8 @@ class BatchStats(C.Structure):
                 ("gpu_ms", C.c_double),
                 ("passA_ms", C.c_double), ("passB_ms", C.c_double),
                 ("passA_launches", C.c_int64), ("passB_launches", C.c_int64),
-                ("kc", C.c_int32), ("nsplit", C.c_int32), ("gemm_mode", C.c_int32), ("reserved_", C.c_int32)]
+                ("kc", C.c_int32), ("nsplit", C.c_int32), ("gemm_mode", C.c_int32), ("reserved_", C.c_int32),
+                ("tail_iterations", C.c_int64), ("tail_live_columns", C.c_int64), ("tail_ms", C.c_double)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -282,27 +282,6 @@ class cNMF:
             alpha_usage=alpha_usage, alpha_spectra=alpha_spectra, init=init, max_iter=max_NMF_iter)
         self.save_nmf_iter_params(replicate_params, run_params)
 
-    def select_highvar_genes(self, tpm, numgenes=2000, expected_fano_threshold=None, minimal_mean=0.5):
-        """``get_highvar_genes`` (cnmf.py:192-246 / 136-188) with the per-gene moments computed on the device:
-        ``tpm`` is the cells x ALL-genes TPM matrix (DataFrame, ndarray or scipy CSR).  Returns
-        ``(gene_stats DataFrame, fano params, list of selected columns)``.  The matrix is uploaded to this
-        object's context and replaced by the next ``prepare_from_*`` call."""
-        from .hvg import highvar_genes_from_moments
-        cols = tpm.columns if isinstance(tpm, pd.DataFrame) else None
-        vals = tpm.values if isinstance(tpm, pd.DataFrame) else tpm
-        eng = self.engine
-        eng.set_matrix(vals)
-        self._engine_key = None
-        self._resident_obj = None
-        mean, var = eng.col_mean_var()
-        stats, params = highvar_genes_from_moments(mean, var, numgenes=numgenes,
-                                                   expected_fano_threshold=expected_fano_threshold,
-                                                   minimal_mean=minimal_mean)
-        if cols is not None:
-            stats.index = cols
-        chosen = list(stats.index[stats["high_var"].values])
-        return stats, params, chosen
-
     def prepare_from_counts(self, counts, components, n_iter=100, seed=None, beta_loss="frobenius",
                             alpha_usage=0.0, alpha_spectra=0.0, init="random", max_NMF_iter=1000, tpm=None):
         """``get_norm_counts`` + the tail of ``prepare`` (cnmf.py:540-556, 452-459) with the
@@ -664,7 +643,7 @@ class cNMF:
                     norm_tpm = (np.asarray(tpm_x[:, hidx].todense()) if have_sparse else tpm_x[:, hidx]).astype(np.float64) / std1
                     rf = self.refit_usage(norm_tpm, Hrf.astype(norm_tpm.dtype))
                 else:
-                    rf, _ = eng.nnls_gram(H_prod, Hrf @ Hrf.T, **solver_kw)
+                    rf, _ = eng.nnls_gram(H_prod, Hrf @ Hrf.T, n_features=len(hvgs), **solver_kw)
                 rf_usages = pd.DataFrame(np.asarray(rf, dtype=xdt), index=norm_counts.index, columns=spectra_tpm_rf.index)
 
         save_df_to_npz(median_spectra, self.paths["consensus_spectra"] % (k, density_threshold_repl))
@@ -717,19 +696,3 @@ class cNMF:
         save_df_to_npz(stats, self.paths["k_selection_stats"])
         return stats
 
-
-def _ols_all_cols(X, Y, batch_size=1024):
-    """efficient_ols_all_cols(X, Y, normalize_y=True) (cnmf.py:55-125), dense Y."""
-    mean = Y.mean(axis=0)
-    var = Y.var(axis=0)
-    var[var < 1e-12] = 1e-12
-    std = np.sqrt(var)
-    XtX = np.zeros((X.shape[1], X.shape[1]))
-    XtY = np.zeros((X.shape[1], Y.shape[1]))
-    for s in range(0, X.shape[0], batch_size):
-        e = min(s + batch_size, X.shape[0])
-        Xb = X[s:e]
-        XtX += Xb.T @ Xb
-        XtY += Xb.T @ ((Y[s:e] - mean) / std)
-    beta, *_ = np.linalg.lstsq(XtX, XtY, rcond=None)
-    return beta

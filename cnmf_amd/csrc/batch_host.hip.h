@@ -319,10 +319,30 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         HIP_TRY(ctx, hipGetLastError());
     }
 
-    // restarts in descending rank so that freed slots can always be reused
+    // Queue order.  Restarts are independent, so the order they run in is free; what it decides is the TAIL of the
+    // call: once the queue is dry the columns of finished restarts stay empty, and the call ends when the LONGEST
+    // restart still in flight converges (iterations per restart span 35 ... 1000 and depend mostly on the rank: ranks
+    // far from the data's own need the most).  Hence longest-expected-first:
+    //   * start: the ranks interleaved (round-robin over the distinct ranks, largest first inside a round), so every
+    //     rank is sampled within the first fill of the packed columns;
+    //   * as restarts retire, the mean iteration count per rank is learned and the pending queue is re-sorted by it,
+    //     descending (LPT) -- the short restarts are kept for the end, where they fill the columns the long ones free.
+    // CNMF_QUEUE=rank restores the plain descending-rank order (A/B).
     std::vector<int> order(n);
-    for (int r = 0; r < n; ++r) order[r] = r;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kk[a] > kk[b]; });
+    const bool queue_by_rank = getenv("CNMF_QUEUE") && !strcmp(getenv("CNMF_QUEUE"), "rank");
+    if (queue_by_rank) {
+        for (int r = 0; r < n; ++r) order[r] = r;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kk[a] > kk[b]; });
+    } else {
+        std::vector<std::vector<int>> by_k(KMAX + 1);
+        for (int r = 0; r < n; ++r) by_k[kk[r]].push_back(r);
+        size_t pos = 0;
+        for (size_t j = 0; pos < (size_t)n; ++j)
+            for (int k = KMAX; k >= 1; --k)
+                if (j < by_k[k].size()) order[pos++] = by_k[k][j];
+    }
+    std::vector<int64_t> k_iters(KMAX + 1, 0), k_done(KMAX + 1, 0);     // learned per rank: sum of n_iter, restarts retired
+    int last_resort_done = 0;
     size_t next = 0;                 // first queue position that may still be pending
     int n_pending = n;
 
@@ -366,6 +386,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         else nsplitA = std::min(pick_nsplit_A3(ctx, KC, jwA), ctx->nsplitA_alloc);   // few tiles: K split + reduce
     }
     int n_done = 0;
+    hipEvent_t ev_tail = nullptr;    // recorded when the queue runs dry
+    int64_t tail_its = 0, tail_live = 0;
 
     auto retire = [&](int s, const SlotDesc& snap) -> int {
         HostSlot& h = hs[s];
@@ -380,6 +402,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (viol_out) viol_out[r] = snap.viol_last;
         restart_iters += snap.iter;
         restart_col_iters += (int64_t)snap.iter * k;
+        k_iters[k] += snap.iter; k_done[k] += 1;
         cols.release(h.off, k);
         h.state = 0; h.restart = -1;
         --n_active; ++n_done;
@@ -611,6 +634,11 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         HIP_TRY(ctx, hipGetLastError());
         snap_nslots[it % RING] = nslots;
         column_iters += KC;
+        if (n_pending == 0) {
+            int live = 0;
+            for (int s2 = 0; s2 < nslots; ++s2) if (hs[s2].state) live += hs[s2].k;
+            ++tail_its; tail_live += live;
+        }
         if (dbg) {
             int live = 0;
             for (int s2 = 0; s2 < nslots; ++s2) if (hs[s2].state) live += hs[s2].k;
@@ -632,6 +660,21 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                 rc2 = retire(s, sp[s]);
                 if (rc2) return rc2;
             }
+        // longest-expected-first: re-sort what is still pending by the mean iteration count learned per rank (ranks
+        // without a finished restart yet count as longest: they are sampled first), every 8 retirements
+        if (!queue_by_rank && n_pending > 1 && n_done - last_resort_done >= 8) {
+            last_resort_done = n_done;
+            std::vector<int> rest;
+            rest.reserve(n_pending);
+            for (size_t pi = next; pi < order.size(); ++pi) if (order[pi] >= 0) rest.push_back(order[pi]);
+            auto expect = [&](int r) { const int k = kk[r]; return k_done[k] ? (double)k_iters[k] / (double)k_done[k] : 1e30; };
+            std::stable_sort(rest.begin(), rest.end(), [&](int a, int b) {
+                const double ea = expect(a), eb = expect(b);
+                return ea != eb ? ea > eb : kk[a] > kk[b];
+            });
+            order.resize(next);
+            order.insert(order.end(), rest.begin(), rest.end());
+        }
         return CNMF_OK;
     };
 
@@ -649,6 +692,9 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             // On the count path a 256-column iteration (~250 us of GEMM at 50k x 2000) costs no more than a
             // 64-column one on the f32 pipe and far less than a 128-column one: leave it only for 32 columns.
             if (usec && KCn > 32 && !f32_tail) KCn = KC;
+            // General (non-count) split-operand path, 6 MFMAs per product: a 256-column iteration still beats 128
+            // columns on the f32 pipe (417 / 2 vs 157 TF of roof per live column), not 64.
+            else if (use3 && !usec && KCn > 64 && !f32_tail) KCn = KC;
             if (KCn < KC) {
                 int rcp = repack_left(KCn);
                 if (rcp) return rcp;
@@ -674,6 +720,11 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         int n_new = 0;
         if ((rc = refill(n_new))) return rc;
         if (n_active == 0 && n_pending == 0) break;
+        if (n_pending == 0 && !ev_tail && stats) {
+            ev_tail = events.get();
+            POOL_TRY(ctx, events);
+            HIP_TRY(ctx, hipEventRecord(ev_tail, st));
+        }
         if ((rc = iterate(n_new))) return rc;
         if ((rc = inspect())) return rc;
         if ((rc = compact())) return rc;
@@ -701,6 +752,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         stats->restart_column_iterations = restart_col_iters;
         stats->kc = KC0; stats->nsplit = gemm_mode_used ? nsplit3 : ctx->nsplit_alloc;
         stats->gemm_mode = gemm_mode_used;
+        stats->tail_iterations = tail_its; stats->tail_live_columns = tail_live;
+        if (ev_tail) { float tms = 0.f; hipEventElapsedTime(&tms, ev_tail, ev_end); stats->tail_ms = tms; }
         for (size_t i = 0; i + 3 < gev.size(); i += 4) {
             float a = 0.f, b = 0.f;
             hipEventElapsedTime(&a, gev[i], gev[i + 1]);

@@ -187,9 +187,9 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
         if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
         dim3 gp((G + 255) / 256, chunks);
         col_partial_f64_kernel<<<gp, 256, 0, st>>>(dX, ld, Rk, G, rpc, nullptr, dcpart);
-        col_combine_f64_kernel<<<(G + 255) / 256, 256, 0, st>>>(dcpart, chunks, G, 1.0 / Rk, dmean);
+        col_combine_f64_kernel<<<(G + 255) / 256, 256, 0, st>>>(dcpart, chunks, G, (double)Rk, dmean);
         col_partial_f64_kernel<<<gp, 256, 0, st>>>(dX, ld, Rk, G, rpc, dmean, dcpart);
-        col_combine_f64_kernel<<<(G + 255) / 256, 256, 0, st>>>(dcpart, chunks, G, 1.0 / Rk, dvar);
+        col_combine_f64_kernel<<<(G + 255) / 256, 256, 0, st>>>(dcpart, chunks, G, (double)Rk, dvar);
     }
     center_rows_kernel<<<Rk, 256, 0, st>>>(dX, ld, G, dmean, dxsq);
     std::vector<double> hvar(G);

@@ -196,9 +196,26 @@ extern "C" int cnmf_debug_gemm3c(cnmf_ctx* ctx, const float* A, const float* Bn,
 // C[KC][J] = A[KC][K] . Bn[J][K]^T through the f16 two-plane count kernel (kernels_gemm2h.hip.h): Bn holds
 // non-negative integers <= 65535, A arbitrary non-negative float32.  KC % 256 == 0, K % 64 == 0.  nsub = 1 | 2 sub-blocks
 // per barrier pair (2 only without a second count plane, K % 32 == 0).
+// The row-scale bound the W half-step reports instead of the exact maximum (kernels_sweep.hip.h, RMX = false):
+// sqrt(sum of w^2 over the <= 1024 cells of one sweep workgroup) * 1.0001, one partial per workgroup.
+// grid = (parts, rows / 4): one wave per row and part.
+__global__ __launch_bounds__(256) void debug_rowbound_part_kernel(const float* __restrict__ V, int ld, int L, int span,
+                                                                  int parts, float* __restrict__ rmax_part)
+{
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, p = blockIdx.x;
+    const int j0 = p * span, j1 = min(L, j0 + span);
+    float s = 0.f;
+    for (int j = j0 + lane; j < j1; j += 64) { const float x = V[(size_t)row * ld + j]; s = fmaf(x, x, s); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) rmax_part[(size_t)row * parts + p] = sqrtf(s) * 1.0001f;
+}
+
 extern "C" int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, int KC, int K, int J,
                                  int nsplit, int nsub, double* ms_out, int reps)
 {
+    const bool sweep_bound = (nsub & 128) != 0;          // bit 7: scale the rows by the W half-step's BOUND, not the exact maximum
+    nsub &= 127;
     if (!ctx || !A || !Bn || !C) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
     if (KC % 256 || K % 64 || J < 1 || nsplit < 1) { SET_ERR(ctx, "debug_gemm2h needs KC %% 256 == 0, K %% 64 == 0"); return CNMF_EINVAL; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -211,7 +228,8 @@ extern "C" int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn,
     float* dA = pool.get<float>((size_t)KC * K);
     float* dB = pool.get<float>((size_t)J * K);
     float* dUnit = pool.get<float>(K);
-    float* dRmax = pool.get<float>(KC);
+    const int bparts = sweep_bound ? (K + 1023) / 1024 : 1;
+    float* dRmax = pool.get<float>((size_t)KC * bparts);
     float* dInv = pool.get<float>(KC);
     unsigned char* dA2 = pool.get<unsigned char>((size_t)KC * Kb * G2_ROWB);
     unsigned char* dB1 = pool.get<unsigned char>((size_t)Jp * Kb * 32);
@@ -225,8 +243,12 @@ extern "C" int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn,
     HIP_TRY(ctx, hipMemcpyAsync(dA, A, (size_t)KC * K * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dB, Bn, (size_t)J * K * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dUnit, ones.data(), (size_t)K * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, launch_rowmax_part(st, dA, K, K, KC, K, nullptr, 1, dRmax));
-    HIP_TRY(ctx, launch_split2h(st, dA, K, KC, K, dA2, G3_MW, nullptr, dRmax, 1, dInv));
+    if (sweep_bound) {
+        debug_rowbound_part_kernel<<<dim3(bparts, KC / 4), 256, 0, st>>>(dA, K, K, 1024, bparts, dRmax);
+        HIP_TRY(ctx, hipGetLastError());
+    } else
+        HIP_TRY(ctx, launch_rowmax_part(st, dA, K, K, KC, K, nullptr, 1, dRmax));
+    HIP_TRY(ctx, launch_split2h(st, dA, K, KC, K, dA2, G3_MW, nullptr, dRmax, bparts, dInv));
     {
         const long long total = (long long)Jp * Kb;
         count_planes_f16_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(dB, K, J, K, Jp, K, G3C_JW, dUnit,

@@ -16,12 +16,9 @@ static hipError_t launch_gemm_t(hipStream_t st, const float* A, int lda, const f
     constexpr int MW = WM * MTW * 32, JW = WN * 32;
     const int Kper = round_up((Ktot + nsplit - 1) / nsplit, BK);
     dim3 grid((J + JW - 1) / JW, KC / MW, nsplit);
-    static bool attr_set = false;
     constexpr size_t lds = gemm_lds_bytes<MTW, WM, WN, NN, TBK>();
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<MTW, WM, WN, NN, TBK>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    {
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm_kernel<MTW, WM, WN, NN, TBK>, (int)lds)) return e_;
     }
     gemm_kernel<MTW, WM, WN, NN, TBK><<<grid, 256, lds, st>>>(A, lda, B, ldb, C, ldc, cstride, Kper,
                                                              Ktot, J);
@@ -69,15 +66,13 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
                                float* rmax_part = nullptr, const double* rmax_scale = nullptr, bool psum = false)
 {
     dim3 grid(parts, nslots);
-    static bool attr_set = false;
-    if (!attr_set) {      // ranks above 32 need more than the default 64 KB of dynamic LDS
-        hipFuncSetAttribute((const void*)sweep_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
-        hipFuncSetAttribute((const void*)sweep_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
-        hipFuncSetAttribute((const void*)sweep_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
-        hipFuncSetAttribute((const void*)sweep_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
-        hipFuncSetAttribute((const void*)sweep_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
-        hipFuncSetAttribute((const void*)sweep_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
-        attr_set = true;
+    {      // ranks above 32 need more than the default 64 KB of dynamic LDS
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, false>, (int)sweep_lds_bytes(KMAX))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, false>, (int)sweep_lds_bytes(KMAX))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, false>, (int)sweep_lds_bytes(KMAX))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, true>, (int)sweep_lds_bytes(KMAX))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, true>, (int)sweep_lds_bytes(KMAX))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, true>, (int)sweep_lds_bytes(KMAX))) return e_;
     }
     // one launch per rank tier present among the live slots; a launch skips the slots of other tiers at once.
     // rmax_scale != nullptr selects the exact row-maximum report (the H half-step of the f16 plane split).
@@ -86,12 +81,10 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
 #define CNMF_SWEEP(T_, R_) sweep_kernel<T_, R_><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax, rmax_part, rmax_scale)
 #define CNMF_SWEEP_PSUM(T_) sweep_kernel<T_, true, true><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax, rmax_part, rmax_scale)
     if (psum) {                 // split-K partial planes summed (and column-scaled) inside the sweep: sp = psum_info(...)
-        static bool attr_psum = false;
-        if (!attr_psum) {
-            hipFuncSetAttribute((const void*)sweep_kernel<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
-            hipFuncSetAttribute((const void*)sweep_kernel<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
-            hipFuncSetAttribute((const void*)sweep_kernel<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes(KMAX));
-            attr_psum = true;
+        {
+            if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, true, true>, (int)sweep_lds_bytes(KMAX))) return e_;
+            if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, true, true>, (int)sweep_lds_bytes(KMAX))) return e_;
+            if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, true, true>, (int)sweep_lds_bytes(KMAX))) return e_;
         }
         if (tiers & 1) CNMF_SWEEP_PSUM(0);
         if (tiers & 2) CNMF_SWEEP_PSUM(1);
@@ -141,11 +134,8 @@ static hipError_t launch_streamk_passA(hipStream_t st, const StreamK& sk, const 
                                        const float* B, int ldb, float* C0, float* C1, int ldc, int Jtot)
 {
     constexpr size_t lds = gemm_lds_bytes<4, 1, 4, false>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_streamk_kernel<4, 1, 4, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    {
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm_streamk_kernel<4, 1, 4, false>, (int)lds)) return e_;
     }
     gemm_streamk_kernel<4, 1, 4, false><<<sk.P, 256, lds, st>>>(A, lda, B, ldb, C0, C1, ldc, sk.MG, sk.T,
                                                                sk.nk, Jtot);
@@ -199,11 +189,9 @@ static int gemm3_jw() { return G3_JW; }     // j extent of a tile = row tile of 
 static hipError_t launch_gemm3(hipStream_t st, const unsigned char* A3, const unsigned char* B3, int Kb,
                                float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
-        hipFuncSetAttribute((const void*)gemm3g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3G_LDS_BYTES);
-        attr_set = true;
+    {
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm3_kernel, G3_LDS_BYTES)) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm3g_kernel, G3G_LDS_BYTES)) return e_;
     }
     const int kb_per = (Kb + nsplit - 1) / nsplit;
     dim3 grid(Jpad / gemm3_jw(), KC / G3_MW, (Kb + kb_per - 1) / kb_per);
@@ -260,11 +248,9 @@ static StreamK3 plan_streamk3(int KC, int N_pad, int G_pad, int n_wg_slots, int 
 static hipError_t launch_gemm3_streamk(hipStream_t st, const StreamK3& sk, const unsigned char* A3,
                                        const unsigned char* B3, float* C0, float* C1, float* C2, int ldc)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm3_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
-        hipFuncSetAttribute((const void*)gemm3g_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3G_LDS_BYTES);
-        attr_set = true;
+    {
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm3_streamk_kernel, G3_LDS_BYTES)) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm3g_streamk_kernel, G3G_LDS_BYTES)) return e_;
     }
     if (gemm3_mode() >= 2)
         gemm3g_streamk_kernel<<<sk.P, 512, G3G_LDS_BYTES, st>>>(A3, B3, sk.Kb, C0, C1, C2, ldc, sk.MG, sk.T);
@@ -298,10 +284,8 @@ static hipError_t launch_gemm3c(hipStream_t st, const unsigned char* A3, const u
                                 const unsigned char* Bhi, const unsigned int* hiflag, int Kb,
                                 float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm3c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, g3c_lds_bytes(true));
-        attr_set = true;
+    {
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm3c_kernel, g3c_lds_bytes(true))) return e_;
     }
     const int kb_per = (Kb + nsplit - 1) / nsplit;
     dim3 grid(Jpad / G3C_JW, KC / G3_MW, (Kb + kb_per - 1) / kb_per);
@@ -313,10 +297,8 @@ static hipError_t launch_gemm3c_streamk(hipStream_t st, const StreamK3& sk, cons
                                         const unsigned char* B1, const unsigned char* Bhi,
                                         const unsigned int* hiflag, float* C0, float* C1, float* C2, int ldc)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm3c_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, g3c_lds_bytes(true));
-        attr_set = true;
+    {
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm3c_streamk_kernel, g3c_lds_bytes(true))) return e_;
     }
     gemm3c_streamk_kernel<<<sk.P, 512, g3c_lds_bytes(Bhi != nullptr), st>>>(A3, B1, Bhi, hiflag, sk.Kb, C0, C1, C2, ldc,
                                                                             sk.MG, sk.T);
@@ -346,11 +328,9 @@ static hipError_t launch_gemm2h_t(hipStream_t st, const unsigned char* A2, const
                                   const unsigned char* Bhi, const unsigned int* hiflag, const float* rscale, int Kb,
                                   float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
 {
-    static bool attr_set = false;
     constexpr int lds = g2_lds_bytes(NSUB, HI);
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm2h_kernel<NSUB, HI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+    {
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm2h_kernel<NSUB, HI, VAR>, lds)) return e_;
     }
     int kb_per = (Kb + nsplit - 1) / nsplit;
     kb_per = ((kb_per + NSUB - 1) / NSUB) * NSUB;            // whole steps
@@ -392,11 +372,9 @@ static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, co
                                           const unsigned int* hiflag, const float* rscale, int Kb, float* C0, float* C1,
                                           float* C2, int ldc)
 {
-    static bool attr_set = false;
     constexpr int lds = g2_lds_bytes(NSUB, HI);
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm2h_streamk_kernel<NSUB, HI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+    {
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm2h_streamk_kernel<NSUB, HI, VAR>, lds)) return e_;
     }
     gemm2h_streamk_kernel<NSUB, HI, VAR><<<sk.P, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T);
     return hipGetLastError();

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const double* __restrict
 
 // The same statistics with the rows spread over many workgroups (col_stats_kernel walks all R rows with 4 row groups
 // per 64 columns: 32 workgroups at G = 2000 -- 0.7 ms at R = 4900).  part[chunk][g] = sum over the chunk's rows of x
-// (mean == nullptr) or (x - mean[g])^2; col_combine_f64_kernel adds the chunks in order and scales.
+// (mean == nullptr) or (x - mean[g])^2; col_combine_f64_kernel adds the chunks in order and divides by the row count.
 __global__ __launch_bounds__(256) void col_partial_f64_kernel(const double* __restrict__ X, int ld, int R, int G,
                                                               int rows_per_chunk, const double* __restrict__ mean,
                                                               double* __restrict__ part)
@@ -287,13 +287,13 @@ __global__ __launch_bounds__(256) void col_partial_f64_kernel(const double* __re
 }
 
 __global__ __launch_bounds__(256) void col_combine_f64_kernel(const double* __restrict__ part, int chunks, int G,
-                                                              double scale, double* __restrict__ out)
+                                                              double divisor, double* __restrict__ out)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= G) return;
     double s = 0.0;
     for (int c = 0; c < chunks; ++c) s += part[(size_t)c * G + g];
-    out[g] = s * scale;
+    out[g] = s / divisor;               // a true division, like numpy's mean (sum * (1/R) can differ by 1 ulp)
 }
 
 // X[r][g] -= mean[g];  sq[r] = |X[r]|^2

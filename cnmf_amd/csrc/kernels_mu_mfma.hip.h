@@ -621,12 +621,13 @@ __global__ __launch_bounds__(1024) void mu_colsum_batch_final_kernel(MuBatch mb,
     }
 }
 
-// X [N_pad][ldx] -> Xt [Gs][ldxt] (zero beyond N x G).  grid = (ceil(Gs / 32), ceil(ldxt / 32)), block = (32, 8)
+// X [N_pad][ldx] -> Xt [Gs][ldxt] (zero beyond N x G).  grid = (ceil(ldxt / 32), ceil(Gs / 32)), block = (32, 8): the CELL
+// dimension rides on grid.x (2^31 - 1 blocks), the gene dimension (<= 2^24 / 32 ... in practice a few hundred) on grid.y
 __global__ __launch_bounds__(256) void mu_transpose_kernel(const float* __restrict__ X, int ldx, int N, int G,
                                                            float* __restrict__ Xt, int ldxt, int Gs)
 {
     __shared__ float tile[32][33];
-    const int g0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int g0 = blockIdx.y * 32, r0 = blockIdx.x * 32;
     for (int j = threadIdx.y; j < 32; j += 8) {
         const int r = r0 + j, g = g0 + threadIdx.x;
         tile[j][threadIdx.x] = (r < N && g < G) ? X[(size_t)r * ldx + g] : 0.f;

@@ -49,7 +49,7 @@ static int mu_run_one(cnmf_ctx* ctx, hipStream_t st, int N, int G, int k, float*
     double prev = err0, err = err0;
     const float l1W = (float)prm->l1_reg_W, l2W = (float)prm->l2_reg_W;
     const float l1H = (float)prm->l1_reg_H, l2H = (float)prm->l2_reg_H;
-    int it = 0;
+    int it = 0, err_it = 0;
     bool hsum_valid = false;
     for (it = 1; it <= prm->max_iter; ++it) {
         if (BETA1 && !hsum_valid) { colsum(dHt, G, dHsum); hsum_valid = true; }
@@ -64,12 +64,17 @@ static int mu_run_one(cnmf_ctx* ctx, hipStream_t st, int N, int G, int k, float*
         if (prm->tol > 0 && it % 10 == 0) {
             rc = divergence(&err);
             if (rc) return rc;
+            err_it = it;
             hsum_valid = true;                       // divergence() refreshed Hsum
             if ((prev - err) / err0 < prm->tol) break;
             prev = err;
         }
     }
     *n_iter_out = std::min(it, prm->max_iter);
+    if (err_it != *n_iter_out) {                     // report the divergence of the FINAL factors (tol = 0, or max_iter % 10 != 0)
+        rc = divergence(&err);
+        if (rc) return rc;
+    }
     *err_out = err;
     return CNMF_OK;
 }
@@ -82,10 +87,19 @@ static int mu_ensure_xt(cnmf_ctx* ctx, int Gs)
 {
     if (ctx->XtF) return CNMF_OK;
     const size_t n = (size_t)Gs * ctx->N_pad;
-    HIP_TRY(ctx, hipMalloc(&ctx->XtF, n * sizeof(float)));
-    dim3 grid(Gs / 32, ctx->N_pad / 32), block(32, 8);
-    mu_transpose_kernel<<<grid, block, 0, ctx->stream>>>(ctx->X, ctx->G_pad, (int)ctx->N, (int)ctx->G, ctx->XtF, ctx->N_pad, Gs);
-    HIP_TRY(ctx, hipGetLastError());
+    if (Gs / 32 > 65535) { SET_ERR(ctx, "X^T build: %d gene rows exceed the launch grid", Gs); return CNMF_EUNSUPPORTED; }
+    float* xt = nullptr;
+    HIP_TRY(ctx, hipMalloc(&xt, n * sizeof(float)));
+    dim3 grid(ctx->N_pad / 32, Gs / 32), block(32, 8);        // cells on grid.x: no 65 535-block limit on N_pad
+    mu_transpose_kernel<<<grid, block, 0, ctx->stream>>>(ctx->X, ctx->G_pad, (int)ctx->N, (int)ctx->G, xt, ctx->N_pad, Gs);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);       // built once per matrix: check it really ran
+    if (e != hipSuccess) {
+        // never leave a half-built X^T behind: the next call would skip the build and iterate on garbage
+        hipFree(xt);
+        HIP_TRY(ctx, e);
+    }
+    ctx->XtF = xt;
     return CNMF_OK;
 }
 
@@ -107,7 +121,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
     const float l1W = (float)prm->l1_reg_W, l2W = (float)prm->l2_reg_W;
     const float l1H = (float)prm->l1_reg_H, l2H = (float)prm->l2_reg_H;
 
-    struct Slot { MuSlotDev d; int job = -1; int it = 0; double err0 = 0, prev = 0, err = 0; bool fresh = false; };
+    struct Slot { MuSlotDev d; int job = -1; int it = 0, err_it = -1; double err0 = 0, prev = 0, err = 0; bool fresh = false; };
     std::vector<Slot> slots(R);
     DevPool pool;
     int kmax = 1;
@@ -137,12 +151,10 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
 
     constexpr int coop_lds = 2 * MuLds<KP>::BUF;
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute((const void*)mu_h_coop_kernel<KP, BETA1>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
-            hipFuncSetAttribute((const void*)mu_w_coop_kernel<KP, 0, BETA1>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
-            hipFuncSetAttribute((const void*)mu_w_coop_kernel<KP, 1, BETA1>, hipFuncAttributeMaxDynamicSharedMemorySize, coop_lds);
-            attr_set = true;
+        {
+            HIP_TRY(ctx, dyn_lds_optin((const void*)mu_h_coop_kernel<KP, BETA1>, coop_lds));
+            HIP_TRY(ctx, dyn_lds_optin((const void*)mu_w_coop_kernel<KP, 0, BETA1>, coop_lds));
+            HIP_TRY(ctx, dyn_lds_optin((const void*)mu_w_coop_kernel<KP, 1, BETA1>, coop_lds));
         }
     }
     auto batch_of = [&](const std::vector<int>& ids) { MuBatch mb; mb.n = (int)ids.size(); for (int i = 0; i < mb.n; ++i) mb.s[i] = slots[ids[i]].d; return mb; };
@@ -210,6 +222,19 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         s.job = -1;
         return CNMF_OK;
     };
+    std::function<int(const std::vector<int>&, std::vector<double>&)> divergence_fn;
+    // err_out is the divergence of the FINAL factors (what sklearn's reconstruction_err_ reports): a slot whose last
+    // evaluation is older than its last iteration (tol = 0, or max_iter not a multiple of 10) is evaluated once more
+    auto retire_final = [&](int si) -> int {
+        Slot& s = slots[si];
+        if (err_out && s.err_it != s.it) {
+            std::vector<double> e;
+            int rcf = divergence_fn(std::vector<int>{si}, e);
+            if (rcf) return rcf;
+            s.err = e[0]; s.err_it = s.it;
+        }
+        return retire(si);
+    };
     // divergence of the current factors of the slots `ids` -> err[] (host)
     auto divergence = [&](const std::vector<int>& ids, std::vector<double>& err) -> int {
         const MuBatch mb = batch_of(ids);
@@ -236,6 +261,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         return CNMF_OK;
     };
 
+    divergence_fn = divergence;
     size_t next = 0;
     std::vector<int> ids;
     std::vector<double> errs;
@@ -265,6 +291,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
                 if (rc) return rc;
                 for (size_t i = 0; i < ids.size(); ++i) {
                     Slot& s = slots[ids[i]];
+                    s.err_it = s.it;
                     if (s.fresh) { s.err0 = s.prev = s.err = errs[i]; s.fresh = false; continue; }
                     s.err = errs[i];
                     if ((s.prev - s.err) / s.err0 < prm->tol) { rc = retire(ids[i]); if (rc) return rc; }
@@ -274,7 +301,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         }
         // slots that have used up their iterations
         for (int si = 0; si < R; ++si)
-            if (slots[si].job >= 0 && slots[si].it >= prm->max_iter) { rc = retire(si); if (rc) return rc; }
+            if (slots[si].job >= 0 && slots[si].it >= prm->max_iter) { rc = retire_final(si); if (rc) return rc; }
         ids.clear();
         for (int si = 0; si < R; ++si) if (slots[si].job >= 0) ids.push_back(si);
         if (ids.empty()) { if (next >= jobs.size()) break; else continue; }

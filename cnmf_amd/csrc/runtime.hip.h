@@ -111,4 +111,24 @@ struct EventPool {
         }                                                                                     \
     } while (0)
 
+// Opt a kernel into more than the default 64 KB of dynamic LDS -- once per (kernel, DEVICE): the attribute belongs to
+// the device's code object, so a process that drives several GPUs (one context each) must set it on every one of them
+// (a function-local `static bool` did it for the first device only).  Thread-safe; the return code is checked.
+#include <mutex>
+#include <set>
+#include <utility>
+static hipError_t dyn_lds_optin(const void* fn, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({fn, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({fn, dev});
+    return e;
+}
+
 static inline int round_up(int64_t v, int m) { return (int)(((v + m - 1) / m) * m); }

@@ -254,9 +254,12 @@ extern "C" int cnmf_nnls_spectra(cnmf_ctx* ctx, int k, const double* W, const cn
 // pipe, up to 256 packed columns per pass), swept together.  gram_in (nullable): [sum k_r^2] caller-supplied Gram
 // matrices H_r.H_r^T to use INSTEAD of the Gram of the rows multiplied (cnmf_nnls_gram).  W_out (nullable):
 // [N][k_r] blocks; err_out (nullable): ||X - W_r H_r||^2 (float64, W_r taken from the device).
+// H64 (nullable): the same spectra in float64 -- when given, the prediction error is taken against THEM (the
+// reference's stats branch computes ||X - W.median||^2 with the float64 medians, cnmf.py:926-930), not against the
+// float32 copy the refit multiplied.
 static int nnls_batch_impl(cnmf_ctx* ctx, int n, const int32_t* ks, const float* Hin, const float* gram_in,
                            const cnmf_cd_params* prm, float* W_out, int32_t* n_iter_out, double* viol_out,
-                           double* err_out)
+                           double* err_out, const double* H64 = nullptr)
 {
     using namespace cnmf;
     if (!ctx || !ks || !Hin || n < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
@@ -337,10 +340,13 @@ static int nnls_batch_impl(cnmf_ctx* ctx, int n, const int32_t* ks, const float*
                 // residual_sq_kernel wants H as [k][G]: the packed input block is exactly that (float32 -> float64)
                 {
                     const long long nh = (long long)k * G;
-                    f32_to_f64_kernel<<<(unsigned)((nh + 255) / 256), 256, 0, st>>>(dHin + (size_t)off * G, nh, dH64);
+                    if (H64)
+                        HIP_TRY(ctx, hipMemcpyAsync(dH64, H64 + hoff + (size_t)off * G, (size_t)nh * sizeof(double), hipMemcpyHostToDevice, st));
+                    else
+                        f32_to_f64_kernel<<<(unsigned)((nh + 255) / 256), 256, 0, st>>>(dHin + (size_t)off * G, nh, dH64);
                 }
                 const size_t lds = (size_t)k * 256 * sizeof(double);
-                HIP_TRY(ctx, hipFuncSetAttribute((const void*)residual_sq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (lds > 48 * 1024) HIP_TRY(ctx, hipFuncSetAttribute((const void*)residual_sq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 residual_sq_kernel<<<grid, 256, lds, st>>>(ctx->X, ctx->G_pad, N, G, dW64, dH64, k, rpb, dpart);
                 sum_kernel<<<1, 256, 0, st>>>(dpart, (int)(grid.x * grid.y), dsum);
                 HIP_TRY(ctx, hipGetLastError());
@@ -410,5 +416,5 @@ extern "C" int cnmf_kselect_stats(cnmf_ctx* ctx, int n, const int32_t* ks, const
     // in norm_counts' dtype; float32 on the device)
     for (size_t i = 0; i < med.size(); ++i) medf[i] = (float)med[i];
     if (median_out) memcpy(median_out, med.data(), med.size() * sizeof(double));
-    return nnls_batch_impl(ctx, n, ks, medf.data(), nullptr, prm, nullptr, nnls_iter_out, nullptr, pred_err_out);
+    return nnls_batch_impl(ctx, n, ks, medf.data(), nullptr, prm, nullptr, nnls_iter_out, nullptr, pred_err_out, med.data());
 }

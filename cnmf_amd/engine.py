@@ -79,9 +79,11 @@ class Engine:
             msg = self._lib.cnmf_last_error(self._ctx).decode()
             raise _ERR.get(rc, RuntimeError)("cnmf_hip: %s (code %d)" % (msg, rc))
 
-    def _params(self, tol, max_iter, alpha_W, alpha_H, l1_ratio, kc_max=0, lag=0, profile=0):
+    def _params(self, tol, max_iter, alpha_W, alpha_H, l1_ratio, kc_max=0, lag=0, profile=0, n_features=None):
+        """``n_features``: the feature count sklearn would see (it scales the W penalties, _nmf.py:1254-1265) when the
+        solved problem uses a column SUBSET of the resident matrix (nnls_gram)."""
         N, G = self.shape
-        l1W, l1H, l2W, l2H = regularization(N, G, alpha_W, alpha_H, l1_ratio)
+        l1W, l1H, l2W, l2H = regularization(N, G if n_features is None else int(n_features), alpha_W, alpha_H, l1_ratio)
         return _lib.CdParams(float(tol), int(max_iter), int(kc_max), l1W, l2W, l1H, l2H, int(lag), int(profile))
 
     # ------------------------------------------------------------------ data matrix
@@ -387,10 +389,12 @@ class Engine:
             W_list = [W_out[offs[r] * N:offs[r + 1] * N].reshape(N, ks[r]) for r in range(n)]
         return W_list, n_iter, err
 
-    def nnls_gram(self, H_prod, gram, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0):
+    def nnls_gram(self, H_prod, gram, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0, n_features=None):
         """Usage refit whose product uses the rows ``H_prod`` (k x G) but whose Gram matrix is GIVEN
         (``gram`` k x k): ``X_sub @ H_sub.T`` for a scaled column subset of the resident matrix is
-        ``X @ H_prod.T`` with ``H_prod`` zero outside the subset (cnmf.py:960-975 without a second upload)."""
+        ``X @ H_prod.T`` with ``H_prod`` zero outside the subset (cnmf.py:960-975 without a second upload).
+        ``n_features`` = the size of that subset: the reference refits on ``tpm[:, hvgs]``, so scikit-learn scales
+        ``alpha_W`` by the number of HVGs, not by the width of the resident TPM matrix."""
         if self.shape is None:
             raise RuntimeError("set_matrix() has not been called")
         N, G = self.shape
@@ -399,7 +403,7 @@ class Engine:
         g = np.ascontiguousarray(gram, dtype=np.float32)
         if g.shape != (k, k):
             raise ValueError("gram must be (k, k)")
-        prm = self._params(tol, max_iter, alpha_W, 0.0, l1_ratio)
+        prm = self._params(tol, max_iter, alpha_W, 0.0, l1_ratio, n_features=n_features)
         W = np.empty((N, k), dtype=np.float32)
         n_iter = C.c_int32(0)
         viol = C.c_double(0.0)
@@ -735,9 +739,11 @@ class Engine:
                                                 C.byref(ms), int(reps)))
         return Cout, ms.value
 
-    def debug_gemm2h(self, A, Bn, nsplit=1, nsub=2, reps=0):
+    def debug_gemm2h(self, A, Bn, nsplit=1, nsub=2, reps=0, sweep_bound=False):
         """A [KC, K] . Bn [J, K]^T through the f16 two-plane count kernel (A >= 0, Bn: integers <= 65535);
-        returns (C, ms)."""
+        returns (C, ms).  ``sweep_bound=True`` scales the rows of A by the bound the W half-step reports
+        (sqrt(sum w^2) per 1024-entry block) instead of the exact row maximum -- the production pass-B scaling."""
+        nsub = int(nsub) | (128 if sweep_bound else 0)
         A = np.ascontiguousarray(A, dtype=np.float32)
         Bn = np.ascontiguousarray(Bn, dtype=np.float32)
         KC, K = A.shape

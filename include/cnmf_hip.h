@@ -65,9 +65,15 @@ typedef struct cnmf_batch_stats {
     int32_t kc;                    /* packed column count used                                  */
     int32_t nsplit;                /* split-K factor of pass B                                  */
     int32_t gemm_mode;             /* GEMM path of the 256-column phase of this call: 0 = exact-f32 MFMA,
-                                      1/2 = split-operand bf16 MFMA (CNMF_GEMM3), 3 = the same with X as one
-                                      integer plane (count-structured data detected)               */
+                                      1/2 = split-operand bf16 MFMA (3 x 3 planes, any X), 3 = count-structured X
+                                      as one integer bf16 plane x 3 factor planes, 4 (the default when the count
+                                      structure is detected) = integer f16 plane x 2 f16 factor planes         */
     int32_t reserved_;
+    /* the tail of the call: from the moment the queue of pending restarts ran dry (nothing left to refill freed
+     * columns with) to the end -- what strong scaling over more GPUs pays for (fewer restarts per rank)          */
+    int64_t tail_iterations;       /* batch iterations enqueued after the queue ran dry                         */
+    int64_t tail_live_columns;     /* sum over those iterations of the columns still iterating (host view)      */
+    double  tail_ms;               /* device time of that phase (hipEvent)                                      */
 } cnmf_batch_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------- */
@@ -284,7 +290,9 @@ int cnmf_debug_gemm3c(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, 
                       int nsplit, double* ms_out, int reps);
 /* the same on the f16 matrix pipe (the default for count-structured data): Bn <= 2048 in ONE f16 plane (a
  * flagged second plane above that), A >= 0 as TWO f16 planes with a per-row exponent; 2 MFMAs per product.
- * KC % 256 == 0, K % 64 == 0; nsub = 16-k sub-blocks per barrier pair (1 | 2).                          */
+ * KC % 256 == 0, K % 64 == 0; nsub = 16-k sub-blocks per barrier pair (1 | 2); nsub | 128: scale every row of A by
+ * the BOUND the W half-step reports (sqrt of the sum of squares over 1024-entry blocks x 1.0001) instead of the exact
+ * row maximum -- the production pass-B scaling, for the accuracy tests.                                   */
 int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, int KC, int K, int J,
                       int nsplit, int nsub, double* ms_out, int reps);
 /* numpy RandomState(seed).standard_normal(n) reproduced on the device. */

@@ -29,26 +29,9 @@ import cnmf.cnmf as _ref                      # the UNMODIFIED reference module
 from cnmf.cnmf import load_df_from_npz, save_df_to_npz, worker_filter
 
 from cnmf_amd.engine import Engine
+from cnmf_amd.standins import DeviceKMeans, device_euclidean_distances, device_silhouette_score
 
 _DEVICE_SOLVERS = {("cd", "frobenius"), ("cd", 2), ("mu", "kullback-leibler"), ("mu", "itakura-saito"), ("mu", 1), ("mu", 0)}
-
-
-class _DeviceKMeans:
-    """Stand-in for ``sklearn.cluster.KMeans`` inside ``consensus`` (cnmf.py:908-911): ``fit`` + ``labels_``.
-    ``KMeans(n_clusters=k, n_init=10, random_state=1)`` -> ``Engine.consensus(skip_density=True)`` on the rows it is
-    given (bit-identical labels, DESIGN.md section 4 "Consensus in float64")."""
-
-    def __init__(self, engine, n_clusters, n_init=10, random_state=1, **kw):
-        self._engine, self.n_clusters, self.n_init, self.random_state = engine, n_clusters, n_init, random_state
-
-    def fit(self, X, y=None):
-        vals = X.values if hasattr(X, "values") else np.asarray(X)
-        out = self._engine.consensus(vals, self.n_clusters, skip_density=True, want_silhouette=True,
-                                     random_state=self.random_state, n_init=self.n_init)
-        self.labels_ = out["labels"].astype(np.int32)
-        self.inertia_ = out["inertia"]
-        self._silhouette = (vals.shape, out["silhouette"])
-        return self
 
 
 class cNMF(_ref.cNMF):
@@ -142,20 +125,14 @@ class cNMF(_ref.cNMF):
         eng, saved, last = self._engine, {}, {}
 
         def kmeans(n_clusters, **kw):
-            last["km"] = _DeviceKMeans(eng, n_clusters, **kw)
+            last["km"] = DeviceKMeans(eng, n_clusters, **kw)
             return last["km"]
 
         def euclidean_distances(X, Y=None, **kw):
-            assert Y is None
-            vals = X.values if hasattr(X, "values") else np.asarray(X)
-            # rows are already L2-normalised (cnmf.py:882): the distance matrix of the device's consensus core
-            return eng.consensus(vals, 1, skip_density=True, return_dist=True, n_init=1)["topics_dist"]
+            return device_euclidean_distances(eng, X, Y, **kw)
 
         def silhouette_score(X, labels, metric="euclidean", **kw):
-            km = last.get("km")                 # the fit of cnmf.py:909 already produced it on the device
-            if km is not None and km._silhouette[0] == np.shape(X) and metric == "euclidean":
-                return km._silhouette[1]
-            return saved["silhouette_score"](X, labels, metric=metric, **kw)
+            return device_silhouette_score(last.get("km"), saved["silhouette_score"], X, labels, metric=metric, **kw)
 
         repl = dict(KMeans=kmeans, euclidean_distances=euclidean_distances, silhouette_score=silhouette_score)
         for name, fn in repl.items():

@@ -58,30 +58,54 @@ def test_rccl_communicator_world1_and_resident_store(tmp_path):
         assert eng.spectra_rows == 0
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """bench.py's N > 1 bookkeeping (ledger sharding by rank, ragged gather of spectra, barrier, max-over-ranks
-    timing, summed restart counts) with two real ranks -- on the one GPU a test box has, over gloo
-    (CNMF_BENCH_BACKEND / CNMF_BENCH_ONE_GPU test hooks; the driver's multi-GPU runs use nccl = RCCL)."""
+def _bench(args, env, timeout=900):
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CNMF_BENCH_BACKEND="gloo", CNMF_BENCH_ONE_GPU="1", CNMF_GATHER="torch",
-               MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29561", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "C1", "--kmin", "6", "--kmax", "7",
-           "--restarts-per-k", "3", "--no-cpu-baseline"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
-    assert p.returncode == 0, p.stderr[-3000:]
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "CNMF_GATHER", "CNMF_BENCH_BACKEND", "CNMF_RCCL_ID_FILE"):
+        e.pop(k, None)
+    e.update(env)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=e, capture_output=True, text=True,
+                       timeout=timeout, cwd=root)
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    return p, lines, (json.loads(lines[0]) if len(lines) == 1 and p.returncode == 0 else None)
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_two_self_spawned_ranks_on_one_gpu(scaling):
+    """`python bench.py --gpus 2` SPAWNS its two ranks itself (no torch.distributed.run).  bench.py's N > 1
+    bookkeeping (ledger sharding by rank, ragged gather of spectra, barrier, max-over-ranks timing, summed restart
+    counts) with two real ranks -- on the one GPU a test box has, over gloo (CNMF_BENCH_BACKEND / CNMF_BENCH_ONE_GPU
+    test hooks; real multi-GPU runs use the in-library RCCL gather).  strong: ONE job of 2 x 3 restarts sharded idx % 2;
+    weak: 6 restarts per rank."""
+    args = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "C1", "--kmin", "6", "--kmax", "7",
+            "--restarts-per-k", "3", "--no-cpu-baseline", "--scaling", scaling]
+    p, lines, d = _bench(args, dict(CNMF_BENCH_BACKEND="gloo", CNMF_BENCH_ONE_GPU="1", CNMF_GATHER="torch"))
+    assert p.returncode == 0, p.stderr[-3000:]
     assert len(lines) == 1, p.stdout[-2000:]                   # exactly ONE JSON line on stdout
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["config"]["restarts_per_step_per_gpu"] == 6 and d["config"]["gather"] == "torch"
-    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 12) < 1e-6      # 2 ranks x 6 restarts
-    assert "cpu_baseline" not in d                             # rank 0 at N = 1 only
+    total = 6 if scaling == "strong" else 12
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == scaling
+    assert d["config"]["restarts_per_step"] == total and d["config"]["restarts_per_step_per_gpu"] == total // 2
+    assert d["config"]["gather"] == "torch" and len(d["config"]["per_rank"]) == 2
+    assert sum(r["restarts"] for r in d["config"]["per_rank"]) == total
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - total) < 1e-6
+    assert "cpu_baseline" not in d and "e2e" not in d          # rank 0 at N = 1 only
+
+
+def test_bench_gpus_2_on_a_one_gpu_box_fails_loudly():
+    """The default transport with more ranks than GPUs must die (rank 1 has no device 1 / RCCL refuses two ranks on
+    one device) -- never fall back to a 1-GPU run labelled otherwise."""
+    args = ["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "C1", "--kmin", "6", "--kmax", "6",
+            "--restarts-per-k", "2", "--no-cpu-baseline"]
+    if Engine(0)._lib.cnmf_device_count() >= 2:
+        pytest.skip("this box really has two GPUs")
+    p, lines, d = _bench(args, {})
+    assert p.returncode != 0 and d is None and not [ln for ln in lines if ln.startswith("{")]
+    p, lines, d = _bench(args, dict(CNMF_BENCH_ONE_GPU="1"), timeout=300)       # both on device 0: ncclCommInitRank refuses
+    assert p.returncode != 0 and d is None
 
 
 def test_bench_default_multi_gpu_transport_is_the_library_rccl_gather(tmp_path):
@@ -89,20 +113,11 @@ def test_bench_default_multi_gpu_transport_is_the_library_rccl_gather(tmp_path):
     max-over-ranks, bootstrapped through a file, no torch anywhere -- driven at world = 1 (CNMF_BENCH_FORCE_DIST;
     RCCL refuses two ranks on one device, "Duplicate GPU detected", so a one-GPU box cannot form a larger
     communicator; the N = 2 packing/unpacking is covered over gloo above and in tests/test_dist_gloo.py)."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CNMF_BENCH_FORCE_DIST="1", CNMF_RCCL_ID_FILE=str(tmp_path / "id"))
-    env.pop("CNMF_GATHER", None); env.pop("CNMF_BENCH_BACKEND", None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-           "--workload", "C1", "--kmin", "6", "--kmax", "7", "--restarts-per-k", "3", "--no-cpu-baseline"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    p, lines, d = _bench(["--gpus", "1", "--steps", "1", "--warmup", "1", "--workload", "C1", "--kmin", "6", "--kmax", "7",
+                          "--restarts-per-k", "3", "--no-cpu-baseline", "--no-extras"],
+                         dict(CNMF_BENCH_FORCE_DIST="1", CNMF_RCCL_ID_FILE=str(tmp_path / "id")))
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
-    d = json.loads(lines[0])
     assert d["config"]["gather"] == "rccl" and d["n_gpus"] == 1
     assert d["config"]["torch_in_process"] is False            # the launcher's env is all the N > 1 path needs
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 6) < 1e-6

@@ -97,11 +97,20 @@ def test_prediction_error_vs_numpy(engine):
     assert abs(engine.prediction_error(W, H) - ref) <= 1e-6 * ref
 
 
-def test_consensus_stress_C5_shape(engine):
-    """BASELINE config 5 shape (5000 x 2000, k=20): size-independent properties at full size."""
+def test_consensus_stress_C5_full_size_vs_oracle(engine):
+    """BASELINE config 5 at FULL size (5000 x 2000, k=20) against oracle/consensus.py (the numpy restatement pinned to
+    sklearn / pandas in tests/test_oracle_consensus.py): density to 1e-9, filter and k-means labels exact, medians to
+    1e-12, inertia to 1e-9 -- plus the size-independent properties."""
     S, truth = synth.consensus_stress(R=5000, G=2000, k=20, n_outliers=100, seed=0)
     out = engine.consensus(S, 20, density_threshold=0.5)
+    ref = oc.consensus_core(S, np.abs(np.random.RandomState(0).standard_normal((20, 2000))), 20, density_threshold=0.5)
+    assert np.abs(out["local_density"] - ref["local_density"]).max() < 1e-9
+    assert np.array_equal(out["density_filter"], ref["density_filter"])
     kept = out["density_filter"]
+    assert (out["labels"][~kept] == -1).all()
+    assert np.array_equal(out["labels"][kept] + 1, ref["kmeans_labels"])
+    assert np.abs(out["median_spectra"] - ref["median_spectra"]).max() < 1e-12
+    assert abs(out["inertia"] - ref["inertia"]) <= 1e-9 * ref["inertia"]
     assert kept.sum() == 4900 and not kept[truth < 0].any()              # exactly the noise rows go
     assert _same_partition(out["labels"][kept], truth[kept])             # the planted clusters come back
     assert np.allclose(out["median_spectra"].sum(axis=1), 1.0, atol=1e-12)

@@ -110,3 +110,24 @@ def test_C4_csr_restarts_vs_sklearn_golden(engine):
         assert int(n_iter[r]) == 10
         maxabs, relfro = nmf_cd.spectra_error(g["seed%d_H10" % seed], H[r])
         assert maxabs <= 1e-4 and relfro <= 1e-3, (seed, maxabs, relfro)
+
+
+def test_C4_count_valued_csr_vs_sklearn_golden(engine):
+    """BASELINE config 4 as it occurs in practice: a COUNT-valued 200 000 x 2000 matrix (Poisson counts / std, handed
+    over as CSR like a sparse h5ad) -- the default f16 integer-plane kernels (gemm_mode 4) with 782 cell tiles, i.e.
+    ~3 tiles per persistent stream-K workgroup, a shape no smaller test reaches.  scikit-learn's float64 output after
+    10 iterations (tools/make_golden_big.py c4counts) vs the device inside a 260-column batch: 1e-4 / 1e-3."""
+    g = np.load(os.path.join(GOLD, "ref_c4_counts.npz"))
+    X = sp.csr_matrix(synth.make_config("C4", dtype=np.float32))
+    assert tuple(g["shape"]) == X.shape and int(g["nnz"][0]) == X.nnz
+    assert abs(float(X.data.astype(np.float64).sum()) - float(g["x_checksum"][0])) <= 1e-9 * float(g["x_checksum"][0])
+    engine.set_matrix(X)                                       # CSR upload, densified on the device
+    ks = [20] * 13                                             # 13 x 20 = 260 columns: a full 256-column batch + one refill
+    seeds = [21, 22] + list(range(301, 312))
+    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=10, warn=False)
+    st = engine.last_stats
+    assert st["kc"] == 256 and st["gemm_mode"] == 4, st       # the count structure was detected: f16 two-plane path
+    for r, seed in enumerate((21, 22)):
+        assert int(n_iter[r]) == 10
+        maxabs, relfro = nmf_cd.spectra_error(g["seed%d_H10" % seed], H[r])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (seed, maxabs, relfro)

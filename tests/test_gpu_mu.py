@@ -73,8 +73,8 @@ def test_mu_through_cnmf_callsite(engine, X, tmp_path):
     import yaml
     kw = yaml.load(open(obj.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
     assert kw["solver"] == "mu" and kw["beta_loss"] == "kullback-leibler"       # as the reference writes it
-    from oracle import sklearn_ref
-    led = sklearn_ref.ledger([4], 3, 14)
+    from cnmf_amd.cnmf import ledger_seeds
+    led = ledger_seeds([4], 3, 14)
     _, H_ref, _ = nmf_mu.nmf_mu(X, 4, seed=led[0][2], max_iter=120)
     maxabs, relfro = nmf_cd.spectra_error(H_ref, merged.values[:4])
     assert maxabs <= 1e-4 and relfro <= 1e-3

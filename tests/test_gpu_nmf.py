@@ -129,6 +129,39 @@ def test_f16_count_path_gemm_accuracy(engine, big, nsub):
         assert np.array_equal(out, out2)
 
 
+@pytest.mark.parametrize("outlier", [1.0, 1e4, 1e6])
+def test_f16_scale_bound_of_the_W_half_step_with_outlier_cells(engine, outlier):
+    """Pass B (X^T.W) scales every component row of W by the BOUND the W half-step reports -- sqrt(sum w^2) over the
+    <= 1024 cells of a sweep workgroup, up to 32 x the true maximum -- and ONE huge cell (a doublet, a cell with an
+    enormous library: 10^4 x and 10^6 x the typical usage of its component) pushes every other entry of that row far
+    below the row scale, where the two f16 planes keep an ABSOLUTE accuracy (2^-39 of the scale) rather than a
+    relative one.  The product is held per element against float64, in units of |W|^T.|n| (the natural scale of the
+    sum): the measured worst case is the number DESIGN.md section 4 quotes."""
+    rs = np.random.RandomState(21)
+    K, J = 4096, 520                                      # K = cells (the reduction), J = genes
+    A = np.abs(rs.standard_normal((256, K)) * np.exp(0.5 * rs.standard_normal((256, K)))).astype(np.float32)
+    A[rs.rand(256, K) < 0.3] = 0.0
+    if outlier > 1.0:
+        for c in range(0, 256, 2):                        # every other component has one outlier cell
+            A[c, rs.randint(K)] = np.float32(outlier * (1.0 + rs.rand()))
+    A[7] = 1.0                                            # a dense, flat component: the bound is its full 32 x above the maximum
+    B = rs.poisson(0.4, size=(J, K)).astype(np.float32)   # sparse counts: most genes see NOTHING of the outlier cell
+    A64, B64 = A.astype(np.float64), B.astype(np.float64)
+    ref = A64 @ B64.T
+    scale = np.maximum(np.abs(A64) @ np.abs(B64).T, 1e-300)
+    worst = {}
+    for bound in (False, True):
+        out, _ = engine.debug_gemm2h(A, B, nsplit=4, nsub=2, sweep_bound=bound)
+        worst[bound] = float((np.abs(out - ref) / scale).max())
+    print("f16 scale bound: outlier %g -> max |err| / (|W|^T.|n|): exact row maximum %.3g, sweep bound %.3g"
+          % (outlier, worst[False], worst[True]))
+    # float32 itself carries 6e-8 per operand and ~1e-7 x sqrt(terms) per accumulation; 2e-6 is the bound the exact-f32
+    # pipe is held to (test_gemm_vs_numpy).  With a 10^6 outlier the ordinary entries sit 2^-20 below the row scale and
+    # keep ~19 significant bits: 4e-6.
+    assert worst[False] < (2e-6 if outlier < 1e6 else 4e-6), worst
+    assert worst[True] < (2e-6 if outlier < 1e6 else 4e-6), worst
+
+
 def test_count_structure_is_detected_only_where_it_exists(engine):
     """X = counts / std (cnmf.py:546) has the structure (gemm_mode 4: f16 planes), also with a few counts above
     2048 (second plane); the same matrix with one entry nudged off the integer grid, or with a count above 65 535,

@@ -1,0 +1,81 @@
+"""Option B (integration/hip_backend.py) on the DEVICE.  The CPU test tests/test_integration_option_b.py runs the
+unmodified reference through the subclass with a recorder in place of the engine; the call tuples it logs --
+
+    consensus(l2_spectra, 1, skip_density=True, return_dist=True, n_init=1)         euclidean_distances stand-in
+    DeviceKMeans(k, n_init=10, random_state=1).fit(l2_spectra[density_filter])      -> consensus(..., want_silhouette=True)
+    silhouette_score(l2_spectra, labels)                                            handed over from that fit
+    nnls(median_spectra) / nmf_batch(ks, seeds, tol=1e-4, max_iter=1000)
+
+-- are replayed here against libcnmf_hip.so (the reference tree does not exist on the GPU box) and compared with the
+LIVE scikit-learn functions those stand-ins replace inside the reference's consensus body (cnmf.py:891, 908-911, 923)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from cnmf_amd import standins, synth
+from cnmf_amd.cnmf import ledger_seeds
+from oracle import consensus as oc
+from oracle import nmf_cd
+
+pytestmark = pytest.mark.gpu
+
+
+def _merged_like_the_reference(R_per, k, G, seed):
+    """l2-normalised merged spectra as the reference's consensus body holds them (cnmf.py:882), as a DataFrame."""
+    S, _ = synth.consensus_stress(R=R_per * k, G=G, k=k, n_outliers=max(2, R_per // 4), seed=seed)
+    l2 = (S.T / np.sqrt((S ** 2).sum(axis=1))).T
+    return pd.DataFrame(l2, index=["iter%d_topic%d" % (i // k, i % k + 1) for i in range(l2.shape[0])])
+
+
+@pytest.mark.parametrize("R_per,k,G", [(4, 4, 120), (30, 7, 333)])
+def test_euclidean_distances_standin_matches_sklearn(engine, R_per, k, G):
+    from sklearn.metrics.pairwise import euclidean_distances
+    l2 = _merged_like_the_reference(R_per, k, G, seed=3)
+    D = standins.device_euclidean_distances(engine, l2)                       # the recorded call: k=1, n_init=1, return_dist
+    ref = euclidean_distances(l2.values)
+    assert D.shape == ref.shape
+    assert np.abs(D - ref).max() < 1e-7                                      # sqrt amplifies 1e-16 near 0
+    with pytest.raises(NotImplementedError):
+        standins.device_euclidean_distances(engine, l2, l2)
+
+
+@pytest.mark.parametrize("R_per,k,G", [(4, 4, 120), (30, 7, 333)])
+def test_device_kmeans_and_silhouette_handoff_match_sklearn(engine, R_per, k, G):
+    from sklearn.cluster import KMeans
+    from sklearn.metrics import silhouette_score
+    l2 = _merged_like_the_reference(R_per, k, G, seed=5)
+    dens = oc.local_density(oc.euclidean_distances(l2.values), int(0.30 * l2.shape[0] / k))
+    kept = l2.loc[dens < np.median(dens) * 3.0, :]                            # the rows the reference hands to KMeans
+    km = standins.DeviceKMeans(engine, n_clusters=k, n_init=10, random_state=1).fit(kept)      # cnmf.py:908-909
+    sk = KMeans(n_clusters=k, n_init=10, random_state=1).fit(kept)
+    assert km.labels_.dtype == np.int32 and np.array_equal(km.labels_, sk.labels_)
+    assert abs(km.inertia_ - sk.inertia_) <= 1e-9 * sk.inertia_
+    # cnmf.py:923: silhouette_score(l2_spectra.values, kmeans_cluster_labels, metric='euclidean') -- served by the fit
+    sil = standins.device_silhouette_score(km, silhouette_score, kept.values, km.labels_ + 1, metric="euclidean")
+    assert abs(sil - silhouette_score(kept.values, sk.labels_ + 1, metric="euclidean")) < 1e-9
+    # any other request goes to the real function
+    other = standins.device_silhouette_score(km, silhouette_score, kept.values[:-1], sk.labels_[:-1], metric="euclidean")
+    assert abs(other - silhouette_score(kept.values[:-1], sk.labels_[:-1])) < 1e-12
+
+
+def test_factorize_and_refit_calls_of_the_subclass(engine):
+    """``nmf_batch(ks, seeds=..., tol=1e-4, max_iter=1000)`` for a whole ledger (hip_backend.factorize) and
+    ``nnls(median_spectra)`` (hip_backend._nmf with update_H=False) with the arguments the reference's kwargs imply."""
+    C, _ = synth.topic_counts(200, 300, 4, mu_lib=7.0, sigma_lib=0.3, seed=11)
+    C = C[:, C.sum(axis=0) > 0][:, :120]
+    C = C[C.sum(axis=1) > 0]
+    X = C.astype(np.float64) / C.std(axis=0, ddof=1)
+    engine.set_matrix(X)
+    led = ledger_seeds([4, 5], 4, 14)
+    ks, seeds = [k for k, _, _ in led], [int(s) for _, _, s in led]
+    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, tol=1e-4, max_iter=1000, alpha_W=0.0, alpha_H=0.0, l1_ratio=0.0)
+    merged = {k: [] for k in (4, 5)}
+    for k, seed, h, n in zip(ks, seeds, H, n_iter):
+        _, H_ref, n_ref = nmf_cd.nmf(X, k, seed=seed)
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, h)
+        assert maxabs <= 1e-4 and relfro <= 1e-3 and abs(int(n) - n_ref) <= max(3, n_ref // 100), (k, seed, maxabs, relfro)
+        merged[k].append(h)
+    med = oc.consensus_core(np.concatenate(merged[4]), X, 4, density_threshold=2.0)["median_spectra"]
+    W, n = engine.nnls(med, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0)
+    W_ref, n_ref = nmf_cd.nnls(X, med)
+    assert abs(n - n_ref) <= 2 and np.abs(W - W_ref).max() <= 1e-3 * np.abs(W_ref).max()

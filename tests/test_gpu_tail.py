@@ -146,3 +146,28 @@ def test_mirror_class_consensus_from_reference_merged_spectra(engine, g, tmp_pat
     obj.consensus(5, density_threshold=0.5, local_neighborhood_size=0.2)
     import json
     assert json.load(open(obj.paths["local_density_cache"] % 5 + ".meta.json"))["local_neighborhood_size"] == 0.2
+
+
+def test_final_usage_refit_with_alpha_usage_scales_by_hvg_count(engine, g):
+    """cnmf.py:960-975 with alpha_usage != 0: the reference refits on tpm[:, hvgs], so scikit-learn scales the W
+    penalty by n_features = len(hvgs) (sklearn _nmf.py:1254-1265) -- NOT by the width of the resident TPM matrix
+    (ADVICE round 2).  Against the float64 oracle on the HVG sub-matrix."""
+    tpm = g["tpm"]
+    genes = list(g["genes"])
+    hidx = np.array([list(g["tpm_genes"]).index(x) for x in genes])
+    assert len(hidx) < tpm.shape[1]                       # the two feature counts really differ
+    norm_tpm = tpm[:, hidx].astype(np.float64)
+    std1 = norm_tpm.std(axis=0, ddof=1)
+    norm_tpm = norm_tpm / std1
+    srf = g["gene_spectra_tpm_k5"][:, hidx] / g["tpm_stats"][hidx, 1]
+    engine.set_matrix(tpm)
+    H_prod = np.zeros((5, tpm.shape[1]))
+    H_prod[:, hidx] = srf / std1
+    for alpha in (0.0, 0.02):
+        W_ref, n_ref = nmf_cd.nnls(norm_tpm, srf, alpha_W=alpha, l1_ratio=0.0)
+        W, n = engine.nnls_gram(H_prod, srf @ srf.T, alpha_W=alpha, n_features=len(hidx))
+        assert abs(n - n_ref) <= 2
+        assert np.abs(W - W_ref).max() <= 1e-3 * np.abs(W_ref).max(), alpha
+    # and the mis-scaled penalty (all TPM genes) is measurably different: the override matters
+    W_bad, _ = engine.nnls_gram(H_prod, srf @ srf.T, alpha_W=0.02)
+    assert np.abs(W_bad - W_ref).max() > 1e-2 * np.abs(W_ref).max()

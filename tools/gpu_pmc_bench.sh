@@ -8,7 +8,7 @@ cd /tmp
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   stag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmcb/$stag -o pmc --output-format csv -- \
-     python $R/bench.py --steps 1 --warmup 0 --restarts-per-k 3 --no-cpu-baseline > $R/gpurun_out/pmcb/$stag.log 2>&1
+     python $R/bench.py --steps 1 --warmup 0 --restarts-per-k 3 --no-cpu-baseline --no-extras > $R/gpurun_out/pmcb/$stag.log 2>&1
 done
 cd $R
 python - <<PY
@@ -38,6 +38,9 @@ out["algorithmic_bytes_per_launch"]={
   "passA": xplane + KC*G_pad*4 + KC*N_pad*4,
   "passB": xplane + KC*N_pad*4 + 32*KC*G_pad*4,
   "note": "count plane of X (or X^T) once (2 B per element, f16) + the factor's two f16 planes once (4 B per element) + the product written once (pass A: one XHt plane of 51 MB -- the stream-K partial planes of cut tiles come on top; pass B: 32 split-K partial planes of 2 MB)"}
+import sys; sys.path.insert(0, R)
+from bench import source_hashes
+out['kernel_source_sha256']=source_hashes()
 json.dump(out, open(R+'/gpurun_out/pmc_traffic.json','w'), indent=1)
 print(json.dumps({k:(v if not isinstance(v,dict) else {kk:vv for kk,vv in v.items() if kk in('hbm_bytes_per_launch','mfma_busy_frac','launches')}) for k,v in out.items() if k!='_source'}, indent=1))
 PY

@@ -9,7 +9,8 @@ K = 5..13, n_iter = 100) whose run needs >= 300 outer iterations: spectra after 
 (`max_iter`, the same truncation the device is asked for) and at the stopping rule (tol 1e-4, max_iter 1000), the
 final objective, and -- as calibration of what float32 can deliver on these ill-conditioned trajectories -- the
 drift of scikit-learn's own float32 path from its float64 path at the same truncations.
-C4 (200 000 x 2000 CSR, ~8 % dense, K = 20): two restarts x 10 outer iterations on the sparse input.
+C4 (200 000 x 2000 CSR, ~8 % dense, K = 20): two restarts x 10 outer iterations on the sparse input -- once with gamma-
+distributed values (the general GEMM path) and once COUNT-valued (Poisson counts / std: the default f16 count path).
 
     python tools/make_golden_big.py        # ~15 min on 8 cores
 """
@@ -82,8 +83,32 @@ def make_c4():
     np.savez_compressed(os.path.join(OUT, "ref_c4_csr.npz"), **out)
 
 
+def c4_counts_matrix():
+    """A COUNT-valued C4: the gamma-Poisson counts of synth.CONFIGS["C4"] (200 000 x 2000, K_true = 20) scaled to unit
+    variance per gene like the reference's prepare (cnmf.py:540-548), handed over as CSR float32 -- what a real
+    "200k-cell sparse h5ad" is.  The device detects the count structure and takes the f16 integer-plane kernels
+    (gemm_mode 4) with 782 cell tiles."""
+    X = synth.make_config("C4", dtype=np.float32)
+    return sp.csr_matrix(X)
+
+
+def make_c4_counts():
+    X = c4_counts_matrix()
+    out = {"shape": np.array(X.shape), "nnz": np.array([X.nnz]),
+           "x_checksum": np.array([float(X.data.astype(np.float64).sum())])}
+    X64 = X.astype(np.float64)
+    for seed in (21, 22):
+        t0 = time.time()
+        H, _, n = sklearn_ref.nmf(X64, 20, seed, max_iter=10)
+        print("C4 counts seed=%d: n_iter=%d (%.0f s)" % (seed, n, time.time() - t0), flush=True)
+        out["seed%d_H10" % seed] = H.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "ref_c4_counts.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c3", "c4"]
+    which = sys.argv[1:] or ["c3", "c4", "c4counts"]
+    if "c4counts" in which:
+        make_c4_counts()
     if "c4" in which:
         make_c4()
     if "c3" in which:
