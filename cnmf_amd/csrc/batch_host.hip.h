@@ -188,14 +188,28 @@ static int wait_snapshot(cnmf_ctx* ctx, const SlotDesc* sp, int n, int stamp)
     return CNMF_OK;
 }
 
-static int pick_kc(int64_t total_k, int max_k, int kc_max)
+// Packed component columns of a call.  32 ... 256 by the total rank of the job (powers of two); on the matrix-pipe
+// split-operand paths a job of >= 3 x 512 columns runs 512 wide (`wide_ok`): both GEMM passes then read every X tile
+// once per 512 columns instead of once per 256, the stream-K partial planes of pass A and the latency-bound H half-step
+// are amortised over twice the columns (+10 % restarts/s at 50 000 x 2000), at the price of a longer tail -- hence
+// only for jobs that are long against it, and the batch narrows to 256 again once the queue is dry (compact()).
+// kc_max: 0 = auto, else an upper bound (multiple of 32; above 256 in steps of 256, up to CNMF_KC_LIMIT).
+constexpr int CNMF_KC_LIMIT = 1024;
+static int pick_kc(int64_t total_k, int max_k, int kc_max, bool wide_ok)
 {
-    if (kc_max <= 0) kc_max = 256;
-    if (const char* s = getenv("CNMF_KC")) { int v = atoi(s); if (v >= 32) kc_max = v; }
-    kc_max = std::max(32, std::min(256, (kc_max / 32) * 32));
+    bool forced = false;
+    if (const char* s = getenv("CNMF_KC")) { int v = atoi(s); if (v >= 32) { kc_max = v; forced = true; } }
+    const bool autosize = kc_max <= 0;
+    if (autosize) kc_max = 256;
+    kc_max = std::max(32, std::min(CNMF_KC_LIMIT, (kc_max / 32) * 32));
+    if (kc_max > 256) kc_max = wide_ok ? (kc_max / 256) * 256 : 256;
     int kc = 32;
-    while (kc < kc_max && kc < total_k) kc *= 2;
+    while (kc < std::min(kc_max, 256) && kc < total_k) kc *= 2;
     kc = std::min(kc, kc_max);
+    if (wide_ok && kc == 256) {
+        if (autosize && !getenv("CNMF_NO_WIDE") && total_k >= 3 * 512) kc = 512;
+        else if (!autosize && kc_max > 256 && (forced || total_k > 256)) kc = (int)std::min<int64_t>(kc_max, round_up(total_k, 256));
+    }
     if (kc < max_k) kc = round_up(max_k, 32);
     return kc;
 }
@@ -240,7 +254,10 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         hoff[r + 1] = hoff[r] + (size_t)kk[r] * G;
         woff[r + 1] = woff[r] + (size_t)kk[r] * N;
     }
-    int KC = pick_kc(total_k, max_k, prm->kc_max);
+    // (wide batches need the whole-tile matrix-pipe kernels and a matrix large enough to be worth them)
+    const bool wide_can = gemm3_mode() != 0 && gemm3_enabled(ctx, 512);
+    const bool wide_auto = wide_can && (int64_t)ctx->N_pad * ctx->G_pad >= (1ll << 24);
+    int KC = pick_kc(total_k, max_k, prm->kc_max, (prm->kc_max > 256 || getenv("CNMF_KC")) ? wide_can : wide_auto);
     // 65..128 columns of a count-structured matrix: the 256-column integer-plane kernels (half empty) are still
     // faster than 128 columns on the f32 pipe
     if (KC == 128 && prm->kc_max <= 0 && !getenv("CNMF_KC") && gemm3_mode() >= 3 && gemm3_enabled(ctx, 256) &&
@@ -268,7 +285,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     const int nsubA = use2h ? gemm2h_nsub(ctx->C1h != nullptr, KbA) : 1, nsubB = use2h ? gemm2h_nsub(ctx->Ct1h != nullptr, KbB) : 1;
     if (use3 && !usec) { rc = ensure_planes(ctx); if (rc) return rc; }
     const int jwA = usec ? G3C_JW : G3_JW;         // width of a pass-A / pass-B tile
-    const int nsplit3 = use3 ? pick_nsplit3(ctx, KC, jwA) : 1;
+    int nsplit3 = use3 ? pick_nsplit3(ctx, KC, jwA) : 1;
     const int fin_y = (max_k * max_k + 255) / 256;       // finalize blocks per slot
     const int lag_env = getenv("CNMF_LAG") ? atoi(getenv("CNMF_LAG")) : 0;
     const int lag = std::max(1, std::min(RING - 2, prm->lag > 0 ? prm->lag : (lag_env > 0 ? lag_env : 2)));
@@ -688,13 +705,15 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             int live_cols = 0;
             for (int s = 0; s < nslots; ++s) if (hs[s].state) live_cols += hs[s].k;
             int KCn = 32;
-            while (KCn < live_cols) KCn *= 2;
+            while (KCn < live_cols && KCn < 256) KCn *= 2;
+            if (live_cols > 256) KCn = round_up(live_cols, 256);
             // On the count path a 256-column iteration (~250 us of GEMM at 50k x 2000) costs no more than a
             // 64-column one on the f32 pipe and far less than a 128-column one: leave it only for 32 columns.
-            if (usec && KCn > 32 && !f32_tail) KCn = KC;
             // General (non-count) split-operand path, 6 MFMAs per product: a 256-column iteration still beats 128
             // columns on the f32 pipe (417 / 2 vs 157 TF of roof per live column), not 64.
-            else if (use3 && !usec && KCn > 64 && !f32_tail) KCn = KC;
+            // A WIDE batch (512+) narrows in steps of 256 columns and stays on the same kernels.
+            bool stay3 = false;
+            if (use3 && !f32_tail && KCn > (usec ? 32 : 64)) { KCn = round_up(std::max(live_cols, 1), 256); stay3 = true; }
             if (KCn < KC) {
                 int rcp = repack_left(KCn);
                 if (rcp) return rcp;
@@ -702,6 +721,12 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                 cols = ColAlloc(KC);
                 for (int s = 0; s < nslots; ++s) if (hs[s].state) cols.alloc(hs[s].k);
                 const int cap = (ctx->nsplit_alloc * KC0) / KC;
+                if (stay3) {
+                    nsplit3 = std::max(1, std::min(pick_nsplit3(ctx, KC, jwA), cap));
+                    sk3 = plan_streamk3(KC, ctx->N_pad, ctx->G_pad, gemm3_wg_slots(), jwA, nsubA);
+                    if (sk3.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk3.flags.data(), sk3.flags.size(), hipMemcpyHostToDevice, st));
+                    else nsplitA = std::max(1, std::min(pick_nsplit_A3(ctx, KC, jwA), (ctx->nsplitA_alloc * KC0) / KC));
+                } else {
                 nsplit = std::max(1, std::min(pick_nsplit(ctx, KC), cap));
                 use3 = usec = use2h = false;        // fewer than 256 packed columns: the f32 pipe takes over
                 sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
@@ -710,6 +735,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                 if (sk.on) {
                     // the flags of the old plan may still be read by an in-flight sweep: same stream -> ordered
                     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
+                }
                 }
             }
         }

@@ -235,10 +235,13 @@ static StreamK3 plan_streamk3(int KC, int N_pad, int G_pad, int n_wg_slots, int 
     sk.on = true;
     sk.flags.assign(sk.T, 0);
     const long long U = (long long)sk.T * sk.Kb;
+    // the kernels walk the tiles component-group-major (o = mg * NJ + jt); the sweep looks the flags up by jt * MG + mg
+    const int NJ = sk.T / sk.MG;
     for (int p = 1; p < sk.P; ++p) {
         const long long b = U * p / sk.P;
         if (b % sk.Kb) {
-            unsigned char& f = sk.flags[b / sk.Kb];
+            const int o = (int)(b / sk.Kb);
+            unsigned char& f = sk.flags[(o % NJ) * sk.MG + o / NJ];
             f = f ? 3 : 1;
         }
     }

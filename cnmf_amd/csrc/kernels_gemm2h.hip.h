@@ -589,16 +589,20 @@ __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __rest
                                                      int kb_per)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    int jt = blockIdx.x, z = blockIdx.z;
-    if (gridDim.y == 1 && (gridDim.z & 7) == 0) {
-        const int L = blockIdx.x + gridDim.x * blockIdx.z;
+    int jt = blockIdx.x, mg = blockIdx.y, z = blockIdx.z;
+    if ((gridDim.z & 7) == 0) {
+        // XCD-aware order (block L runs on XCD L % 8, each XCD has its own L2): one XCD gets ALL row tiles jt and ALL
+        // component groups mg of the K splits z = xcd, xcd + 8, ... -- the workgroups that share a factor segment
+        // (same mg, z) or a count-plane segment (same jt, z) then share it in one L2.
+        const int L = blockIdx.x + (int)gridDim.x * (blockIdx.y + (int)gridDim.y * blockIdx.z);
         const int xcd = L & 7, idx = L >> 3;
-        z = xcd + 8 * (idx / (int)gridDim.x);
         jt = idx % (int)gridDim.x;
+        mg = (idx / (int)gridDim.x) % (int)gridDim.y;
+        z = xcd + 8 * (idx / (int)(gridDim.x * gridDim.y));
     }
     const int kb0 = z * kb_per;
     const int nkb = min(kb_per, Kb - kb0);
-    gemm2h_segment<NSUB, HI, VAR>(A2, B1, Bhi, hiflag, rscale, Kb, C + (size_t)z * c_split_stride, ldc, blockIdx.y * G3_MW,
+    gemm2h_segment<NSUB, HI, VAR>(A2, B1, Bhi, hiflag, rscale, Kb, C + (size_t)z * c_split_stride, ldc, mg * G3_MW,
                                   jt * G3C_JW, kb0, nkb, smem3);
 }
 
@@ -617,10 +621,14 @@ __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char
     const long long U = (long long)T * Ks;
     long long u = U * blockIdx.x / gridDim.x;
     const long long u1 = U * (blockIdx.x + 1) / gridDim.x;
+    const int NJ = T / MG;
     while (u < u1) {
+        // work order: component group major (tile o = mg * NJ + jt) -- with more than one component group, workgroups p
+        // and p + P / MG (the same XCD: P / MG is a multiple of 8) then stream the SAME row tile jt of the count plane at
+        // the same time and share it in their L2.  The cut flags the sweep reads are indexed jt * MG + mg (plan_streamk3).
         const int tile = (int)(u / Ks), ks = (int)(u % Ks);
         const int ke = (int)min((long long)Ks, ks + (u1 - u));
-        const int jt = tile / MG, mg = tile % MG;
+        const int mg = tile / NJ, jt = tile % NJ;
         gemm2h_segment<NSUB, HI, VAR>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
                                       jt * G3C_JW, ks * NSUB, (ke - ks) * NSUB, smem3);
         u += ke - ks;

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_streamk_kernel(const unsigned ch
     while (u < u1) {
         const int tile = (int)(u / Kb), kb = (int)(u % Kb);
         const int ke = (int)min((long long)Kb, kb + (u1 - u));
-        const int jt = tile / MG, mg = tile % MG;
+        const int mg = tile / (T / MG), jt = tile % (T / MG);     // component-group-major work order (see gemm2h_streamk_kernel)
         gemm3_segment(A3, B3, Kb, (kb == 0) ? C0 : (ke == Kb ? C1 : C2), ldc, mg * G3_MW, jt * G3_JW, kb,
                       ke - kb, smem3);
         u += ke - kb;
@@ -484,17 +484,19 @@ __global__ __launch_bounds__(512) void gemm3g_kernel(const unsigned char* __rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     // XCD-aware tile order: workgroups are dealt to the 8 XCDs round robin, and every j tile of one K
     // split re-reads the same slice of A3.  Give each XCD whole K splits (all their j tiles), so a
-    // slice is fetched into ONE L2 instead of eight.  Needs gridDim.y == 1 and gridDim.z % 8 == 0.
-    int jt = blockIdx.x, z = blockIdx.z;
-    if (gridDim.y == 1 && (gridDim.z & 7) == 0) {
-        const int L = blockIdx.x + gridDim.x * blockIdx.z;
+    // slice is fetched into ONE L2 instead of eight.  Needs gridDim.z % 8 == 0.
+    // (several component groups, gridDim.y > 1: one XCD gets all j tiles AND all groups of its K splits)
+    int jt = blockIdx.x, mg = blockIdx.y, z = blockIdx.z;
+    if ((gridDim.z & 7) == 0) {
+        const int L = blockIdx.x + (int)gridDim.x * (blockIdx.y + (int)gridDim.y * blockIdx.z);
         const int xcd = L & 7, idx = L >> 3;
-        z = xcd + 8 * (idx / (int)gridDim.x);
         jt = idx % (int)gridDim.x;
+        mg = (idx / (int)gridDim.x) % (int)gridDim.y;
+        z = xcd + 8 * (idx / (int)(gridDim.x * gridDim.y));
     }
     const int kb0 = z * kb_per;
     const int nkb = min(kb_per, Kb - kb0);
-    gemm3g_segment(A3, B3, Kb, C + (size_t)z * c_split_stride, ldc, blockIdx.y * G3_MW, jt * G3_JW, kb0, nkb,
+    gemm3g_segment(A3, B3, Kb, C + (size_t)z * c_split_stride, ldc, mg * G3_MW, jt * G3_JW, kb0, nkb,
                    smem3);
 }
 
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(512) void gemm3g_streamk_kernel(const unsigned char
     while (u < u1) {
         const int tile = (int)(u / Kb), kb = (int)(u % Kb);
         const int ke = (int)min((long long)Kb, kb + (u1 - u));
-        const int jt = tile / MG, mg = tile % MG;
+        const int mg = tile / (T / MG), jt = tile % (T / MG);     // component-group-major work order (see gemm2h_streamk_kernel)
         gemm3g_segment(A3, B3, Kb, (kb == 0) ? C0 : (ke == Kb ? C1 : C2), ldc, mg * G3_MW, jt * G3_JW, kb,
                        ke - kb, smem3);
         u += ke - kb;
@@ -666,16 +668,17 @@ __global__ __launch_bounds__(512) void gemm3c_kernel(const unsigned char* __rest
                                                      int kb_per)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    int jt = blockIdx.x, z = blockIdx.z;                 // XCD-aware order, as in gemm3g_kernel
-    if (gridDim.y == 1 && (gridDim.z & 7) == 0) {
-        const int L = blockIdx.x + gridDim.x * blockIdx.z;
+    int jt = blockIdx.x, mg = blockIdx.y, z = blockIdx.z;       // XCD-aware order, as in gemm3g_kernel
+    if ((gridDim.z & 7) == 0) {
+        const int L = blockIdx.x + (int)gridDim.x * (blockIdx.y + (int)gridDim.y * blockIdx.z);
         const int xcd = L & 7, idx = L >> 3;
-        z = xcd + 8 * (idx / (int)gridDim.x);
         jt = idx % (int)gridDim.x;
+        mg = (idx / (int)gridDim.x) % (int)gridDim.y;
+        z = xcd + 8 * (idx / (int)(gridDim.x * gridDim.y));
     }
     const int kb0 = z * kb_per;
     const int nkb = min(kb_per, Kb - kb0);
-    gemm3c_segment(A3, B1, Bhi, hiflag, Kb, C + (size_t)z * c_split_stride, ldc, blockIdx.y * G3_MW, jt * G3C_JW, kb0,
+    gemm3c_segment(A3, B1, Bhi, hiflag, Kb, C + (size_t)z * c_split_stride, ldc, mg * G3_MW, jt * G3C_JW, kb0,
                    nkb, smem3);
 }
 
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(512) void gemm3c_streamk_kernel(const unsigned char
     while (u < u1) {
         const int tile = (int)(u / Kb), kb = (int)(u % Kb);
         const int ke = (int)min((long long)Kb, kb + (u1 - u));
-        const int jt = tile / MG, mg = tile % MG;
+        const int mg = tile / (T / MG), jt = tile % (T / MG);     // component-group-major work order (see gemm2h_streamk_kernel)
         gemm3c_segment(A3, B1, Bhi, hiflag, Kb, (kb == 0) ? C0 : (ke == Kb ? C1 : C2), ldc, mg * G3_MW, jt * G3C_JW, kb,
                        ke - kb, smem3);
         u += ke - kb;

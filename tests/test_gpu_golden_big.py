@@ -63,6 +63,18 @@ def test_C3_long_restarts_vs_sklearn_golden(engine):
             dev = g["k%d_f32dev%d" % (k, T)]
             maxabs, relfro = nmf_cd.spectra_error(g["k%d_H%d" % (k, T)], H[r])
             assert maxabs <= max(1e-4, 4 * dev[0]) and relfro <= max(1e-3, 4 * dev[1]), (k, T, maxabs, relfro, dev)
+    # (a') the same at 50 iterations in a WIDE batch (512 packed columns = two component groups per GEMM pass: stream-K
+    #      pass A walking 392 tiles component-group-major on 256 workgroups, pass B spread over the XCDs by (row tile,
+    #      group, K split)) -- the width large jobs run at by default
+    fk2, fs2 = _fillers(seed=78)
+    H, _, n_iter, _ = engine.nmf_batch(ks + fk2, seeds=seeds + fs2, max_iter=50, warn=False, kc_max=512)
+    st = engine.last_stats
+    assert st["kc"] == 512 and st["gemm_mode"] >= 3
+    for r, k in enumerate(ks3):
+        assert int(n_iter[r]) == 50
+        dev = g["k%d_f32dev50" % k]
+        maxabs, relfro = nmf_cd.spectra_error(g["k%d_H50" % k], H[r])
+        assert maxabs <= max(1e-4, 4 * dev[0]) and relfro <= max(1e-3, 4 * dev[1]), (k, "wide", maxabs, relfro, dev)
     # (b) to the stopping rule (tol 1e-4, max_iter 1000): iteration count, objective and spectra.  The OBJECTIVE is a
     #     stable functional of the trajectory and is held tightly; the spectra of these long ill-conditioned runs to
     #     5e-3 / 5e-3 (after 400-1000 iterations the float32 drift of (a) has grown accordingly; 2e-2 for the run that

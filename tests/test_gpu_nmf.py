@@ -238,6 +238,37 @@ def test_full_width_batch_matches_oracle_in_every_gemm_mode(engine, monkeypatch,
     assert list(n2) == list(n_iter) and all(np.array_equal(a, b) for a, b in zip(H, H2))
 
 
+@pytest.mark.parametrize("g3mode,kc", [("4", 512), ("4", 768), ("3", 512), ("2", 512)])
+def test_wide_batch_512_columns_matches_oracle(engine, monkeypatch, g3mode, kc):
+    """Wide batches (512 / 768 packed columns = 2 / 3 component groups per GEMM pass: the default for jobs of >= 1536
+    columns on large matrices): pass A walks its tiles component-group-major, pass B spreads (row tile, group, K split)
+    over the XCDs, the cut flags are looked up by (row tile, group) -- every restart against its float64 oracle run, on
+    the count path (f16 and bf16 planes) and the general split-operand path; then the tail narrows the batch in steps
+    of 256 columns on the same kernels (more restarts than fit at once, all of different length)."""
+    monkeypatch.setenv("CNMF_GEMM3", g3mode)
+    X64 = synth.make_config("C1", dtype=np.float64)
+    engine.set_matrix(X64)
+    rs = np.random.RandomState(12)
+    n = 150
+    ks = [int(k) for k in rs.randint(5, 10, size=n)]
+    seeds = [int(s) for s in rs.randint(1, 2**31 - 1, size=n)]
+    assert sum(ks) > kc + 256
+    H, _, n_iter, viol = engine.nmf_batch(ks, seeds=seeds, kc_max=kc)
+    assert engine.last_stats["kc"] == kc and engine.last_stats["gemm_mode"] == int(g3mode)
+    for k, seed, h, it in list(zip(ks, seeds, H, n_iter))[::7]:
+        _, H_ref, n_ref = nmf_cd.nmf(X64, k, seed=seed)
+        _check(H_ref, n_ref, h, it, slack=3)
+    assert (viol[n_iter < 1000] <= 1e-4).all()
+    H2, _, n2, _ = engine.nmf_batch(ks, seeds=seeds, kc_max=kc)
+    assert list(n2) == list(n_iter) and all(np.array_equal(a, b) for a, b in zip(H, H2))     # deterministic
+    # the same restarts in a 256-wide batch: same answers to rounding (other split-K / stream-K partitions)
+    H3, _, n3, _ = engine.nmf_batch(ks[:40], seeds=seeds[:40], kc_max=256)
+    for a, b, na, nb in zip(H[:40], H3, n_iter[:40], n3):
+        assert abs(int(na) - int(nb)) <= max(2, int(nb) // 100)
+        maxabs, relfro = nmf_cd.spectra_error(b, a)
+        assert maxabs <= 1e-4 and relfro <= 1e-3
+
+
 def test_device_standard_normal_matches_numpy(engine):
     """numpy RandomState(seed).standard_normal reproduced on the device (MT19937 +
     legacy polar gauss); known-answer vector from SURVEY.md 8c first."""
