@@ -189,10 +189,10 @@ static int wait_snapshot(cnmf_ctx* ctx, const SlotDesc* sp, int n, int stamp)
 }
 
 // Packed component columns of a call.  32 ... 256 by the total rank of the job (powers of two); on the matrix-pipe
-// split-operand paths a job of >= 3 x 512 columns runs 512 wide (`wide_ok`): both GEMM passes then read every X tile
-// once per 512 columns instead of once per 256, the stream-K partial planes of pass A and the latency-bound H half-step
-// are amortised over twice the columns (+10 % restarts/s at 50 000 x 2000), at the price of a longer tail -- hence
-// only for jobs that are long against it, and the batch narrows to 256 again once the queue is dry (compact()).
+// split-operand paths (`wide_ok`) a larger job runs WIDE, up to 1024 columns = four 256-column component groups per GEMM
+// pass: both passes then read every X tile once per 1024 columns instead of once per 256, the stream-K partial planes of
+// pass A and the latency-bound H half-step are amortised over four times the columns (169 -> 198 -> 215 restarts/s at
+// 256 / 512 / 1024 columns, 50 000 x 2000); the batch narrows in 256-column steps once the queue is dry (compact()).
 // kc_max: 0 = auto, else an upper bound (multiple of 32; above 256 in steps of 256, up to CNMF_KC_LIMIT).
 constexpr int CNMF_KC_LIMIT = 1024;
 static int pick_kc(int64_t total_k, int max_k, int kc_max, bool wide_ok)
@@ -206,10 +206,14 @@ static int pick_kc(int64_t total_k, int max_k, int kc_max, bool wide_ok)
     int kc = 32;
     while (kc < std::min(kc_max, 256) && kc < total_k) kc *= 2;
     kc = std::min(kc, kc_max);
-    if (wide_ok && kc == 256) {
-        if (autosize && !getenv("CNMF_NO_WIDE") && total_k >= 3 * 512) kc = 512;
-        else if (!autosize && kc_max > 256 && (forced || total_k > 256)) kc = (int)std::min<int64_t>(kc_max, round_up(total_k, 256));
+    if (wide_ok && kc == 256 && total_k > 256) {
+        // as wide as the job, up to the limit: a job that fits entirely starts every restart at once and the batch
+        // narrows behind the ones that finish (compact()); measured and simulated on the iteration counts of the
+        // north-star job (tools/sim_schedule.py): 113 restarts run 187 / 172 / 145 restarts/s at 1024 / 512 / 256 columns
+        if (autosize && !getenv("CNMF_NO_WIDE")) kc = (int)std::min<int64_t>(CNMF_KC_LIMIT, round_up(total_k, 256));
+        else if (!autosize && kc_max > 256) kc = (int)std::min<int64_t>(kc_max, round_up(total_k, 256));
     }
+    (void)forced;
     if (kc < max_k) kc = round_up(max_k, 32);
     return kc;
 }

@@ -48,7 +48,7 @@ typedef struct cnmf_cd_params {
     int    max_iter;     /* 1000 (cnmf.py:567,625)                               */
     int    kc_max;       /* max packed component columns in flight: 32..256 in steps of 32, 512 / 768 / 1024 (wide batches:
                             several 256-column component groups per GEMM pass, matrix-pipe paths only); 0 = auto
-                            (256; 512 for jobs of >= 1536 columns on matrices of >= 2^24 padded entries)            */
+                            (up to 256; as wide as the job up to 1024 on matrices of >= 2^24 padded entries)        */
     double l1_reg_W, l2_reg_W, l1_reg_H, l2_reg_H;
     int    lag;          /* host polls convergence `lag` iterations behind the GPU; 0 = default (2) */
     int    profile;      /* n > 0: bracket the two GEMM passes of every n-th iteration with HIP events

@@ -120,11 +120,11 @@ def test_streamk_split_operand_path_at_scale(engine, monkeypatch):
     ks = [9] * 29
     seeds = [int(s) for s in np.random.RandomState(5).randint(1, 2**31 - 1, size=29)]
     monkeypatch.setenv("CNMF_GEMM3", "2")
-    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
+    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False, kc_max=256)
     st = engine.last_stats
     assert st["kc"] == 256 and st["gemm_mode"] == 2
     assert list(n_iter) == [25] * 29
-    H2, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
+    H2, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False, kc_max=256)
     assert all(np.array_equal(a, b) for a, b in zip(H, H2))
     X64 = X.astype(np.float64)
     for r in (0, 14, 28):

@@ -55,7 +55,7 @@ def test_C3_long_restarts_vs_sklearn_golden(engine):
     #     device must stay within the usual 1e-4 / 1e-3, or within 4 x that measured float32 drift where float32
     #     itself cannot do better.
     for T in (50, 150):
-        H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=T, warn=False)
+        H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=T, warn=False, kc_max=256)
         st = engine.last_stats
         assert st["kc"] == 256 and st["gemm_mode"] >= 3
         for r, k in enumerate(ks3):
@@ -79,8 +79,8 @@ def test_C3_long_restarts_vs_sklearn_golden(engine):
     #     stable functional of the trajectory and is held tightly; the spectra of these long ill-conditioned runs to
     #     5e-3 / 5e-3 (after 400-1000 iterations the float32 drift of (a) has grown accordingly; 2e-2 for the run that
     #     stops at max_iter without converging) and the iteration count to 5 %.
-    H, W, n_iter, viol = engine.nmf_batch(ks, seeds=seeds, warn=False, return_W=True)
-    assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] >= 3
+    H, W, n_iter, viol = engine.nmf_batch(ks, seeds=seeds, warn=False, return_W=True)       # default width: 512 for 316 columns
+    assert engine.last_stats["kc"] == 512 and engine.last_stats["gemm_mode"] >= 3
     for r, k in enumerate(ks3):
         n_full = int(g["k%d_seed" % k][2])
         assert abs(int(n_iter[r]) - n_full) <= max(3, n_full // 20), (k, int(n_iter[r]), n_full)
@@ -116,7 +116,7 @@ def test_C4_csr_restarts_vs_sklearn_golden(engine):
     # ... and inside a full-width batch (13 x 20 = 260 columns: 256-column split-operand kernels + one refill)
     ks = [20] * 13
     seeds = [11, 12] + list(range(201, 212))
-    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=10, warn=False)
+    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=10, warn=False, kc_max=256)
     assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] >= 2
     for r, seed in enumerate((11, 12)):
         assert int(n_iter[r]) == 10
@@ -136,10 +136,11 @@ def test_C4_count_valued_csr_vs_sklearn_golden(engine):
     engine.set_matrix(X)                                       # CSR upload, densified on the device
     ks = [20] * 13                                             # 13 x 20 = 260 columns: a full 256-column batch + one refill
     seeds = [21, 22] + list(range(301, 312))
-    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=10, warn=False)
-    st = engine.last_stats
-    assert st["kc"] == 256 and st["gemm_mode"] == 4, st       # the count structure was detected: f16 two-plane path
-    for r, seed in enumerate((21, 22)):
-        assert int(n_iter[r]) == 10
-        maxabs, relfro = nmf_cd.spectra_error(g["seed%d_H10" % seed], H[r])
-        assert maxabs <= 1e-4 and relfro <= 1e-3, (seed, maxabs, relfro)
+    for kc in (256, 0):                                        # a 256-column batch with one refill; the default: 512 wide
+        H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=10, warn=False, kc_max=kc)
+        st = engine.last_stats
+        assert st["kc"] == (kc or 512) and st["gemm_mode"] == 4, st       # the count structure was detected: f16 two-plane path
+        for r, seed in enumerate((21, 22)):
+            assert int(n_iter[r]) == 10
+            maxabs, relfro = nmf_cd.spectra_error(g["seed%d_H10" % seed], H[r])
+            assert maxabs <= 1e-4 and relfro <= 1e-3, (kc, seed, maxabs, relfro)
