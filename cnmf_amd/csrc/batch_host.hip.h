@@ -318,7 +318,11 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         d_Hres = pool.get<float>(hoff[n]);
     }
     if (W_out) d_Wres = pool.get<float>(woff[n]);
+    int* d_repack = pool.get<int>((size_t)3 * KC0);            // re-packing: column map, moved slot ids, their new offsets
     POOL_TRY(ctx, pool);
+    struct PinnedInts { int* p = nullptr; ~PinnedInts() { if (p) hipHostFree(p); } } repack_host;
+    HIP_TRY(ctx, hipHostMalloc(&repack_host.p, (size_t)RING * 3 * KC0 * sizeof(int)));
+    int* h_repack = repack_host.p;
 
     // init_mode 1: sklearn's init='random' for EVERY restart of the call, generated up front on the
     // device (one workgroup per restart) into a component-major store; install = row copy.
@@ -433,29 +437,38 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     // Move the live slots to the left end of the packed columns (ascending offset order, through the stage
     // buffers) and zero everything from the first free column up to `width`.  Used by the tail compaction
     // (narrower batch) and by the refill's defragmentation (same width).
+    // (one launch sequence per re-packing, whatever the number of slots: at 1024 packed columns the per-slot moves of
+    //  round 2 -- four launches each, host-bound at ~5 us per launch -- had grown to 10 % of the wall time)
+    int n_repack = 0;
     auto repack_left = [&](int width) -> int {
         std::vector<int> idx;
         for (int s = 0; s < nslots; ++s) if (hs[s].state) idx.push_back(s);
         std::sort(idx.begin(), idx.end(), [&](int a, int b) { return hs[a].off < hs[b].off; });
-        int pos = 0;
+        int* hm = h_repack + (size_t)(n_repack++ % RING) * 3 * KC0;      // [colmap | slot ids | new offsets], pinned
+        int* d_colmap = d_repack, *d_ids = d_repack + KC0, *d_offs = d_repack + 2 * KC0;
+        int pos = 0, nmove = 0;
         for (int s : idx) {
             HostSlot& h = hs[s];
-            if (h.off != pos) {
-                dim3 gH((G + 255) / 256, h.k), gW((N + 255) / 256, h.k), gI((std::max(N, G) + 255) / 256, h.k);
-                extract_kernel<<<gH, 256, 0, st>>>(ctx->H, ctx->G_pad, G, h.off, h.k, ctx->stageH, 0);
-                extract_kernel<<<gW, 256, 0, st>>>(ctx->Wt, ctx->N_pad, N, h.off, h.k, ctx->stageW, 0);
-                install_cm_kernel<<<gI, 256, 0, st>>>(ctx->stageH, ctx->stageW, ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, pos);
-                set_slot_off_kernel<<<1, 1, 0, st>>>(ctx->d_slots, s, pos);
-                h.off = pos;
-            }
+            for (int c = 0; c < h.k; ++c) hm[pos + c] = h.off + c;
+            if (h.off != pos) { hm[KC0 + nmove] = s; hm[2 * KC0 + nmove] = pos; ++nmove; h.off = pos; }
             pos += h.k;
         }
-        if (pos < width) {
-            dim3 gc((ctx->G_pad + 255) / 256, width - pos), gw((ctx->N_pad + 255) / 256, width - pos);
-            clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, pos, width - pos);
-            clear_rows_kernel<<<gw, 256, 0, st>>>(ctx->Wt, ctx->N_pad, ctx->N_pad, pos, width - pos);
+        for (int c = pos; c < width; ++c) hm[c] = -1;                    // zero rows behind the live ones
+        if (nmove || pos < width) {
+            HIP_TRY(ctx, hipMemcpyAsync(d_colmap, hm, (size_t)width * sizeof(int), hipMemcpyHostToDevice, st));
+            // staging = the product buffers (scratch between two iterations): XHt [>= KC0][N_pad], XtW [>= KC0][G_pad]
+            gather_rows_cm_kernel<<<dim3((ctx->N_pad / 4 + 255) / 256, width), 256, 0, st>>>(ctx->Wt, ctx->N_pad, d_colmap, ctx->XHt);
+            gather_rows_cm_kernel<<<dim3((ctx->G_pad / 4 + 255) / 256, width), 256, 0, st>>>(ctx->H, ctx->G_pad, d_colmap, ctx->XtW);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->Wt, ctx->XHt, (size_t)width * ctx->N_pad * sizeof(float), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->H, ctx->XtW, (size_t)width * ctx->G_pad * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if (nmove) {
+                HIP_TRY(ctx, hipMemcpyAsync(d_ids, hm + KC0, (size_t)nmove * sizeof(int), hipMemcpyHostToDevice, st));
+                HIP_TRY(ctx, hipMemcpyAsync(d_offs, hm + 2 * KC0, (size_t)nmove * sizeof(int), hipMemcpyHostToDevice, st));
+                set_slot_offs_kernel<<<(nmove + 255) / 256, 256, 0, st>>>(ctx->d_slots, d_ids, d_offs, nmove);
+                HIP_TRY(ctx, hipGetLastError());
+            }
         }
-        HIP_TRY(ctx, hipGetLastError());
         h3_valid = false;                 // rows of H moved: its planes are stale
         // moved rows of slots that no longer iterate are not swept again: refresh their row maxima here
         if (use2h) HIP_TRY(ctx, launch_rowmax_part(st, ctx->Wt, ctx->N_pad, N, KC, chunksW * 256, nullptr, partsW, ctx->rmaxW));

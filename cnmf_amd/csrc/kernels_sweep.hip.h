@@ -626,6 +626,25 @@ __global__ void install_cm_kernel(const float* __restrict__ H0, const float* __r
 
 __global__ void set_slot_off_kernel(SlotDesc* slots, int slot, int off) { slots[slot].off = off; }
 
+// Re-packing of the component columns in ONE pass: stage[j][:] = V[colmap[j]][:]  (colmap[j] < 0: a zero row), then the
+// staged rows are copied back with one device-to-device copy.  grid = (ceil(ld / 1024), rows), 256 threads x float4.
+__global__ __launch_bounds__(256) void gather_rows_cm_kernel(const float* __restrict__ V, int ld,
+                                                             const int* __restrict__ colmap, float* __restrict__ stage)
+{
+    const int j = blockIdx.y, i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= ld) return;                                        // ld is a multiple of 4 (padded leading dimensions)
+    const int c = colmap[j];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c >= 0) v = *reinterpret_cast<const float4*>(V + (size_t)c * ld + i);
+    *reinterpret_cast<float4*>(stage + (size_t)j * ld + i) = v;
+}
+
+__global__ void set_slot_offs_kernel(SlotDesc* slots, const int* __restrict__ ids, const int* __restrict__ offs, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[ids[i]].off = offs[i];
+}
+
 // Zero a range of packed component rows (freed slot -> contributes nothing to the GEMMs).
 __global__ void clear_rows_kernel(float* __restrict__ V, int ldv, int L, int off, int k)
 {
