@@ -30,7 +30,8 @@ SYMBOLS = [
 
 COMM_ID_BYTES = 128
 
-CNMF_KMAX = 64
+CNMF_KMAX = 128
+CNMF_MU_KMAX = 64
 
 
 class CdParams(C.Structure):

@@ -196,12 +196,14 @@ class cNMF:
         if type(ks) is int:
             ks = [ks]
         k_list = sorted(set(list(ks)))
-        from ._lib import CNMF_KMAX
-        if k_list and max(k_list) > CNMF_KMAX:
-            # fail at prepare time, not after the restarts were paid for (the device sweep / k-means hold a
-            # rank in registers; the reference CLI cannot reach this either, cnmf.py:1251)
-            raise NotImplementedError("n_components=%d > %d is not supported by the device engine"
-                                      % (max(k_list), CNMF_KMAX))
+        from ._lib import CNMF_KMAX, CNMF_MU_KMAX
+        kmax = CNMF_KMAX if beta_loss == "frobenius" else (CNMF_MU_KMAX if beta_loss == "kullback-leibler" else 32)
+        if k_list and max(k_list) > kmax:
+            # fail at prepare time, not after the restarts were paid for (the reference itself has no limit,
+            # cnmf.py:1243; the device engine: 128 for the coordinate-descent solver, 64 / 32 for the
+            # multiplicative-update solver with the Kullback-Leibler / Itakura-Saito loss)
+            raise NotImplementedError("n_components=%d > %d is not supported by the device engine (beta_loss=%r)"
+                                      % (max(k_list), kmax, beta_loss))
         replicate_params = []
         for k, r, nmf_seed in ledger_seeds(ks, n_iter, random_state_seed):
             done = os.path.exists(self.paths["iter_spectra"] % (k, r))

@@ -290,6 +290,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     if (use3 && !usec) { rc = ensure_planes(ctx); if (rc) return rc; }
     const int jwA = usec ? G3C_JW : G3_JW;         // width of a pass-A / pass-B tile
     int nsplit3 = use3 ? pick_nsplit3(ctx, KC, jwA) : 1;
+    const int nsplit3_first = nsplit3;             // (reported: the tail narrows the batch and re-plans)
     const int fin_y = (max_k * max_k + 255) / 256;       // finalize blocks per slot
     const int lag_env = getenv("CNMF_LAG") ? atoi(getenv("CNMF_LAG")) : 0;
     const int lag = std::max(1, std::min(RING - 2, prm->lag > 0 ? prm->lag : (lag_env > 0 ? lag_env : 2)));
@@ -543,7 +544,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     auto iterate = [&](int n_new) -> int {
         int tiers = 0;
         for (int s2 = 0; s2 < nslots; ++s2)
-            if (hs[s2].state) tiers |= hs[s2].k <= 16 ? 1 : (hs[s2].k <= 32 ? 2 : 4);
+            if (hs[s2].state) tiers |= hs[s2].k <= 16 ? 1 : (hs[s2].k <= 32 ? 2 : (hs[s2].k <= KSMALL ? 4 : 8));
         const bool time_gemm = time_stride > 0 && it % time_stride == 0;
         if (time_gemm) {
             for (int i = 0; i < 4; ++i) gev.push_back(events.get());
@@ -631,7 +632,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                                            ctx->G_pad, nsplit));
         if (time_gemm) hipEventRecord(gev[gev.size() - 1], st);
         // H half-step.  On the f16 path the split-K partials are summed (and scaled by d) inside the sweep itself.
-        if (use2h && !no_psum) {
+        if (use2h && !no_psum && !(tiers & 8)) {      // (ranks above 64 take the separately reduced product)
             HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
                                       ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers,
                                       psum_info(nsB, (long long)KC * ctx->G_pad, ctx->d_scale), ctx->rmaxH, ctx->d_scale, true));
@@ -793,7 +794,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         stats->restart_iterations = restart_iters;
         stats->column_iterations = column_iters;
         stats->restart_column_iterations = restart_col_iters;
-        stats->kc = KC0; stats->nsplit = gemm_mode_used ? nsplit3 : ctx->nsplit_alloc;
+        stats->kc = KC0; stats->nsplit = gemm_mode_used ? nsplit3_first : ctx->nsplit_alloc;
         stats->gemm_mode = gemm_mode_used;
         stats->tail_iterations = tail_its; stats->tail_live_columns = tail_live;
         if (ev_tail) { float tms = 0.f; hipEventElapsedTime(&tms, ev_tail, ev_end); stats->tail_ms = tms; }
@@ -838,7 +839,7 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
     if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int N = (int)ctx->N, G = (int)ctx->G;
-    const int KC = k <= 32 ? 32 : 64;
+    const int KC = k <= 32 ? 32 : (k <= 64 ? 64 : 128);
     rc = ensure_batch(ctx, KC, k, k);
     if (rc) return rc;
     rc = ensure_stage(ctx, (size_t)N * KMAX, (size_t)G * KMAX);
@@ -874,7 +875,7 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
         for (int b = 0; b < burst; ++b) {
             HIP_TRY(ctx, launch_sweep(st, 1, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
                                       ctx->d_slots, (float)prm->l1_reg_W, ctx->gram_part, ctx->viol_part,
-                                      chunksW, partsW, 0, k, k <= 16 ? 1 : (k <= 32 ? 2 : 4)));
+                                      chunksW, partsW, 0, k, k <= 16 ? 1 : (k <= 32 ? 2 : (k <= KSMALL ? 4 : 8))));
             finalize_kernel<<<dim3(1, 1), 256, 0, st>>>(ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, 0.f,
                                                ctx->d_slots, 2, prm->tol, prm->max_iter, 0, k);
         }

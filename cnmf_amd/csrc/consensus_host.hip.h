@@ -62,7 +62,7 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     if (!ctx || !spectra || !prm || !labels_out || !median_out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
     const int k = prm->k;
     if (R < 1 || G < 1 || k < 1 || k > R) { SET_ERR(ctx, "bad shape R=%d G=%d k=%d", R, G, k); return CNMF_EINVAL; }
-    if (k > 64) { SET_ERR(ctx, "k=%d > 64 clusters is not supported", k); return CNMF_EUNSUPPORTED; }
+    if (k > KM_CID) { SET_ERR(ctx, "k=%d > %d clusters is not supported", k, KM_CID); return CNMF_EUNSUPPORTED; }
     const int n_init = prm->n_init > 0 ? prm->n_init : 10;
     const int max_iter = prm->max_iter > 0 ? prm->max_iter : 300;
     const double tol = prm->tol >= 0 ? prm->tol : 1e-4;
@@ -167,7 +167,7 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     double* dsums = pool.get<double>((size_t)I * k * ld);
     int* dcounts = pool.get<int>((size_t)I * k);
     double* ddist = pool.get<double>((size_t)I * Rkp);
-    int* dcids = pool.get<int>((size_t)I * 64);
+    int* dcids = pool.get<int>((size_t)I * KM_CID);
     int* dc0 = pool.get<int>(I);
     int* dneed = pool.get<int>(I);
     KmState* dst = pool.get<KmState>(I, true, st);
@@ -199,8 +199,9 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     for (int g = 0; g < G; ++g) vsum += hvar[g];
     const double tol_ = (vsum / G) * tol;                      // _tolerance, sklearn _kmeans.py:279-288
 
-    const size_t acc_lds = (size_t)k * 256 * sizeof(double);
-    CONS_TRY(hipFuncSetAttribute((const void*)accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
+    const int acc_bw = k <= 64 ? 256 : 128;                      // columns per block of the M step: k x acc_bw doubles of LDS
+    const size_t acc_lds = (size_t)k * acc_bw * sizeof(double);
+    CONS_TRY(dyn_lds_optin((const void*)accumulate_kernel, 160 * 1024 - 64));
     auto dots = [&](const double* A, int M) {     // ddots[M][Rkp] = A[M][ld] . X^T  (one product for every init)
         dgemm_nt_small_kernel<<<dim3(Rkp / 16, M / 64), 256, 0, st>>>(A, ld, dX, ld, ddots, Rkp, ld);
     };
@@ -234,7 +235,7 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
         dots(cur, MT);
         km_reset_kernel<<<1, 64, 0, st>>>(dst, I);
         assign_kernel<<<dim3((Rk + 255) / 256, I), 256, 0, st>>>(ddots, kd, dcsq, dlabels, dst, 0, nullptr);
-        accumulate_kernel<<<dim3((G + 255) / 256, nchunks, I), 256, acc_lds, st>>>(dX, kd, dlabels, rows_per_chunk, nchunks, dpartial, dpcount, dst);
+        accumulate_kernel<<<dim3((G + acc_bw - 1) / acc_bw, nchunks, I), acc_bw, acc_lds, st>>>(dX, kd, dlabels, rows_per_chunk, nchunks, dpartial, dpcount, dst);
         reduce_partial_kernel<<<dim3((G + 255) / 256, k, I), 256, 0, st>>>(dpartial, dpcount, nchunks, kd, dsums, dcounts, dst);
         row_center_dist_kernel<<<dim3(Rk, I), 256, 0, st>>>(dX, kd, cur, dlabels, ddist, dst, 0);
         relocate_empty_kernel<<<I, 256, 0, st>>>(dX, kd, dlabels, ddist, dsums, dcounts, dst);
@@ -338,7 +339,7 @@ extern "C" int cnmf_prediction_error(cnmf_ctx* ctx, int k, const double* W, cons
     using namespace cnmf;
     if (!ctx || !W || !H || !err_out || k < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
     if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
-    if (k > 64) { SET_ERR(ctx, "k > 64"); return CNMF_EUNSUPPORTED; }
+    if (k > KMAX) { SET_ERR(ctx, "k=%d > %d", k, KMAX); return CNMF_EUNSUPPORTED; }
     CONS_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int N = (int)ctx->N, G = (int)ctx->G;
@@ -346,15 +347,16 @@ extern "C" int cnmf_prediction_error(cnmf_ctx* ctx, int k, const double* W, cons
     double* dW = pool.get<double>((size_t)N * k);
     double* dH = pool.get<double>((size_t)k * G);
     const int rpb = 512;
-    dim3 grid((G + 255) / 256, (N + rpb - 1) / rpb);
+    const int bw = k <= 64 ? 256 : 128;                     // genes per block: the block's H columns sit in LDS (k x bw doubles)
+    dim3 grid((G + bw - 1) / bw, (N + rpb - 1) / rpb);
     double* dpart = pool.get<double>((size_t)grid.x * grid.y);
     double* dsum = pool.get<double>(1);
     if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
     CONS_TRY(hipMemcpyAsync(dW, W, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, st));
     CONS_TRY(hipMemcpyAsync(dH, H, (size_t)k * G * sizeof(double), hipMemcpyHostToDevice, st));
-    const size_t lds = (size_t)k * 256 * sizeof(double);
-    CONS_TRY(hipFuncSetAttribute((const void*)residual_sq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    residual_sq_kernel<<<grid, 256, lds, st>>>(ctx->X, ctx->G_pad, N, G, dW, dH, k, rpb, dpart);
+    const size_t lds = (size_t)k * bw * sizeof(double);
+    CONS_TRY(dyn_lds_optin((const void*)residual_sq_kernel, 160 * 1024 - 64));
+    residual_sq_kernel<<<grid, bw, lds, st>>>(ctx->X, ctx->G_pad, N, G, dW, dH, k, rpb, dpart);
     sum_kernel<<<1, 256, 0, st>>>(dpart, (int)(grid.x * grid.y), dsum);
     CONS_TRY(hipGetLastError());
     CONS_TRY(hipMemcpyAsync(err_out, dsum, sizeof(double), hipMemcpyDeviceToHost, st));

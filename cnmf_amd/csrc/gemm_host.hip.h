@@ -67,12 +67,12 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
 {
     dim3 grid(parts, nslots);
     {      // ranks above 32 need more than the default 64 KB of dynamic LDS
-        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, false>, (int)sweep_lds_bytes(KMAX))) return e_;
-        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, false>, (int)sweep_lds_bytes(KMAX))) return e_;
-        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, false>, (int)sweep_lds_bytes(KMAX))) return e_;
-        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, true>, (int)sweep_lds_bytes(KMAX))) return e_;
-        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, true>, (int)sweep_lds_bytes(KMAX))) return e_;
-        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, true>, (int)sweep_lds_bytes(KMAX))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, false>, (int)sweep_lds_bytes(KSMALL))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, false>, (int)sweep_lds_bytes(KSMALL))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, false>, (int)sweep_lds_bytes(KSMALL))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, true>, (int)sweep_lds_bytes(KSMALL))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, true>, (int)sweep_lds_bytes(KSMALL))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, true>, (int)sweep_lds_bytes(KSMALL))) return e_;
     }
     // one launch per rank tier present among the live slots; a launch skips the slots of other tiers at once.
     // rmax_scale != nullptr selects the exact row-maximum report (the H half-step of the f16 plane split).
@@ -82,9 +82,9 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
 #define CNMF_SWEEP_PSUM(T_) sweep_kernel<T_, true, true><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax, rmax_part, rmax_scale)
     if (psum) {                 // split-K partial planes summed (and column-scaled) inside the sweep: sp = psum_info(...)
         {
-            if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, true, true>, (int)sweep_lds_bytes(KMAX))) return e_;
-            if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, true, true>, (int)sweep_lds_bytes(KMAX))) return e_;
-            if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, true, true>, (int)sweep_lds_bytes(KMAX))) return e_;
+            if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, true, true>, (int)sweep_lds_bytes(KSMALL))) return e_;
+            if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, true, true>, (int)sweep_lds_bytes(KSMALL))) return e_;
+            if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, true, true>, (int)sweep_lds_bytes(KSMALL))) return e_;
         }
         if (tiers & 1) CNMF_SWEEP_PSUM(0);
         if (tiers & 2) CNMF_SWEEP_PSUM(1);
@@ -100,6 +100,19 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
     }
 #undef CNMF_SWEEP_PSUM
 #undef CNMF_SWEEP
+    if (tiers & 8) {            // ranks 65..128: sweep_big_kernel (+ the Gram of the updated rows as its own launch)
+        if (psum) return hipErrorInvalidValue;                 // the caller reduces the split-K planes first
+        const size_t blds = sweep_big_lds_bytes();
+        if (rmax_part && rmax_scale) {
+            if (hipError_t e_ = dyn_lds_optin((const void*)sweep_big_kernel<true>, (int)blds)) return e_;
+            sweep_big_kernel<true><<<grid, 256, blds, st>>>(V, ldv, L, P, sp, gram, slots, l1, viol_part, chunks, rmax_part, rmax_scale);
+        } else {
+            if (hipError_t e_ = dyn_lds_optin((const void*)sweep_big_kernel<false>, (int)blds)) return e_;
+            sweep_big_kernel<false><<<grid, 256, blds, st>>>(V, ldv, L, P, sp, gram, slots, l1, viol_part, chunks, nullptr, nullptr);
+        }
+        if (want_gram)
+            gram_big_kernel<<<grid, 256, 0, st>>>(V, ldv, L, slots, gram_part, chunks, kmax, (rmax_part && !rmax_scale) ? rmax_part : nullptr);
+    }
     return hipGetLastError();
 }
 
@@ -369,7 +382,7 @@ static hipError_t launch_gemm2h(hipStream_t st, const unsigned char* A2, const u
 }
 static int gemm2h_nsub(bool hi, int Kb) { return (!hi && g2_nsub() == 2 && Kb % 2 == 0) ? 2 : 1; }
 
-template <int NSUB, bool HI, int VAR = 0>
+template <int NSUB, bool HI, int VAR = 0, bool NTB = true>
 static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, const unsigned char* A2,
                                           const unsigned char* B1, const unsigned char* Bhi,
                                           const unsigned int* hiflag, const float* rscale, int Kb, float* C0, float* C1,
@@ -377,9 +390,10 @@ static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, co
 {
     constexpr int lds = g2_lds_bytes(NSUB, HI);
     {
-        if (hipError_t e_ = dyn_lds_optin((const void*)gemm2h_streamk_kernel<NSUB, HI, VAR>, lds)) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm2h_streamk_kernel<NSUB, HI, VAR, NTB>, lds)) return e_;
     }
-    gemm2h_streamk_kernel<NSUB, HI, VAR><<<sk.P, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T);
+    static const int xmap = getenv("CNMF_G2_XMAP") ? atoi(getenv("CNMF_G2_XMAP")) : 1;      // (0: A/B, the identity order)
+    gemm2h_streamk_kernel<NSUB, HI, VAR, NTB><<<sk.P, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T, xmap);
     return hipGetLastError();
 }
 
@@ -388,8 +402,14 @@ static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, cons
                                         const unsigned char* B1, const unsigned char* Bhi, const unsigned int* hiflag,
                                         const float* rscale, int Kb, float* C0, float* C1, float* C2, int ldc)
 {
-    if (Bhi) return launch_gemm2h_streamk_t<1, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc);
+    // several component groups share every count-plane tile in the L2: no non-temporal loads then (CNMF_G2_NT=1: A/B)
+    static const bool force_nt = getenv("CNMF_G2_NT") != nullptr;
+    const bool shared = sk.MG > 1 && !force_nt;
+    if (Bhi) return shared ? launch_gemm2h_streamk_t<1, true, 0, false>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc)
+                           : launch_gemm2h_streamk_t<1, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc);
     if (gemm2h_nsub(false, Kb) == 2) {
+        if (shared && g2_var() == CNMF_G2_VAR_DEFAULT)
+            return launch_gemm2h_streamk_t<2, false, CNMF_G2_VAR_DEFAULT, false>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
         switch (g2_var()) {
             case 1: return launch_gemm2h_streamk_t<2, false, 1>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
             case 2: return launch_gemm2h_streamk_t<2, false, 2>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);

@@ -18,6 +18,7 @@
 
 namespace cnmf {
 
+constexpr int KM_CID = 128;          // largest number of clusters (= largest rank, CNMF_KMAX): centre ids per init, per-cluster sums
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -337,7 +338,7 @@ __global__ void pp_seed_kernel(const double* __restrict__ X, KmDims d, const int
 {
     const int init = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < d.ld) centers[(size_t)(init * d.k) * d.ld + g] = (g < d.G) ? X[(size_t)c0[init] * d.ld + g] : 0.0;
-    if (g == 0) center_ids[init * 64] = c0[init];
+    if (g == 0) center_ids[init * KM_CID] = c0[init];
 }
 
 // closest[r] = max(0, sq_c + sq_r - 2 dot[centre 0][r]); pot = sum closest          grid = n_init
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void pp_pick_kernel(const double* __restrict__
         best_s = best;
         st[init].pot = cpot[init * 8 + best];
         st[init].best = st[init].cand[best];
-        center_ids[init * 64 + c] = st[init].cand[best];
+        center_ids[init * KM_CID + c] = st[init].cand[best];
     }
     __syncthreads();
     const int best = best_s, row = st[init].cand[best];
@@ -508,18 +509,19 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const double* __restric
                                                          double* __restrict__ partial,
                                                          int* __restrict__ pcount, const KmState* __restrict__ st)
 {
-    extern __shared__ __attribute__((aligned(16))) double accs[];     // [k][256]
+    extern __shared__ __attribute__((aligned(16))) double accs[];     // [k][blockDim.x]  (256 columns per block; 128 for k > 64)
     const int init = blockIdx.z;
     if (st[init].done) return;
-    const int g = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y, k = d.k;
+    const int bw = (int)blockDim.x;
+    const int g = blockIdx.x * bw + threadIdx.x, chunk = blockIdx.y, k = d.k;
     const int* lab = labels + (size_t)init * d.Rp;
-    for (int j = 0; j < k; ++j) accs[j * 256 + threadIdx.x] = 0.0;
+    for (int j = 0; j < k; ++j) accs[j * bw + threadIdx.x] = 0.0;
     const int rb = chunk * rows_per_chunk, re = min(rb + rows_per_chunk, d.R);
     if (g < d.G)
-        for (int r = rb; r < re; ++r) accs[lab[r] * 256 + threadIdx.x] += X[(size_t)r * d.ld + g];
+        for (int r = rb; r < re; ++r) accs[lab[r] * bw + threadIdx.x] += X[(size_t)r * d.ld + g];
     double* pp = partial + (((size_t)init * nchunks + chunk) * k) * d.ld;
     if (g < d.G)
-        for (int j = 0; j < k; ++j) pp[(size_t)j * d.ld + g] = accs[j * 256 + threadIdx.x];
+        for (int j = 0; j < k; ++j) pp[(size_t)j * d.ld + g] = accs[j * bw + threadIdx.x];
     if (blockIdx.x == 0 && (int)threadIdx.x < k) {
         int c = 0;
         for (int r = rb; r < re; ++r) c += (lab[r] == (int)threadIdx.x) ? 1 : 0;
@@ -779,7 +781,7 @@ __global__ __launch_bounds__(256) void silhouette_kernel(const double* __restric
                                                          double* __restrict__ sil)
 {
     __shared__ double red[4];
-    __shared__ double csum[64];
+    __shared__ double csum[KM_CID];
     const int q = blockIdx.x;
     const int i = rowid[q];
     for (int j = 0; j < k; ++j) {
@@ -811,16 +813,17 @@ __global__ __launch_bounds__(256) void residual_sq_kernel(const float* __restric
                                                           const double* __restrict__ W, const double* __restrict__ H,
                                                           int k, int rows_per_block, double* __restrict__ part)
 {
-    extern __shared__ __attribute__((aligned(16))) double Hs[];       // [k][256]
+    extern __shared__ __attribute__((aligned(16))) double Hs[];       // [k][blockDim.x]  (256 genes per block; 128 for k > 64)
     __shared__ double red[4];
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    for (int c = 0; c < k; ++c) Hs[c * 256 + threadIdx.x] = (g < G) ? H[(size_t)c * G + g] : 0.0;
+    const int bw = (int)blockDim.x;
+    const int g = blockIdx.x * bw + threadIdx.x;
+    for (int c = 0; c < k; ++c) Hs[c * bw + threadIdx.x] = (g < G) ? H[(size_t)c * G + g] : 0.0;
     const int rb = blockIdx.y * rows_per_block, re = min(rb + rows_per_block, N);
     double s = 0.0;
     if (g < G)
         for (int i = rb; i < re; ++i) {
             double p = 0.0;
-            for (int c = 0; c < k; ++c) p += W[(size_t)i * k + c] * Hs[c * 256 + threadIdx.x];
+            for (int c = 0; c < k; ++c) p += W[(size_t)i * k + c] * Hs[c * bw + threadIdx.x];
             const double d = (double)X[(size_t)i * ldx + g] - p;
             s += d * d;
         }

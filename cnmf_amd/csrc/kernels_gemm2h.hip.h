@@ -326,7 +326,10 @@ __device__ __forceinline__ void glds16_asm_nt(const void* gsrc, unsigned lds_dst
 //   VAR 2 / 3 (timing ablations, results meaningless): the spread stream WITHOUT its MFMAs (fill + fragment reads
 //          only) / WITHOUT its steady-state DMA (MFMAs + fragment reads on stale images).  s_setprio around the MFMA
 //          halves was tried and is neutral (profiles/r2_probe_gemm2h_variants.txt).
-template <int NSUB, bool HI, int VAR = 0>
+// NTB: the count plane is loaded non-temporally (every tile is read by ONE workgroup per pass: 256 packed columns, or pass B
+// with its XCD-aware order); with several component groups in pass A the workgroups p, p + P / MG stream the SAME tile at
+// the same time and must find it in their L2: default cache policy (PMC, 1024 columns: 607 -> see profiles/r3_pmc_*).
+template <int NSUB, bool HI, int VAR = 0, bool NTB = true>
 __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__ A2, const unsigned char* __restrict__ B1,
                                                const unsigned char* __restrict__ Bhi,
                                                const unsigned int* __restrict__ hiflag,
@@ -391,12 +394,12 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
         /* the count planes are read once per pass: non-temporal */                                \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)                                             \
             __builtin_amdgcn_global_load_lds(G3_AS1(bbase + (size_t)(s_) * (NSUB * G2_B) + i * 8192), \
-                                             G3_AS3(d_ + OFF_B + i * 8192), 16, 0, 2);             \
+                                             G3_AS3(d_ + OFF_B + i * 8192), 16, 0, NTB ? 2 : 0);   \
         if (HI) {                                                                                  \
             _Pragma("unroll") for (int i = 0; i < NB; ++i)                                         \
                 if (G2_BLKFLAG((s_) * NSUB + i))                                                   \
                     __builtin_amdgcn_global_load_lds(G3_AS1(hbase + (size_t)(s_) * (NSUB * G2_B) + i * 8192), \
-                                                     G3_AS3(d_ + OFF_H + i * 8192), 16, 0, 2);     \
+                                                     G3_AS3(d_ + OFF_H + i * 8192), 16, 0, NTB ? 2 : 0); \
         }                                                                                          \
         }                                                                                          \
     }
@@ -486,7 +489,7 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
                                                  G3_AS3(d_ + (i_) * 8192), 16, 0, 0);              \
             else                                                                                   \
                 __builtin_amdgcn_global_load_lds(G3_AS1(bbase + (size_t)(s_) * (NSUB * G2_B) + ((i_) - NA) * 8192), \
-                                                 G3_AS3(d_ + OFF_B + ((i_) - NA) * 8192), 16, 0, 2); \
+                                                 G3_AS3(d_ + OFF_B + ((i_) - NA) * 8192), 16, 0, NTB ? 2 : 0); \
             __builtin_amdgcn_sched_barrier(0);                                                     \
         }
 #define G2_MF(u_, m_, q_)                                                                          \
@@ -607,29 +610,34 @@ __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __rest
 }
 
 // pass A: stream-K over persistent workgroups, unit = one step of NSUB blocks (Kb % NSUB == 0)
-template <int NSUB, bool HI, int VAR = 0>
+template <int NSUB, bool HI, int VAR = 0, bool NTB = true>
 __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char* __restrict__ A2,
                                                              const unsigned char* __restrict__ B1,
                                                              const unsigned char* __restrict__ Bhi,
                                                              const unsigned int* __restrict__ hiflag,
                                                              const float* __restrict__ rscale, int Kb,
                                                              float* __restrict__ C0, float* __restrict__ C1,
-                                                             float* __restrict__ C2, int ldc, int MG, int T)
+                                                             float* __restrict__ C2, int ldc, int MG, int T, int xmap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int Ks = Kb / NSUB;                             // steps per tile
     const long long U = (long long)T * Ks;
-    long long u = U * blockIdx.x / gridDim.x;
-    const long long u1 = U * (blockIdx.x + 1) / gridDim.x;
+    // Work order: component group major (tile o = mg * NJ + jt), and -- xmap -- workgroup p takes the q-th share with
+    // q = (p % MG) * (P / MG) + p / MG: block p runs on XCD p % 8, so each XCD works inside ONE component group and its
+    // 4 MB L2 keeps that group's factor planes (2 MB at 2000 genes; the planes of four groups would thrash it: 1.5 GB
+    // fetched per launch at 1024 columns, PMC), while neighbouring XCDs stream the SAME row tile jt of the count plane at
+    // the same time (one HBM fetch, the others find it in the Infinity Cache).  The cut flags the sweep reads are indexed
+    // jt * MG + mg (plan_streamk3); the set of cut positions does not depend on the permutation.
+    const int P = (int)gridDim.x;
+    const int q = (xmap && MG > 1 && P % MG == 0) ? ((int)blockIdx.x % MG) * (P / MG) + (int)blockIdx.x / MG : (int)blockIdx.x;
+    long long u = U * q / P;
+    const long long u1 = U * (q + 1) / P;
     const int NJ = T / MG;
     while (u < u1) {
-        // work order: component group major (tile o = mg * NJ + jt) -- with more than one component group, workgroups p
-        // and p + P / MG (the same XCD: P / MG is a multiple of 8) then stream the SAME row tile jt of the count plane at
-        // the same time and share it in their L2.  The cut flags the sweep reads are indexed jt * MG + mg (plan_streamk3).
         const int tile = (int)(u / Ks), ks = (int)(u % Ks);
         const int ke = (int)min((long long)Ks, ks + (u1 - u));
         const int mg = tile / NJ, jt = tile % NJ;
-        gemm2h_segment<NSUB, HI, VAR>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
+        gemm2h_segment<NSUB, HI, VAR, NTB>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
                                       jt * G3C_JW, ks * NSUB, (ke - ks) * NSUB, smem3);
         u += ke - ks;
         G3_WAIT_VM(0);

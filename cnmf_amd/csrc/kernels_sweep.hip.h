@@ -21,13 +21,14 @@
 
 namespace cnmf {
 
-constexpr int KMAX = 64;            // largest rank handled by the register-resident sweep
+constexpr int KMAX = 128;           // largest rank: <= 64 in the register-resident sweep_kernel, 65..128 in sweep_big_kernel
+constexpr int KSMALL = 64;          // largest rank of sweep_kernel (tiers 0..2)
 constexpr int GRAM_LD = KMAX;       // final gram matrices are stored [slot][64][64]
 constexpr int GRAM_SZ = KMAX * KMAX;
 
 // dynamic LDS of sweep_kernel for a batch whose largest rank is kmax:
 //   Gs [KG][KG+4] | vred [4] doubles | rmx [4][64] | Ws [4][64][wstride]      (KG = 16 / 32 / 64)
-static inline int sweep_kg(int kmax) { return kmax <= 16 ? 16 : (kmax <= 32 ? 32 : 64); }
+static inline int sweep_kg(int kmax) { return kmax <= 16 ? 16 : (kmax <= 32 ? 32 : 64); }      // (ranks > 64: sweep_big_kernel)
 static inline int sweep_wstride(int kmax) { return sweep_kg(kmax) + 1; }
 static inline size_t sweep_lds_bytes(int kmax)
 {
@@ -375,6 +376,192 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 
 #undef CNMF_SW
 }
 
+// ------------------------------------------------------------------------------------------
+// Ranks 65 .. 128 (tier 3).  The register-resident body above unrolls k x k multiply-adds and holds w, p (and the Gram
+// accumulators of the matrix pipe) in registers -- at rank 128 that is 16 384 unrolled FMAs and > 512 registers.  Here:
+//   * one lane per row as before, the row's w[128] in registers; the component loop runs over blocks of 32 components
+//     (unrolled 4 x) with a RUNTIME loop inside a block: the dot product  grad = -p_t + sum_r G[t][r] w[r]  reads all
+//     128 registers statically (same summation order r = 0 .. k-1 as _update_cdnmf_fast: the terms r >= k are + 0), the
+//     one dynamically indexed register write w[t] = new value is a 32-way select chain on the wave-uniform index;
+//   * p_t and the running w_t of the current block sit in a per-lane LDS strip (stride 33: conflict-free), G [128][132]
+//     in LDS is read with broadcast 16-byte loads;
+//   * the Gram matrix of the updated rows is a separate launch (gram_big_kernel, matrix pipe, re-reads the rows) and the
+//     split-K partial planes of pass B are reduced by reduce_splits_kernel first (no PSUM) -- ranks this large are the
+//     rare case; what matters is that they run, correctly, next to the small ones in the same batch.
+// RMX: exact per-component maxima (x the per-row scale) for the f16 plane split of the H half-step.
+constexpr int KBIG = 128;
+constexpr int KBIG_GS = KBIG + 4;
+static inline size_t sweep_big_lds_bytes() { return sizeof(float) * (size_t)(KBIG * KBIG_GS + 2 * 256 * 33 + 4 * KBIG + 16); }
+
+template <bool RMX>
+__global__ __launch_bounds__(256) void sweep_big_kernel(
+    float* __restrict__ V, int ldv, int L, const float* __restrict__ P, SplitInfo sp, const float* __restrict__ gram,
+    const SlotDesc* __restrict__ slots, float l1_reg, double* __restrict__ viol_part, int chunks_per_block,
+    float* __restrict__ rmax_part, const double* __restrict__ rmax_scale)
+{
+    const int slot = blockIdx.y;
+    const SlotDesc sd = slots[slot];
+    if (!sd.active || sd.k <= KSMALL) return;
+    extern __shared__ __attribute__((aligned(16))) float sweep_lds[];
+    float* Gs = sweep_lds;                                  // [128][132]
+    float* Pl = Gs + KBIG * KBIG_GS;                        // [256][33]  p_t - l1 of the current 32-block, per lane
+    float* Wl = Pl + 256 * 33;                              // [256][33]  running w_t of the current 32-block, per lane
+    float* rmx = Wl + 256 * 33;                             // [4][128]
+    double* vred = reinterpret_cast<double*>(rmx + 4 * KBIG);
+    const int k = sd.k, off = sd.off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < KBIG * KBIG; e += 256) {
+        const int r = e / KBIG, c = e % KBIG;
+        Gs[r * KBIG_GS + c] = (r < k && c < k) ? gram[(size_t)slot * GRAM_SZ + r * GRAM_LD + c] : 0.f;
+    }
+    if (RMX) for (int e = tid; e < 4 * KBIG; e += 256) rmx[e] = 0.f;
+    __syncthreads();
+    float viol = 0.f;
+    float* pl = Pl + tid * 33;
+    float* wl = Wl + tid * 33;
+    for (int ch = 0; ch < chunks_per_block; ++ch) {
+        const int row = (blockIdx.x * chunks_per_block + ch) * 256 + tid;
+        const bool live = row < L;
+        const int rowc = min(row, L - 1);
+        int cut0 = 0, cut1 = 0, mg_edge = 1 << 30;
+        if (sp.plane1) {                                    // stream-K pass A: cut flags of this wave's row tile
+            const int rt = __builtin_amdgcn_readfirstlane(rowc / sp.tile_rows);
+            const int g0 = off / sp.tile_cols, g1 = (off + k - 1) / sp.tile_cols;
+            mg_edge = (g0 + 1) * sp.tile_cols;
+            cut0 = sp.split[rt * sp.mgroups + g0];
+            cut1 = sp.split[rt * sp.mgroups + g1];
+        }
+        float w[KBIG];
+#pragma unroll
+        for (int c = 0; c < KBIG; ++c) {
+            const float v = V[(size_t)(off + min(c, k - 1)) * ldv + rowc];
+            w[c] = (live && c < k) ? v : 0.f;
+        }
+        float dsc = 1.0f;
+        if (RMX && rmax_scale) dsc = (float)rmax_scale[rowc];
+#pragma unroll
+        for (int tb = 0; tb < KBIG / 32; ++tb) {
+            if (tb * 32 < k) {                              // wave-uniform
+#pragma unroll
+                for (int rr = 0; rr < 32; ++rr) {
+                    const int c = tb * 32 + rr;
+                    const size_t idx = (size_t)(off + min(c, k - 1)) * ldv + rowc;
+                    float pv = P[idx];
+                    const int cut = ((off + c) < mg_edge) ? cut0 : cut1;
+                    if (cut & 1) pv += sp.plane1[idx];      // (wave-uniform per component)
+                    if (cut & 2) pv += sp.plane2[idx];
+                    pl[rr] = (live && c < k) ? pv - l1_reg : 0.f;
+                    wl[rr] = w[c];
+                }
+                __builtin_amdgcn_wave_barrier();            // per-lane strips: LDS operations of one wave are in order
+                const int tend = min(32, k - tb * 32);
+                for (int tt = 0; tt < tend; ++tt) {
+                    const int t = tb * 32 + tt;
+                    const float4* g4 = reinterpret_cast<const float4*>(Gs + t * KBIG_GS);
+                    float grad = -pl[tt];
+#pragma unroll
+                    for (int r4 = 0; r4 < KBIG / 4; ++r4) {
+                        const float4 g = g4[r4];
+                        grad = fmaf(g.x, w[4 * r4 + 0], grad);
+                        grad = fmaf(g.y, w[4 * r4 + 1], grad);
+                        grad = fmaf(g.z, w[4 * r4 + 2], grad);
+                        grad = fmaf(g.w, w[4 * r4 + 3], grad);
+                    }
+                    const float wt = wl[tt];
+                    const float pg = (wt == 0.f) ? fminf(0.f, grad) : grad;
+                    viol += live ? fabsf(pg) : 0.f;
+                    const float hess = Gs[t * KBIG_GS + t];
+                    float wn = wt;
+                    if (hess != 0.f) wn = fmaxf(wt - grad / hess, 0.f);
+#pragma unroll
+                    for (int rr = 0; rr < 32; ++rr) w[tb * 32 + rr] = (rr == tt) ? wn : w[tb * 32 + rr];
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < KBIG; ++c)
+                if (c < k) V[(size_t)(off + c) * ldv + row] = w[c];
+        }
+        if (RMX) {
+#pragma unroll
+            for (int c = 0; c < KBIG; ++c) {
+                if (c < k) {                                // wave-uniform
+                    float v = w[c] * dsc;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+                    if (lane == 0) rmx[wave * KBIG + c] = fmaxf(rmx[wave * KBIG + c], v);
+                }
+            }
+        }
+    }
+    double dv = (double)viol;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dv += __shfl_xor(dv, o, 64);
+    if (lane == 0) vred[wave] = dv;
+    __syncthreads();
+    if (tid == 0) viol_part[(size_t)slot * gridDim.x + blockIdx.x] = vred[0] + vred[1] + vred[2] + vred[3];
+    if (RMX && rmax_part && tid < k)
+        rmax_part[(size_t)(off + tid) * gridDim.x + blockIdx.x] =
+            fmaxf(fmaxf(rmx[tid], rmx[KBIG + tid]), fmaxf(rmx[2 * KBIG + tid], rmx[3 * KBIG + tid]));
+}
+
+// Gram partial of the rows of one (row block, slot) for ranks 65..128: gram_part[slot][block] = V_rows^T . V_rows on the
+// exact-f32 matrix pipe, 32 rows staged through LDS per step, each wave a 64 x 64 quadrant (2 x 2 tiles of 32 x 32).
+// Also (rmax_part != nullptr) the row-scale bound of the f16 plane split, sqrt of the diagonal (see sweep_body).
+__global__ __launch_bounds__(256) void gram_big_kernel(const float* __restrict__ V, int ldv, int L,
+                                                       const SlotDesc* __restrict__ slots, float* __restrict__ gram_part,
+                                                       int chunks_per_block, int gld, float* __restrict__ rmax_part)
+{
+    const int slot = blockIdx.y;
+    const SlotDesc sd = slots[slot];
+    if (!sd.active || sd.k <= KSMALL) return;
+    __shared__ float T[32][KBIG_GS];
+    __shared__ float diag[KBIG];
+    const int k = sd.k, off = sd.off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int r_begin = blockIdx.x * chunks_per_block * 256, r_end = min(L, r_begin + chunks_per_block * 256);
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + 256 * i, c = e >> 5, rr = e & 31;
+            T[rr][c] = (r0 + rr < r_end && c < k) ? V[(size_t)(off + c) * ldv + r0 + rr] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const float a0 = T[2 * s2 + h][wr * 64 + li], a1 = T[2 * s2 + h][wr * 64 + 32 + li];
+            const float b0 = T[2 * s2 + h][wc * 64 + li], b1 = T[2 * s2 + h][wc * 64 + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* gp = gram_part + ((size_t)slot * gridDim.x + blockIdx.x) * (size_t)(gld * gld);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, gc = wc * 64 + j * 32 + li;
+                if (gr < k && gc < k) gp[gr * gld + gc] = acc[i][j][r];
+                if (gr == gc && gr < KBIG) diag[gr] = acc[i][j][r];
+            }
+    __syncthreads();
+    if (rmax_part && tid < k) rmax_part[(size_t)(off + tid) * gridDim.x + blockIdx.x] = sqrtf(diag[tid]) * 1.0001f;
+}
+
 // Sum the split-K partials of pass B in split order (deterministic): out = sum_s P[s].
 // float4 grid-stride; rows of inactive / unused component columns are skipped via `rows`.
 __global__ __launch_bounds__(256) void reduce_splits_kernel(
@@ -556,40 +743,37 @@ __global__ __launch_bounds__(256) void split2h_finalize_kernel(const float* __re
 
 // Gram matrix of the k rows [off, off+k) of a component-major factor (used once
 // per restart, for the initial HHt of H0; sklearn _nmf.py:386).  One workgroup per slot.
-__global__ __launch_bounds__(256) void gram_rows_kernel(
-    const float* __restrict__ V, int ldv, int L,
-    const SlotDesc* __restrict__ slots, const int* __restrict__ slot_list,
-    float* __restrict__ gram_out, float l2_reg)
+template <int KR, int GC>
+__device__ __forceinline__ void gram_rows_body(const float* __restrict__ V, int ldv, int L, int k, int off, int slot,
+                                               float* __restrict__ gram_out, float l2_reg, float* lds)
 {
-    const int slot = slot_list[blockIdx.x];
-    const SlotDesc sd = slots[slot];
-    const int k = sd.k, off = sd.off;
-    __shared__ float tile[KMAX][129];
+    float (*tile)[GC + 1] = reinterpret_cast<float (*)[GC + 1]>(lds);
     const int tid = threadIdx.x;
-    // thread owns the (a,b) pairs e = tid + 256*i, e < k*k  (k <= 64 -> at most 16 pairs)
-    double acc[16];
+    // thread owns the (a,b) pairs e = tid + 256*i, e < k*k
+    constexpr int NP = KR * KR / 256;
+    double acc[NP];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-    for (int g0 = 0; g0 < L; g0 += 128) {
-        for (int e = tid; e < k * 128; e += 256) {
-            const int c = e / 128, g = e % 128;
+    for (int i = 0; i < NP; ++i) acc[i] = 0.0;
+    for (int g0 = 0; g0 < L; g0 += GC) {
+        for (int e = tid; e < k * GC; e += 256) {
+            const int c = e / GC, g = e % GC;
             tile[c][g] = (g0 + g < L) ? V[(size_t)(off + c) * ldv + g0 + g] : 0.f;
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const int e = tid + 256 * i;
             if (e < k * k) {
                 const int a = e / k, b = e % k;
                 float s = 0.f;
-                for (int g = 0; g < 128; ++g) s = fmaf(tile[a][g], tile[b][g], s);
+                for (int g = 0; g < GC; ++g) s = fmaf(tile[a][g], tile[b][g], s);
                 acc[i] += (double)s;
             }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NP; ++i) {
         const int e = tid + 256 * i;
         if (e < k * k) {
             const int a = e / k, b = e % k;
@@ -598,6 +782,19 @@ __global__ __launch_bounds__(256) void gram_rows_kernel(
             gram_out[(size_t)slot * GRAM_SZ + a * GRAM_LD + b] = s;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void gram_rows_kernel(
+    const float* __restrict__ V, int ldv, int L,
+    const SlotDesc* __restrict__ slots, const int* __restrict__ slot_list,
+    float* __restrict__ gram_out, float l2_reg)
+{
+    const int slot = slot_list[blockIdx.x];
+    const SlotDesc sd = slots[slot];
+    __shared__ __attribute__((aligned(16))) float lds[KSMALL * 129];          // = 64 x 129 >= 128 x 65
+    // ranks <= 64: 128 columns per step (as in rounds 1-2: same bits); 65..128: 64 columns per step
+    if (sd.k <= KSMALL) gram_rows_body<KSMALL, 128>(V, ldv, L, sd.k, sd.off, slot, gram_out, l2_reg, lds);
+    else gram_rows_body<KMAX, 64>(V, ldv, L, sd.k, sd.off, slot, gram_out, l2_reg, lds);
 }
 
 // Install a restart into its slot: H0 [k][G] row-major -> H_all rows, W0 [N][k]

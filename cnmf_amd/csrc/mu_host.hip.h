@@ -346,7 +346,7 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
     for (int r = 0; r < n; ++r) {
         const int k = kk[r];
         if (k < 1) { SET_ERR(ctx, "n_components must be >= 1"); return CNMF_EINVAL; }
-        if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
+        if (k > CNMF_MU_KMAX) { SET_ERR(ctx, "n_components=%d > %d is not supported by the multiplicative-update solver on the device", k, CNMF_MU_KMAX); return CNMF_EUNSUPPORTED; }
         if (k > 32 && beta != 1) { SET_ERR(ctx, "itakura-saito with n_components > 32 is not supported on the device"); return CNMF_EUNSUPPORTED; }
     }
     // rank <= 32: batched on the matrix pipe (kernels_mu_mfma.hip.h); the rest below, one by one

@@ -22,8 +22,10 @@ __global__ __launch_bounds__(256) void xtw_f64_kernel(const float* __restrict__ 
                                                       const double* __restrict__ W, int k, int zs,
                                                       const double* __restrict__ mean,
                                                       const double* __restrict__ inv_std, int rows_per_block,
-                                                      double* __restrict__ part)
+                                                      double* __restrict__ part, int t0 = 0, int ktot = 0)
 {
+    // (ranks above 64: the columns [t0, t0 + k) of a W with `ktot` columns per row; part rows t0 + t of ktot)
+    if (ktot == 0) ktot = k;
     __shared__ double Ws[64 * KT];                       // 64 rows of W at a time
     const int g = blockIdx.x * 256 + threadIdx.x;
     const int rb = blockIdx.y * rows_per_block, re = min(rb + rows_per_block, N);
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(256) void xtw_f64_kernel(const float* __restrict__ 
     for (int i0 = rb; i0 < re; i0 += 64) {
         const int nr = min(64, re - i0);
         __syncthreads();
-        for (int e = threadIdx.x; e < nr * k; e += 256) Ws[(e / k) * KT + (e % k)] = W[(size_t)(i0 + e / k) * k + (e % k)];
+        for (int e = threadIdx.x; e < nr * k; e += 256) Ws[(e / k) * KT + (e % k)] = W[(size_t)(i0 + e / k) * ktot + t0 + (e % k)];
         __syncthreads();
         if (g < G)
             for (int r = 0; r < nr; ++r) {
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void xtw_f64_kernel(const float* __restrict__ 
             }                                                                              //  of no consequence: never stored)
     }
     if (g < G)
-        for (int t = 0; t < k; ++t) part[((size_t)blockIdx.y * k + t) * G + g] = acc[t];
+        for (int t = 0; t < k; ++t) part[((size_t)blockIdx.y * ktot + t0 + t) * G + g] = acc[t];
 }
 
 // out[t][g] = sum_rb part[rb][t][g]   (block order: deterministic)
@@ -105,7 +107,10 @@ static int xtw_f64_device(cnmf_ctx* ctx, DevPool& pool, const double* dW, int k,
     POOL_TRY(ctx, pool);
     dim3 grid(gx, nrb);
 #define CNMF_XTW(KT_) xtw_f64_kernel<KT_><<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, dW, k, zs, dmean, dinv, rpb, dpart)
-    if (k <= 8) CNMF_XTW(8); else if (k <= 16) CNMF_XTW(16); else if (k <= 32) CNMF_XTW(32); else CNMF_XTW(64);
+    if (k <= 8) CNMF_XTW(8); else if (k <= 16) CNMF_XTW(16); else if (k <= 32) CNMF_XTW(32); else if (k <= 64) CNMF_XTW(64);
+    else
+        for (int t0 = 0; t0 < k; t0 += 64)          // ranks 65..128: 64 columns of W per launch
+            xtw_f64_kernel<64><<<grid, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, dW, std::min(64, k - t0), zs, dmean, dinv, rpb, dpart, t0, k);
 #undef CNMF_XTW
     const long long n = (long long)k * G;
     sum_parts_f64_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dpart, nrb, n, d_out);
@@ -173,7 +178,7 @@ static int nnls_sweep_loop(cnmf_ctx* ctx, int nslots, float* V, int ldv, int L, 
 static int tiers_of(const int32_t* ks, int n)
 {
     int t = 0;
-    for (int i = 0; i < n; ++i) t |= ks[i] <= 16 ? 1 : (ks[i] <= 32 ? 2 : 4);
+    for (int i = 0; i < n; ++i) t |= ks[i] <= 16 ? 1 : (ks[i] <= 32 ? 2 : (ks[i] <= KSMALL ? 4 : 8));
     return t;
 }
 
@@ -205,7 +210,7 @@ extern "C" int cnmf_nnls_spectra(cnmf_ctx* ctx, int k, const double* W, const cn
     if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int N = (int)ctx->N, G = (int)ctx->G;
-    const int KC = k <= 32 ? 32 : 64;
+    const int KC = k <= 32 ? 32 : (k <= 64 ? 64 : 128);
     rc = ensure_batch(ctx, KC, k, k);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
@@ -331,7 +336,8 @@ static int nnls_batch_impl(cnmf_ctx* ctx, int n, const int32_t* ks, const float*
                 double* dW64 = p2.get<double>((size_t)N * k);
                 double* dH64 = p2.get<double>((size_t)k * G);
                 const int rpb = 512;
-                dim3 grid((G + 255) / 256, (N + rpb - 1) / rpb);
+                const int bw = k <= 64 ? 256 : 128;
+                dim3 grid((G + bw - 1) / bw, (N + rpb - 1) / rpb);
                 double* dpart = p2.get<double>((size_t)grid.x * grid.y);
                 double* dsum = p2.get<double>(1);
                 POOL_TRY(ctx, p2);
@@ -345,9 +351,9 @@ static int nnls_batch_impl(cnmf_ctx* ctx, int n, const int32_t* ks, const float*
                     else
                         f32_to_f64_kernel<<<(unsigned)((nh + 255) / 256), 256, 0, st>>>(dHin + (size_t)off * G, nh, dH64);
                 }
-                const size_t lds = (size_t)k * 256 * sizeof(double);
-                if (lds > 48 * 1024) HIP_TRY(ctx, hipFuncSetAttribute((const void*)residual_sq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                residual_sq_kernel<<<grid, 256, lds, st>>>(ctx->X, ctx->G_pad, N, G, dW64, dH64, k, rpb, dpart);
+                const size_t lds = (size_t)k * bw * sizeof(double);
+                HIP_TRY(ctx, dyn_lds_optin((const void*)residual_sq_kernel, 160 * 1024 - 64));
+                residual_sq_kernel<<<grid, bw, lds, st>>>(ctx->X, ctx->G_pad, N, G, dW64, dH64, k, rpb, dpart);
                 sum_kernel<<<1, 256, 0, st>>>(dpart, (int)(grid.x * grid.y), dsum);
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipMemcpyAsync(&err_out[done_n + s], dsum, sizeof(double), hipMemcpyDeviceToHost, st));

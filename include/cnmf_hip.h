@@ -35,7 +35,10 @@ extern "C" {
 #define CNMF_EUNSUPPORTED -5   /* e.g. rank > CNMF_KMAX (NotImplementedError)    */
 #define CNMF_ECOMM        -6   /* RCCL failure                                   */
 
-#define CNMF_KMAX 64           /* largest rank handled by the device sweep       */
+#define CNMF_KMAX 128          /* largest rank of the coordinate-descent / NNLS / consensus entry points
+                                  (<= 64: register-resident sweep; 65..128: sweep_big_kernel)              */
+
+#define CNMF_MU_KMAX 64        /* largest rank of the multiplicative-update solver (cnmf_nmf_mu_batch)      */
 
 typedef struct cnmf_ctx cnmf_ctx;
 

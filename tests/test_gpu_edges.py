@@ -15,7 +15,8 @@ def _x(n, g, seed=0):
 
 
 @pytest.mark.parametrize("n,g,k", [(7, 5, 2), (33, 31, 3), (129, 33, 5), (257, 65, 1), (200, 140, 32), (64, 128, 9),
-                                   (300, 150, 33), (260, 200, 48), (400, 180, 64)])
+                                   (300, 150, 33), (260, 200, 48), (400, 180, 64),
+                                   (300, 170, 65), (500, 260, 96), (1100, 300, 128)])
 def test_small_and_ragged_shapes(engine, n, g, k):
     X = _x(n, g, seed=n + g)
     engine.set_matrix(X)
@@ -28,6 +29,47 @@ def test_small_and_ragged_shapes(engine, n, g, k):
     # same init, same component order: compare the reconstructions (robust to near-degenerate factors)
     R, R_ref = W[0].astype(np.float64) @ H[0], W_ref @ H_ref
     assert np.abs(R - R_ref).max() <= 2e-3 * max(1.0, np.abs(R_ref).max())
+
+
+def test_ranks_above_64_next_to_small_ones_and_their_refits(engine):
+    """Ranks 65 .. 128 (sweep_big_kernel: w in registers, p / running w in per-lane LDS strips, Gram as its own launch)
+    in ONE batch with small ranks (the register-resident tiers), to sklearn's stopping rule; then the NNLS refit and the
+    prediction error at rank 100, and the rank limit itself."""
+    X = _x(700, 260, seed=21)
+    engine.set_matrix(X)
+    ks = [5, 128, 9, 70, 33, 96, 64, 65]
+    seeds = list(range(31, 31 + len(ks)))
+    H, W, n_iter, viol = engine.nmf_batch(ks, seeds=seeds, max_iter=80, return_W=True, warn=False)
+    for k, s_, h, w, n in zip(ks, seeds, H, W, n_iter):
+        W_ref, H_ref, n_ref = nmf_cd.nmf(X, k, seed=s_, max_iter=80)
+        assert h.shape == (k, 260) and w.shape == (700, k) and abs(int(n) - n_ref) <= 2, (k, int(n), n_ref)
+        if int(n) != n_ref:
+            W_ref, H_ref, _ = nmf_cd.nmf(X, k, seed=s_, max_iter=int(n), tol=0.0)
+        R, R_ref = w.astype(np.float64) @ h, W_ref @ H_ref
+        assert np.abs(R - R_ref).max() <= 2e-3 * max(1.0, np.abs(R_ref).max()), k
+    H2, _, n2, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=80, warn=False)
+    assert list(n2) == list(n_iter) and all(np.array_equal(a, b) for a, b in zip(H, H2))      # deterministic
+    _, Hr, _ = nmf_cd.nmf(X, 100, seed=3, max_iter=30)
+    W_ref, n_ref = nmf_cd.nnls(X, Hr, max_iter=60)
+    Wd, nd = engine.nnls(Hr, max_iter=60, warn=False)
+    assert abs(nd - n_ref) <= 2 and np.abs(Wd - W_ref).max() <= 2e-3 * np.abs(W_ref).max()
+    ref = ((X - W_ref @ Hr) ** 2).sum()
+    assert abs(engine.prediction_error(W_ref, Hr) - ref) <= 1e-6 * ref
+    with pytest.raises(NotImplementedError):
+        engine.nmf_batch([129], seeds=[1], max_iter=5)
+
+
+def test_consensus_with_more_than_64_clusters(engine):
+    """KMeans / medians / silhouette of the consensus core with k = 100 clusters against the oracle."""
+    from cnmf_amd import synth
+    from oracle import consensus as oc
+    S, _ = synth.consensus_stress(R=1200, G=150, k=100, n_outliers=40, seed=6)
+    ref = oc.consensus_core(S, np.abs(np.random.RandomState(0).standard_normal((20, 150))), 100, density_threshold=0.5)
+    out = engine.consensus(S, 100, density_threshold=0.5, want_silhouette=True)
+    assert np.array_equal(out["density_filter"], ref["density_filter"])
+    assert np.array_equal(out["labels"][out["density_filter"]] + 1, ref["kmeans_labels"])
+    assert np.abs(out["median_spectra"] - ref["median_spectra"]).max() < 1e-12
+    assert abs(out["silhouette"] - oc.silhouette_score(ref["l2_spectra"], ref["kmeans_labels"])) < 1e-9
 
 
 def test_empty_restart_list(engine):

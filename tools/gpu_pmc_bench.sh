@@ -8,7 +8,7 @@ cd /tmp
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   stag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmcb/$stag -o pmc --output-format csv -- \
-     python $R/bench.py --steps 1 --warmup 0 --restarts-per-k 3 --no-cpu-baseline --no-extras > $R/gpurun_out/pmcb/$stag.log 2>&1
+     python $R/bench.py --steps 1 --warmup 0 --restarts-per-k ${RPK:-100} --no-cpu-baseline --no-extras > $R/gpurun_out/pmcb/$stag.log 2>&1
 done
 cd $R
 python - <<PY
@@ -22,8 +22,15 @@ for f in glob.glob(R+'/gpurun_out/pmcb/*/**/*counter_collection.csv', recursive=
 def mean(name_part, c):
     v=[x for n,cs in acc.items() if name_part in n for x in cs.get(c,[])]
     return (sum(v)/len(v), len(v)) if v else (None, 0)
-N_pad, G_pad, KC = 50176, 2048, 256
-out={"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES (separate passes, --kernel-trace only) around \`bench.py --steps 1 --warmup 0 --restarts-per-k 3 --no-cpu-baseline\` on the default path (CNMF_GEMM3=4: count structure detected -> f16 two-plane kernels), tools/gpu_pmc_bench.sh; mean over all launches of the kernel. FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B/lane reads, LDS-DMA included; Infinity-Cache hits are counted). mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs)."}
+N_pad, G_pad = 50176, 2048
+# the batch geometry of the profiled run, from its own JSON line (written by the WRITE_SIZE pass)
+try:
+    bl=[l for l in open(R+'/gpurun_out/pmcb/WRITE_SIZE.log') if l.startswith('{')][-1]; bj=json.loads(bl)
+    KC=int(bj['config']['packed_columns']); NSPLIT=int(bj['config']['splitk_passB'])
+except Exception:
+    KC, NSPLIT = 1024, 8
+out_geom={"packed_columns": KC, "splitk_passB": NSPLIT}
+out={"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES (separate passes, --kernel-trace only) around \`bench.py --steps 1 --warmup 0 --restarts-per-k 100 --no-cpu-baseline --no-extras\` (the bench step itself: 900 restarts, wide batch of 1024 packed columns narrowing in the tail) on the default path (CNMF_GEMM3=4: count structure detected -> f16 two-plane kernels), tools/gpu_pmc_bench.sh; mean over all launches of the kernel. FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B/lane reads, LDS-DMA included; Infinity-Cache hits are counted). mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs)."}
 for key, part in (("passA","gemm2h_streamk_kernel"),("passB","gemm2h_kernel"),("sweepW","sweep_kernel<0, false, false>"),("split","split2h_finalize_kernel")):
     e={"kernel": part}
     for c in ("FETCH_SIZE","WRITE_SIZE","SQ_VALU_MFMA_BUSY_CYCLES","GRBM_GUI_ACTIVE"):
@@ -36,11 +43,14 @@ for key, part in (("passA","gemm2h_streamk_kernel"),("passB","gemm2h_kernel"),("
 xplane = N_pad*G_pad*2
 out["algorithmic_bytes_per_launch"]={
   "passA": xplane + KC*G_pad*4 + KC*N_pad*4,
-  "passB": xplane + KC*N_pad*4 + 32*KC*G_pad*4,
-  "note": "count plane of X (or X^T) once (2 B per element, f16) + the factor's two f16 planes once (4 B per element) + the product written once (pass A: one XHt plane of 51 MB -- the stream-K partial planes of cut tiles come on top; pass B: 32 split-K partial planes of 2 MB)"}
+  "passB": xplane + KC*N_pad*4 + NSPLIT*KC*G_pad*4,
+  "note": "count plane of X (or X^T) once (2 B per element, f16) + the factor's two f16 planes once (4 B per element) + the product written once (pass A: one XHt plane of 51 MB -- the stream-K partial planes of cut tiles come on top; pass B: the split-K partial planes)"}
 import sys; sys.path.insert(0, R)
 from bench import source_hashes
 out['kernel_source_sha256']=source_hashes()
+out['geometry']=out_geom
 json.dump(out, open(R+'/gpurun_out/pmc_traffic.json','w'), indent=1)
 print(json.dumps({k:(v if not isinstance(v,dict) else {kk:vv for kk,vv in v.items() if kk in('hbm_bytes_per_launch','mfma_busy_frac','launches')}) for k,v in out.items() if k!='_source'}, indent=1))
 PY
+# the raw per-dispatch counter CSVs (hundreds of MB at 5000+ launches per kernel) stay on the GPU box
+rm -rf $R/gpurun_out/pmcb/FETCH_SIZE $R/gpurun_out/pmcb/WRITE_SIZE $R/gpurun_out/pmcb/SQ_VALU_MFMA_BUSY_CYCLES
