@@ -197,11 +197,11 @@ class cNMF:
             ks = [ks]
         k_list = sorted(set(list(ks)))
         from ._lib import CNMF_KMAX, CNMF_MU_KMAX
-        kmax = CNMF_KMAX if beta_loss == "frobenius" else (CNMF_MU_KMAX if beta_loss == "kullback-leibler" else 32)
+        kmax = CNMF_KMAX if beta_loss == "frobenius" else CNMF_MU_KMAX
         if k_list and max(k_list) > kmax:
             # fail at prepare time, not after the restarts were paid for (the reference itself has no limit,
-            # cnmf.py:1243; the device engine: 128 for the coordinate-descent solver, 64 / 32 for the
-            # multiplicative-update solver with the Kullback-Leibler / Itakura-Saito loss)
+            # cnmf.py:1243; the device engine: 128 for the coordinate-descent solver, 64 for the
+            # multiplicative-update solver)
             raise NotImplementedError("n_components=%d > %d is not supported by the device engine (beta_loss=%r)"
                                       % (max(k_list), kmax, beta_loss))
         replicate_params = []
@@ -417,7 +417,7 @@ class cNMF:
                       l1_ratio=_nmf_kwargs.get("l1_ratio", 0.0))
         init_kw = dict(seeds=seeds)
         if _nmf_kwargs.get("init") == "nndsvd":
-            inits = [eng.nndsvd_init(k, random_state=s) for k, s in zip(ks, seeds)]
+            inits = eng.nndsvd_init_batch(ks, seeds)           # range finders of up to 13 restarts per pass over X
             init_kw = dict(W0=[w for w, _ in inits], H0=[h for _, h in inits])
         if _nmf_kwargs.get("solver", "cd") == "mu":
             H_list, _, n_iter, _ = eng.nmf_mu_batch(ks, beta_loss=_nmf_kwargs["beta_loss"], **init_kw, **common)

@@ -347,7 +347,6 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
         const int k = kk[r];
         if (k < 1) { SET_ERR(ctx, "n_components must be >= 1"); return CNMF_EINVAL; }
         if (k > CNMF_MU_KMAX) { SET_ERR(ctx, "n_components=%d > %d is not supported by the multiplicative-update solver on the device", k, CNMF_MU_KMAX); return CNMF_EUNSUPPORTED; }
-        if (k > 32 && beta != 1) { SET_ERR(ctx, "itakura-saito with n_components > 32 is not supported on the device"); return CNMF_EUNSUPPORTED; }
     }
     // rank <= 32: batched on the matrix pipe (kernels_mu_mfma.hip.h); the rest below, one by one
     std::vector<char> done(n, 0);
@@ -417,9 +416,7 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
                                                  dpart, dcs, update_H, prm, &nit, &err)                              \
                          : mu_run_one<KP_, false>(ctx, st, N, G, k, dW, dHt, dHsum, dWsum, pnum, pden, nchunks, rpc, \
                                                   dpart, dcs, update_H, prm, &nit, &err)
-        if (KP == 8) { MU_GO(8); } else if (KP == 16) { MU_GO(16); } else if (KP == 32) { MU_GO(32); }
-        else rc = mu_run_one<64, true>(ctx, st, N, G, k, dW, dHt, dHsum, dWsum, pnum, pden, nchunks, rpc, dpart,
-                                       dcs, update_H, prm, &nit, &err);
+        if (KP == 8) { MU_GO(8); } else if (KP == 16) { MU_GO(16); } else if (KP == 32) { MU_GO(32); } else { MU_GO(64); }
 #undef MU_GO
         if (rc) return rc;
         if (H_out && update_H) {

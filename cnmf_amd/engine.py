@@ -518,61 +518,130 @@ class Engine:
         return out
 
     def nndsvd_init(self, n_components, random_state=None, eps=1e-6):
-        """sklearn's ``init='nndsvd'`` (decomposition/_nmf.py:316-354) with every product against X
-        on the device: ``_randomized_svd`` (utils/extmath.py:531-602: n_oversamples=10, n_iter 7|4,
-        LU-normalised power iterations, final QR, small SVD, svd_flip), then the positive/negative
-        split.  Returns (W0, H0) in float64 (cast to X's dtype by the caller, like sklearn)."""
+        """sklearn's ``init='nndsvd'`` for ONE restart (decomposition/_nmf.py:316-354); see :meth:`nndsvd_init_batch`.
+        Returns (W0, H0) in float64 (cast to X's dtype by the caller, like sklearn)."""
+        return self.nndsvd_init_batch([n_components], [random_state], eps=eps)[0]
+
+    def nndsvd_init_batch(self, ks, random_states, eps=1e-6, max_cols=256, threads=None):
+        """sklearn's ``init='nndsvd'`` (decomposition/_nmf.py:316-354) for MANY restarts: ``_randomized_svd``
+        (utils/extmath.py:531-602: n_oversamples=10, n_iter 7|4, LU-normalised power iterations, final QR, small
+        SVD, svd_flip), then the positive/negative split.
+
+        Every product against X runs on the device, and the range finders of a whole GROUP of restarts ride in one
+        pass: their (k + 10)-column blocks sit side by side (up to ``max_cols`` = 256 columns: 13 restarts of rank 9),
+        so the 2 * n_iter + 2 passes over X are paid once per group, not once per restart.  The factorizations of the
+        (k + 10)-wide blocks (LU / QR / SVD, LAPACK releases the GIL) run on a thread pool between two passes.
+        Returns a list of (W0, H0) in float64."""
+        from concurrent.futures import ThreadPoolExecutor
         from scipy import linalg
+        import os
         N, G = self.shape
-        k = int(n_components)
-        if k > min(N, G):
-            raise ValueError("init = 'nndsvd' can only be used when n_components <= min(n_samples, n_features)")
-        n_random = k + 10
-        n_iter = 7 if k < 0.1 * min(N, G) else 4
+        ks = [int(k) for k in ks]
+        if len(ks) != len(random_states):
+            raise ValueError("need one random_state per restart")
+        for k in ks:
+            if k > min(N, G):
+                raise ValueError("init = 'nndsvd' can only be used when n_components <= min(n_samples, n_features)")
         transpose = N < G                                     # M = X.T when n_samples < n_features
         M_rows, M_cols = (G, N) if transpose else (N, G)
-        mm = lambda Q: self.x_matmul(Q, trans=transpose).astype(np.float64)        # M @ Q      # noqa: E731
-        mtm = lambda Q: self.x_matmul(Q, trans=not transpose).astype(np.float64)   # M.T @ Q    # noqa: E731
-        rng = np.random.RandomState(random_state) if not isinstance(random_state, np.random.RandomState) else random_state
-        Q = rng.normal(size=(M_cols, n_random))
-        for _ in range(n_iter):
-            Q, _ = linalg.lu(mm(Q), permute_l=True, check_finite=False)
-            Q, _ = linalg.lu(mtm(Q), permute_l=True, check_finite=False)
-        Q, _ = linalg.qr(mm(Q), mode="economic", check_finite=False)
-        B = mtm(Q).T                                          # Q.T @ M
-        Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver="gesdd")
-        U = Q @ Uhat
-        if not transpose:                                     # svd_flip(u_based_decision=True)
-            signs = np.sign(U[np.argmax(np.abs(U), axis=0), np.arange(U.shape[1])])
-        else:
-            signs = np.sign(Vt[np.arange(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])
-        U = U * signs[np.newaxis, :]
-        Vt = Vt * signs[:, np.newaxis]
-        if transpose:
-            U, S, V = Vt[:k, :].T, s[:k], U[:, :k].T
-        else:
-            U, S, V = U[:, :k], s[:k], Vt[:k, :]
-        W = np.zeros_like(U)
-        H = np.zeros_like(V)
-        W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0])
-        H[0, :] = np.sqrt(S[0]) * np.abs(V[0, :])
-        for j in range(1, k):
-            x, y = U[:, j], V[j, :]
-            x_p, y_p = np.maximum(x, 0), np.maximum(y, 0)
-            x_n, y_n = np.abs(np.minimum(x, 0)), np.abs(np.minimum(y, 0))
-            x_p_nrm, y_p_nrm = np.sqrt(x_p @ x_p), np.sqrt(y_p @ y_p)
-            x_n_nrm, y_n_nrm = np.sqrt(x_n @ x_n), np.sqrt(y_n @ y_n)
-            m_p, m_n = x_p_nrm * y_p_nrm, x_n_nrm * y_n_nrm
-            if m_p > m_n:
-                u, v, sigma = x_p / x_p_nrm, y_p / y_p_nrm, m_p
+        n_rand = [k + 10 for k in ks]
+        n_iters = [7 if k < 0.1 * min(N, G) else 4 for k in ks]
+        if max(n_rand) > max_cols:
+            raise NotImplementedError("n_components + 10 = %d columns exceed one device pass (%d)" % (max(n_rand), max_cols))
+        if threads is None:                                  # CPUs this process may really use (affinity, cgroup quota)
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                threads = os.cpu_count() or 1
+            try:
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+                if quota != "max":
+                    threads = max(1, min(threads, int(float(quota) / float(period))))
+            except Exception:
+                pass
+        pool = ThreadPoolExecutor(max(1, min(threads, 64)))
+        # one LAPACK thread per factorization: the parallelism is ACROSS the restarts of a group (a BLAS that spawns its
+        # own 64 threads inside each of 16 pool threads runs slower than one thread would)
+        try:
+            from threadpoolctl import threadpool_limits
+            blas_limit = threadpool_limits(1)
+        except Exception:
+            blas_limit = None
+
+        def passes(Qs, trans):
+            """[M_r @ Q_r] (trans=False) or [M_r.T @ Q_r] for the blocks of one group: ONE device product."""
+            out = self.x_matmul(np.concatenate(Qs, axis=1), trans=trans).astype(np.float64)
+            offs = np.cumsum([0] + [q.shape[1] for q in Qs])
+            return [out[:, offs[i]:offs[i + 1]] for i in range(len(Qs))]
+
+        def lu_pl(A):
+            return linalg.lu(A, permute_l=True, check_finite=False)[0]
+
+        def finish(args):
+            k, Q, B = args                                    # Q [M_rows, c] orthonormal, B = Q.T @ M  [c, M_cols]
+            Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver="gesdd")
+            U = Q @ Uhat
+            if not transpose:                                 # svd_flip(u_based_decision=True)
+                signs = np.sign(U[np.argmax(np.abs(U), axis=0), np.arange(U.shape[1])])
             else:
-                u, v, sigma = x_n / x_n_nrm, y_n / y_n_nrm, m_n
-            lbd = np.sqrt(S[j] * sigma)
-            W[:, j] = lbd * u
-            H[j, :] = lbd * v
-        W[W < eps] = 0
-        H[H < eps] = 0
-        return W, H
+                signs = np.sign(Vt[np.arange(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])
+            U = U * signs[np.newaxis, :]
+            Vt = Vt * signs[:, np.newaxis]
+            if transpose:
+                U, S, V = Vt[:k, :].T, s[:k], U[:, :k].T
+            else:
+                U, S, V = U[:, :k], s[:k], Vt[:k, :]
+            W = np.zeros_like(U)
+            H = np.zeros_like(V)
+            W[:, 0] = np.sqrt(S[0]) * np.abs(U[:, 0])
+            H[0, :] = np.sqrt(S[0]) * np.abs(V[0, :])
+            for j in range(1, k):
+                x, y = U[:, j], V[j, :]
+                x_p, y_p = np.maximum(x, 0), np.maximum(y, 0)
+                x_n, y_n = np.abs(np.minimum(x, 0)), np.abs(np.minimum(y, 0))
+                x_p_nrm, y_p_nrm = np.sqrt(x_p @ x_p), np.sqrt(y_p @ y_p)
+                x_n_nrm, y_n_nrm = np.sqrt(x_n @ x_n), np.sqrt(y_n @ y_n)
+                m_p, m_n = x_p_nrm * y_p_nrm, x_n_nrm * y_n_nrm
+                if m_p > m_n:
+                    u, v, sigma = x_p / x_p_nrm, y_p / y_p_nrm, m_p
+                else:
+                    u, v, sigma = x_n / x_n_nrm, y_n / y_n_nrm, m_n
+                lbd = np.sqrt(S[j] * sigma)
+                W[:, j] = lbd * u
+                H[j, :] = lbd * v
+            W[W < eps] = 0
+            H[H < eps] = 0
+            return W, H
+
+        results = [None] * len(ks)
+        # groups of restarts whose blocks fit one pass AND that make the same number of power iterations
+        order = sorted(range(len(ks)), key=lambda r: (n_iters[r], ks[r]))
+        groups, cur, cols = [], [], 0
+        for r in order:
+            if cur and (cols + n_rand[r] > max_cols or n_iters[r] != n_iters[cur[0]]):
+                groups.append(cur); cur, cols = [], 0
+            cur.append(r); cols += n_rand[r]
+        if cur:
+            groups.append(cur)
+        try:
+            for grp in groups:
+                Qs = []
+                for r in grp:
+                    rs = random_states[r]
+                    rng = rs if isinstance(rs, np.random.RandomState) else np.random.RandomState(rs)
+                    Qs.append(rng.normal(size=(M_cols, n_rand[r])))
+                for _ in range(n_iters[grp[0]]):
+                    Qs = list(pool.map(lu_pl, passes(Qs, trans=transpose)))            # Q = PL of M @ Q
+                    Qs = list(pool.map(lu_pl, passes(Qs, trans=not transpose)))        # Q = PL of M.T @ Q
+                Qs = list(pool.map(lambda A: linalg.qr(A, mode="economic", check_finite=False)[0], passes(Qs, trans=transpose)))
+                Bs = [b.T for b in passes(Qs, trans=not transpose)]                    # Q.T @ M
+                for r, wh in zip(grp, pool.map(finish, [(ks[r], Q, B) for r, Q, B in zip(grp, Qs, Bs)])):
+                    results[r] = wh
+        finally:
+            pool.shutdown(wait=True)
+            if blas_limit is not None:
+                blas_limit.restore_original_limits()
+        return results
 
     # ------------------------------------------------------------------ consensus core
     def consensus(self, spectra, k, density_threshold=0.5, local_neighborhood_size=0.30,

@@ -104,7 +104,7 @@ class cNMF(_ref.cNMF):
                       alpha_H=kw.get("alpha_H", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
         init = dict(seeds=seeds)
         if kw.get("init") == "nndsvd":
-            inits = [eng.nndsvd_init(k, random_state=s) for k, s in zip(ks, seeds)]
+            inits = eng.nndsvd_init_batch(ks, seeds)           # range finders of up to 13 restarts per pass over X
             init = dict(W0=[w for w, _ in inits], H0=[h for _, h in inits])
         if kw.get("solver", "cd") == "mu":
             H, _, _, _ = eng.nmf_mu_batch(ks, beta_loss=kw["beta_loss"], **init, **common)

@@ -138,8 +138,19 @@ def test_large_rank_refit_and_mu(engine):
     assert int(nm[0]) == n_ref
     R, R_ref = Wm[0].astype(np.float64) @ Hm[0], W_ref @ H_ref
     assert np.abs(R - R_ref).max() <= 2e-3 * np.abs(R_ref).max()
+    # Itakura-Saito above rank 32 (vector-ALU kernels, one restart at a time) -- no longer refused
+    Xp = X + 0.05                                              # IS needs strictly positive data
+    engine.set_matrix(Xp)
+    for k_is in (40, 64):
+        W_ref, H_ref, n_ref = nmf_mu.nmf_mu(Xp, k_is, seed=6, beta_loss="itakura-saito", max_iter=40)
+        Hi, Wi, ni, _ = engine.nmf_mu_batch([k_is], seeds=[6], beta_loss="itakura-saito", max_iter=40, return_W=True, warn=False)
+        assert abs(int(ni[0]) - n_ref) <= 10
+        if int(ni[0]) != n_ref:
+            W_ref, H_ref, _ = nmf_mu.nmf_mu(Xp, k_is, seed=6, beta_loss="itakura-saito", max_iter=int(ni[0]), tol=0.0)
+        R, R_ref = Wi[0].astype(np.float64) @ Hi[0], W_ref @ H_ref
+        assert np.abs(R - R_ref).max() <= 5e-3 * np.abs(R_ref).max(), k_is
     with pytest.raises(NotImplementedError):
-        engine.nmf_mu_batch([40], seeds=[1], beta_loss="itakura-saito", max_iter=5)
+        engine.nmf_mu_batch([65], seeds=[1], max_iter=5)      # CNMF_MU_KMAX = 64
 
 
 @pytest.mark.parametrize("n,g,k", [(7, 5, 2), (33, 31, 3), (129, 33, 5), (257, 65, 1), (200, 140, 32), (64, 128, 16),

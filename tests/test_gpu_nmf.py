@@ -373,7 +373,7 @@ def test_rank_above_kmax_is_rejected(engine):
     X64 = synth.make_config("C1", dtype=np.float64, n_cells=300)
     engine.set_matrix(X64)
     with pytest.raises(NotImplementedError):
-        engine.nmf_batch([65], seeds=[1])
+        engine.nmf_batch([129], seeds=[1])
 
 
 def test_negative_input_raises(engine):
@@ -410,3 +410,10 @@ def test_nndsvd_init_matches_sklearn(engine, shape):
                                             random_state=42)
     H, _, n_iter, _ = engine.nmf_batch([6], W0=[W0], H0=[H0])
     _check(Hr, nr, H[0], n_iter[0], slack=3)
+    # the batched form (range finders of several restarts side by side in ONE pass over X): every restart as sklearn's
+    ks, seeds = [4, 6, 6, 9, 5, 30], [1, 42, 7, 3, 11, 5]
+    for (k, seed), (Wb, Hb) in zip(zip(ks, seeds), engine.nndsvd_init_batch(ks, seeds)):
+        W_ref, H_ref = _initialize_nmf(X, k, init="nndsvd", random_state=seed)
+        assert Wb.shape == W_ref.shape and Hb.shape == H_ref.shape
+        assert np.abs(Wb - W_ref).max() <= 1e-3 * np.abs(W_ref).max(), (k, seed)
+        assert np.abs(Hb - H_ref).max() <= 1e-3 * np.abs(H_ref).max(), (k, seed)
