@@ -56,7 +56,9 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf
 #   3  : count-structured X = (integers <= 256) x per-gene scale -> ONE integer plane, (ah + am + al)*n, all exact
 #   4  : the same on the f16 pipe (kernels_gemm2h.hip.h): counts <= 2048 in one f16 plane, the factor as TWO f16 planes
 #        with a per-row exponent (within 1 ulp_f32 of the f32 value, exact for 3 in 4), partial products exact
-SPLIT_MFMAS_PER_PRODUCT = {1: 6, 2: 6, 3: 3, 4: 2}
+#   5  : any other X on the f16 pipe: X and the factor both as two f16 planes with a per-row exponent, all four plane
+#        products (the 3 x 3 bf16 scheme of modes 1/2 drops the terms below 2^-18)
+SPLIT_MFMAS_PER_PRODUCT = {1: 6, 2: 6, 3: 3, 4: 2, 5: 4}
 HBM_PEAK_GBS = 8000.0
 # device sources whose text the committed PMC / ablation profiles describe: a profile taken from other sources is stale
 PROFILED_SOURCES = ("cnmf_amd/csrc/kernels_gemm2h.hip.h", "cnmf_amd/csrc/kernels_sweep.hip.h",
@@ -353,7 +355,7 @@ def pmc_traffic(key, gemm_mode):
     collected in separate rocprofv3 --pmc passes (tools/gpu_pmc_bench.sh) and committed under
     profiles/ -- counters cannot be read from inside an un-profiled run.  (detail, usable)."""
     name = {0: "r1_pmc_traffic.json", 1: "r1_pmc_traffic_split.json", 2: "r1_pmc_traffic_split.json",
-            3: "r1_pmc_traffic_counts.json", 4: "r3_pmc_traffic_f16.json"}[gemm_mode]
+            3: "r1_pmc_traffic_counts.json", 4: "r3_pmc_traffic_f16.json", 5: "r3_pmc_traffic_general.json"}[gemm_mode]
     d, verdict = load_profile(name)
     if d is None or key not in d:
         return None, False
@@ -402,8 +404,8 @@ def consensus_wallclock(eng, with_cpu=True):
 
 def general_path_step(X, ks_all, by_k, restarts_per_k, event_stride):
     """The same step on a matrix that is NOT count-structured as far as the engine is concerned (count detection off:
-    what a Harmony-corrected or TPM-normalised input gets, reference preprocess.py:270-358): the any-X split-operand
-    kernels, 3 x 3 bf16 planes, 6 MFMAs per f32-class product.  Bounded (restarts_per_k restarts per K)."""
+    what a Harmony-corrected or TPM-normalised input gets, reference preprocess.py:270-358): X itself as two f16
+    planes with a per-row exponent, 4 MFMAs per f32-class product (gemm_mode 5).  Bounded (restarts_per_k restarts per K)."""
     from cnmf_amd.engine import Engine
     N, G = X.shape
     eng = Engine(0, detect_counts=False)
@@ -433,11 +435,13 @@ def general_path_step(X, ks_all, by_k, restarts_per_k, event_stride):
                         % (len(ks), ks_all[0], ks_all[-1]),
             "restarts_per_s": len(ks) / dt, "restart_iterations_per_s": float(np.sum(n_iter)) / dt,
             "mean_iterations_per_restart": float(np.mean(n_iter)), "gemm_mode": int(st["gemm_mode"]),
-            "kernel": ("gemm3g_streamk_kernel (pass A, 3 x 3 bf16 planes)" if dom == "A" else "gemm3g_kernel (pass B, 3 x 3 bf16 planes)")
-                      if int(st["gemm_mode"]) in (1, 2) else "gemm_mode %d" % int(st["gemm_mode"]),
+            "kernel": (("gemm3g_streamk_kernel (pass A, 3 x 3 bf16 planes)" if dom == "A" else "gemm3g_kernel (pass B, 3 x 3 bf16 planes)")
+                       if int(st["gemm_mode"]) in (1, 2) else
+                       ("gemm2h_streamk_kernel<1, HI> (pass A, 2 x 2 f16 planes)" if dom == "A" else "gemm2h_kernel<1, HI> (pass B, 2 x 2 f16 planes)")
+                       if int(st["gemm_mode"]) == 5 else "gemm_mode %d" % int(st["gemm_mode"])),
             "avg_launch_ms": {"passA": avgA, "passB": avgB},
             "achieved_TFLOPs": tfA if dom == "A" else tfB, "peak_TFLOPs": peak, "frac": (tfA if dom == "A" else tfB) / peak,
-            "flop_basis": "f32-equivalent flops; peak = bf16 dense MFMA peak / %d MFMAs per product" % per,
+            "flop_basis": "f32-equivalent flops; peak = bf16 / f16 dense MFMA peak / %d MFMAs per product" % per,
             "column_utilisation": int(st["restart_column_iterations"]) / max(int(st["column_iterations"]), 1),
             "gemm_share_of_gpu_time": (avgA + avgB) * launches / max(st["gpu_ms"], 1e-9)}
 
@@ -732,7 +736,11 @@ def main():
             # f32-accurate products on the f16 / bf16 matrix pipe: 2 / 3 / 6 MFMAs per product, so the roofline of the
             # scheme in f32-equivalent flops is the dense peak / that
             peak = BF16_MFMA_PEAK_TFLOPS / per_product
-            if agg["gemm_mode"] == 4:
+            if agg["gemm_mode"] == 5:
+                kern = ("gemm2h_streamk_kernel<1, HI> (pass A: X.Ht; X and the factor as 2 f16 planes each, 4 MFMAs per product)"
+                        if dom == "A" else
+                        "gemm2h_kernel<1, HI> (pass B: Xt.W; X and the factor as 2 f16 planes each, 4 MFMAs per product)")
+            elif agg["gemm_mode"] == 4:
                 kern = ("gemm2h_streamk_kernel (pass A: X.Ht; X = one integer f16 plane x per-gene scale, factor = 2 f16 planes)"
                         if dom == "A" else
                         "gemm2h_kernel (pass B: Xt.W; X = one integer f16 plane x per-gene scale, factor = 2 f16 planes)")
@@ -746,7 +754,7 @@ def main():
         else:
             peak = FP32_MFMA_PEAK_TFLOPS
             kern = "gemm_streamk_kernel<NT> (pass A: X.Ht)" if dom == "A" else "gemm_kernel<NN> (pass B: Xt.W)"
-        xbytes = {0: 4, 1: 6, 2: 6, 3: 2, 4: 2}[agg["gemm_mode"]]     # bytes per element of X as the GEMM reads it
+        xbytes = {0: 4, 1: 6, 2: 6, 3: 2, 4: 2, 5: 4}[agg["gemm_mode"]]     # bytes per element of X as the GEMM reads it
         tr, tr_ok = pmc_traffic("passA" if dom == "A" else "passB", agg["gemm_mode"])
         roof = {
             "bound": "mfma",
@@ -819,7 +827,8 @@ def main():
             # f32 results; the products run on the f16 / bf16 matrix pipe from exact operand planes
             "dtype": ({1: "f32 (3x3 bf16 planes, f32 accumulate)", 2: "f32 (3x3 bf16 planes, f32 accumulate)",
                        3: "f32 (exact integer bf16 plane x 3 bf16 planes, f32 accumulate)",
-                       4: "f32 (exact integer f16 plane x 2 f16 planes with per-row exponent, f32 accumulate)"}.get(agg["gemm_mode"], "f32")),
+                       4: "f32 (exact integer f16 plane x 2 f16 planes with per-row exponent, f32 accumulate)",
+                       5: "f32 (2 f16 planes with per-row exponent for X and for the factor, f32 accumulate)"}.get(agg["gemm_mode"], "f32")),
             "data": "synthetic",
             "config": {"workload": "%s: %d cells x %d HVGs synthetic dense, K=%d..%d, %d restarts per K per step (%s), "
                                    "sklearn CD solver tol=1e-4 max_iter=1000, init=random from ledger seeds"

@@ -283,12 +283,23 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (rc) return rc;
         usec = ctx->count_state == 1;
     }
-    bool use2h = usec && ctx->count_fmt == 4;      // ... on the f16 pipe: two factor planes, 2 MFMAs per product
-    const int gemm_mode_used = !use3 ? 0 : (usec ? (use2h ? 4 : 3) : std::min(gemm3_mode(), 2));
+    // any OTHER matrix in the default mode: X itself as two f16 planes with a per-row exponent, 4 MFMAs per product
+    // (gemm_mode 5; CNMF_G2G=0 keeps the 3 x 3 bf16 planes of rounds 1-2, 6 MFMAs)
+    static const bool g2g_off = getenv("CNMF_G2G") && atoi(getenv("CNMF_G2G")) == 0;
+    bool use2g = use3 && !usec && gemm3_mode() >= 4 && !g2g_off && ctx->G_pad % G3C_JW == 0 && ctx->N_pad % G3C_JW == 0;
+    if (use2g) { rc = ensure_x2planes(ctx); if (rc) return rc; }
+    bool use2h = (usec && ctx->count_fmt == 4) || use2g;      // ... on the f16 pipe: two f16 factor planes
+    const int gemm_mode_used = !use3 ? 0 : (use2g ? 5 : (usec ? (use2h ? 4 : 3) : std::min(gemm3_mode(), 2)));
     const int KbA = ctx->G_pad / 16, KbB = ctx->N_pad / 16;
-    const int nsubA = use2h ? gemm2h_nsub(ctx->C1h != nullptr, KbA) : 1, nsubB = use2h ? gemm2h_nsub(ctx->Ct1h != nullptr, KbB) : 1;
-    if (use3 && !usec) { rc = ensure_planes(ctx); if (rc) return rc; }
-    const int jwA = usec ? G3C_JW : G3_JW;         // width of a pass-A / pass-B tile
+    // the X-side operands of the f16 kernels: the integer count plane(s), or the two planes of a general matrix
+    const unsigned char *xA = use2g ? ctx->X2h : ctx->C1, *xAhi = use2g ? ctx->X2m : ctx->C1h;
+    const unsigned char *xB = use2g ? ctx->Xt2h : ctx->Ct1, *xBhi = use2g ? ctx->Xt2m : ctx->Ct1h;
+    const unsigned int *xAfl = use2g ? ctx->onesA : ctx->hiA, *xBfl = use2g ? ctx->onesB : ctx->hiB;
+    const float *csA = use2g ? ctx->x2sA : nullptr, *csB = use2g ? ctx->x2sB : nullptr;      // 2^-s per output column
+    const double* dsc = use2g ? nullptr : ctx->d_scale;                                      // per-gene scale of the count path
+    const int nsubA = use2h ? gemm2h_nsub(xAhi != nullptr, KbA) : 1, nsubB = use2h ? gemm2h_nsub(xBhi != nullptr, KbB) : 1;
+    if (use3 && !usec && !use2g) { rc = ensure_planes(ctx); if (rc) return rc; }
+    const int jwA = (usec || use2g) ? G3C_JW : G3_JW;         // width of a pass-A / pass-B tile
     int nsplit3 = use3 ? pick_nsplit3(ctx, KC, jwA) : 1;
     const int nsplit3_first = nsplit3;             // (reported: the tail narrows the batch and re-plans)
     const int fin_y = (max_k * max_k + 255) / 256;       // finalize blocks per slot
@@ -557,16 +568,16 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             // H3 was produced together with the previous iteration's H finalize; rows installed since then
             // (and the very first iteration) need a split of their own.  Count path: H' = H * d.
             if ((n_new > 0 || !h3_valid) && use2h) {
-                HIP_TRY(ctx, launch_rowmax_part(st, ctx->H, ctx->G_pad, G, KC, chunksH * 256, ctx->d_scale, partsH, ctx->rmaxH));
-                HIP_TRY(ctx, launch_split2h(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, ctx->d_scale, ctx->rmaxH,
+                HIP_TRY(ctx, launch_rowmax_part(st, ctx->H, ctx->G_pad, G, KC, chunksH * 256, dsc, partsH, ctx->rmaxH));
+                HIP_TRY(ctx, launch_split2h(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, dsc, ctx->rmaxH,
                                             partsH, ctx->iscaleH));
             } else if (n_new > 0 || !h3_valid)
                 HIP_TRY(ctx, launch_split3(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, usec ? ctx->d_scale : nullptr));
             if (time_gemm) hipEventRecord(gev[gev.size() - 4], st);
             if (sk3.on) {
                 if (use2h)
-                    HIP_TRY(ctx, launch_gemm2h_streamk(st, sk3, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->iscaleH, KbA,
-                                                       ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
+                    HIP_TRY(ctx, launch_gemm2h_streamk(st, sk3, ctx->H3, xA, xAhi, xAfl, ctx->iscaleH, KbA,
+                                                       ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad, csA));
                 else if (usec)
                     HIP_TRY(ctx, launch_gemm3c_streamk(st, sk3, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->XHt, ctx->XHt1,
                                                        ctx->XHt2, ctx->N_pad));
@@ -574,8 +585,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                     HIP_TRY(ctx, launch_gemm3_streamk(st, sk3, ctx->H3, ctx->X3, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
                 spA = SplitInfo{ctx->XHt1, ctx->d_split, jwA, G3_MW, sk3.MG, ctx->XHt2};
             } else if (use2h) {
-                HIP_TRY(ctx, launch_gemm2h(st, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->iscaleH, KbA, ctx->XHt, ctx->N_pad,
-                                           (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
+                HIP_TRY(ctx, launch_gemm2h(st, ctx->H3, xA, xAhi, xAfl, ctx->iscaleH, KbA, ctx->XHt, ctx->N_pad,
+                                           (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA, csA));
             } else if (usec) {
                 HIP_TRY(ctx, launch_gemm3c(st, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
                                            (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
@@ -618,8 +629,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         // pass B : XtW[S][KC][G] = Wt_all . X  (split over cells)  (sklearn _nmf.py:505-507)
         const int nsB = use2h ? gemm2h_splits(KbB, nsplit3, nsubB) : (use3 ? nsplit3 : nsplit);
         if (use2h)
-            HIP_TRY(ctx, launch_gemm2h(st, ctx->Wt3, ctx->Ct1, ctx->Ct1h, ctx->hiB, ctx->iscaleW, KbB, ctx->XtW, ctx->G_pad,
-                                       (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3));
+            HIP_TRY(ctx, launch_gemm2h(st, ctx->Wt3, xB, xBhi, xBfl, ctx->iscaleW, KbB, ctx->XtW, ctx->G_pad,
+                                       (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3, csB));
         else if (usec)
             HIP_TRY(ctx, launch_gemm3c(st, ctx->Wt3, ctx->Ct1, ctx->Ct1h, ctx->hiB, ctx->N_pad / 16, ctx->XtW, ctx->G_pad,
                                        (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3));
@@ -635,14 +646,14 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (use2h && !no_psum && !(tiers & 8)) {      // (ranks above 64 take the separately reduced product)
             HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
                                       ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers,
-                                      psum_info(nsB, (long long)KC * ctx->G_pad, ctx->d_scale), ctx->rmaxH, ctx->d_scale, true));
+                                      psum_info(nsB, (long long)KC * ctx->G_pad, dsc), ctx->rmaxH, dsc, true));
         } else {
             HIP_TRY(ctx, launch_reduce_splits(st, ctx->XtW, nsB, (long long)KC * ctx->G_pad,
-                                              (long long)KC * ctx->G_pad, usec ? ctx->d_scale : nullptr, ctx->G_pad));
+                                              (long long)KC * ctx->G_pad, usec ? dsc : nullptr, ctx->G_pad));
             HIP_TRY(ctx, launch_sweep(st, nslots, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW,
                                       ctx->d_slots, l1H, ctx->gram_part, ctx->viol_part, chunksH, partsH, 1, max_k, tiers,
                                       SplitInfo{nullptr, nullptr, 1, 1, 1}, use2h ? ctx->rmaxH : nullptr,
-                                      use2h ? ctx->d_scale : nullptr));
+                                      use2h ? dsc : nullptr));
         }
         // the H finalize also publishes every slot's state into the host-mapped ring entry of this
         // iteration (stamp it + 1): no copy kernel and no event per iteration
@@ -652,7 +663,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         if (use2h) {
             const FinalizeArgs fa{ctx->gram_part, ctx->viol_part, partsH, ctx->gramH, l2W, ctx->d_slots, 1, prm->tol,
                                   prm->max_iter, 1, max_k, snap_dev, (int)(it + 1)};
-            HIP_TRY(ctx, launch_split2h_finalize(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, ctx->d_scale,
+            HIP_TRY(ctx, launch_split2h_finalize(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, dsc,
                                                  ctx->rmaxH, partsH, ctx->iscaleH, fa, nslots, fin_y));
             h3_valid = true;
         } else if (use3) {
@@ -746,7 +757,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                     else nsplitA = std::max(1, std::min(pick_nsplit_A3(ctx, KC, jwA), (ctx->nsplitA_alloc * KC0) / KC));
                 } else {
                 nsplit = std::max(1, std::min(pick_nsplit(ctx, KC), cap));
-                use3 = usec = use2h = false;        // fewer than 256 packed columns: the f32 pipe takes over
+                use3 = usec = use2h = use2g = false; // fewer than 256 packed columns: the f32 pipe takes over
                 sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
                 nsplitA = (sk.on && gvarA == 0) ? 1
                         : std::max(1, std::min(pick_nsplit_A(ctx, KC), (ctx->nsplitA_alloc * KC0) / KC));

@@ -86,6 +86,13 @@ extern "C" cnmf_ctx* cnmf_create(int device)
     return ctx;
 }
 
+static void free_x2(cnmf_ctx* c)
+{
+    hipFree(c->X2h); hipFree(c->X2m); hipFree(c->Xt2h); hipFree(c->Xt2m); hipFree(c->x2sA); hipFree(c->x2sB);
+    hipFree(c->onesA); hipFree(c->onesB);
+    c->X2h = c->X2m = c->Xt2h = c->Xt2m = nullptr; c->x2sA = c->x2sB = nullptr; c->onesA = c->onesB = nullptr;
+}
+
 static void free_batch(cnmf_ctx* c)
 {
     hipFree(c->H); hipFree(c->Wt); hipFree(c->XHt); hipFree(c->XHt1); hipFree(c->XHt2); hipFree(c->XtW); hipFree(c->d_split);
@@ -112,6 +119,7 @@ extern "C" void cnmf_destroy(cnmf_ctx* ctx)
     free_batch(ctx);
     cnmf_comm_finalize(ctx);
     hipFree(ctx->X); hipFree(ctx->X3); hipFree(ctx->Xt3); hipFree(ctx->XtF);
+    free_x2(ctx);
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     hipFree(ctx->stageW); hipFree(ctx->stageH); hipFree(ctx->spectra);
@@ -131,6 +139,7 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     hipFree(ctx->X); ctx->X = nullptr;
     hipFree(ctx->XtF); ctx->XtF = nullptr;
     hipFree(ctx->X3); hipFree(ctx->Xt3); ctx->X3 = ctx->Xt3 = nullptr;
+    free_x2(ctx);
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     ctx->C1 = ctx->Ct1 = ctx->C1h = ctx->Ct1h = nullptr; ctx->hiA = ctx->hiB = nullptr;

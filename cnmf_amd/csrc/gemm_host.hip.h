@@ -294,6 +294,50 @@ static int ensure_planes(cnmf_ctx* ctx)
     return CNMF_OK;
 }
 
+// planes of a general (not count-structured) matrix for the f16 pipe (gemm_mode 5, kernels_gemm2h.hip.h)
+static int ensure_x2planes(cnmf_ctx* ctx)
+{
+    if (ctx->X2h) return CNMF_OK;
+    hipStream_t st = ctx->stream;
+    const int N = (int)ctx->N, G = (int)ctx->G, Np = ctx->N_pad, Gp = ctx->G_pad;
+    const size_t pb = (size_t)Np * Gp * 2;
+    const size_t fa = (size_t)(Np / G3C_JW) * ((Gp / 16 + 31) / 32) * sizeof(unsigned), fb = (size_t)(Gp / G3C_JW) * ((Np / 16 + 31) / 32) * sizeof(unsigned);
+    DevPool pool;
+    int* shA = pool.get<int>(Np);
+    int* shB = pool.get<int>(Gp);
+    POOL_TRY(ctx, pool);
+    unsigned char *a = nullptr, *am = nullptr, *b = nullptr, *bm = nullptr;
+    float *sa = nullptr, *sb = nullptr;
+    unsigned *oa = nullptr, *ob = nullptr;
+    hipError_t e = hipMalloc(&a, pb);
+    if (e == hipSuccess) e = hipMalloc(&am, pb);
+    if (e == hipSuccess) e = hipMalloc(&b, pb);
+    if (e == hipSuccess) e = hipMalloc(&bm, pb);
+    if (e == hipSuccess) e = hipMalloc(&sa, (size_t)Np * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&sb, (size_t)Gp * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&oa, fa);
+    if (e == hipSuccess) e = hipMalloc(&ob, fb);
+    if (e == hipSuccess) e = hipMemsetAsync(oa, 0xff, fa, st);
+    if (e == hipSuccess) e = hipMemsetAsync(ob, 0xff, fb, st);
+    if (e == hipSuccess) {
+        x2h_rowshift_kernel<<<(Np + 3) / 4, 256, 0, st>>>(ctx->X, Gp, N, G, 0, Np, shA, sa);
+        x2h_rowshift_kernel<<<(Gp + 255) / 256, 256, 0, st>>>(ctx->X, Gp, N, G, 1, Gp, shB, sb);
+        const long long total = (long long)Np * (Gp / 16);
+        x2h_planes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(ctx->X, Gp, N, G, Np, Gp, G3C_JW, shA,
+                                                                            (unsigned short*)a, (unsigned short*)am);
+        x2h_planes_transpose_kernel<<<dim3((Gp + 255) / 256, Np / 16), 256, 0, st>>>(ctx->X, Gp, N, G, Gp, Np, G3C_JW, shB,
+                                                                                    (unsigned short*)b, (unsigned short*)bm);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);      // the shift scratch is freed on return
+    if (e != hipSuccess) {
+        hipFree(a); hipFree(am); hipFree(b); hipFree(bm); hipFree(sa); hipFree(sb); hipFree(oa); hipFree(ob);
+        HIP_TRY(ctx, e);
+    }
+    ctx->X2h = a; ctx->X2m = am; ctx->Xt2h = b; ctx->Xt2m = bm; ctx->x2sA = sa; ctx->x2sB = sb; ctx->onesA = oa; ctx->onesB = ob;
+    return CNMF_OK;
+}
+
 // ---- count-structured data: launchers of the 256 x 256 integer-plane kernel
 // Bhi / hiflag: second integer plane and its block flags (nullptr when no count exceeds 256)
 static hipError_t launch_gemm3c(hipStream_t st, const unsigned char* A3, const unsigned char* B1,
@@ -342,7 +386,8 @@ static int g2_var()
 template <int NSUB, bool HI, int VAR = 0>
 static hipError_t launch_gemm2h_t(hipStream_t st, const unsigned char* A2, const unsigned char* B1,
                                   const unsigned char* Bhi, const unsigned int* hiflag, const float* rscale, int Kb,
-                                  float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
+                                  float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit,
+                                  const float* cscale = nullptr)
 {
     constexpr int lds = g2_lds_bytes(NSUB, HI);
     {
@@ -351,7 +396,7 @@ static hipError_t launch_gemm2h_t(hipStream_t st, const unsigned char* A2, const
     int kb_per = (Kb + nsplit - 1) / nsplit;
     kb_per = ((kb_per + NSUB - 1) / NSUB) * NSUB;            // whole steps
     dim3 grid(Jpad / G3C_JW, KC / G3_MW, (Kb + kb_per - 1) / kb_per);
-    gemm2h_kernel<NSUB, HI, VAR><<<grid, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, kb_per);
+    gemm2h_kernel<NSUB, HI, VAR><<<grid, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, kb_per, cscale);
     return hipGetLastError();
 }
 
@@ -365,9 +410,11 @@ static int gemm2h_splits(int Kb, int nsplit, int nsub)
 
 static hipError_t launch_gemm2h(hipStream_t st, const unsigned char* A2, const unsigned char* B1,
                                 const unsigned char* Bhi, const unsigned int* hiflag, const float* rscale, int Kb,
-                                float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit)
+                                float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit,
+                                const float* cscale = nullptr)
 {
-    if (Bhi) return launch_gemm2h_t<1, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
+    if (Bhi) return launch_gemm2h_t<1, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale);
+    if (cscale) return hipErrorInvalidValue;              // a column scale exists only on the two-plane operand path
     if (g2_nsub() == 2 && Kb % 2 == 0) {
         switch (g2_var()) {
             case 1: return launch_gemm2h_t<2, false, 1>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
@@ -386,27 +433,29 @@ template <int NSUB, bool HI, int VAR = 0, bool NTB = true>
 static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, const unsigned char* A2,
                                           const unsigned char* B1, const unsigned char* Bhi,
                                           const unsigned int* hiflag, const float* rscale, int Kb, float* C0, float* C1,
-                                          float* C2, int ldc)
+                                          float* C2, int ldc, const float* cscale = nullptr)
 {
     constexpr int lds = g2_lds_bytes(NSUB, HI);
     {
         if (hipError_t e_ = dyn_lds_optin((const void*)gemm2h_streamk_kernel<NSUB, HI, VAR, NTB>, lds)) return e_;
     }
     static const int xmap = getenv("CNMF_G2_XMAP") ? atoi(getenv("CNMF_G2_XMAP")) : 1;      // (0: A/B, the identity order)
-    gemm2h_streamk_kernel<NSUB, HI, VAR, NTB><<<sk.P, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T, xmap);
+    gemm2h_streamk_kernel<NSUB, HI, VAR, NTB><<<sk.P, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T, xmap, cscale);
     return hipGetLastError();
 }
 
 // (the plan `sk` must have been made with unit = gemm2h_nsub(Bhi != nullptr, Kb))
 static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, const unsigned char* A2,
                                         const unsigned char* B1, const unsigned char* Bhi, const unsigned int* hiflag,
-                                        const float* rscale, int Kb, float* C0, float* C1, float* C2, int ldc)
+                                        const float* rscale, int Kb, float* C0, float* C1, float* C2, int ldc,
+                                        const float* cscale = nullptr)
 {
     // several component groups share every count-plane tile in the L2: no non-temporal loads then (CNMF_G2_NT=1: A/B)
     static const bool force_nt = getenv("CNMF_G2_NT") != nullptr;
     const bool shared = sk.MG > 1 && !force_nt;
-    if (Bhi) return shared ? launch_gemm2h_streamk_t<1, true, 0, false>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc)
-                           : launch_gemm2h_streamk_t<1, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc);
+    if (Bhi) return shared ? launch_gemm2h_streamk_t<1, true, 0, false>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale)
+                           : launch_gemm2h_streamk_t<1, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale);
+    if (cscale) return hipErrorInvalidValue;
     if (gemm2h_nsub(false, Kb) == 2) {
         if (shared && g2_var() == CNMF_G2_VAR_DEFAULT)
             return launch_gemm2h_streamk_t<2, false, CNMF_G2_VAR_DEFAULT, false>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);

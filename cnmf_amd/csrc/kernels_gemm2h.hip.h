@@ -280,6 +280,80 @@ __global__ __launch_bounds__(256) void count_planes_f16_transpose_kernel(const f
     }
 }
 
+// ---- general (NOT count-structured) X on the f16 pipe, gemm_mode 5: every row r of the operand (a cell for pass A, a
+// gene for pass B) is held as TWO f16 planes of  y = x * 2^s_r  (h = f16(y), m = f16(y - h): within 1 ulp_f32 of x,
+// exactly like the factor planes), s_r from the row maximum; the GEMM multiplies all four plane pairs (4 MFMAs per
+// product, the `HI` instantiation with every block flagged) and its epilogue undoes 2^s_r per OUTPUT column.
+// Replaces the 3 x 3 bf16 planes of rounds 1-2 (6 MFMAs per product, terms below 2^-18 dropped).
+// row maxima: rows of X (transpose = 0: one wave per row) or columns of X (transpose = 1: one thread per column)
+__global__ __launch_bounds__(256) void x2h_rowshift_kernel(const float* __restrict__ X, int ld, int N, int G,
+                                                           int transpose, int rows_pad, int* __restrict__ shift,
+                                                           float* __restrict__ inv_scale)
+{
+    if (!transpose) {
+        const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (row >= rows_pad) return;
+        float mx = 0.f;
+        if (row < N) for (int g = lane; g < G; g += 64) mx = fmaxf(mx, X[(size_t)row * ld + g]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) { const int s = g2_row_shift(mx); shift[row] = s; inv_scale[row] = ldexpf(1.0f, -s); }
+    } else {
+        const int g = blockIdx.x * 256 + threadIdx.x;
+        if (g >= rows_pad) return;
+        float mx = 0.f;
+        if (g < G) for (int r = 0; r < N; ++r) mx = fmaxf(mx, X[(size_t)r * ld + g]);
+        const int s = g2_row_shift(mx);
+        shift[g] = s; inv_scale[g] = ldexpf(1.0f, -s);
+    }
+}
+
+// rows = cells, k = genes (pass A's operand).  One thread per (row, 16-k block).
+__global__ __launch_bounds__(256) void x2h_planes_kernel(const float* __restrict__ X, int ld, int N, int G, int rows_pad,
+                                                         int K, int TR, const int* __restrict__ shift,
+                                                         unsigned short* __restrict__ dst_h, unsigned short* __restrict__ dst_m)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int Kb = K / 16;
+    if (t >= (long long)rows_pad * Kb) return;
+    const int row = (int)(t / Kb), kb = (int)(t % Kb);
+    const int s = shift[row];
+    unsigned short ph[16], pm[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int g = kb * 16 + i;
+        const float x = (row < N && g < G) ? X[(size_t)row * ld + g] : 0.f;
+        split2h(ldexpf(x, s), ph[i], pm[i]);
+    }
+    const size_t blk = (size_t)(row / TR) * Kb + kb;
+    store_plane_row_swz(dst_h + (blk * TR + (row % TR)) * 16, ph, row % TR);
+    store_plane_row_swz(dst_m + (blk * TR + (row % TR)) * 16, pm, row % TR);
+}
+
+// rows = genes, k = cells (pass B's operand).  One thread per (gene row j, block); lanes run along j.
+__global__ __launch_bounds__(256) void x2h_planes_transpose_kernel(const float* __restrict__ X, int ld, int N, int G,
+                                                                   int rows_pad, int K, int TR,
+                                                                   const int* __restrict__ shift,
+                                                                   unsigned short* __restrict__ dst_h,
+                                                                   unsigned short* __restrict__ dst_m)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int kb = blockIdx.y;
+    if (j >= rows_pad) return;
+    const int Kb = K / 16;
+    const int s = shift[j];
+    unsigned short ph[16], pm[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = kb * 16 + i;
+        const float x = (j < G && c < N) ? X[(size_t)c * ld + j] : 0.f;
+        split2h(ldexpf(x, s), ph[i], pm[i]);
+    }
+    const size_t blk = (size_t)(j / TR) * Kb + kb;
+    store_plane_row_swz(dst_h + (blk * TR + (j % TR)) * 16, ph, j % TR);
+    store_plane_row_swz(dst_m + (blk * TR + (j % TR)) * 16, pm, j % TR);
+}
+
 // does any column need the second plane?  (max n > base)
 __global__ __launch_bounds__(256) void count_max_base_kernel(const float* __restrict__ X, int ld, int N, int G,
                                                              const float* __restrict__ unit, float base,
@@ -335,7 +409,7 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
                                                const unsigned int* __restrict__ hiflag,
                                                const float* __restrict__ rscale,
                                                int Kb, float* __restrict__ C, int ldc, int m0, int j0, int kb0,
-                                               int nkb, unsigned char* smem)
+                                               int nkb, unsigned char* smem, const float* __restrict__ cscale = nullptr)
 {
     constexpr int IMGS = g2_imgs(NSUB);
     constexpr int IMG = g2_img_bytes(NSUB, HI);
@@ -568,6 +642,9 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
 #undef G2_BLKFLAG
 
     const int j = j0 + wn * 64 + li;
+    // general (not count-structured) X as two f16 planes of x * 2^s_j (x2h_planes_kernel): the per-column exponent is
+    // undone here (a power of two: exact); 1 otherwise
+    const float cs[2] = {(HI && cscale) ? cscale[j] : 1.0f, (HI && cscale) ? cscale[j + 32] : 1.0f};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int cbase = m0 + grp * 128 + m * 32 + 4 * h;
@@ -576,7 +653,7 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = cbase + (r & 3) + 8 * (r >> 2);
-                C[(size_t)row * ldc + j + n * 32] = acc[m][n][r] * rscale[row];
+                C[(size_t)row * ldc + j + n * 32] = (acc[m][n][r] * rscale[row]) * cs[n];
             }
     }
 }
@@ -589,7 +666,7 @@ __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __rest
                                                      const unsigned int* __restrict__ hiflag,
                                                      const float* __restrict__ rscale, int Kb,
                                                      float* __restrict__ C, int ldc, long long c_split_stride,
-                                                     int kb_per)
+                                                     int kb_per, const float* __restrict__ cscale = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     int jt = blockIdx.x, mg = blockIdx.y, z = blockIdx.z;
@@ -606,7 +683,7 @@ __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __rest
     const int kb0 = z * kb_per;
     const int nkb = min(kb_per, Kb - kb0);
     gemm2h_segment<NSUB, HI, VAR>(A2, B1, Bhi, hiflag, rscale, Kb, C + (size_t)z * c_split_stride, ldc, mg * G3_MW,
-                                  jt * G3C_JW, kb0, nkb, smem3);
+                                  jt * G3C_JW, kb0, nkb, smem3, cscale);
 }
 
 // pass A: stream-K over persistent workgroups, unit = one step of NSUB blocks (Kb % NSUB == 0)
@@ -617,7 +694,8 @@ __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char
                                                              const unsigned int* __restrict__ hiflag,
                                                              const float* __restrict__ rscale, int Kb,
                                                              float* __restrict__ C0, float* __restrict__ C1,
-                                                             float* __restrict__ C2, int ldc, int MG, int T, int xmap)
+                                                             float* __restrict__ C2, int ldc, int MG, int T, int xmap,
+                                                             const float* __restrict__ cscale = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int Ks = Kb / NSUB;                             // steps per tile
@@ -638,7 +716,7 @@ __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char
         const int ke = (int)min((long long)Ks, ks + (u1 - u));
         const int mg = tile / NJ, jt = tile % NJ;
         gemm2h_segment<NSUB, HI, VAR, NTB>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
-                                      jt * G3C_JW, ks * NSUB, (ke - ks) * NSUB, smem3);
+                                      jt * G3C_JW, ks * NSUB, (ke - ks) * NSUB, smem3, cscale);
         u += ke - ks;
         G3_WAIT_VM(0);
         __syncthreads();                 // the images are refilled by the next segment's DMA

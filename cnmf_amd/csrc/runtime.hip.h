@@ -24,6 +24,11 @@ struct cnmf_ctx {
     unsigned int *hiA = nullptr, *hiB = nullptr;   // their flags: one bit per (tile row, block)
     double* d_scale = nullptr;                     // per-gene scale d [G_pad]
     int count_fmt = 0;                             // 3 = bf16 planes (base 256), 4 = f16 planes (base 2048, swizzled slots)
+    // any OTHER matrix on the f16 pipe (gemm_mode 5): two f16 planes of x * 2^s_row for X (rows = cells) and X^T (rows =
+    // genes), the per-row 2^-s, and all-ones block flags for the two-plane ("HI") instantiation of the count kernels
+    unsigned char *X2h = nullptr, *X2m = nullptr, *Xt2h = nullptr, *Xt2m = nullptr;
+    float *x2sA = nullptr, *x2sB = nullptr;
+    unsigned int *onesA = nullptr, *onesB = nullptr;
     float* XtF = nullptr;                          // X^T [round_up(G_pad, 64)][N_pad] float32, built on first use by the
                                                    // Kullback-Leibler solver (kernels_mu_mfma.hip.h)
 

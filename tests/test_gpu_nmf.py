@@ -165,7 +165,7 @@ def test_f16_scale_bound_of_the_W_half_step_with_outlier_cells(engine, outlier):
 def test_count_structure_is_detected_only_where_it_exists(engine):
     """X = counts / std (cnmf.py:546) has the structure (gemm_mode 4: f16 planes), also with a few counts above
     2048 (second plane); the same matrix with one entry nudged off the integer grid, or with a count above 65 535,
-    does not (general three-plane path, 2)."""
+    does not (the general path: X itself as two f16 planes with a per-row exponent, 5)."""
     C, _ = synth.topic_counts(1024, 520, 6, 5.0, 0.3, 2)
     C = C[:, C.sum(axis=0) > 0]
     C = C[C.sum(axis=1) > 0]
@@ -186,7 +186,7 @@ def test_count_structure_is_detected_only_where_it_exists(engine):
         H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=20, warn=False)
         assert engine.last_stats["kc"] == 256
         results[tag] = (engine.last_stats["gemm_mode"], H)
-    assert [results[t][0] for t in ("counts", "big", "nudged", "huge")] == [4, 4, 2, 2]
+    assert [results[t][0] for t in ("counts", "big", "nudged", "huge")] == [4, 4, 5, 5]      # 5: any X as two f16 planes
     # and the count path (with and without the second plane) computes the same factorisation as the exact-f32 pipe
     import os
     for tag in ("counts", "big"):
@@ -208,11 +208,33 @@ def test_count_structure_is_detected_only_where_it_exists(engine):
     try:
         engine.set_matrix(X)
         Hn, _, _, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=20, warn=False)
-        assert engine.last_stats["gemm_mode"] == 2
+        assert engine.last_stats["gemm_mode"] == 5
         for a, b in zip(results["counts"][1], Hn):
             assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
     finally:
         engine.set_count_detection(True)
+
+
+def test_general_matrix_on_the_f16_pipe_matches_oracle(engine):
+    """gemm_mode 5 (the default for any matrix that is NOT count-structured: Harmony-corrected, TPM-normalised ...): X
+    and X^T as two f16 planes of x * 2^s_row each, the factor likewise, all four plane products (4 MFMAs), the per-row
+    exponent undone per output column in the GEMM epilogue.  Every restart of a full-width batch against its float64
+    oracle run, on a matrix with a wide dynamic range per row and per column; the product itself against float64."""
+    rs = np.random.RandomState(17)
+    X64 = synth.make_config("C1", dtype=np.float64)
+    X64 = X64 * np.exp(0.8 * rs.standard_normal((X64.shape[0], 1))) * np.exp(0.8 * rs.standard_normal((1, X64.shape[1])))
+    X64 += 0.01 * np.abs(rs.standard_normal(X64.shape))          # nothing integer-like about it
+    engine.set_matrix(X64)
+    ks = [int(k) for k in rs.randint(5, 10, size=44)]
+    seeds = [int(s) for s in rs.randint(1, 2**31 - 1, size=44)]
+    H, _, n_iter, viol = engine.nmf_batch(ks, seeds=seeds)
+    assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] == 5
+    for k, seed, h, n in list(zip(ks, seeds, H, n_iter))[::3]:
+        _, H_ref, n_ref = nmf_cd.nmf(X64, k, seed=seed)
+        _check(H_ref, n_ref, h, n, slack=3)
+    H2, _, n2, _ = engine.nmf_batch(ks, seeds=seeds)
+    assert list(n2) == list(n_iter) and all(np.array_equal(a, b) for a, b in zip(H, H2))
+    # against the 3 x 3 bf16 planes of rounds 1-2 (CNMF_G2G=0 is read once per process: compared through the oracle only)
 
 
 @pytest.mark.parametrize("g3mode", ["0", "1", "2", "3", "4"])
