@@ -517,21 +517,44 @@ class Engine:
         self._check(self._lib.cnmf_x_matmul(self._ctx, int(bool(trans)), _fp(Q), Q.shape[1], _fp(out)))
         return out
 
+    def range_finder(self, Q0_blocks, n_iter, transpose):
+        """``cnmf_range_finder``: the power iterations of sklearn's ``randomized_range_finder`` for a GROUP of Gaussian
+        start blocks (list of [M_cols, c_b] arrays, sum c_b <= 256) entirely on the device; returns the lists
+        ``Q_b`` ([M_rows, c_b], orthonormal columns) and ``B_b = Q_b.T @ M`` ([c_b, M_cols]) in float32."""
+        N, G = self.shape
+        M_rows, M_cols = (G, N) if transpose else (N, G)
+        widths = np.ascontiguousarray([q.shape[1] for q in Q0_blocks], dtype=np.int32)
+        Ctot = int(widths.sum())
+        Q0 = np.ascontiguousarray(np.concatenate(Q0_blocks, axis=1), dtype=np.float32)
+        if Q0.shape != (M_cols, Ctot):
+            raise ValueError("start blocks must be [%d, c]" % M_cols)
+        Q = np.empty((M_rows, Ctot), dtype=np.float32)
+        B = np.empty((Ctot, M_cols), dtype=np.float32)
+        self._check(self._lib.cnmf_range_finder(self._ctx, int(bool(transpose)), len(Q0_blocks),
+                                                widths.ctypes.data_as(C.POINTER(C.c_int32)), _fp(Q0), int(n_iter),
+                                                _fp(Q), _fp(B)))
+        offs = np.concatenate([[0], np.cumsum(widths)])
+        return ([Q[:, offs[i]:offs[i + 1]] for i in range(len(widths))],
+                [B[offs[i]:offs[i + 1]] for i in range(len(widths))])
+
     def nndsvd_init(self, n_components, random_state=None, eps=1e-6):
         """sklearn's ``init='nndsvd'`` for ONE restart (decomposition/_nmf.py:316-354); see :meth:`nndsvd_init_batch`.
         Returns (W0, H0) in float64 (cast to X's dtype by the caller, like sklearn)."""
         return self.nndsvd_init_batch([n_components], [random_state], eps=eps)[0]
 
-    def nndsvd_init_batch(self, ks, random_states, eps=1e-6, max_cols=256, threads=None):
+    def nndsvd_init_batch(self, ks, random_states, eps=1e-6, max_cols=256, threads=None, device_range_finder=True):
         """sklearn's ``init='nndsvd'`` (decomposition/_nmf.py:316-354) for MANY restarts: ``_randomized_svd``
         (utils/extmath.py:531-602: n_oversamples=10, n_iter 7|4, LU-normalised power iterations, final QR, small
         SVD, svd_flip), then the positive/negative split.
 
-        Every product against X runs on the device, and the range finders of a whole GROUP of restarts ride in one
-        pass: their (k + 10)-column blocks sit side by side (up to ``max_cols`` = 256 columns: 13 restarts of rank 9),
-        so the 2 * n_iter + 2 passes over X are paid once per group, not once per restart.  The factorizations of the
-        (k + 10)-wide blocks (LU / QR / SVD, LAPACK releases the GIL) run on a thread pool between two passes.
-        Returns a list of (W0, H0) in float64."""
+        The range finders of a whole GROUP of restarts ride in one pass over X: their (k + 10)-column blocks sit side by
+        side (up to ``max_cols`` = 256 columns: 13 restarts of rank 9), so the 2 * n_iter + 2 passes over X are paid
+        once per group, not once per restart, and (``device_range_finder=True``, the default; needs k + 10 <= 128) the
+        normalisation between two passes stays on the device too (``cnmf_range_finder``: Cholesky-QR instead of
+        scikit-learn's pivoted LU -- any normaliser leaves the iterated subspace unchanged).  What remains on the host
+        per restart is the (k + 10) x G SVD, the sign flip and the positive / negative split.
+        ``device_range_finder=False``: every product on the device, LU / QR on a host thread pool (the round-2 scheme,
+        batched).  Returns a list of (W0, H0) in float64."""
         from concurrent.futures import ThreadPoolExecutor
         from scipy import linalg
         import os
@@ -623,6 +646,7 @@ class Engine:
             cur.append(r); cols += n_rand[r]
         if cur:
             groups.append(cur)
+        on_device = device_range_finder and max(n_rand) <= _lib.CNMF_KMAX
         try:
             for grp in groups:
                 Qs = []
@@ -630,6 +654,12 @@ class Engine:
                     rs = random_states[r]
                     rng = rs if isinstance(rs, np.random.RandomState) else np.random.RandomState(rs)
                     Qs.append(rng.normal(size=(M_cols, n_rand[r])))
+                if on_device:
+                    Qd, Bd = self.range_finder(Qs, n_iters[grp[0]], transpose)
+                    jobs = [(ks[r], Q.astype(np.float64), B.astype(np.float64)) for r, Q, B in zip(grp, Qd, Bd)]
+                    for r, wh in zip(grp, pool.map(finish, jobs)):
+                        results[r] = wh
+                    continue
                 for _ in range(n_iters[grp[0]]):
                     Qs = list(pool.map(lu_pl, passes(Qs, trans=transpose)))            # Q = PL of M @ Q
                     Qs = list(pool.map(lu_pl, passes(Qs, trans=not transpose)))        # Q = PL of M.T @ Q

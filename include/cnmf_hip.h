@@ -300,6 +300,14 @@ int cnmf_debug_gemm3c(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, 
  * row maximum -- the production pass-B scaling, for the accuracy tests.                                   */
 int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, int KC, int K, int J,
                       int nsplit, int nsub, double* ms_out, int reps);
+/* The range finder of sklearn's randomized_svd (utils/extmath.py:287-357) -- the O(N G) part of init='nndsvd'
+ * (decomposition/_nmf.py:316-354; `--init nndsvd`, cnmf.py:1252) -- for a GROUP of restarts: `nblocks` blocks of
+ * widths[b] = k_b + 10 columns side by side (sum <= 256, each <= CNMF_KMAX).  transpose = 0: M = X; 1: M = X^T
+ * (sklearn transposes when n_samples < n_features).  Q0 [M_cols][C] row-major: the Gaussian start (host RNG, numpy's
+ * stream).  n_iter power iterations, normalised by Cholesky-QR on the device; Q_out [M_rows][C]: orthonormal columns
+ * per block, B_out [C][M_cols] = Q^T M.  The small SVD / sign flip / NNDSVD split stay with the caller.           */
+int cnmf_range_finder(cnmf_ctx* ctx, int transpose, int nblocks, const int32_t* widths, const float* Q0, int n_iter,
+                      float* Q_out, float* B_out);
 /* numpy RandomState(seed).standard_normal(n) reproduced on the device. */
 int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t n, double* out);
 

@@ -432,9 +432,12 @@ def test_nndsvd_init_matches_sklearn(engine, shape):
                                             random_state=42)
     H, _, n_iter, _ = engine.nmf_batch([6], W0=[W0], H0=[H0])
     _check(Hr, nr, H[0], n_iter[0], slack=3)
-    # the batched form (range finders of several restarts side by side in ONE pass over X): every restart as sklearn's
+    # the batched form (range finders of several restarts side by side in ONE pass over X): every restart as sklearn's,
+    # with the power iterations entirely on the device (Cholesky-QR normaliser) and with the host LU of round 2
     ks, seeds = [4, 6, 6, 9, 5, 30], [1, 42, 7, 3, 11, 5]
-    for (k, seed), (Wb, Hb) in zip(zip(ks, seeds), engine.nndsvd_init_batch(ks, seeds)):
+    for (k, seed), (Wb, Hb), (Wh, Hh) in zip(zip(ks, seeds), engine.nndsvd_init_batch(ks, seeds),
+                                             engine.nndsvd_init_batch(ks, seeds, device_range_finder=False)):
+        assert np.abs(Wh - Wb).max() <= 1e-3 * np.abs(Wb).max() and np.abs(Hh - Hb).max() <= 1e-3 * np.abs(Hb).max()
         W_ref, H_ref = _initialize_nmf(X, k, init="nndsvd", random_state=seed)
         assert Wb.shape == W_ref.shape and Hb.shape == H_ref.shape
         assert np.abs(Wb - W_ref).max() <= 1e-3 * np.abs(W_ref).max(), (k, seed)
