@@ -146,24 +146,25 @@ __device__ __forceinline__ void sweep_body(
                 const size_t stride = (size_t)sp.tile_rows * (1u << 20) + (size_t)sp.tile_cols;
                 // U planes' loads in flight at a time; the additions keep the split order (bit-identical to
                 // reduce_splits_kernel)
+                // the remainder of the split count is batched too (clamped plane index, wave-uniform guard on the
+                // addition): with 8 planes (a 1024-column batch) the former `s + U <= nsplit` loop never took a full
+                // batch and added all seven planes one memory round trip after the other
                 constexpr int U = KP <= 16 ? 8 : (KP <= 32 ? 2 : 1);
-                int s = 1;
-                for (; s + U <= nsplit; s += U) {
+                for (int s = 1; s < nsplit; s += U) {
                     float q[U][KP];
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
+                    for (int u = 0; u < U; ++u) {
+                        const int ss = min(s + u, nsplit - 1);
 #pragma unroll
                         for (int c = 0; c < KP; ++c)
-                            q[u][c] = P[(s + u) * stride + (size_t)(off + min(c, k - 1)) * ldv + rowc];
+                            q[u][c] = P[ss * stride + (size_t)(off + min(c, k - 1)) * ldv + rowc];
+                    }
 #pragma unroll
                     for (int u = 0; u < U; ++u)
+                        if (s + u < nsplit) {
 #pragma unroll
-                        for (int c = 0; c < KP; ++c) p[c] += q[u][c];
-                }
-                for (; s < nsplit; ++s) {
-#pragma unroll
-                    for (int c = 0; c < KP; ++c)
-                        p[c] += P[s * stride + (size_t)(off + min(c, k - 1)) * ldv + rowc];
+                            for (int c = 0; c < KP; ++c) p[c] += q[u][c];
+                        }
                 }
                 const double* colscale = reinterpret_cast<const double*>(sp.split);
                 if (colscale) {
