@@ -391,6 +391,12 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int snap_nslots[RING] = {0};
     const bool no_defrag = getenv("CNMF_NO_DEFRAG") != nullptr;
     const bool no_psum = getenv("CNMF_NO_PSUM") != nullptr;          // (A/B knob: keep the separate split-K reduce)
+    // partial-tile passes in the tail (the f16 kernels skip the MFMAs of 32-column tiles without a live restart, the live
+    // restarts dealt evenly to the component groups): built and measured in round 3 -- 183.0 vs 182.2 restarts/s on the
+    // 113-restart shard, 216.5 vs 215.7 on the full job: within noise (the skipping variant is ~4 % slower with all tiles
+    // live, and a tail pass is bound by streaming the count plane as much as by its MFMAs).  Opt-in: CNMF_PART=1.
+    const bool no_part = getenv("CNMF_PART") == nullptr || getenv("CNMF_NO_PART") != nullptr;
+    int64_t last_tail_repack = -1000;
     int64_t last_defrag = -8, n_defrag = 0;
     bool h3_valid = false;           // H3 holds the planes of the current H (split-operand modes)
     // stamps restart at 1 in every call: forget the ones a previous call left in the ring (nothing is in flight here)
@@ -440,7 +446,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         restart_iters += snap.iter;
         restart_col_iters += (int64_t)snap.iter * k;
         k_iters[k] += snap.iter; k_done[k] += 1;
-        cols.release(h.off, k);
+        if (n_pending > 0) cols.release(h.off, k);       // (after the queue ran dry nothing is allocated any more)
         h.state = 0; h.restart = -1;
         --n_active; ++n_done;
         return CNMF_OK;
@@ -452,13 +458,39 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     // (one launch sequence per re-packing, whatever the number of slots: at 1024 packed columns the per-slot moves of
     //  round 2 -- four launches each, host-bound at ~5 us per launch -- had grown to 10 % of the wall time)
     int n_repack = 0;
-    auto repack_left = [&](int width) -> int {
+    // balanced (the tail of a wide batch only: nothing will be installed any more): the live restarts are dealt to the
+    // 256-column component groups so that every group holds about the same number of live 32-column tiles -- the GEMM
+    // workgroups of ALL groups then skip the same share of their MFMAs (a pass lasts as long as its slowest workgroup)
+    auto repack_left = [&](int width, bool balanced = false) -> int {
         std::vector<int> idx;
         for (int s = 0; s < nslots; ++s) if (hs[s].state) idx.push_back(s);
         std::sort(idx.begin(), idx.end(), [&](int a, int b) { return hs[a].off < hs[b].off; });
         int* hm = h_repack + (size_t)(n_repack++ % RING) * 3 * KC0;      // [colmap | slot ids | new offsets], pinned
         int* d_colmap = d_repack, *d_ids = d_repack + KC0, *d_offs = d_repack + 2 * KC0;
         int pos = 0, nmove = 0;
+        const int ngroups = width / 256;
+        if (balanced && ngroups > 1) {
+            for (int c = 0; c < width; ++c) hm[c] = -1;
+            std::vector<int> fill(ngroups, 0), byk(idx);
+            std::stable_sort(byk.begin(), byk.end(), [&](int a, int b) { return hs[a].k > hs[b].k; });
+            bool ok = true;
+            std::vector<int> newoff(nslots, -1);
+            for (int s : byk) {
+                int g = -1;
+                for (int q = 0; q < ngroups; ++q) if (fill[q] + hs[s].k <= 256 && (g < 0 || fill[q] < fill[g])) g = q;
+                if (g < 0) { ok = false; break; }
+                newoff[s] = g * 256 + fill[g]; fill[g] += hs[s].k;
+            }
+            if (ok) {
+                for (int s : idx) {
+                    HostSlot& h = hs[s];
+                    for (int c = 0; c < h.k; ++c) hm[newoff[s] + c] = h.off + c;
+                    if (h.off != newoff[s]) { hm[KC0 + nmove] = s; hm[2 * KC0 + nmove] = newoff[s]; ++nmove; h.off = newoff[s]; }
+                }
+                pos = 0;                                                  // (there are zero rows inside [0, width) now)
+            } else balanced = false;
+        } else balanced = false;
+        if (!balanced) {
         for (int s : idx) {
             HostSlot& h = hs[s];
             for (int c = 0; c < h.k; ++c) hm[pos + c] = h.off + c;
@@ -466,6 +498,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             pos += h.k;
         }
         for (int c = pos; c < width; ++c) hm[c] = -1;                    // zero rows behind the live ones
+        }
         if (nmove || pos < width) {
             HIP_TRY(ctx, hipMemcpyAsync(d_colmap, hm, (size_t)width * sizeof(int), hipMemcpyHostToDevice, st));
             // staging = the product buffers (scratch between two iterations): XHt [>= KC0][N_pad], XtW [>= KC0][G_pad]
@@ -556,6 +589,19 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         int tiers = 0;
         for (int s2 = 0; s2 < nslots; ++s2)
             if (hs[s2].state) tiers |= hs[s2].k <= 16 ? 1 : (hs[s2].k <= 32 ? 2 : (hs[s2].k <= KSMALL ? 4 : 8));
+        // the tail (nothing left to refill with): the f16 kernels skip the 32-column tiles without a live restart
+        unsigned long long livemask = ~0ull;
+        if (use2h && n_pending == 0 && !no_part) {
+            livemask = 0ull;
+            for (int s2 = 0; s2 < nslots; ++s2)
+                if (hs[s2].state)
+                    for (int t = hs[s2].off / 32; t <= (hs[s2].off + hs[s2].k - 1) / 32 && t < 64; ++t) livemask |= 1ull << t;
+            // the skipping variant of the kernels is ~4 % slower with everything live, and a pass lasts as long as its
+            // fullest component group: use it only when EVERY group has at least two dead tiles
+            int fullest = 0;
+            for (int g = 0; g < KC / 256; ++g) fullest = std::max(fullest, __builtin_popcountll((livemask >> (8 * g)) & 0xffull));
+            if (fullest > 6) livemask = ~0ull;
+        }
         const bool time_gemm = time_stride > 0 && it % time_stride == 0;
         if (time_gemm) {
             for (int i = 0; i < 4; ++i) gev.push_back(events.get());
@@ -577,7 +623,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             if (sk3.on) {
                 if (use2h)
                     HIP_TRY(ctx, launch_gemm2h_streamk(st, sk3, ctx->H3, xA, xAhi, xAfl, ctx->iscaleH, KbA,
-                                                       ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad, csA));
+                                                       ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad, csA, livemask));
                 else if (usec)
                     HIP_TRY(ctx, launch_gemm3c_streamk(st, sk3, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->XHt, ctx->XHt1,
                                                        ctx->XHt2, ctx->N_pad));
@@ -586,7 +632,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                 spA = SplitInfo{ctx->XHt1, ctx->d_split, jwA, G3_MW, sk3.MG, ctx->XHt2};
             } else if (use2h) {
                 HIP_TRY(ctx, launch_gemm2h(st, ctx->H3, xA, xAhi, xAfl, ctx->iscaleH, KbA, ctx->XHt, ctx->N_pad,
-                                           (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA, csA));
+                                           (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA, csA, livemask));
             } else if (usec) {
                 HIP_TRY(ctx, launch_gemm3c(st, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->G_pad / 16, ctx->XHt, ctx->N_pad,
                                            (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA));
@@ -630,7 +676,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         const int nsB = use2h ? gemm2h_splits(KbB, nsplit3, nsubB) : (use3 ? nsplit3 : nsplit);
         if (use2h)
             HIP_TRY(ctx, launch_gemm2h(st, ctx->Wt3, xB, xBhi, xBfl, ctx->iscaleW, KbB, ctx->XtW, ctx->G_pad,
-                                       (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3, csB));
+                                       (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3, csB, livemask));
         else if (usec)
             HIP_TRY(ctx, launch_gemm3c(st, ctx->Wt3, ctx->Ct1, ctx->Ct1h, ctx->hiB, ctx->N_pad / 16, ctx->XtW, ctx->G_pad,
                                        (long long)KC * ctx->G_pad, KC, ctx->G_pad, nsplit3));
@@ -743,8 +789,26 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             // A WIDE batch (512+) narrows in steps of 256 columns and stays on the same kernels.
             bool stay3 = false;
             if (use3 && !f32_tail && KCn > (usec ? 32 : 64)) { KCn = round_up(std::max(live_cols, 1), 256); stay3 = true; }
+            if (KCn == KC && use2h && !no_part && it - last_tail_repack >= 16) {
+                // same width, but the live restarts lie scattered: pack them to the left so that whole 32-column
+                // tiles fall dead (the GEMM passes skip those) -- when that frees at least 2 tiles and an eighth of them
+                unsigned long long m = 0ull;
+                for (int s = 0; s < nslots; ++s)
+                    if (hs[s].state)
+                        for (int t = hs[s].off / 32; t <= (hs[s].off + hs[s].k - 1) / 32 && t < 64; ++t) m |= 1ull << t;
+                const int ng = KC / 256;
+                int fullest = 0;
+                for (int g = 0; g < ng; ++g) fullest = std::max(fullest, __builtin_popcountll((m >> (8 * g)) & 0xffull));
+                const int ideal = ((live_cols + 31) / 32 + ng - 1) / ng;       // tiles per group if dealt evenly
+                if (ideal <= 6 && fullest >= ideal + 2) {
+                    int rcp = repack_left(KC, true);
+                    if (rcp) return rcp;
+                    last_tail_repack = it;
+                }
+            }
             if (KCn < KC) {
-                int rcp = repack_left(KCn);
+                last_tail_repack = it;
+                int rcp = repack_left(KCn, stay3 && use2h && !no_part);
                 if (rcp) return rcp;
                 KC = KCn;
                 cols = ColAlloc(KC);

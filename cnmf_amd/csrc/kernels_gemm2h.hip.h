@@ -403,13 +403,18 @@ __device__ __forceinline__ void glds16_asm_nt(const void* gsrc, unsigned lds_dst
 // NTB: the count plane is loaded non-temporally (every tile is read by ONE workgroup per pass: 256 packed columns, or pass B
 // with its XCD-aware order); with several component groups in pass A the workgroups p, p + P / MG stream the SAME tile at
 // the same time and must find it in their L2: default cache policy (PMC, 1024 columns: 607 -> see profiles/r3_pmc_*).
-template <int NSUB, bool HI, int VAR = 0, bool NTB = true>
+// PART: only the 32-row component tiles named in `live` (bit t = rows 32 t .. 32 t + 31 of this 256-row group) are
+// multiplied and stored -- the tail of a call, when restarts have finished and nothing is left to refill their columns:
+// a wave skips the MFMAs of its dead tiles (wave-uniform scalar branches), so a pass costs what its live columns cost,
+// down to the floor of streaming the count plane.  The operand traffic is unchanged.
+template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false>
 __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__ A2, const unsigned char* __restrict__ B1,
                                                const unsigned char* __restrict__ Bhi,
                                                const unsigned int* __restrict__ hiflag,
                                                const float* __restrict__ rscale,
                                                int Kb, float* __restrict__ C, int ldc, int m0, int j0, int kb0,
-                                               int nkb, unsigned char* smem, const float* __restrict__ cscale = nullptr)
+                                               int nkb, unsigned char* smem, const float* __restrict__ cscale = nullptr,
+                                               unsigned live = 0xffu)
 {
     constexpr int IMGS = g2_imgs(NSUB);
     constexpr int IMG = g2_img_bytes(NSUB, HI);
@@ -422,6 +427,9 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
     const int grp = wave >> 2, wn = wave & 3;
     const int li = lane & 31, h = lane >> 5;
     const int nst = nkb / NSUB;                          // steps in this segment
+    // the wave's four component tiles (rows grp * 128 + m * 32 ...): which of them hold live columns?
+    const unsigned lv = PART ? (unsigned)__builtin_amdgcn_readfirstlane((int)((live >> (grp * 4)) & 0xfu)) : 0xfu;
+#define G2_LIVE(m_) (!PART || ((lv >> (m_)) & 1u))
 
     const size_t jblk = ((size_t)(j0 / G3C_JW) * Kb + kb0);
     const unsigned char* abase = A2 + ((size_t)(m0 / G3_MW) * Kb + kb0) * G2_A + tid * 16;
@@ -494,8 +502,9 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
     }
 // two component tiles at a time, small plane first: consecutive MFMAs cycle through four accumulators
 #define G2_MFMA(b_, u_, m_, q_)                                                                    \
+    if (G2_LIVE(m_)) {                                                                             \
     acc[m_][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[u_][m_][q_], b_[u_][0], acc[m_][0], 0, 0, 0); \
-    acc[m_][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[u_][m_][q_], b_[u_][1], acc[m_][1], 0, 0, 0);
+    acc[m_][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[u_][m_][q_], b_[u_][1], acc[m_][1], 0, 0, 0); }
 #define G2_MFMA4(b_, u_, ma_, mb_)                                                                 \
     G2_MFMA(b_, u_, ma_, 1) G2_MFMA(b_, u_, mb_, 1) G2_MFMA(b_, u_, ma_, 0) G2_MFMA(b_, u_, mb_, 0)
 #define G2_HALF(ma_, mb_)                                                                          \
@@ -647,6 +656,7 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
     const float cs[2] = {(HI && cscale) ? cscale[j] : 1.0f, (HI && cscale) ? cscale[j + 32] : 1.0f};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
+        if (!G2_LIVE(m)) continue;                       // nobody reads the products of dead columns
         const int cbase = m0 + grp * 128 + m * 32 + 4 * h;
 #pragma unroll
         for (int n = 0; n < 2; ++n)
@@ -656,17 +666,19 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
                 C[(size_t)row * ldc + j + n * 32] = (acc[m][n][r] * rscale[row]) * cs[n];
             }
     }
+#undef G2_LIVE
 }
 
 // pass B (and pass A on few tiles): split-K launch, XCD-aware order as gemm3c_kernel.  kb_per is a multiple of NSUB.
-template <int NSUB, bool HI, int VAR = 0>
+template <int NSUB, bool HI, int VAR = 0, bool PART = false>
 __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __restrict__ A2,
                                                      const unsigned char* __restrict__ B1,
                                                      const unsigned char* __restrict__ Bhi,
                                                      const unsigned int* __restrict__ hiflag,
                                                      const float* __restrict__ rscale, int Kb,
                                                      float* __restrict__ C, int ldc, long long c_split_stride,
-                                                     int kb_per, const float* __restrict__ cscale = nullptr)
+                                                     int kb_per, const float* __restrict__ cscale = nullptr,
+                                                     unsigned long long livemask = ~0ull)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     int jt = blockIdx.x, mg = blockIdx.y, z = blockIdx.z;
@@ -682,12 +694,12 @@ __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __rest
     }
     const int kb0 = z * kb_per;
     const int nkb = min(kb_per, Kb - kb0);
-    gemm2h_segment<NSUB, HI, VAR>(A2, B1, Bhi, hiflag, rscale, Kb, C + (size_t)z * c_split_stride, ldc, mg * G3_MW,
-                                  jt * G3C_JW, kb0, nkb, smem3, cscale);
+    gemm2h_segment<NSUB, HI, VAR, true, PART>(A2, B1, Bhi, hiflag, rscale, Kb, C + (size_t)z * c_split_stride, ldc, mg * G3_MW,
+                                              jt * G3C_JW, kb0, nkb, smem3, cscale, (unsigned)((livemask >> (8 * mg)) & 0xffu));
 }
 
 // pass A: stream-K over persistent workgroups, unit = one step of NSUB blocks (Kb % NSUB == 0)
-template <int NSUB, bool HI, int VAR = 0, bool NTB = true>
+template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false>
 __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char* __restrict__ A2,
                                                              const unsigned char* __restrict__ B1,
                                                              const unsigned char* __restrict__ Bhi,
@@ -695,7 +707,8 @@ __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char
                                                              const float* __restrict__ rscale, int Kb,
                                                              float* __restrict__ C0, float* __restrict__ C1,
                                                              float* __restrict__ C2, int ldc, int MG, int T, int xmap,
-                                                             const float* __restrict__ cscale = nullptr)
+                                                             const float* __restrict__ cscale = nullptr,
+                                                             unsigned long long livemask = ~0ull)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int Ks = Kb / NSUB;                             // steps per tile
@@ -715,8 +728,9 @@ __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char
         const int tile = (int)(u / Ks), ks = (int)(u % Ks);
         const int ke = (int)min((long long)Ks, ks + (u1 - u));
         const int mg = tile / NJ, jt = tile % NJ;
-        gemm2h_segment<NSUB, HI, VAR, NTB>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
-                                      jt * G3C_JW, ks * NSUB, (ke - ks) * NSUB, smem3, cscale);
+        gemm2h_segment<NSUB, HI, VAR, NTB, PART>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
+                                                 jt * G3C_JW, ks * NSUB, (ke - ks) * NSUB, smem3, cscale,
+                                                 (unsigned)((livemask >> (8 * mg)) & 0xffu));
         u += ke - ks;
         G3_WAIT_VM(0);
         __syncthreads();                 // the images are refilled by the next segment's DMA
