@@ -25,7 +25,7 @@ SYMBOLS = [
     "cnmf_comm_unique_id", "cnmf_comm_init", "cnmf_comm_finalize", "cnmf_comm_rank", "cnmf_comm_world",
     "cnmf_allgather_bytes", "cnmf_allgather_spectra",
     "cnmf_spectra_rows", "cnmf_spectra_reset", "cnmf_spectra_fetch",
-    "cnmf_range_finder", "cnmf_debug_gemm", "cnmf_debug_gemm3", "cnmf_debug_gemm3c", "cnmf_debug_gemm2h", "cnmf_debug_standard_normal",
+    "cnmf_range_finder", "cnmf_debug_stream", "cnmf_debug_gemm", "cnmf_debug_gemm3", "cnmf_debug_gemm3c", "cnmf_debug_gemm2h", "cnmf_debug_standard_normal",
 ]
 
 COMM_ID_BYTES = 128
@@ -149,6 +149,8 @@ def load():
     lib.cnmf_prediction_error.argtypes = [vp, i32, dblp, dblp, dblp]
     lib.cnmf_x_matmul.restype = i32
     lib.cnmf_x_matmul.argtypes = [vp, i32, f32p, i32, f32p]
+    lib.cnmf_debug_stream.restype = i32
+    lib.cnmf_debug_stream.argtypes = [vp, i32, C.c_longlong, i32]
     lib.cnmf_range_finder.restype = i32
     lib.cnmf_range_finder.argtypes = [vp, i32, i32, i32p, f32p, i32, f32p, f32p]
     lib.cnmf_xt_matmul_f64.restype = i32

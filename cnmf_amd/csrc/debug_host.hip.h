@@ -291,6 +291,54 @@ extern "C" int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn,
     return CNMF_OK;
 }
 
+// ---- calibration streams for the PMC byte counters (tools/pmc_calibrate.py): a copy of `n_floats` floats with the
+// access width of the sweeps (4 B per lane: width = 1) or of the plane kernels (16 B per lane: width = 4), and a read-only
+// LDS-DMA stream (global_load_lds_dwordx4, what the GEMMs use: width = 0).  Known bytes -> FETCH_SIZE / WRITE_SIZE ratios.
+namespace cnmf {
+__global__ __launch_bounds__(256) void calib_copy1_kernel(const float* __restrict__ a, float* __restrict__ b, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void calib_copy4_kernel(const float4* __restrict__ a, float4* __restrict__ b, long long n4)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void calib_ldsdma_kernel(const unsigned char* __restrict__ a, long long nbytes, float* __restrict__ sink)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char buf[4][4096];
+    const long long chunk = 4096;                                   // one 16-B load per lane x 256 lanes
+    float acc = 0.f;
+    for (long long off = (long long)blockIdx.x * chunk; off + chunk <= nbytes; off += (long long)gridDim.x * chunk) {
+        const int w = (threadIdx.x >> 6);
+        __builtin_amdgcn_global_load_lds(G3_AS1(a + off + threadIdx.x * 16), G3_AS3(&buf[0][0] + w * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        acc += reinterpret_cast<const float*>(&buf[0][0])[threadIdx.x];
+    }
+    if (acc == 1.2345f) sink[0] = acc;                              // keep the loads alive
+}
+}  // namespace cnmf
+
+extern "C" int cnmf_debug_stream(cnmf_ctx* ctx, int width, long long n_floats, int reps)
+{
+    using namespace cnmf;
+    if (!ctx || n_floats < 1024 || reps < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevPool pool;
+    n_floats = (n_floats / 1024) * 1024;
+    float* a = pool.get<float>((size_t)n_floats, true, st);
+    float* b = pool.get<float>((size_t)n_floats, true, st);
+    POOL_TRY(ctx, pool);
+    for (int r = 0; r < reps; ++r) {
+        if (width == 1) calib_copy1_kernel<<<4096, 256, 0, st>>>(a, b, n_floats);
+        else if (width == 4) calib_copy4_kernel<<<4096, 256, 0, st>>>((const float4*)a, (float4*)b, n_floats / 4);
+        else calib_ldsdma_kernel<<<2048, 256, 0, st>>>((const unsigned char*)a, n_floats * 4, b);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return CNMF_OK;
+}
+
 extern "C" int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t n, double* out)
 {
     if (!ctx || !out || n < 0) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }

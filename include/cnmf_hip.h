@@ -308,6 +308,9 @@ int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, 
  * per block, B_out [C][M_cols] = Q^T M.  The small SVD / sign flip / NNDSVD split stay with the caller.           */
 int cnmf_range_finder(cnmf_ctx* ctx, int transpose, int nblocks, const int32_t* widths, const float* Q0, int n_iter,
                       float* Q_out, float* B_out);
+/* calibration streams of known byte counts for the PMC counters (tools/pmc_calibrate.py): width 1 = a copy with 4 B per
+ * lane, 4 = 16 B per lane, 0 = a read-only LDS-DMA stream (global_load_lds_dwordx4); n_floats floats, `reps` launches.  */
+int cnmf_debug_stream(cnmf_ctx* ctx, int width, long long n_floats, int reps);
 /* numpy RandomState(seed).standard_normal(n) reproduced on the device. */
 int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t n, double* out);
 
