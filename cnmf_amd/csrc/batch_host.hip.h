@@ -84,6 +84,8 @@ static int ensure_batch(cnmf_ctx* ctx, int KC, int max_k = KMAX, int min_k = 1)
         HIP_TRY(ctx, hipMemsetAsync(ctx->rmaxW, 0, (size_t)KC * parts * sizeof(float), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->iscaleH, 0, (size_t)KC * sizeof(float), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->iscaleW, 0, (size_t)KC * sizeof(float), ctx->stream));
+        HIP_TRY(ctx, hipMalloc(&ctx->shiftW, (size_t)3 * KC * sizeof(int)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->shiftW, 0, (size_t)3 * KC * sizeof(int), ctx->stream));
     }
     HIP_TRY(ctx, hipMalloc(&ctx->d_split, (size_t)(KC / 32 + 1) * (ctx->N_pad / 128 + 1)));
     HIP_TRY(ctx, hipMalloc(&ctx->XtW, hb * nsplit));
@@ -298,6 +300,13 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     const float *csA = use2g ? ctx->x2sA : nullptr, *csB = use2g ? ctx->x2sB : nullptr;      // 2^-s per output column
     const double* dsc = use2g ? nullptr : ctx->d_scale;                                      // per-gene scale of the count path
     const int nsubA = use2h ? gemm2h_nsub(xAhi != nullptr, KbA) : 1, nsubB = use2h ? gemm2h_nsub(xBhi != nullptr, KbB) : 1;
+    // W planes written by the W sweep itself (kernels_sweep.hip.h, PLN) instead of a separate pass over W; ranks above
+    // 64 (sweep_big_kernel) keep the separate split for the whole call.  CNMF_FUSE_W=0: the round-2 scheme (A/B).
+    static const bool fuse_off = getenv("CNMF_FUSE_W") && atoi(getenv("CNMF_FUSE_W")) == 0;
+    const bool fuseW = use2h && !fuse_off && max_k <= KSMALL && ctx->shiftW != nullptr;
+    int shgen = 0;                                        // generation of the exponents the NEXT W sweep uses
+    int* const shW[2] = {ctx->shiftW, ctx->shiftW ? ctx->shiftW + ctx->kc_alloc : nullptr};
+    if (fuseW) HIP_TRY(ctx, hipMemsetAsync(ctx->shiftW, 0, (size_t)3 * ctx->kc_alloc * sizeof(int), ctx->stream));
     if (use3 && !usec && !use2g) { rc = ensure_planes(ctx); if (rc) return rc; }
     const int jwA = (usec || use2g) ? G3C_JW : G3_JW;         // width of a pass-A / pass-B tile
     int nsplit3 = use3 ? pick_nsplit3(ctx, KC, jwA) : 1;
@@ -507,6 +516,14 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipMemcpyAsync(ctx->Wt, ctx->XHt, (size_t)width * ctx->N_pad * sizeof(float), hipMemcpyDeviceToDevice, st));
             HIP_TRY(ctx, hipMemcpyAsync(ctx->H, ctx->XtW, (size_t)width * ctx->G_pad * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if (fuseW) {
+                int* tmp = ctx->shiftW + 2 * ctx->kc_alloc;
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    permute_ints_kernel<<<(width + 255) / 256, 256, 0, st>>>(shW[g2], d_colmap, tmp, width);
+                    HIP_TRY(ctx, hipMemcpyAsync(shW[g2], tmp, (size_t)width * sizeof(int), hipMemcpyDeviceToDevice, st));
+                }
+                HIP_TRY(ctx, hipGetLastError());
+            }
             if (nmove) {
                 HIP_TRY(ctx, hipMemcpyAsync(d_ids, hm + KC0, (size_t)nmove * sizeof(int), hipMemcpyHostToDevice, st));
                 HIP_TRY(ctx, hipMemcpyAsync(d_offs, hm + 2 * KC0, (size_t)nmove * sizeof(int), hipMemcpyHostToDevice, st));
@@ -551,6 +568,19 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                 install_cm_kernel<<<gI, 256, 0, st>>>(d_H0 + hoff[r], d_Wt0 + woff[r], ctx->H, ctx->G_pad, G, ctx->Wt, ctx->N_pad, N, off);
             }
             HIP_TRY(ctx, hipGetLastError());
+            if (fuseW) {
+                // exponent of the planes the FIRST W sweep of this restart writes: from the size of its W0 (random init:
+                // avg |N(0,1)|, the maximum of 50 000 draws is ~4.5 avg), two bits of headroom; the check behind the sweep
+                // re-converts the rows whose first update left the window
+                float mx = 0.f;
+                if (init_mode == 1) mx = 6.0f * (float)avg[r];
+                else for (size_t q = 0; q < (size_t)k * N; ++q) mx = std::max(mx, W0[woff[r] + q]);
+                int e2 = 0;
+                if (mx > 0.f) std::frexp(mx, &e2);
+                const int sh0 = mx > 0.f ? std::max(-110, std::min(120, 13 - e2)) : 0;
+                set_ints_kernel<<<1, 128, 0, st>>>(shW[0], shW[1], off, k, sh0);
+                HIP_TRY(ctx, hipGetLastError());
+            }
             SlotDesc* d = &ctx->h_slots[s];
             memset(d, 0, sizeof *d);
             d->off = off; d->k = k; d->active = 1; d->iter = 0; d->restart = r;
@@ -652,14 +682,19 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             HIP_TRY(ctx, launch_reduce_splits(st, ctx->XHt, use2h ? gemm2h_splits(KbA, nsplitA, nsubA) : nsplitA,
                                               (long long)KC * ctx->N_pad, (long long)KC * ctx->N_pad));
         // W half-step                                             (sklearn _nmf.py:500)
+        const bool fuse_now = fuseW && use2h;
         HIP_TRY(ctx, launch_sweep(st, nslots, ctx->Wt, ctx->N_pad, N, ctx->XHt, ctx->gramH,
                                   ctx->d_slots, l1W, ctx->gram_part, ctx->viol_part, chunksW, partsW, 1, max_k, tiers, spA,
-                                  use2h ? ctx->rmaxW : nullptr, nullptr));
+                                  use2h ? ctx->rmaxW : nullptr, nullptr, false,
+                                  fuse_now ? PlaneOut{(unsigned short*)ctx->Wt3, shW[shgen], KbB, G3_MW} : PlaneOut{nullptr, nullptr, 0, 0}));
         if (use2h) {
             const FinalizeArgs fa{ctx->gram_part, ctx->viol_part, partsW, ctx->gramW, l2H, ctx->d_slots, 0, prm->tol,
                                   prm->max_iter, 1, max_k, nullptr, 0};
+            // (fused: the sweep wrote the planes; this launch checks their exponents, publishes 2^-s and the next exponents)
             HIP_TRY(ctx, launch_split2h_finalize(st, ctx->Wt, ctx->N_pad, KC, ctx->N_pad, ctx->Wt3, G3_MW, nullptr, ctx->rmaxW,
-                                                 partsW, ctx->iscaleW, fa, nslots, fin_y));
+                                                 partsW, ctx->iscaleW, fa, nslots, fin_y,
+                                                 fuse_now ? SplitFused{shW[shgen], shW[shgen ^ 1]} : SplitFused{nullptr, nullptr}));
+            if (fuse_now) shgen ^= 1;
         } else if (use3) {
             // finalize of the W sweep + the plane split of its result in one launch (writing the planes from
             // inside the sweep was measured slower: 2-byte stores, lower occupancy)

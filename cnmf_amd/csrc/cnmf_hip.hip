@@ -97,8 +97,8 @@ static void free_batch(cnmf_ctx* c)
 {
     hipFree(c->H); hipFree(c->Wt); hipFree(c->XHt); hipFree(c->XHt1); hipFree(c->XHt2); hipFree(c->XtW); hipFree(c->d_split);
     hipFree(c->H3); hipFree(c->Wt3);
-    hipFree(c->rmaxH); hipFree(c->rmaxW); hipFree(c->iscaleH); hipFree(c->iscaleW);
-    c->rmaxH = c->rmaxW = c->iscaleH = c->iscaleW = nullptr;
+    hipFree(c->rmaxH); hipFree(c->rmaxW); hipFree(c->iscaleH); hipFree(c->iscaleW); hipFree(c->shiftW);
+    c->rmaxH = c->rmaxW = c->iscaleH = c->iscaleW = nullptr; c->shiftW = nullptr;
     c->XHt1 = c->XHt2 = nullptr; c->d_split = nullptr; c->H3 = c->Wt3 = nullptr;
     hipFree(c->gramH); hipFree(c->gramW); hipFree(c->gram_part); hipFree(c->viol_part);
     hipFree(c->d_slots); hipFree(c->d_slot_list);

@@ -63,9 +63,25 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
                                const float* gram, const SlotDesc* slots, float l1, float* gram_part,
                                double* viol_part, int chunks, int parts, int want_gram, int kmax, int tiers,
                                SplitInfo sp = SplitInfo{nullptr, nullptr, 1, 1, 1},
-                               float* rmax_part = nullptr, const double* rmax_scale = nullptr, bool psum = false)
+                               float* rmax_part = nullptr, const double* rmax_scale = nullptr, bool psum = false,
+                               PlaneOut po = PlaneOut{nullptr, nullptr, 0, 0})
 {
     dim3 grid(parts, nslots);
+    if (po.dst) {
+        // the W half-step of the f16 paths, planes written by the sweep itself (ranks <= 64 only: the caller checks)
+        if (psum || (rmax_part && rmax_scale) || (tiers & 8)) return hipErrorInvalidValue;
+        const size_t pl = sweep_lds_bytes(kmax, true);
+        const int kgp = sweep_kg(kmax);
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, false, false, true>, (int)sweep_lds_bytes(KSMALL, true))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, false, false, true>, (int)sweep_lds_bytes(KSMALL, true))) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, false, false, true>, (int)sweep_lds_bytes(KSMALL, true))) return e_;
+#define CNMF_SWEEP_PLN(T_) sweep_kernel<T_, false, false, true><<<grid, 256, pl, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kgp, kmax, rmax_part, nullptr, po)
+        if (tiers & 1) CNMF_SWEEP_PLN(0);
+        if (tiers & 2) CNMF_SWEEP_PLN(1);
+        if (tiers & 4) CNMF_SWEEP_PLN(2);
+#undef CNMF_SWEEP_PLN
+        return hipGetLastError();
+    }
     {      // ranks above 32 need more than the default 64 KB of dynamic LDS
         if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, false>, (int)sweep_lds_bytes(KSMALL))) return e_;
         if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, false>, (int)sweep_lds_bytes(KSMALL))) return e_;
@@ -228,7 +244,8 @@ static hipError_t launch_split3_finalize(hipStream_t st, const float* src, int l
 
 static hipError_t launch_split2h_finalize(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst,
                                           int TR, const double* kscale, const float* rmax_part, int parts,
-                                          float* inv_scale, const FinalizeArgs& fa, int nslots, int fin_y);
+                                          float* inv_scale, const FinalizeArgs& fa, int nslots, int fin_y,
+                                          SplitFused fu = SplitFused{nullptr, nullptr});
 
 // ---- stream-K plan for the split-operand pass A (tile = 256 components x 128 cells, up to 2 cuts per tile)
 struct StreamK3 {
@@ -634,17 +651,17 @@ static int pick_nsplit3(const cnmf_ctx* ctx, int KC, int jw)
 
 static hipError_t launch_split2h_finalize(hipStream_t st, const float* src, int ld, int rows, int K, unsigned char* dst,
                                           int TR, const double* kscale, const float* rmax_part, int parts,
-                                          float* inv_scale, const FinalizeArgs& fa, int nslots, int fin_y)
+                                          float* inv_scale, const FinalizeArgs& fa, int nslots, int fin_y, SplitFused fu)
 {
     const int bx = split2h_col_groups(K, rows);
     if (split2h_wide(K)) {
         const int by = rows / 16;
         split2h_finalize_kernel<16, 16><<<bx * by + nslots * fin_y, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale,
-                                                                                rmax_part, parts, inv_scale, bx, by, fa, fin_y);
+                                                                                rmax_part, parts, inv_scale, bx, by, fa, fin_y, fu);
     } else {
         const int by = rows / 64;
         split2h_finalize_kernel<64, 4><<<bx * by + nslots * fin_y, 256, 0, st>>>(src, ld, K, TR, (unsigned short*)dst, kscale,
-                                                                               rmax_part, parts, inv_scale, bx, by, fa, fin_y);
+                                                                               rmax_part, parts, inv_scale, bx, by, fa, fin_y, fu);
     }
     return hipGetLastError();
 }

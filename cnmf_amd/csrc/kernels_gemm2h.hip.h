@@ -70,12 +70,20 @@ __device__ __forceinline__ void split2h(float y, unsigned short& h, unsigned sho
 //   rmax_part [rows][parts] : per-row maxima of the values to convert (after kscale), one per sweep workgroup
 //   inv_scale [rows]        : 2^-s_c, written by the workgroups of the first k column (bx == 0)
 // `tile` = unsigned short [TKB][TROWS][32] (16 KB), `red` = float [256 / TROWS][TROWS] (1 KB, may alias the tile)
+// Fused mode (round 3, the W half-step: shift_in != nullptr): the sweep has ALREADY written the planes of its rows, scaled
+// by the exponent shift_in[row] chosen one iteration earlier.  This body then only (i) reduces the row maxima the sweep
+// reported, (ii) checks that the exponent used was adequate -- largest scaled entry below the f16 overflow and not more
+// than 5 bits under the target (the f16 planes keep an absolute accuracy 2^-39 of the scale: 5 bits of slack is what the
+// sqrt(sum w^2) bound costs anyway) --, (iii) publishes 2^-s for pass B and the exponent of the NEXT iteration
+// (shift_out: unchanged while the scaled maximum stays in [2^13, 2^15.5), else re-centred), and (iv) re-converts its 16
+// rows from the float32 factor ONLY when one of them failed the check (a restart's first iterations).
+struct SplitFused { const int* shift_in; int* shift_out; };
 template <int TROWS, int TKB>
 __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src, int ld, int K, int TR,
                                                    unsigned short* __restrict__ dst, const double* __restrict__ kscale,
                                                    const float* __restrict__ rmax_part, int parts,
                                                    float* __restrict__ inv_scale, int bx, int nbx, int by,
-                                                   unsigned short* tile_, float* red_)
+                                                   unsigned short* tile_, float* red_, SplitFused fu = SplitFused{nullptr, nullptr})
 {
     static_assert(TROWS * TKB == 256, "tile = 256 (row, block) pairs");
     constexpr int NQ = 256 / TROWS;                      // threads per row in the maximum reduction
@@ -88,8 +96,9 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
     const int kq = t % KQ, rr = t / KQ;                  // float4 index along k, row within a pass
     const int ntiles = K / (16 * TKB);
     // the data of the first k tile and the row maxima are requested together (one memory latency, not two)
+    const bool fused = fu.shift_in != nullptr;
     float4 v[4];
-    {
+    if (!fused) {
         const int k0 = bx * 16 * TKB;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -103,6 +112,7 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
     }
     __syncthreads();
     int sh[4];
+    bool redo = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = rr + RPP * i;
@@ -110,7 +120,23 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
 #pragma unroll
         for (int q = 0; q < NQ; ++q) mx = fmaxf(mx, red[q][row]);
         sh[i] = g2_row_shift(mx);
+        if (fused) {
+            const int su = fu.shift_in[r0 + row];
+            const float ymax = ldexpf(mx, su);
+            const bool ok = !(mx > 0.f) || (ymax < 60000.0f && ymax >= 1024.0f);
+            const bool keep = !(mx > 0.f) || (ymax < 46340.0f && ymax >= 8192.0f);
+            if (bx == 0 && kq == 0) fu.shift_out[r0 + row] = (ok && keep) ? su : sh[i];
+            if (ok) sh[i] = su; else redo = true;
+        }
         if (bx == 0 && kq == 0) inv_scale[r0 + row] = ldexpf(1.0f, -sh[i]);
+    }
+    if (fused) {
+        // every thread looked at 4 of the TROWS rows: does ANY row of the workgroup need the conversion?
+        if (!__syncthreads_or(redo ? 1 : 0)) return;
+        const int k0 = bx * 16 * TKB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[i] = *reinterpret_cast<const float4*>(src + (size_t)(r0 + rr + RPP * i) * ld + k0 + kq * 4);
     }
     __syncthreads();                                     // `red` may alias the tile
     const int Kb = K / 16;

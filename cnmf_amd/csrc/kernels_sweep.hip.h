@@ -30,9 +30,11 @@ constexpr int GRAM_SZ = KMAX * KMAX;
 //   Gs [KG][KG+4] | vred [4] doubles | rmx [4][64] | Ws [4][64][wstride]      (KG = 16 / 32 / 64)
 static inline int sweep_kg(int kmax) { return kmax <= 16 ? 16 : (kmax <= 32 ? 32 : 64); }      // (ranks > 64: sweep_big_kernel)
 static inline int sweep_wstride(int kmax) { return sweep_kg(kmax) + 1; }
-static inline size_t sweep_lds_bytes(int kmax)
+static inline size_t sweep_lds_bytes(int kmax, bool planes = false)
 {
     const int kg = sweep_kg(kmax);
+    if (planes)         // + the transposition strips [4 waves][kg][64] dwords and kg exponents (PLN)
+        return sweep_lds_bytes(kmax, false) + sizeof(float) * (size_t)(4 * kg * 64 + kg);
     // ranks <= 16 stage the Gram operand 32 rows at a time: 11 KB per workgroup, so that a sweep workgroup fits beside
     // a GEMM workgroup (144 KB of the 160 KB) when two batches share the GPU
     return sizeof(float) * (size_t)(kg * (kg + 4) + 8 + 256 + 4 * (kg == 16 ? 32 : 64) * sweep_wstride(kmax));
@@ -59,6 +61,20 @@ struct SplitInfo {                  // further partial planes of a stream-K prod
     const float* plane2 = nullptr;
 };
 
+// PLN (round 3, the W half-step of the f16 paths): the sweep also writes the two f16 planes of the rows it has just
+// updated, in the block-major layout pass B multiplies (kernels_gemm2h.hip.h), scaled by the per-component exponent
+// `shift[component]` chosen one iteration earlier (split2h_tiled_body's fused mode checks it afterwards and re-converts the
+// rare row whose exponent was off).  A wave holds 64 consecutive cells of k components in registers; the layout wants, per
+// component and 16-cell block, 8 cells of one plane per 16-byte slot: each lane packs (h | m << 16) of one cell, the wave
+// transposes through a private LDS strip [component][64 cells], and every lane then gathers 8 cells of one (component,
+// block, half) and stores the h slot and the m slot.  Saves the plane split's re-read of the factor (205 MB per 1024
+// columns at 50 000 cells) and its launch.
+struct PlaneOut {
+    unsigned short* dst;            // planes of the packed factor (nullptr: none)
+    const int* shift;               // [KC] exponent per component row
+    int Kb, TR;                     // 16-cell blocks per row (cells_pad / 16), row-tile height (256)
+};
+
 // Body of the sweep for one (row chunk, slot); KP = k rounded up (compile-time register array
 // size: multiples of 4 up to 32, then 48 and 64).  Gram of the updated rows on the matrix pipe:
 //   KP <= 16 : v_mfma_f32_16x16x4_f32  (16 MFMAs of 32 cycles per 64 rows)
@@ -73,13 +89,13 @@ struct SplitInfo {                  // further partial planes of a stream-K prod
 // PSUM: the products arrive as `sp.mgroups` split-K partial planes (stride sp.tile_rows * 2^20 + sp.tile_cols floats,
 // see psum_info) that are summed here in split order and scaled by the per-row constant sp.split (reinterpreted as
 // const double*) -- the work of reduce_splits_kernel folded into the H half-step (no extra launch, no extra pass).
-template <int KP, bool RMX, bool PSUM = false>
+template <int KP, bool RMX, bool PSUM = false, bool PLN = false>
 __device__ __forceinline__ void sweep_body(
     float* __restrict__ V, int ldv, int L, const float* __restrict__ P, const SplitInfo& sp,
     const float* __restrict__ gram, const SlotDesc& sd, int slot, float l1_reg,
     float* __restrict__ gram_part, double* __restrict__ viol_part,
     int chunks_per_block, int want_gram, float* lds, int kg, int gld,
-    float* __restrict__ rmax_part, const double* __restrict__ rmax_scale)
+    float* __restrict__ rmax_part, const double* __restrict__ rmax_scale, const PlaneOut& po = PlaneOut{nullptr, nullptr, 0, 0})
 {
     constexpr int GMODE = (KP <= 16) ? 0 : ((KP <= 32) ? 1 : 2);
     constexpr int GR = (GMODE == 0) ? 16 : ((GMODE == 1) ? 32 : 64);       // gram tile edge
@@ -88,6 +104,9 @@ __device__ __forceinline__ void sweep_body(
     double* vred = reinterpret_cast<double*>(lds + kg * gs);
     float* rmx = lds + kg * gs + 8;                                       // [4][64] per-wave row maxima
     float* Wsb = rmx + 256;
+    // PLN: [4 waves][kg components][64 cells] dwords + kg exponents, behind the Gram staging (sweep_lds_bytes(kmax, true))
+    unsigned* Tpl = reinterpret_cast<unsigned*>(Wsb + 4 * (kg == 16 ? 32 : 64) * (kg + 1));
+    int* shl = reinterpret_cast<int*>(Tpl + 4 * kg * 64);
 #define GS(t_, r_) Gsb[(t_) * gs + (r_)]
     constexpr int SR = (GMODE == 0) ? 32 : 64;                            // rows of a wave staged at a time
 #define WS(wv_, r_, c_) Wsb[((wv_) * SR + (r_)) * wstride + (c_)]
@@ -97,6 +116,7 @@ __device__ __forceinline__ void sweep_body(
         const int r = e / KP, c = e % KP;
         GS(r, c) = (r < k && c < k) ? gram[(size_t)slot * GRAM_SZ + r * GRAM_LD + c] : 0.f;
     }
+    if constexpr (PLN) { if (tid < KP) shl[tid] = po.shift[off + min(tid, k - 1)]; }
     __syncthreads();
 
     f32x16 gacc[GMODE == 2 ? 4 : 1];
@@ -271,6 +291,37 @@ __device__ __forceinline__ void sweep_body(
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if constexpr (PLN) {
+            // (h | m << 16) of this lane's cell for every component -> the wave's strip
+            unsigned* tw = Tpl + wave * (kg * 64);
+#pragma unroll
+            for (int c = 0; c < KP; ++c) {
+                if (c < k) {
+                    const float y = ldexpf(w[c], shl[c]);
+                    unsigned short hb, mb;
+                    split2h(y, hb, mb);
+                    tw[c * 64 + lane] = (unsigned)hb | ((unsigned)mb << 16);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int kb0 = ((blockIdx.x * chunks_per_block + ch) * 256 + wave * 64) >> 4;       // first 16-cell block of the wave
+            for (int item = lane; item < 8 * k; item += 64) {
+                const int c = item >> 3, b = (item >> 1) & 3, hf = item & 1;
+                if (kb0 + b >= po.Kb) continue;                                  // row blocks past the padded length
+                const u32x4 d0 = *reinterpret_cast<const u32x4*>(tw + c * 64 + b * 16 + hf * 8);
+                const u32x4 d1 = *reinterpret_cast<const u32x4*>(tw + c * 64 + b * 16 + hf * 8 + 4);
+                u32x4 oh, om;
+                oh.x = (d0.x & 0xffffu) | (d0.y << 16); oh.y = (d0.z & 0xffffu) | (d0.w << 16);
+                oh.z = (d1.x & 0xffffu) | (d1.y << 16); oh.w = (d1.z & 0xffffu) | (d1.w << 16);
+                om.x = (d0.x >> 16) | (d0.y & 0xffff0000u); om.y = (d0.z >> 16) | (d0.w & 0xffff0000u);
+                om.z = (d1.x >> 16) | (d1.y & 0xffff0000u); om.w = (d1.z >> 16) | (d1.w & 0xffff0000u);
+                const int r = off + c, tr = r / po.TR, rin = r % po.TR, swz = (rin >> 2) & 3;
+                unsigned short* g = po.dst + (((size_t)tr * po.Kb + (kb0 + b)) * po.TR + rin) * 32;
+                *reinterpret_cast<u32x4*>(g + ((0 + hf) ^ swz) * 8) = oh;
+                *reinterpret_cast<u32x4*>(g + ((2 + hf) ^ swz) * 8) = om;
+            }
+            __builtin_amdgcn_wave_barrier();                                     // the strip is rewritten by the next chunk
+        }
     }
 
     // ---- row maxima: wave reduce -> LDS -> one partial per (component, workgroup)
@@ -336,8 +387,8 @@ __device__ __forceinline__ void sweep_body(
 // give the common small-rank case the register allocation of the largest (232 VGPR + 64 AGPR = one
 // wave per SIMD).  The host launches only the tiers present in the batch.
 // (TIER 0 without the exact report is the W half-step of the common ranks: held to 5 waves per SIMD)
-template <int TIER, bool RMX = false, bool PSUM = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 && !RMX) ? 5 : 1, 8))) void sweep_kernel(
+template <int TIER, bool RMX = false, bool PSUM = false, bool PLN = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 && !RMX && !PLN) ? 5 : (TIER == 0 && !RMX ? 4 : 1), 8))) void sweep_kernel(
     float* __restrict__ V, int ldv, int L,
     const float* __restrict__ P,             // [KC][ldv] products (split-K already reduced)
     SplitInfo sp,
@@ -348,15 +399,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 
     double* __restrict__ viol_part,          // [nslots][gridDim.x]
     int chunks_per_block, int want_gram, int kg, int gld,
     float* __restrict__ rmax_part = nullptr,     // [KC][gridDim.x] largest updated entry per component and workgroup
-    const double* __restrict__ rmax_scale = nullptr)
+    const double* __restrict__ rmax_scale = nullptr,
+    PlaneOut po = PlaneOut{nullptr, nullptr, 0, 0})
 {
     const int slot = blockIdx.y;
     const SlotDesc sd = slots[slot];
     if (!sd.active) return;
     extern __shared__ __attribute__((aligned(16))) float sweep_lds[];
 #define CNMF_SW(KP_)                                                                              \
-        sweep_body<KP_, RMX, PSUM>(V, ldv, L, P, sp, gram, sd, slot, l1_reg, gram_part, viol_part, \
-                        chunks_per_block, want_gram, sweep_lds, kg, gld, rmax_part, rmax_scale);
+        sweep_body<KP_, RMX, PSUM, PLN>(V, ldv, L, P, sp, gram, sd, slot, l1_reg, gram_part, viol_part, \
+                        chunks_per_block, want_gram, sweep_lds, kg, gld, rmax_part, rmax_scale, po);
     const int k = sd.k;
     if (TIER == 0) {
         if (k > 16) return;
@@ -728,14 +780,15 @@ __global__ __launch_bounds__(256) void split2h_finalize_kernel(const float* __re
                                                                const double* __restrict__ kscale,
                                                                const float* __restrict__ rmax_part, int parts,
                                                                float* __restrict__ inv_scale, int split_bx,
-                                                               int split_by, FinalizeArgs fa, int fin_y)
+                                                               int split_by, FinalizeArgs fa, int fin_y,
+                                                               SplitFused fu = SplitFused{nullptr, nullptr})
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[256 * 32 * 2];      // 16 KB (see split2h_tiled_kernel)
     const int b = blockIdx.x, nsplit = split_bx * split_by;
     if (b < nsplit) {
         split2h_tiled_body<TROWS, TKB>(src, ld, K, TR, dst, kscale, rmax_part, parts, inv_scale, b % split_bx, split_bx,
                                        b / split_bx, reinterpret_cast<unsigned short*>(lds),
-                                       reinterpret_cast<float*>(lds));
+                                       reinterpret_cast<float*>(lds), fu);
     } else {
         const int f = b - nsplit;
         finalize_body(fa, f / fin_y, f % fin_y, reinterpret_cast<double*>(lds));
@@ -835,6 +888,18 @@ __global__ __launch_bounds__(256) void gather_rows_cm_kernel(const float* __rest
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c >= 0) v = *reinterpret_cast<const float4*>(V + (size_t)c * ld + i);
     *reinterpret_cast<float4*>(stage + (size_t)j * ld + i) = v;
+}
+
+__global__ void set_ints_kernel(int* __restrict__ a, int* __restrict__ b, int off, int n, int value)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[off + i] = value; b[off + i] = value; }
+}
+// dst[j] = colmap[j] >= 0 ? src[colmap[j]] : 0   (the per-column exponents follow their columns through a re-packing)
+__global__ void permute_ints_kernel(const int* __restrict__ src, const int* __restrict__ colmap, int* __restrict__ dst, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) { const int c = colmap[j]; dst[j] = c >= 0 ? src[c] : 0; }
 }
 
 __global__ void set_slot_offs_kernel(SlotDesc* slots, const int* __restrict__ ids, const int* __restrict__ offs, int n)

@@ -40,6 +40,7 @@ struct cnmf_ctx {
     unsigned char* d_split = nullptr;   // stream-K cut flags of the current plan
     // f16 two-plane factor split (kernels_gemm2h.hip.h): per-row maxima reported by the sweeps, 2^-s per row
     float *rmaxH = nullptr, *rmaxW = nullptr, *iscaleH = nullptr, *iscaleW = nullptr;
+    int* shiftW = nullptr;              // [3][kc_alloc]: exponents of the W planes written by the sweep (two generations + scratch)
     float *gramH = nullptr, *gramW = nullptr, *gram_part = nullptr;
     double* viol_part = nullptr;
     SlotDesc* d_slots = nullptr;
