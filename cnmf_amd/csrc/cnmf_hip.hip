@@ -123,6 +123,8 @@ extern "C" void cnmf_destroy(cnmf_ctx* ctx)
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     hipFree(ctx->stageW); hipFree(ctx->stageH); hipFree(ctx->spectra);
+    ctx->cons_ws.release();
+    if (ctx->cons_pinned) hipHostFree(ctx->cons_pinned);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -84,7 +84,9 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
         fprintf(stderr, "[cnmf consensus] %-28s %8.2f ms\n", what, t - t_prev);
         t_prev = t;
     };
-    DevPool pool;
+    Arena& pool = ctx->cons_ws;                      // blocks stay with the context: no hipMalloc / hipFree per call
+    pool.reset();
+    struct Trim { Arena& a; ~Trim() { if (a.total() > Arena::keep_limit) a.release(); } } trim{pool};
     const int ld = round_up(G, 16);
     const int Rp = round_up(R, 64);
 
@@ -98,15 +100,15 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     lap("alloc + upload + l2");
 
     // ---- all-pairs distances + KNN local density (cnmf.py:891-898)
-    const bool need_dist = !prm->skip_density || prm->want_silhouette || dist_out;
+    const bool need_dist = true;      // k-means++ reads its squared distances from this matrix (pp_fused_kernel)
     double* dD = nullptr;
     std::vector<double> density(R, 0.0);
     std::vector<int> keep_idx;
     if (need_dist) {
         dD = pool.get<double>((size_t)Rp * Rp);
         if (pool.err) { SET_ERR(ctx, "device allocation failed (distance matrix)"); return CNMF_ENOMEM; }
-        dgemm_nt_kernel<<<dim3(Rp / 64, Rp / 64), 256, 0, st>>>(dL2, ld, dL2, ld, dD, Rp, ld);
-        dist_epilogue_kernel<<<dim3((R + 255) / 256, R), 256, 0, st>>>(dD, Rp, R, dsq);
+        const int nt = Rp / 64;                      // lower-triangular tiles; the epilogue writes both halves
+        dist_sym_kernel<<<nt * (nt + 1) / 2, 256, 0, st>>>(dL2, ld, ld, dsq, R, dD, Rp);
         CONS_TRY(hipGetLastError());
         if (dist_out)
             CONS_TRY(hipMemcpy2DAsync(dist_out, (size_t)R * sizeof(double), dD, (size_t)Rp * sizeof(double),
@@ -116,13 +118,15 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     if (!prm->skip_density) {
         double* ddens = pool.get<double>(R);
         if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
-        const size_t lds = (size_t)R * sizeof(double);
-        if (lds <= 150 * 1024 && !getenv("CNMF_KNN_GLOBAL")) {
-            CONS_TRY(hipFuncSetAttribute((const void*)knn_density_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            knn_density_kernel<true><<<R, 256, lds, st>>>(dD, Rp, R, prm->n_neighbors + 1, prm->n_neighbors, ddens);
-        } else {                      // more than 19 200 merged spectra: selection passes over the L2-resident row
-            knn_density_kernel<false><<<R, 256, 0, st>>>(dD, Rp, R, prm->n_neighbors + 1, prm->n_neighbors, ddens);
+        const int m_sel = prm->n_neighbors + 1, vpt = (R + 255) / 256;
+#define KNN_REG(V) knn_density_reg_kernel<V><<<R, 256, 0, st>>>(dD, Rp, R, m_sel, prm->n_neighbors, ddens)
+        if (vpt <= 80 && !getenv("CNMF_KNN_GLOBAL")) {   // the row in registers, 4-way search (up to 20 480 merged spectra)
+            if (vpt <= 4) KNN_REG(4); else if (vpt <= 8) KNN_REG(8); else if (vpt <= 16) KNN_REG(16);
+            else if (vpt <= 24) KNN_REG(24); else if (vpt <= 40) KNN_REG(40); else KNN_REG(80);
+        } else {                      // selection passes over the L2-resident row: any R
+            knn_density_kernel<<<R, 256, 0, st>>>(dD, Rp, R, m_sel, prm->n_neighbors, ddens);
         }
+#undef KNN_REG
         CONS_TRY(hipGetLastError());
         CONS_TRY(hipMemcpyAsync(density.data(), ddens, (size_t)R * sizeof(double), hipMemcpyDeviceToHost, st));
         CONS_TRY(hipStreamSynchronize(st));
@@ -142,7 +146,7 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     // ---- KMeans on the kept rows (cnmf.py:908-909; sklearn _kmeans.py:1427-1555), all inits batched
     const int Rkp = round_up(Rk, 64);
     const int I = n_init;
-    const int MT = round_up(I * k, 64), MC = round_up(I * L, 64), MD = std::max(MT, MC);
+    const int MT = round_up(I * k, 64);
     const size_t ustride = 1 + (size_t)(k - 1) * L;
     const KmDims kd{Rk, Rkp, G, ld, k, L};
     int* dkeep = pool.get<int>(Rk);
@@ -150,15 +154,12 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     double* dxsq = pool.get<double>(Rkp, true, st);
     double* dmean = pool.get<double>(ld, true, st);
     double* dvar = pool.get<double>(ld, true, st);
+    double* dtol = pool.get<double>(1);
     double* dcA = pool.get<double>((size_t)MT * ld, true, st);
     double* dcB = pool.get<double>((size_t)MT * ld, true, st);
-    double* dcand = pool.get<double>((size_t)MC * ld, true, st);
-    double* ddots = pool.get<double>((size_t)MD * Rkp, true, st);
-    double* dclosest = pool.get<double>((size_t)I * Rkp);
-    double* dcum = pool.get<double>((size_t)I * Rkp);
-    double* ddmin = pool.get<double>((size_t)I * 8 * Rkp);
-    double* dcpot = pool.get<double>((size_t)I * 8);
+    double* ddots = pool.get<double>((size_t)MT * Rkp, true, st);
     double* dcsq = pool.get<double>(MT);
+    double* dshift2 = pool.get<double>((size_t)I * KM_CID);
     int* dlabels = pool.get<int>((size_t)I * Rkp);
     const int rows_per_chunk = std::max(64, (Rk + 15) / 16);
     const int nchunks = (Rk + rows_per_chunk - 1) / rows_per_chunk;
@@ -173,15 +174,25 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     KmState* dst = pool.get<KmState>(I, true, st);
     const size_t nu = (size_t)I * ustride;
     double* du = pool.get<double>(nu);
-    KmState* hst = nullptr;
     if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
-    CONS_TRY(hipHostMalloc(&hst, sizeof(KmState) * I));
-    struct HostFree { void* p; ~HostFree() { hipHostFree(p); } } hf{hst};
+    // pinned host block (kept by the context): k-means state | labels of every init | first-centre ids / need flags |
+    // the three index arrays of the median step
+    const size_t pin_state = round_up((int64_t)sizeof(KmState) * I, 256), pin_lab = (size_t)I * Rkp * sizeof(int);
+    const size_t pin_ints = (size_t)(2 * I + 2 * Rk + k + 1) * sizeof(int);
+    const size_t pin_need = pin_state + pin_lab + round_up((int64_t)pin_ints, 256);
+    if (ctx->cons_pinned_bytes < pin_need) {
+        if (ctx->cons_pinned) { hipHostFree(ctx->cons_pinned); ctx->cons_pinned = nullptr; ctx->cons_pinned_bytes = 0; }
+        CONS_TRY(hipHostMalloc(&ctx->cons_pinned, pin_need + pin_need / 2));
+        ctx->cons_pinned_bytes = pin_need + pin_need / 2;
+    }
+    KmState* hst = (KmState*)ctx->cons_pinned;
+    int* h_labels = (int*)((char*)ctx->cons_pinned + pin_state);
+    int* h_ints = (int*)((char*)ctx->cons_pinned + pin_state + pin_lab);
     CONS_TRY(hipMemcpyAsync(dkeep, keep_idx.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
     CONS_TRY(hipMemcpyAsync(du, uniforms, nu * sizeof(double), hipMemcpyHostToDevice, st));
     gather_rows_kernel<<<dim3((G + 255) / 256, Rk), 256, 0, st>>>(dL2, ld, dkeep, Rk, G, dX, ld);
     {   // column mean / population variance of the kept rows (sklearn _kmeans.py:1477-1484, 279-288), rows spread
-        // over 64-row chunks, chunk partials added in order
+        // over 64-row chunks, chunk partials added in order; the tolerance stays on the device (lloyd_decide_kernel)
         const int rpc = 64, chunks = (Rk + rpc - 1) / rpc;
         double* dcpart = pool.get<double>((size_t)chunks * G);
         if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
@@ -190,94 +201,88 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
         col_combine_f64_kernel<<<(G + 255) / 256, 256, 0, st>>>(dcpart, chunks, G, (double)Rk, dmean);
         col_partial_f64_kernel<<<gp, 256, 0, st>>>(dX, ld, Rk, G, rpc, dmean, dcpart);
         col_combine_f64_kernel<<<(G + 255) / 256, 256, 0, st>>>(dcpart, chunks, G, (double)Rk, dvar);
+        km_tolerance_kernel<<<1, 256, 0, st>>>(dvar, G, tol, dtol);
     }
     center_rows_kernel<<<Rk, 256, 0, st>>>(dX, ld, G, dmean, dxsq);
-    std::vector<double> hvar(G);
-    CONS_TRY(hipMemcpyAsync(hvar.data(), dvar, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, st));
-    CONS_TRY(hipStreamSynchronize(st));
-    double vsum = 0.0;
-    for (int g = 0; g < G; ++g) vsum += hvar[g];
-    const double tol_ = (vsum / G) * tol;                      // _tolerance, sklearn _kmeans.py:279-288
 
     const int acc_bw = k <= 64 ? 256 : 128;                      // columns per block of the M step: k x acc_bw doubles of LDS
     const size_t acc_lds = (size_t)k * acc_bw * sizeof(double);
     CONS_TRY(dyn_lds_optin((const void*)accumulate_kernel, 160 * 1024 - 64));
-    auto dots = [&](const double* A, int M) {     // ddots[M][Rkp] = A[M][ld] . X^T  (one product for every init)
-        dgemm_nt_small_kernel<<<dim3(Rkp / 16, M / 64), 256, 0, st>>>(A, ld, dX, ld, ddots, Rkp, ld);
+    auto dots = [&](const double* A, const KmState* live) {   // ddots[MT][Rkp] = A[MT][ld] . X^T  (one product for every init)
+        dgemm_nt_small_kernel<<<dim3(Rkp / 16, MT / 64), 256, 0, st>>>(A, ld, dX, ld, ddots, Rkp, ld, live, k, I);
     };
     lap("kmeans setup (gather, stats)");
 
-    // -- k-means++ for all inits in lock step (sklearn _kmeans.py:174-272)
-    std::vector<int> c0(I);
+    // -- k-means++: one workgroup per init runs all k draws on the distance matrix (sklearn _kmeans.py:174-272)
+    int* c0 = h_ints;
     for (int i = 0; i < I; ++i) c0[i] = std::min(first_center_index(Rk, uniforms[(size_t)i * ustride]), Rk - 1);
-    CONS_TRY(hipMemcpyAsync(dc0, c0.data(), (size_t)I * sizeof(int), hipMemcpyHostToDevice, st));
-    pp_seed_kernel<<<dim3((ld + 255) / 256, I), 256, 0, st>>>(dX, kd, dc0, dcA, dcids);
-    dots(dcA, MT);
-    pp_first_kernel<<<I, 256, 0, st>>>(ddots, kd, dxsq, dc0, dclosest, dst);
-    for (int c = 1; c < k; ++c) {
-        pp_candidates_kernel<<<I, 256, 0, st>>>(dclosest, kd, du, (int)ustride, 1 + (c - 1) * L, dcum, dst);
-        pp_gather_kernel<<<dim3((G + 255) / 256, L, I), 256, 0, st>>>(dX, kd, dst, dcand);
-        dots(dcand, MC);
-        pp_update_kernel<<<dim3(L, I), 256, 0, st>>>(ddots, kd, dxsq, dclosest, dst, ddmin, dcpot);
-        pp_pick_kernel<<<I, 256, 0, st>>>(dcpot, kd, ddmin, dclosest, dst, dX, dcA, c, dcids);
+    CONS_TRY(hipMemcpyAsync(dc0, c0, (size_t)I * sizeof(int), hipMemcpyHostToDevice, st));
+    const int pp_vpt = (Rk + 1023) / 1024;
+#define PP_REG(V) pp_fused_reg_kernel<1024, V><<<I, 1024, 0, st>>>(dD, Rp, dkeep, kd, dc0, du, (int)ustride, dcids)
+    if (pp_vpt <= 8 && !getenv("CNMF_PP_GLOBAL")) {       // closest[] in registers: up to 8192 kept spectra
+        if (pp_vpt <= 1) PP_REG(1); else if (pp_vpt <= 2) PP_REG(2); else if (pp_vpt <= 4) PP_REG(4); else PP_REG(8);
+    } else {
+        double* dclosest = pool.get<double>((size_t)I * Rkp);
+        double* dcum = pool.get<double>((size_t)I * Rkp);
+        double* ddmin = pool.get<double>((size_t)I * 8 * Rkp);
+        if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+        pp_fused_kernel<1024><<<I, 1024, 0, st>>>(dD, Rp, dkeep, kd, dc0, du, (int)ustride, dclosest, dcum, ddmin, dcids);
     }
+#undef PP_REG
+    pp_centers_kernel<<<dim3((ld + 255) / 256, k, I), 256, 0, st>>>(dX, kd, dcids, dcA);
     CONS_TRY(hipGetLastError());
     lap("kmeans++ (all inits)");
 
-    // -- Lloyd for all inits in lock step; an init leaves the loop at its own iteration (sklearn _kmeans.py:624-752)
+    // -- Lloyd for all inits in lock step; an init leaves the loop at its own iteration (sklearn _kmeans.py:624-752).
+    // The stopping rule is applied on the device, so iterations are queued LLOYD_BATCH at a time and the host looks at
+    // the state once per batch (kernels of a finished init return at once; its tiles of the product are skipped).
     double* cur = dcA; double* nxt = dcB;
     CONS_TRY(hipMemsetAsync(dlabels, 0xff, (size_t)I * Rkp * sizeof(int), st));          // labels = -1
-    std::vector<char> done(I, 0), strict(I, 0);
-    std::vector<int> iters(I, 0);
-    int n_done = 0;
-    for (int it = 0; it < max_iter && n_done < I; ++it) {
-        center_norms_kernel<<<I * k, 256, 0, st>>>(cur, ld, G, dcsq);
-        dots(cur, MT);
-        km_reset_kernel<<<1, 64, 0, st>>>(dst, I);
-        assign_kernel<<<dim3((Rk + 255) / 256, I), 256, 0, st>>>(ddots, kd, dcsq, dlabels, dst, 0, nullptr);
-        accumulate_kernel<<<dim3((G + acc_bw - 1) / acc_bw, nchunks, I), acc_bw, acc_lds, st>>>(dX, kd, dlabels, rows_per_chunk, nchunks, dpartial, dpcount, dst);
-        reduce_partial_kernel<<<dim3((G + 255) / 256, k, I), 256, 0, st>>>(dpartial, dpcount, nchunks, kd, dsums, dcounts, dst);
-        row_center_dist_kernel<<<dim3(Rk, I), 256, 0, st>>>(dX, kd, cur, dlabels, ddist, dst, 0);
-        relocate_empty_kernel<<<I, 256, 0, st>>>(dX, kd, dlabels, ddist, dsums, dcounts, dst);
-        finish_centers_kernel<<<I, 256, 0, st>>>(dsums, dcounts, kd, cur, nxt, dst);
+    constexpr int LLOYD_BATCH = 3;
+    for (int it = 0; it < max_iter; ) {
+        const int nb = std::min(LLOYD_BATCH, max_iter - it);
+        for (int b = 0; b < nb; ++b, ++it) {
+            center_norms_kernel<<<I * k, 256, 0, st>>>(cur, ld, G, dcsq);
+            dots(cur, dst);
+            assign_kernel<<<dim3((Rk + 255) / 256, I), 256, 0, st>>>(ddots, kd, dcsq, dlabels, dst, 0, nullptr);
+            accumulate_kernel<<<dim3((G + acc_bw - 1) / acc_bw, nchunks, I), acc_bw, acc_lds, st>>>(dX, kd, dlabels, rows_per_chunk, nchunks, dpartial, dpcount, dst);
+            reduce_partial_kernel<<<dim3((G + 255) / 256, k, I), 256, 0, st>>>(dpartial, dpcount, nchunks, kd, dsums, dcounts, dst);
+            row_center_dist_kernel<<<dim3((Rk + RCD_ROWS - 1) / RCD_ROWS, I), 256, 0, st>>>(dX, kd, cur, dlabels, ddist, dst);
+            relocate_empty_kernel<<<I, 256, 0, st>>>(dX, kd, dlabels, ddist, dsums, dcounts, dst);
+            finish_centers_kernel<<<dim3(k, I), 256, 0, st>>>(dsums, dcounts, kd, cur, nxt, dst, dshift2);
+            lloyd_decide_kernel<<<1, 64, 0, st>>>(dst, dshift2, k, I, dtol, it);
+            std::swap(cur, nxt);
+        }
         CONS_TRY(hipGetLastError());
         CONS_TRY(hipMemcpyAsync(hst, dst, sizeof(KmState) * I, hipMemcpyDeviceToHost, st));
         CONS_TRY(hipStreamSynchronize(st));
-        std::swap(cur, nxt);
-        bool any_new = false;
-        for (int i = 0; i < I; ++i) {
-            if (done[i]) continue;
-            iters[i] = it + 1;
-            if (hst[i].changed == 0) { strict[i] = 1; done[i] = 1; }
-            else if (hst[i].shift_tot <= tol_) done[i] = 1;
-            if (done[i]) { hst[i].done = 1; ++n_done; any_new = true; }
-        }
-        if (any_new)      // publish the done flags (only that field changes; the device copy is otherwise current)
-            for (int i = 0; i < I; ++i)
-                if (done[i]) CONS_TRY(hipMemcpyAsync(&dst[i].done, &hst[i].done, sizeof(int), hipMemcpyHostToDevice, st));
+        bool all_done = true;
+        for (int i = 0; i < I; ++i) all_done &= hst[i].done != 0;
+        if (all_done) break;
     }
     // inits that stopped on the tolerance (or max_iter) re-run the E step so labels match the final centres
-    std::vector<int> need(I, 0);
+    std::vector<int> iters(I, 0);
+    int* need = h_ints + I;
     bool any_need = false;
-    for (int i = 0; i < I; ++i) { need[i] = strict[i] ? 0 : 1; any_need |= need[i] != 0; }
+    for (int i = 0; i < I; ++i) { iters[i] = hst[i].iters; need[i] = hst[i].strict ? 0 : 1; any_need |= need[i] != 0; }
     if (any_need) {
-        CONS_TRY(hipMemcpyAsync(dneed, need.data(), (size_t)I * sizeof(int), hipMemcpyHostToDevice, st));
+        CONS_TRY(hipMemcpyAsync(dneed, need, (size_t)I * sizeof(int), hipMemcpyHostToDevice, st));
         center_norms_kernel<<<I * k, 256, 0, st>>>(cur, ld, G, dcsq);
-        dots(cur, MT);
+        dots(cur, nullptr);
         assign_kernel<<<dim3((Rk + 255) / 256, I), 256, 0, st>>>(ddots, kd, dcsq, dlabels, dst, 1, dneed);
     }
-    row_center_dist_kernel<<<dim3(Rk, I), 256, 0, st>>>(dX, kd, cur, dlabels, ddist, dst, 1);
+    row_center_dist_all_kernel<<<Rk, 256, 0, st>>>(dX, kd, cur, dlabels, ddist, I);
     inertia_kernel<<<I, 256, 0, st>>>(ddist, kd, dst);
     CONS_TRY(hipGetLastError());
-    std::vector<int> all_labels((size_t)I * Rkp);
+    const int* all_labels = h_labels;
     CONS_TRY(hipMemcpyAsync(hst, dst, sizeof(KmState) * I, hipMemcpyDeviceToHost, st));
-    CONS_TRY(hipMemcpyAsync(all_labels.data(), dlabels, all_labels.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    CONS_TRY(hipMemcpyAsync(h_labels, dlabels, (size_t)I * Rkp * sizeof(int), hipMemcpyDeviceToHost, st));
     CONS_TRY(hipStreamSynchronize(st));
     // best-of-n_init in init order (sklearn _kmeans.py:1525-1533)
     std::vector<int> best_labels, labels(Rk);
     double best_inertia = 0.0; int best_iter = 0; bool have_best = false;
     for (int i = 0; i < I; ++i) {
-        std::copy(all_labels.begin() + (size_t)i * Rkp, all_labels.begin() + (size_t)i * Rkp + Rk, labels.begin());
+        std::copy(all_labels + (size_t)i * Rkp, all_labels + (size_t)i * Rkp + Rk, labels.begin());
         const double inertia = hst[i].inertia;
         if (!have_best || (inertia < best_inertia && !same_clustering(labels, best_labels, k))) {
             best_labels = labels; best_inertia = inertia; best_iter = std::min(iters[i], max_iter); have_best = true;
@@ -287,21 +292,22 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     for (int q = 0; q < Rk; ++q) labels_out[keep_idx[q]] = best_labels[q];
 
     // ---- per-cluster per-gene median, rows normalised to sum 1 (cnmf.py:913-916)
-    std::vector<int> seg(k + 1, 0), order(Rk), order_rows(Rk);
+    int* order_rows = h_ints + 2 * I;            // pinned, one upload: order_rows | order | seg
+    int* order = order_rows + Rk;
+    int* seg = order + Rk;
+    for (int j = 0; j <= k; ++j) seg[j] = 0;
     for (int q = 0; q < Rk; ++q) seg[best_labels[q] + 1]++;
     for (int j = 0; j < k; ++j) seg[j + 1] += seg[j];
-    { std::vector<int> pos(seg.begin(), seg.end() - 1);
+    { std::vector<int> pos(seg, seg + k);
       for (int q = 0; q < Rk; ++q) { const int p = pos[best_labels[q]]++; order[p] = q; order_rows[p] = keep_idx[q]; } }
     for (int j = 0; j < k; ++j)
         if (seg[j + 1] == seg[j]) { SET_ERR(ctx, "k-means produced an empty cluster (%d)", j); return CNMF_ESTATE; }
-    int* dorder_rows = pool.get<int>(Rk);
-    int* dorder = pool.get<int>(Rk);
-    int* dseg = pool.get<int>(k + 1);
+    int* dorder_rows = pool.get<int>((size_t)2 * Rk + k + 1);
+    int* dorder = dorder_rows + Rk;
+    int* dseg = dorder + Rk;
     double* dmed = pool.get<double>((size_t)k * G);
     if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
-    CONS_TRY(hipMemcpyAsync(dorder_rows, order_rows.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
-    CONS_TRY(hipMemcpyAsync(dorder, order.data(), (size_t)Rk * sizeof(int), hipMemcpyHostToDevice, st));
-    CONS_TRY(hipMemcpyAsync(dseg, seg.data(), (size_t)(k + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    CONS_TRY(hipMemcpyAsync(dorder_rows, order_rows, (size_t)(2 * Rk + k + 1) * sizeof(int), hipMemcpyHostToDevice, st));
     int max_m = 0;
     for (int j = 0; j < k; ++j) max_m = std::max(max_m, seg[j + 1] - seg[j]);
     if (max_m <= 512)

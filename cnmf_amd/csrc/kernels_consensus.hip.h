@@ -6,7 +6,7 @@
 // and the f64 matrix pipe (v_mfma_f64_16x16x4_f64, 78 TF) makes the R x R Gram matrix a
 // ~1 ms kernel.  Restated functions:
 //   row_norm / l2        cnmf.py:882
-//   dgemm_nt + dist_epi  sklearn/metrics/pairwise.py:419-438  (-2 X.Xt + |x|^2 + |y|^2, clamp, diag=0, sqrt)
+//   dist_sym             sklearn/metrics/pairwise.py:419-438  (-2 X.Xt + |x|^2 + |y|^2, clamp, diag=0, sqrt)
 //   knn_density          cnmf.py:893-898  (sum of the n+1 smallest per row / n)
 //   kmeans++ / Lloyd     sklearn/cluster/_kmeans.py:174-272, :624-752; _k_means_lloyd.pyx:26-219
 //   cluster_median       pandas groupby().median(), cnmf.py:913
@@ -21,6 +21,8 @@ namespace cnmf {
 constexpr int KM_CID = 128;          // largest number of clusters (= largest rank, CNMF_KMAX): centre ids per init, per-cluster sums
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
+struct KmState;
+__device__ __forceinline__ bool km_tile_done(const KmState* st, int m0, int k, int n_init);
 
 // ---------------------------------------------------------------- f64 MFMA GEMM, C = A . B^T
 // A [M][lda], B [N][ldb] both K-contiguous, C [M][ldc].  Workgroup tile 64 x 64, 4 waves
@@ -31,20 +33,32 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int DBK = 16;
 constexpr int DLD = DBK + 2;     // padded LDS row (doubles): 18*8 B = 144 B -> ds_read_b64 conflict-free
 
-__global__ __launch_bounds__(256) void dgemm_nt_kernel(const double* __restrict__ A, int lda,
-                                                       const double* __restrict__ B, int ldb,
-                                                       double* __restrict__ C, int ldc, int K)
+// All-pairs distances of the rows of A (sklearn/metrics/pairwise.py:419-438) in ONE launch: the same 64 x 64 MFMA tile
+// loop over the LOWER-TRIANGULAR tiles only (blockIdx.x = by*(by+1)/2 + bx, bx <= by) with the distance epilogue
+//   D[i][j] = sqrt(max(0, (-2 G_ij + sq_i) + sq_j)), D[i][i] = 0
+// applied to both (i, j) and its mirror (j, i) -- G_ij and G_ji are the same sum of the same products, so the mirror
+// is what the full Gram would have held; only the order in which the two norms are added follows the element's own
+// (row, column), as in the two-sided epilogue this replaces.  The mirrored tile goes through LDS so that its stores
+// are row-contiguous too.  Halves the f64 MFMA work of the dominant consensus kernel and drops one 2 x R^2 x 8 B pass.
+__global__ __launch_bounds__(256) void dist_sym_kernel(const double* __restrict__ A, int lda, int K,
+                                                       const double* __restrict__ sq, int R,
+                                                       double* __restrict__ D, int ldd)
 {
-    __shared__ __attribute__((aligned(16))) double As[2][64 * DLD];
-    __shared__ __attribute__((aligned(16))) double Bs[2][64 * DLD];
+    constexpr int TLD = 65;
+    __shared__ __attribute__((aligned(16))) double smem[4 * 64 * DLD > 64 * TLD ? 4 * 64 * DLD : 64 * TLD];
+    double* As0 = smem;                      // [2][64*DLD]
+    double* Bs0 = smem + 2 * 64 * DLD;       // [2][64*DLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    // staging: 64 rows x 16 doubles = 512 v2d per operand -> 2 per thread
+    int by = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((by + 1) * (by + 2) / 2 <= (int)blockIdx.x) ++by;
+    while (by * (by + 1) / 2 > (int)blockIdx.x) --by;
+    const int bx = (int)blockIdx.x - by * (by + 1) / 2;
+    const int m0 = by * 64, n0 = bx * 64;
     const int s_row = tid >> 3, s_k = (tid & 7) * 2;
     const double* a_src = A + (size_t)(m0 + s_row) * lda + s_k;
-    const double* b_src = B + (size_t)(n0 + s_row) * ldb + s_k;
+    const double* b_src = A + (size_t)(n0 + s_row) * lda + s_k;
     v2d ar[2], br[2];
     f64x4 acc[2][2];
 #pragma unroll
@@ -52,27 +66,27 @@ __global__ __launch_bounds__(256) void dgemm_nt_kernel(const double* __restrict_
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
     const int nk = K / DBK;
-#define DG_LOAD(kt_)                                                                          \
-    {                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                       \
-            ar[i] = *reinterpret_cast<const v2d*>(a_src + (size_t)(32 * i) * lda + (kt_) * DBK); \
-            br[i] = *reinterpret_cast<const v2d*>(b_src + (size_t)(32 * i) * ldb + (kt_) * DBK); \
-        }                                                                                     \
-    }
-#define DG_STORE(buf_)                                                                        \
-    {                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                       \
-            *reinterpret_cast<v2d*>(&As[buf_][(s_row + 32 * i) * DLD + s_k]) = ar[i];         \
-            *reinterpret_cast<v2d*>(&Bs[buf_][(s_row + 32 * i) * DLD + s_k]) = br[i];         \
-        }                                                                                     \
-    }
-    if (nk > 0) { DG_LOAD(0) DG_STORE(0) }
+    auto load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ar[i] = *reinterpret_cast<const v2d*>(a_src + (size_t)(32 * i) * lda + kt * DBK);
+            br[i] = *reinterpret_cast<const v2d*>(b_src + (size_t)(32 * i) * lda + kt * DBK);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<v2d*>(&As0[buf * 64 * DLD + (s_row + 32 * i) * DLD + s_k]) = ar[i];
+            *reinterpret_cast<v2d*>(&Bs0[buf * 64 * DLD + (s_row + 32 * i) * DLD + s_k]) = br[i];
+        }
+    };
+    if (nk > 0) { load(0); store(0); }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) DG_LOAD(kt + 1)
-        const double* as = &As[buf][(wm * 32 + li) * DLD + lk];
-        const double* bs = &Bs[buf][(wn * 32 + li) * DLD + lk];
+        if (kt + 1 < nk) load(kt + 1);
+        const double* as = &As0[buf * 64 * DLD + (wm * 32 + li) * DLD + lk];
+        const double* bs = &Bs0[buf * 64 * DLD + (wn * 32 + li) * DLD + lk];
 #pragma unroll
         for (int q = 0; q < DBK / 4; ++q) {
             const double a0 = as[q * 4], a1 = as[16 * DLD + q * 4];
@@ -82,34 +96,61 @@ __global__ __launch_bounds__(256) void dgemm_nt_kernel(const double* __restrict_
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) DG_STORE(buf ^ 1)
+        if (kt + 1 < nk) store(buf ^ 1);
         __syncthreads();
     }
-#undef DG_LOAD
-#undef DG_STORE
+    // direct tile (rows of the m block) + the raw Gram tile into LDS, transposed, for the mirror
+    double* T = smem;                        // [64 cols of the tile][TLD]: T[c][r] = G[m0 + r][n0 + c]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 32 + i * 16 + lk + 4 * r;
-                const int col = n0 + wn * 32 + j * 16 + li;
-                C[(size_t)row * ldc + col] = acc[i][j][r];
+                const int rl = wm * 32 + i * 16 + lk + 4 * r, cl = wn * 32 + j * 16 + li;
+                const int row = m0 + rl, col = n0 + cl;
+                const double g = acc[i][j][r];
+                T[cl * TLD + rl] = g;
+                if (row < R && col < R) {
+                    double dd = -2.0 * g;
+                    dd += sq[row];
+                    dd += sq[col];
+                    dd = fmax(dd, 0.0);
+                    if (row == col) dd = 0.0;
+                    D[(size_t)row * ldd + col] = sqrt(dd);
+                }
             }
+    if (bx == by) return;                    // a diagonal tile is its own mirror (uniform)
+    __syncthreads();
+    const int cl = tid & 63;
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+        const int rl = rr * 4 + (tid >> 6);
+        const int row = n0 + rl, col = m0 + cl;          // element (row, col) of D = mirror of G[col][row]
+        if (row < R && col < R) {
+            double dd = -2.0 * T[rl * TLD + cl];
+            dd += sq[row];
+            dd += sq[col];
+            dd = fmax(dd, 0.0);
+            D[(size_t)row * ldd + col] = sqrt(dd);
+        }
+    }
 }
 
 // Few-rows variant for the k-means products (M = 64 centre / candidate rows against all N rows):
 // workgroup tile 64 x 16 so that the launch has N/16 workgroups instead of N/64.
+// st != nullptr: rows are the centres of n_init k-means runs (k rows each); a tile whose runs have all finished is skipped.
 __global__ __launch_bounds__(256) void dgemm_nt_small_kernel(const double* __restrict__ A, int lda,
                                                              const double* __restrict__ B, int ldb,
-                                                             double* __restrict__ C, int ldc, int K)
+                                                             double* __restrict__ C, int ldc, int K,
+                                                             const KmState* __restrict__ st, int k, int n_init)
 {
     __shared__ __attribute__((aligned(16))) double As[2][64 * DLD];
     __shared__ __attribute__((aligned(16))) double Bs[2][16 * DLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 16;
+    if (st && km_tile_done(st, m0, k, n_init)) return;
     const int s_row = tid >> 3, s_k = (tid & 7) * 2;
     const double* a_src = A + (size_t)(m0 + s_row) * lda + s_k;
     const double* b_src = B + (size_t)(n0 + (s_row & 15)) * ldb + s_k;
@@ -179,37 +220,17 @@ __global__ __launch_bounds__(256) void l2_rows_kernel(const double* __restrict__
     if (threadIdx.x == 0) sq[r] = s2;
 }
 
-// D[i][j] = sqrt(max(0, sq_i + sq_j - 2 G_ij)), diagonal forced to 0 (in place on the Gram)
-__global__ void dist_epilogue_kernel(double* __restrict__ Dm, int ld, int R, const double* __restrict__ sq)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (i >= R || j >= R) return;
-    double d = -2.0 * Dm[(size_t)i * ld + j];
-    d += sq[i];
-    d += sq[j];
-    d = fmax(d, 0.0);
-    if (i == j) d = 0.0;
-    Dm[(size_t)i * ld + j] = sqrt(d);
-}
-
 // density[i] = (sum of the m smallest entries of row i) / n      (m = n+1, self distance 0 included)
 // Exact selection by bisection on the IEEE bit pattern (non-negative doubles order like uint64).
-// LDS = true: the row is staged in LDS (R <= 19 200); false: the ~64 selection passes re-read the row from
-// global memory (it stays in L2) -- any R.
-template <bool LDS>
+// Fallback for more than 20 480 merged spectra: the ~64 selection passes re-read the row from global memory (it stays
+// in L2) -- any R.
 __global__ __launch_bounds__(256) void knn_density_kernel(const double* __restrict__ Dm, int ld, int R,
                                                           int m, int n, double* __restrict__ density)
 {
-    extern __shared__ __attribute__((aligned(16))) double rowbuf_lds[];
     __shared__ double red[4];
     __shared__ int cnt_s[4];
     const int i = blockIdx.x, tid = threadIdx.x;
-    const double* __restrict__ grow = Dm + (size_t)i * ld;
-    if (LDS) {
-        for (int j = tid; j < R; j += 256) rowbuf_lds[j] = grow[j];
-        __syncthreads();
-    }
-#define rowbuf (LDS ? (const double*)rowbuf_lds : grow)
+    const double* __restrict__ rowbuf = Dm + (size_t)i * ld;
     unsigned long long lo = 0ull, hi = 0x7ff0000000000000ull;   // find smallest T with count(x<=T) >= m
     while (lo < hi) {
         const unsigned long long mid = lo + ((hi - lo) >> 1);
@@ -234,7 +255,63 @@ __global__ __launch_bounds__(256) void knn_density_kernel(const double* __restri
     __syncthreads();
     c = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
     if (tid == 0) density[i] = (s + (double)(m - c) * T) / (double)n;
-#undef rowbuf
+}
+
+// The same selection with the row in REGISTERS (VPT values per thread, R <= 256 * VPT) and a 4-way search: three pivots
+// per pass, their three counts packed into one 64-bit word (21 bits each) for a single reduction -- 32 passes of
+// register compares instead of 63 passes over memory, and no LDS footprint to limit occupancy.  The final sum runs in
+// the order of the fallback kernel (thread-strided, then block_sum), so the density is bit-identical to it.
+template <int VPT>
+__global__ __launch_bounds__(256) void knn_density_reg_kernel(const double* __restrict__ Dm, int ld, int R,
+                                                              int m, int n, double* __restrict__ density)
+{
+    __shared__ double red[4];
+    __shared__ unsigned long long cnt_s[2][4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const double* __restrict__ grow = Dm + (size_t)i * ld;
+    long long key[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int j = tid + 256 * v;
+        key[v] = (j < R) ? __double_as_longlong(grow[j]) : 0x7fffffffffffffffll;
+    }
+    unsigned long long lo = 0ull, hi = 0x7ff0000000000000ull;   // smallest T with count(x <= T) >= m
+    int pass = 0;
+    while (lo < hi) {
+        const unsigned long long q = (hi - lo) >> 2;
+        const long long p1 = (long long)(lo + q), p2 = (long long)(lo + 2 * q), p3 = (long long)(lo + 3 * q);
+        unsigned long long c = 0ull;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v)
+            c += (key[v] <= p1 ? 1ull : 0ull) + (key[v] <= p2 ? (1ull << 21) : 0ull) + (key[v] <= p3 ? (1ull << 42) : 0ull);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        unsigned long long* cs = cnt_s[pass & 1];             // two buffers: one barrier per pass
+        if ((tid & 63) == 0) cs[tid >> 6] = c;
+        __syncthreads();
+        c = cs[0] + cs[1] + cs[2] + cs[3];
+        const int c1 = (int)(c & 0x1fffff), c2 = (int)((c >> 21) & 0x1fffff), c3 = (int)(c >> 42);
+        if (c1 >= m) hi = (unsigned long long)p1;
+        else if (c2 >= m) { lo = (unsigned long long)p1 + 1; hi = (unsigned long long)p2; }
+        else if (c3 >= m) { lo = (unsigned long long)p2 + 1; hi = (unsigned long long)p3; }
+        else lo = (unsigned long long)p3 + 1;
+        ++pass;
+    }
+    const double T = __longlong_as_double((long long)lo);
+    double s = 0.0; int c = 0;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const double x = __longlong_as_double(key[v]);
+        if (tid + 256 * v < R && x < T) { s += x; ++c; }
+    }
+    s = block_sum(s, red);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    __shared__ int ci[4];
+    if ((tid & 63) == 0) ci[tid >> 6] = c;
+    __syncthreads();
+    c = ci[0] + ci[1] + ci[2] + ci[3];
+    if (tid == 0) density[i] = (s + (double)(m - c) * T) / (double)n;
 }
 
 // gather rows: out[q][:] = in[idx[q]][:]   (zero-padded destination rows are cleared by the caller)
@@ -243,31 +320,6 @@ __global__ void gather_rows_kernel(const double* __restrict__ in, int ld_in, con
 {
     const int q = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < nrows && g < G) out[(size_t)q * ld_out + g] = in[(size_t)idx[q] * ld_in + g];
-}
-
-// column statistics of X [R][ld]: mean[g], var[g] (population).  Block = 64 columns x 4 row groups;
-// fixed summation order (row group partials added in group order).
-__global__ __launch_bounds__(256) void col_stats_kernel(const double* __restrict__ X, int ld, int R, int G,
-                                                        double* __restrict__ mean, double* __restrict__ var)
-{
-    __shared__ double part[4][64];
-    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int g = blockIdx.x * 64 + c;
-    const int per = (R + 3) / 4, rb = rg * per, re = min(R, rb + per);
-    double s = 0.0;
-    if (g < G) for (int r = rb; r < re; ++r) s += X[(size_t)r * ld + g];
-    part[rg][c] = s;
-    __syncthreads();
-    const double mu = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / R;
-    __syncthreads();
-    double v = 0.0;
-    if (g < G) for (int r = rb; r < re; ++r) { const double d = X[(size_t)r * ld + g] - mu; v += d * d; }
-    part[rg][c] = v;
-    __syncthreads();
-    if (rg == 0 && g < G) {
-        mean[g] = mu;
-        var[g] = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / R;
-    }
 }
 
 // The same statistics with the rows spread over many workgroups (col_stats_kernel walks all R rows with 4 row groups
@@ -327,130 +379,263 @@ struct KmState {          // device-resident scalars of one k-means run
     int n_empty;
     int cand[8];          // candidate row ids of the current k-means++ step
     int best;
-    int done;             // Lloyd loop finished for this init (host sets it)
+    int done;             // Lloyd loop finished for this init (lloyd_decide_kernel sets it)
+    int iters;            // Lloyd iterations run
+    int strict;           // stopped because no label changed (no final E step needed)
 };
+
+__device__ __forceinline__ bool km_tile_done(const KmState* st, int m0, int k, int n_init)
+{   // rows m0 .. m0+63 of the stacked centre matrix belong to inits m0/k .. (m0+63)/k
+    const int i0 = m0 / k, i1 = min((m0 + 63) / k, n_init - 1);
+    for (int i = i0; i <= i1; ++i) if (!st[i].done) return false;
+    return true;
+}
 
 struct KmDims { int R, Rp, G, ld, k, L; };   // kept rows, padded rows, genes, padded genes, clusters, local trials
 
-// first centre: centers[init*k] = X[c0[init]]
-__global__ void pp_seed_kernel(const double* __restrict__ X, KmDims d, const int* __restrict__ c0,
-                               double* __restrict__ centers, int* __restrict__ center_ids)
-{
-    const int init = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < d.ld) centers[(size_t)(init * d.k) * d.ld + g] = (g < d.G) ? X[(size_t)c0[init] * d.ld + g] : 0.0;
-    if (g == 0) center_ids[init * KM_CID] = c0[init];
-}
-
-// closest[r] = max(0, sq_c + sq_r - 2 dot[centre 0][r]); pot = sum closest          grid = n_init
-__global__ __launch_bounds__(256) void pp_first_kernel(const double* __restrict__ dots, KmDims d,
-                                                       const double* __restrict__ sq, const int* __restrict__ c0,
-                                                       double* __restrict__ closest, KmState* st)
-{
-    __shared__ double red[4];
-    const int init = blockIdx.x;
-    const double* drow = dots + (size_t)(init * d.k) * d.Rp;
-    double* cl = closest + (size_t)init * d.Rp;
-    const double sc = sq[c0[init]];
-    double s = 0.0;
-    for (int r = threadIdx.x; r < d.R; r += 256) {
-        double v = -2.0 * drow[r];
-        v += sc; v += sq[r];
-        v = fmax(v, 0.0);
-        cl[r] = v;
-        s += v;
-    }
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) st[init].pot = s;
-}
-
-// cumulative sum of closest[] (chunked serial scan, like np.cumsum up to rounding) + searchsorted of
-// the L random values u*pot (side='left'), clipped to R-1.                             grid = n_init
-__global__ __launch_bounds__(256) void pp_candidates_kernel(const double* __restrict__ closest, KmDims d,
-                                                            const double* __restrict__ u, int ustride, int uoff,
-                                                            double* __restrict__ cum, KmState* st)
-{
-    __shared__ double part[256];
-    const int init = blockIdx.x, tid = threadIdx.x, R = d.R;
-    const double* cl = closest + (size_t)init * d.Rp;
-    double* cm = cum + (size_t)init * d.Rp;
-    const int per = (R + 255) / 256;
-    const int b = tid * per, e = min(b + per, R);
-    double s = 0.0;
-    for (int r = b; r < e; ++r) s += cl[r];
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) { double run = 0.0; for (int t = 0; t < 256; ++t) { const double v = part[t]; part[t] = run; run += v; } }
-    __syncthreads();
-    double run = part[tid];
-    for (int r = b; r < e; ++r) { run += cl[r]; cm[r] = run; }
-    __syncthreads();
-    if (tid < d.L) {
-        const double v = u[(size_t)init * ustride + uoff + tid] * st[init].pot;
-        int lo = 0, hi = R;                       // first index with cum[idx] >= v
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cm[mid] < v) lo = mid + 1; else hi = mid; }
-        st[init].cand[tid] = min(lo, R - 1);
-    }
-}
-
-// candidate rows of every init into one tall matrix: cand[init*L + j] = X[st[init].cand[j]]   grid (G/256, L, n_init)
-__global__ void pp_gather_kernel(const double* __restrict__ X, KmDims d, const KmState* __restrict__ st,
-                                 double* __restrict__ cand)
-{
-    const int init = blockIdx.z, j = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < d.G) cand[(size_t)(init * d.L + j) * d.ld + g] = X[(size_t)st[init].cand[j] * d.ld + g];
-}
-
-// dmin[init][j][r] = min(closest[r], max(0, sq_cand + sq_r - 2 dots[init*L+j][r])); cpot = sum   grid (L, n_init)
-__global__ __launch_bounds__(256) void pp_update_kernel(const double* __restrict__ dots, KmDims d,
-                                                        const double* __restrict__ sq,
-                                                        const double* __restrict__ closest,
-                                                        const KmState* __restrict__ st, double* __restrict__ dmin,
-                                                        double* __restrict__ cpot)
-{
-    __shared__ double red[4];
-    const int j = blockIdx.x, init = blockIdx.y;
-    const int c = st[init].cand[j];
-    const double* drow = dots + (size_t)(init * d.L + j) * d.Rp;
-    const double* cl = closest + (size_t)init * d.Rp;
-    double* dm = dmin + ((size_t)init * 8 + j) * d.Rp;
-    double s = 0.0;
-    for (int r = threadIdx.x; r < d.R; r += 256) {
-        double v = -2.0 * drow[r];
-        v += sq[c]; v += sq[r];
-        v = fmax(v, 0.0);
-        v = fmin(cl[r], v);
-        dm[r] = v;
-        s += v;
-    }
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) cpot[init * 8 + j] = s;
-}
-
-// choose the candidate with the smallest potential (first min), make it centre `c`      grid = n_init
-__global__ __launch_bounds__(256) void pp_pick_kernel(const double* __restrict__ cpot, KmDims d,
-                                                      const double* __restrict__ dmin,
-                                                      double* __restrict__ closest, KmState* st,
-                                                      const double* __restrict__ X,
-                                                      double* __restrict__ centers, int c,
+// ---------------------------------------------------------------- k-means++ in one launch
+// The whole seeding of one init in ONE workgroup (sklearn _kmeans.py:174-272): every quantity it needs is a squared
+// distance between two DATA points, and those are already on the device -- the all-pairs matrix of the L2-normalised
+// spectra (distances do not change when the column means are subtracted).  So the k-1 draws need no product and no
+// second launch: cumulative sum + searchsorted of the L trial values, min(closest, D[cand]^2) and its potential for the
+// L candidates (one pass, one reduction), first arg-min, next draw.  ~10 us per draw instead of five dependent launches.
+template <int NT>
+__global__ __launch_bounds__(NT) void pp_fused_kernel(const double* __restrict__ Dm, int ldD,
+                                                      const int* __restrict__ keep, KmDims d,
+                                                      const int* __restrict__ c0, const double* __restrict__ u,
+                                                      int ustride, double* closest, double* cum, double* dmin,
                                                       int* __restrict__ center_ids)
 {
-    __shared__ int best_s;
-    const int init = blockIdx.x;
-    if (threadIdx.x == 0) {
-        int best = 0;
-        for (int j = 1; j < d.L; ++j) if (cpot[init * 8 + j] < cpot[init * 8 + best]) best = j;
-        best_s = best;
-        st[init].pot = cpot[init * 8 + best];
-        st[init].best = st[init].cand[best];
-        center_ids[init * KM_CID + c] = st[init].cand[best];
-    }
-    __syncthreads();
-    const int best = best_s, row = st[init].cand[best];
-    const double* dm = dmin + ((size_t)init * 8 + best) * d.Rp;
+    constexpr int NW = NT / 64;
+    __shared__ double part[256];
+    __shared__ double red[NW][8];
+    __shared__ int cand_s[8];
+    const int init = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, R = d.R, L = d.L;
     double* cl = closest + (size_t)init * d.Rp;
-    for (int r = threadIdx.x; r < d.R; r += 256) cl[r] = dm[r];
-    double* cdst = centers + (size_t)(init * d.k + c) * d.ld;
-    for (int g = threadIdx.x; g < d.ld; g += 256) cdst[g] = (g < d.G) ? X[(size_t)row * d.ld + g] : 0.0;
+    double* cm = cum + (size_t)init * d.Rp;
+    double* dm = dmin + (size_t)init * 8 * d.Rp;
+    double pot;
+    {   // first centre: closest = D[c0]^2, pot = sum
+        const int first = c0[init];
+        const double* drow = Dm + (size_t)keep[first] * ldD;
+        double s = 0.0;
+        for (int r = tid; r < R; r += NT) { double v = drow[keep[r]]; v *= v; cl[r] = v; s += v; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) red[wave][0] = s;
+        __syncthreads();
+        pot = 0.0;
+        for (int w = 0; w < NW; ++w) pot += red[w][0];
+        if (tid == 0) center_ids[init * KM_CID] = first;
+    }
+    const int per = (R + 255) / 256;
+    const int sb = min(tid * per, R), se = (tid < 256) ? min(sb + per, R) : sb;     // scan chunk of threads 0..255
+    for (int c = 1; c < d.k; ++c) {
+        __syncthreads();
+        {   // cumulative sum of closest[]: 256 chunks, chunk totals scanned serially, like np.cumsum up to rounding
+            double s = 0.0;
+            for (int r = sb; r < se; ++r) s += cl[r];
+            if (tid < 256) part[tid] = s;
+            __syncthreads();
+            if (tid == 0) {
+                double run = 0.0;
+#pragma unroll 32
+                for (int t = 0; t < 256; ++t) { const double v = part[t]; part[t] = run; run += v; }
+            }
+            __syncthreads();
+            if (tid < 256) { double run = part[tid]; for (int r = sb; r < se; ++r) { run += cl[r]; cm[r] = run; } }
+        }
+        __syncthreads();
+        if (tid < L) {      // searchsorted(cum, u * pot, side='left'), clipped
+            const double v = u[(size_t)init * ustride + 1 + (size_t)(c - 1) * L + tid] * pot;
+            int lo = 0, hi = R;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cm[mid] < v) lo = mid + 1; else hi = mid; }
+            cand_s[tid] = min(lo, R - 1);
+        }
+        __syncthreads();
+        const double* drow[8];
+        double s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] = 0.0; drow[j] = Dm + (size_t)keep[cand_s[j < L ? j : 0]] * ldD; }
+        for (int r = tid; r < R; r += NT) {
+            const double cr = cl[r];
+            const int kr = keep[r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < L) {
+                    double v = drow[j][kr];
+                    v *= v;
+                    v = fmin(cr, v);
+                    dm[(size_t)j * d.Rp + r] = v;
+                    s[j] += v;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < L) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
+                if (lane == 0) red[wave][j] = s[j];
+            }
+        }
+        __syncthreads();
+        int best = 0; double bp = 0.0;
+        for (int j = 0; j < L; ++j) {
+            double t = 0.0;
+            for (int w = 0; w < NW; ++w) t += red[w][j];
+            if (j == 0 || t < bp) { bp = t; best = j; }        // first minimum, np.argmin
+        }
+        pot = bp;
+        if (tid == 0) center_ids[init * KM_CID + c] = cand_s[best];
+        const double* db = dm + (size_t)best * d.Rp;
+        for (int r = tid; r < R; r += NT) cl[r] = db[r];       // each thread re-reads what it wrote itself
+    }
+}
+
+__device__ __forceinline__ double uniform_f64(double v)
+{   // a value every lane holds identically, moved to scalar registers
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// The same seeding with the init's closest[] in REGISTERS (blocked layout: thread t owns rows [t*VPT, (t+1)*VPT); up to
+// 1024*VPT kept rows).  Nothing is materialised: the cumulative sum is a block scan of the thread totals, and
+// searchsorted(cum, v, 'left') is the NUMBER of rows with cum < v -- one packed block reduction for the L trial values.
+// Three barriers per draw; the winning candidate's row of D is re-read (cache hit) instead of keeping L x VPT minima.
+template <int NT, int VPT>
+__global__ __launch_bounds__(NT) void pp_fused_reg_kernel(const double* __restrict__ Dm, int ldD,
+                                                          const int* __restrict__ keep, KmDims d,
+                                                          const int* __restrict__ c0, const double* __restrict__ u,
+                                                          int ustride, int* __restrict__ center_ids)
+{
+    constexpr int NW = NT / 64;
+    __shared__ double wtot[NW];
+    __shared__ double red[NW][8];
+    __shared__ unsigned long long cred[NW][2];
+    const int init = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, R = d.R, L = d.L;
+    const int base = tid * VPT;
+    double cl[VPT];
+    int kr[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) kr[v] = (base + v < R) ? keep[base + v] : -1;
+    double pot;
+    {
+        const int first = c0[init];
+        const double* drow = Dm + (size_t)keep[first] * ldD;
+        double s = 0.0;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            double x = 0.0;
+            if (kr[v] >= 0) { x = drow[kr[v]]; x *= x; }
+            cl[v] = x; s += x;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) red[wave][0] = s;
+        __syncthreads();
+        pot = 0.0;
+        for (int w = 0; w < NW; ++w) pot += red[w][0];
+        pot = uniform_f64(pot);
+        if (tid == 0) center_ids[init * KM_CID] = first;
+    }
+    for (int c = 1; c < d.k; ++c) {
+        // exclusive prefix of this thread's block of closest[]
+        double tt = 0.0;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) tt += cl[v];
+        double x = tt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const double y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wtot[wave] = x;
+        __syncthreads();
+        double excl = 0.0;
+        for (int w = 0; w < wave; ++w) excl += wtot[w];
+        excl += x - tt;
+        // searchsorted of the L trial values: rows with cum < v
+        double tv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tv[j] = (j < L) ? u[(size_t)init * ustride + 1 + (size_t)(c - 1) * L + j] * pot : 0.0;
+        unsigned long long ca = 0ull, cb = 0ull;
+        double run = excl;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            run += cl[v];
+            if (kr[v] >= 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ca += (run < tv[j]) ? (1ull << (16 * j)) : 0ull;
+#pragma unroll
+                for (int j = 4; j < 8; ++j) cb += (run < tv[j]) ? (1ull << (16 * (j - 4))) : 0ull;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ca += __shfl_xor(ca, o, 64); cb += __shfl_xor(cb, o, 64); }
+        if (lane == 0) { cred[wave][0] = ca; cred[wave][1] = cb; }
+        __syncthreads();
+        ca = cb = 0ull;
+        for (int w = 0; w < NW; ++w) { ca += cred[w][0]; cb += cred[w][1]; }
+        int cand[8];
+        const double* drow[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cnt = __builtin_amdgcn_readfirstlane((int)(((j < 4 ? ca : cb) >> (16 * (j & 3))) & 0xffffull));
+            cand[j] = min(cnt, R - 1);
+            drow[j] = Dm + (size_t)keep[j < L ? cand[j] : 0] * ldD;
+        }
+        double s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.0;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v)
+            if (kr[v] >= 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < L) { double t = drow[j][kr[v]]; t *= t; s[j] += fmin(cl[v], t); }
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < L) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
+                if (lane == 0) red[wave][j] = s[j];
+            }
+        __syncthreads();
+        int best = 0; double bp = 0.0;
+        for (int j = 0; j < L; ++j) {
+            double t = 0.0;
+            for (int w = 0; w < NW; ++w) t += red[w][j];
+            if (j == 0 || t < bp) { bp = t; best = j; }
+        }
+        pot = uniform_f64(bp);
+        best = __builtin_amdgcn_readfirstlane(best);
+        int bc = cand[0]; const double* db = drow[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) if (j == best) { bc = cand[j]; db = drow[j]; }
+        if (tid == 0) center_ids[init * KM_CID + c] = bc;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v)
+            if (kr[v] >= 0) { double t = db[kr[v]]; t *= t; cl[v] = fmin(cl[v], t); }
+    }
+}
+
+// centres of every init from the chosen row ids: centers[init*k + c] = X[center_ids[init][c]]   grid (ld/256, k, n_init)
+__global__ void pp_centers_kernel(const double* __restrict__ X, KmDims d, const int* __restrict__ center_ids,
+                                  double* __restrict__ centers)
+{
+    const int init = blockIdx.z, c = blockIdx.y, g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < d.ld)
+        centers[(size_t)(init * d.k + c) * d.ld + g] = (g < d.G) ? X[(size_t)center_ids[init * KM_CID + c] * d.ld + g] : 0.0;
+}
+
+// *tol_out = mean(var) * tol  (sklearn _kmeans.py:279-288)
+__global__ __launch_bounds__(256) void km_tolerance_kernel(const double* __restrict__ var, int G, double tol,
+                                                           double* __restrict__ tol_out)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int g = threadIdx.x; g < G; g += 256) s += var[g];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *tol_out = (s / G) * tol;
 }
 
 // ---------------------------------------------------------------- Lloyd
@@ -464,12 +649,6 @@ __global__ __launch_bounds__(256) void center_norms_kernel(const double* __restr
     for (int g = threadIdx.x; g < G; g += 256) { const double v = centers[(size_t)j * ld + g]; s += v * v; }
     s = block_sum(s, red);
     if (threadIdx.x == 0) csq[j] = s;
-}
-
-__global__ void km_reset_kernel(KmState* st, int n_init)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_init) { st[i].changed = 0; st[i].n_empty = 0; }
 }
 
 // labels[r] = first argmin_j (csq[j] - 2 dots[j][r]); counts changed labels      grid (R/256, n_init)
@@ -518,7 +697,13 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const double* __restric
     for (int j = 0; j < k; ++j) accs[j * bw + threadIdx.x] = 0.0;
     const int rb = chunk * rows_per_chunk, re = min(rb + rows_per_chunk, d.R);
     if (g < d.G)
-        for (int r = rb; r < re; ++r) accs[lab[r] * bw + threadIdx.x] += X[(size_t)r * d.ld + g];
+        for (int r = rb; r < re; r += 16) {             // 16 rows' loads in flight, added in row order as before
+            double x[16]; int l[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const int rr = min(r + q, re - 1); x[q] = X[(size_t)rr * d.ld + g]; l[q] = lab[rr]; }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) if (r + q < re) accs[l[q] * bw + threadIdx.x] += x[q];
+        }
     double* pp = partial + (((size_t)init * nchunks + chunk) * k) * d.ld;
     if (g < d.G)
         for (int j = 0; j < k; ++j) pp[(size_t)j * d.ld + g] = accs[j * bw + threadIdx.x];
@@ -550,23 +735,45 @@ __global__ void reduce_partial_kernel(const double* __restrict__ partial, const 
     }
 }
 
-// squared distance of every row to its assigned centre                          grid (R, n_init)
-// mode 0: only for inits with an empty cluster (relocation); mode 1: all inits (inertia)
+// squared distance of every row to its assigned centre, for the inits that have an empty cluster to relocate (rare: the
+// launch is 16 rows per workgroup so that the usual "nothing to do" exit is cheap)         grid (R/16, n_init)
+constexpr int RCD_ROWS = 16;
 __global__ __launch_bounds__(256) void row_center_dist_kernel(const double* __restrict__ X, KmDims d,
                                                               const double* __restrict__ centers,
                                                               const int* __restrict__ labels,
                                                               double* __restrict__ dist,
-                                                              const KmState* __restrict__ st, int mode)
+                                                              const KmState* __restrict__ st)
 {
     __shared__ double red[4];
     const int init = blockIdx.y;
-    if (mode == 0 && (st[init].done || st[init].n_empty == 0)) return;
+    if (st[init].done || st[init].n_empty == 0) return;
+    for (int r = blockIdx.x * RCD_ROWS; r < min(d.R, (int)(blockIdx.x + 1) * RCD_ROWS); ++r) {
+        const double* c = centers + (size_t)(init * d.k + labels[(size_t)init * d.Rp + r]) * d.ld;
+        double s = 0.0;
+        for (int g = threadIdx.x; g < d.G; g += 256) { const double v = X[(size_t)r * d.ld + g] - c[g]; s += v * v; }
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) dist[(size_t)init * d.Rp + r] = s;
+    }
+}
+
+// The final pass (inertia of every init): one workgroup per row walks all inits, so the row of X is fetched from HBM
+// once and the n_init x k centre rows come out of L2.                                          grid = R
+__global__ __launch_bounds__(256) void row_center_dist_all_kernel(const double* __restrict__ X, KmDims d,
+                                                                  const double* __restrict__ centers,
+                                                                  const int* __restrict__ labels,
+                                                                  double* __restrict__ dist, int n_init)
+{
+    __shared__ double red[4];
     const int r = blockIdx.x;
-    const double* c = centers + (size_t)(init * d.k + labels[(size_t)init * d.Rp + r]) * d.ld;
-    double s = 0.0;
-    for (int g = threadIdx.x; g < d.G; g += 256) { const double v = X[(size_t)r * d.ld + g] - c[g]; s += v * v; }
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) dist[(size_t)init * d.Rp + r] = s;
+    const double* x = X + (size_t)r * d.ld;
+    for (int init = 0; init < n_init; ++init) {
+        const double* c = centers + (size_t)(init * d.k + labels[(size_t)init * d.Rp + r]) * d.ld;
+        double s = 0.0;
+        for (int g = threadIdx.x; g < d.G; g += 256) { const double v = x[g] - c[g]; s += v * v; }
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) dist[(size_t)init * d.Rp + r] = s;
+        __syncthreads();
+    }
 }
 
 // relocate empty clusters to the farthest points (sklearn _k_means_common.pyx:167-211): clusters in
@@ -614,50 +821,59 @@ __global__ __launch_bounds__(256) void relocate_empty_kernel(const double* __res
     }
 }
 
-// new centres = sums * (1/count) (empty -> copy of the heaviest cluster); shift_tot = sum |new-old|^2.
-// A finished init just carries its centres over so both buffers stay valid.             grid = n_init
+// new centre j of init i = sums * (1/count) (empty -> copy of the heaviest cluster); shift2[i][j] = |new - old|^2.
+// A finished init just carries its centres over so both buffers stay valid.             grid (k, n_init)
 __global__ __launch_bounds__(256) void finish_centers_kernel(const double* __restrict__ sums,
                                                              const int* __restrict__ counts, KmDims d,
                                                              const double* __restrict__ old_c,
-                                                             double* __restrict__ new_c, KmState* st)
+                                                             double* __restrict__ new_c, const KmState* __restrict__ st,
+                                                             double* __restrict__ shift2)
 {
     __shared__ double red[4];
-    __shared__ int amax_s;
-    const int init = blockIdx.x, k = d.k;
-    const double* oc = old_c + (size_t)init * k * d.ld;
-    double* nc = new_c + (size_t)init * k * d.ld;
+    const int j = blockIdx.x, init = blockIdx.y, k = d.k;
+    const double* oc = old_c + ((size_t)init * k + j) * d.ld;
+    double* nc = new_c + ((size_t)init * k + j) * d.ld;
     if (st[init].done) {
-        for (int e = threadIdx.x; e < k * d.ld; e += 256) nc[e] = oc[e];
+        for (int e = threadIdx.x; e < d.ld; e += 256) nc[e] = oc[e];
         return;
     }
-    const double* sm = sums + (size_t)init * k * d.ld;
     const int* cn = counts + init * k;
-    if (threadIdx.x == 0) {
-        int am = 0;
-        for (int j = 1; j < k; ++j) if (cn[j] > cn[am]) am = j;
-        amax_s = am;
-    }
-    __syncthreads();
-    const int am = amax_s;
-    double tot = 0.0;
-    for (int j = 0; j < k; ++j) {
-        const int src = (cn[j] > 0) ? j : am;
-        const double alpha = 1.0 / (double)cn[src];
-        double s = 0.0;
-        for (int g = threadIdx.x; g < d.ld; g += 256) {
-            double v = 0.0;
-            if (g < d.G) {
-                v = sm[(size_t)src * d.ld + g] * alpha;
-                const double df = v - oc[(size_t)j * d.ld + g];
-                s += df * df;
-            }
-            nc[(size_t)j * d.ld + g] = v;
+    int src = j;
+    if (cn[j] <= 0) { src = 0; for (int q = 1; q < k; ++q) if (cn[q] > cn[src]) src = q; }
+    const double* sm = sums + ((size_t)init * k + src) * d.ld;
+    const double alpha = 1.0 / (double)cn[src];
+    double s = 0.0;
+    for (int g = threadIdx.x; g < d.ld; g += 256) {
+        double v = 0.0;
+        if (g < d.G) {
+            v = sm[g] * alpha;
+            const double df = v - oc[g];
+            s += df * df;
         }
-        s = block_sum(s, red);
-        const double sh = sqrt(s);
-        tot += sh * sh;
+        nc[g] = v;
     }
-    if (threadIdx.x == 0) st[init].shift_tot = tot;
+    s = block_sum(s, red);
+    const double sh = sqrt(s);
+    if (threadIdx.x == 0) shift2[init * KM_CID + j] = sh * sh;
+}
+
+// The stopping rule of one Lloyd iteration, per init (sklearn _kmeans.py:700-730): no label changed -> strict
+// convergence; else total centre shift <= tol -> converged.  Also clears the per-iteration counters.   one thread per init
+__global__ void lloyd_decide_kernel(KmState* st, const double* __restrict__ shift2, int k, int n_init,
+                                    const double* __restrict__ tol, int it)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_init) return;
+    if (!st[i].done) {
+        double tot = 0.0;
+        for (int j = 0; j < k; ++j) tot += shift2[i * KM_CID + j];
+        st[i].shift_tot = tot;
+        st[i].iters = it + 1;
+        if (st[i].changed == 0) { st[i].strict = 1; st[i].done = 1; }
+        else if (tot <= *tol) st[i].done = 1;
+    }
+    st[i].changed = 0;
+    st[i].n_empty = 0;
 }
 
 // inertia[init] = sum_r dist[init][r]                                                   grid = n_init

@@ -5,6 +5,36 @@ static thread_local std::string g_last_error;
 
 struct cnmf_comm;
 
+// Workspace of the consensus entry points, kept by the context between calls: blocks are handed out by a bump
+// pointer and stay allocated (the ~30 hipMalloc / hipFree pairs of one consensus call cost more than its kernels),
+// released when the context is destroyed or when a call left more than `keep_limit` bytes behind.
+struct Arena {
+    struct Block { char* p; size_t cap, used; };
+    std::vector<Block> blocks;
+    hipError_t err = hipSuccess;
+    static constexpr size_t keep_limit = (size_t)8 << 30;
+    void reset() { err = hipSuccess; for (Block& b : blocks) b.used = 0; }
+    size_t total() const { size_t t = 0; for (const Block& b : blocks) t += b.cap; return t; }
+    void release() { for (Block& b : blocks) hipFree(b.p); blocks.clear(); }
+    template <typename T> T* get(size_t n, bool zero = false, hipStream_t st = nullptr) {
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+        Block* hit = nullptr;
+        for (Block& b : blocks) if (b.cap - b.used >= bytes) { hit = &b; break; }
+        if (!hit) {
+            void* p = nullptr;
+            const size_t cap = std::max(bytes, (size_t)16 << 20);
+            hipError_t e = hipMalloc(&p, cap);
+            if (e != hipSuccess) { err = e; return nullptr; }
+            blocks.push_back(Block{(char*)p, cap, 0});
+            hit = &blocks.back();
+        }
+        T* out = (T*)(hit->p + hit->used);
+        hit->used += bytes;
+        if (zero) hipMemsetAsync(out, 0, bytes, st);
+        return out;
+    }
+};
+
 struct cnmf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -54,6 +84,10 @@ struct cnmf_ctx {
     // resident spectra store (device) for the gather / consensus
     float* spectra = nullptr;
     size_t spectra_cap = 0, spectra_rows = 0;
+
+    Arena cons_ws;                    // consensus workspace (consensus_host.hip.h)
+    void* cons_pinned = nullptr;      // pinned host block of the consensus calls (k-means state read-backs)
+    size_t cons_pinned_bytes = 0;
 
     cnmf_comm* comm = nullptr;        // RCCL communicator (comm_host.hip.h); NULL = single GPU
 };

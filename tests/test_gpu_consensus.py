@@ -125,3 +125,34 @@ def test_median_paths_large_clusters(engine, R, k):
     out = engine.consensus(S, k, density_threshold=2.0)
     assert np.array_equal(out["labels"] + 1, ref["kmeans_labels"])
     assert np.abs(out["median_spectra"] - ref["median_spectra"]).max() < 1e-12
+
+
+def test_large_R_fallback_kernels_agree_with_the_register_kernels(engine, monkeypatch):
+    """More than 8 192 kept spectra seed k-means++ from global memory (pp_fused_kernel) and more than 20 480 select the
+    neighbours by re-reading the row (knn_density_kernel); both are forced here on a case the register kernels handle:
+    the density must be bit-identical, labels / medians the same, and both must match the oracle."""
+    S, _ = synth.consensus_stress(R=1500, G=120, k=7, n_outliers=40, seed=11)
+    ref = oc.consensus_core(S, np.abs(np.random.RandomState(0).standard_normal((20, 120))), 7, density_threshold=0.5)
+    fast = engine.consensus(S, 7, density_threshold=0.5)
+    monkeypatch.setenv("CNMF_PP_GLOBAL", "1")
+    monkeypatch.setenv("CNMF_KNN_GLOBAL", "1")
+    slow = engine.consensus(S, 7, density_threshold=0.5)
+    assert np.array_equal(fast["local_density"], slow["local_density"])
+    for out in (fast, slow):
+        assert np.abs(out["local_density"] - ref["local_density"]).max() < 1e-9
+        assert np.array_equal(out["density_filter"], ref["density_filter"])
+        assert np.array_equal(out["labels"][out["density_filter"]] + 1, ref["kmeans_labels"])
+        assert np.abs(out["median_spectra"] - ref["median_spectra"]).max() < 1e-12
+
+
+def test_kmeans_needs_several_lloyd_batches(engine):
+    """Overlapping clusters: Lloyd runs for many iterations (the device applies the stopping rule; the host looks once per
+    batch of three) and some inits stop on the tolerance -- iteration count, labels and inertia against the oracle."""
+    rng = np.random.RandomState(3)
+    centers = np.abs(rng.standard_normal((6, 40)))
+    S = np.abs(centers[rng.randint(0, 6, 1200)] + 0.9 * rng.standard_normal((1200, 40))) + 1e-3
+    ref = oc.consensus_core(S, np.abs(rng.standard_normal((20, 40))), 6, density_threshold=2.0)
+    out = engine.consensus(S, 6, density_threshold=2.0)
+    assert out["kmeans_n_iter"] == 13                      # KMeans(n_clusters=6, n_init=10, random_state=1).n_iter_ on this input
+    assert np.array_equal(out["labels"] + 1, ref["kmeans_labels"])
+    assert abs(out["inertia"] - ref["inertia"]) <= 1e-9 * ref["inertia"]
