@@ -1,8 +1,8 @@
 // Multiplicative updates (Kullback-Leibler, Itakura-Saito) on the matrix pipe, batched over restarts.
 // Restates sklearn/decomposition/_nmf.py:526-631 (_multiplicative_update_w), :634-728 (_multiplicative_update_h)
 // and :84-194 (_beta_divergence) for beta = 1 / 0 and dense X -- the solver the reference keeps for
-// beta_loss != 'frobenius' (cnmf.py:618-631).  kernels_mu.hip.h holds the vector-ALU version (ranks above 32 and
-// the A/B fallback CNMF_MU_VALU=1).  Below the text describes beta = 1; Itakura-Saito carries a second ratio
+// beta_loss != 'frobenius' (cnmf.py:618-631).  kernels_mu.hip.h holds the vector-ALU version (the A/B fallback
+// CNMF_MU_VALU=1 and matrices beyond the 2^24 addressing bound).  Below the text describes beta = 1; Itakura-Saito carries a second ratio
 // (1 / S for the denominator next to X / S^2 for the numerator) through a second set of accumulators.
 //
 // Per 32 x 32 tile of X and per restart, two chained MFMA products with the elementwise quotient in between:
@@ -124,17 +124,34 @@ __device__ __forceinline__ void mu_planes8(const float (&q)[8], mu_bf16x8& bh, m
     bh = __builtin_bit_cast(mu_bf16x8, u32x4{ph[0], ph[1], ph[2], ph[3]});
     bl = __builtin_bit_cast(mu_bf16x8, u32x4{pl[0], pl[1], pl[2], pl[3]});
 }
+// Shape of one restart inside a workgroup, by padded rank:
+//   KP = 16, 32: 4 restarts x 2 halves of the 128-wide block, two 32-wide tiles per wave, one 32-row M tile of the
+//                second product (for 16 the hi and lo planes are stacked in it);
+//   KP = 64    : 2 restarts x 4 quarters, ONE tile per wave, TWO M tiles (components 0..31 and 32..63) -- the same
+//                register and LDS budget, twice the MFMAs per element, the same quotient work.
+template <int KP> struct MuShape {
+    static constexpr int RPW = KP == 64 ? 2 : 4;         // restarts per workgroup
+    static constexpr int NJT = KP == 64 ? 1 : 2;         // 32-wide tiles per wave
+    static constexpr int NMH = KP == 64 ? 2 : 1;         // M tiles of the second product
+    static constexpr int NA2 = KP == 16 ? 1 : 2 * NMH;   // A fragments of the second product per 16-deep chunk
+    static constexpr int TPR = 512 / RPW;                // loader threads per restart
+};
+template <int KP> struct MuAcc { f32x16 v[MuShape<KP>::NMH]; };
+
 template <int KP>
-__device__ __forceinline__ void mu_accumulate8(f32x16& acc, const mu_bf16x8 (&a2c)[KP == 16 ? 1 : 2], mu_bf16x8 bh, mu_bf16x8 bl)
+__device__ __forceinline__ void mu_accumulate8(MuAcc<KP>& acc, const mu_bf16x8 (&a2c)[MuShape<KP>::NA2], mu_bf16x8 bh, mu_bf16x8 bl)
 {
     if constexpr (KP == 16) {
-        acc = MU_MFMA(a2c[0], bl, acc);
-        acc = MU_MFMA(a2c[0], bh, acc);
+        acc.v[0] = MU_MFMA(a2c[0], bl, acc.v[0]);
+        acc.v[0] = MU_MFMA(a2c[0], bh, acc.v[0]);
     } else {
-        acc = MU_MFMA(a2c[1], bl, acc);
-        acc = MU_MFMA(a2c[1], bh, acc);
-        acc = MU_MFMA(a2c[0], bl, acc);
-        acc = MU_MFMA(a2c[0], bh, acc);
+#pragma unroll
+        for (int mh = 0; mh < MuShape<KP>::NMH; ++mh) {
+            acc.v[mh] = MU_MFMA(a2c[2 * mh + 1], bl, acc.v[mh]);
+            acc.v[mh] = MU_MFMA(a2c[2 * mh + 1], bh, acc.v[mh]);
+            acc.v[mh] = MU_MFMA(a2c[2 * mh], bl, acc.v[mh]);
+            acc.v[mh] = MU_MFMA(a2c[2 * mh], bh, acc.v[mh]);
+        }
     }
 }
 
@@ -144,8 +161,8 @@ __device__ __forceinline__ void mu_accumulate8(f32x16& acc, const mu_bf16x8 (&a2
 // v_rcp_f32 is a quarter-rate instruction: one reciprocal serves two elements, 1/s0 = s1 / (s0 s1)
 // (s >= eps = 1.2e-7: the product cannot underflow).
 template <int KP, bool BETA1>
-__device__ __forceinline__ void mu_quotient_accumulate_chunk(f32x16& acc, f32x16& accd, const f32x16& s, const float (&x)[16],
-                                                             int c, const mu_bf16x8 (&a2c)[KP == 16 ? 1 : 2])
+__device__ __forceinline__ void mu_quotient_accumulate_chunk(MuAcc<KP>& acc, MuAcc<KP>& accd, const f32x16& s, const float (&x)[16],
+                                                             int c, const mu_bf16x8 (&a2c)[MuShape<KP>::NA2])
 {
     float qn[8], qd[BETA1 ? 1 : 8];
 #pragma unroll
@@ -224,11 +241,12 @@ __global__ __launch_bounds__(256) void mu_planes_kernel(const float* __restrict_
 // W half-step epilogue: W[row][c] *= numerator / denominator for the wave's 64 cells, planes refreshed.
 // C layout: register r <-> component m = 8 (r / 4) + 4 h + r % 4, column (cell) l32
 template <int KP, bool BETA1>
-__device__ __forceinline__ void mu_w_epilogue(const MuSlotDev& sd, const f32x16 (&acc)[2], const f32x16 (&accd)[2], int r0,
+__device__ __forceinline__ void mu_w_epilogue(const MuSlotDev& sd, const MuAcc<KP> (&acc)[MuShape<KP>::NJT],
+                                              const MuAcc<KP> (&accd)[MuShape<KP>::NJT], int r0,
                                               int l32, int h, int N, int ldxt, float l1, float l2)
 {
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
+    for (int jt = 0; jt < MuShape<KP>::NJT; ++jt) {
         const int row = r0 + 32 * jt + l32;
         if (row >= N) continue;
         constexpr int NQ = KP / 8;                     // groups of 4 components held by this lane
@@ -238,17 +256,17 @@ __device__ __forceinline__ void mu_w_epilogue(const MuSlotDev& sd, const f32x16 
             float num[4], den[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (KP == 16) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) num[t] = acc[jt][4 * q + t] + acc[jt][4 * q + t + 8];
+                for (int t = 0; t < 4; ++t) num[t] = acc[jt].v[0][4 * q + t] + acc[jt].v[0][4 * q + t + 8];
                 if constexpr (!BETA1) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) den[t] = accd[jt][4 * q + t] + accd[jt][4 * q + t + 8];
+                    for (int t = 0; t < 4; ++t) den[t] = accd[jt].v[0][4 * q + t] + accd[jt].v[0][4 * q + t + 8];
                 }
-            } else {
+            } else {                                   // component 8 q + 4 h + t = 32 (q / 4) + register 4 (q % 4) + t of that M tile
 #pragma unroll
-                for (int t = 0; t < 4; ++t) num[t] = acc[jt][4 * q + t];
+                for (int t = 0; t < 4; ++t) num[t] = acc[jt].v[q / 4][4 * (q % 4) + t];
                 if constexpr (!BETA1) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) den[t] = accd[jt][4 * q + t];
+                    for (int t = 0; t < 4; ++t) den[t] = accd[jt].v[q / 4][4 * (q % 4) + t];
                 }
             }
             float* wp = sd.W + (size_t)row * KP + c0;
@@ -280,22 +298,24 @@ __device__ __forceinline__ void mu_w_epilogue(const MuSlotDev& sd, const f32x16 
     }
 }
 
-// ---- the workgroup: 8 waves = 4 restarts x 2 halves of a 128-wide block of the non-reduced dimension.  Per 32-deep
+// ---- the workgroup: 8 waves = 4 restarts x 2 halves (rank <= 32; 2 restarts x 4 quarters for ranks 33..64, MuShape) of a
+// 128-wide block of the non-reduced dimension.  Per 32-deep
 // step it brings in ONE copy of the X block (32 x 128 floats) and one copy of each restart's factor fragments through
 // LDS (double buffered, one barrier per step); every wave then reads its operands from LDS in the fragment layouts
 // (2 KB of L2 -> CU traffic per tile and restart).
 typedef __amdgpu_buffer_rsrc_t mu_rsrc;
 template <int KP>
 struct MuLds {
+    static constexpr int RPW = MuShape<KP>::RPW, TPR = MuShape<KP>::TPR;
     static constexpr int XS = 136;                                   // floats per X row: 4 rows apart = 32 banks apart
-    static constexpr int A1ROW = KP * 2 + (KP == 32 ? 16 : 0);       // bytes per row of the row-major planes
+    static constexpr int A1ROW = KP * 2 + (KP >= 32 ? 16 : 0);       // bytes per row of the row-major planes
     static constexpr int A2ROW = 80;                                 // bytes per (plane, component): 32 positions + pad
     static constexpr int X_BYTES = 32 * XS * 4;
-    static constexpr int A1_BYTES = 4 * 2 * 32 * A1ROW;              // [restart][plane][row]
-    static constexpr int A2_BYTES = 4 * 2 * KP * A2ROW;              // [restart][plane][component]
+    static constexpr int A1_BYTES = RPW * 2 * 32 * A1ROW;            // [restart][plane][row]
+    static constexpr int A2_BYTES = RPW * 2 * KP * A2ROW;            // [restart][plane][component]
     static constexpr int BUF = X_BYTES + A1_BYTES + A2_BYTES;
-    static constexpr int NA1 = (2 * 32 * KP * 2 / 16) / 128;         // 16-byte chunks per thread and restart
-    static constexpr int NA2 = (2 * KP * 4) / 128;
+    static constexpr int NA1 = (2 * 32 * KP * 2 / 16) / TPR;         // 16-byte chunks per thread and restart
+    static constexpr int NA2 = (2 * KP * 4) / TPR;
 };
 
 struct MuCoopSrc {                   // what one restart streams (the H half-step streams W, the W half-step H)
@@ -326,17 +346,17 @@ struct MuCoop {
         rx[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
         rx[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (unsigned)(64ull * xld), 0);          // row + 16
         if (src_live) {
-            const int tt = tid & 127;
+            const int tt = tid & (L::TPR - 1);
 #pragma unroll
             for (int i = 0; i < L::NA1; ++i) {
-                const int q = tt + 128 * i, plane = q / (2 * KP * 2), within = q % (2 * KP * 2);
+                const int q = tt + L::TPR * i, plane = q / (2 * KP * 2), within = q % (2 * KP * 2);
                 const mu_u16* pp = (plane ? src.a1l : src.a1h) + (size_t)t * 32 * KP;
                 ra1[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(pp) + within * 16);
             }
             if constexpr (SECOND) {
 #pragma unroll
                 for (int i = 0; i < L::NA2; ++i) {
-                    const int q = tt + 128 * i, plane = q / (4 * KP), rem2 = q % (4 * KP), comp = rem2 >> 2, part = rem2 & 3;
+                    const int q = tt + L::TPR * i, plane = q / (4 * KP), rem2 = q % (4 * KP), comp = rem2 >> 2, part = rem2 & 3;
                     ra2[i] = *reinterpret_cast<const u32x4*>(src.a2 + ((size_t)plane * KP + comp) * src.cs + (size_t)t * 32 + part * 8);
                 }
             }
@@ -349,17 +369,17 @@ struct MuCoop {
         *reinterpret_cast<u32x4*>(xs + (tid >> 5) * L::XS + (tid & 31) * 4) = rx[0];
         *reinterpret_cast<u32x4*>(xs + ((tid >> 5) + 16) * L::XS + (tid & 31) * 4) = rx[1];
         if (src_live) {
-            const int tt = tid & 127, rsi = tid >> 7;
+            const int tt = tid & (L::TPR - 1), rsi = tid / L::TPR;
 #pragma unroll
             for (int i = 0; i < L::NA1; ++i) {
-                const int q = tt + 128 * i, plane = q / (2 * KP * 2), within = q % (2 * KP * 2);
+                const int q = tt + L::TPR * i, plane = q / (2 * KP * 2), within = q % (2 * KP * 2);
                 const int row = within / (KP / 8), part = within % (KP / 8);
                 *reinterpret_cast<u32x4*>(b + L::X_BYTES + ((rsi * 2 + plane) * 32 + row) * L::A1ROW + part * 16) = ra1[i];
             }
             if constexpr (SECOND) {
 #pragma unroll
                 for (int i = 0; i < L::NA2; ++i) {
-                    const int q = tt + 128 * i, plane = q / (4 * KP), rem2 = q % (4 * KP), comp = rem2 >> 2, part = rem2 & 3;
+                    const int q = tt + L::TPR * i, plane = q / (4 * KP), rem2 = q % (4 * KP), comp = rem2 >> 2, part = rem2 & 3;
                     *reinterpret_cast<u32x4*>(b + L::X_BYTES + L::A1_BYTES + ((rsi * 2 + plane) * KP + comp) * L::A2ROW + part * 16) = ra2[i];
                 }
             }
@@ -368,7 +388,7 @@ struct MuCoop {
     // fragment reads of the computing wave (restart rs, half gs)
     __device__ __forceinline__ void read_x(int buf, int gs, int jt, int l32, int h, float (&x)[16]) const
     {
-        const float* xs = reinterpret_cast<const float*>(lds + buf * L::BUF) + 4 * h * L::XS + gs * 64 + jt * 32 + l32;
+        const float* xs = reinterpret_cast<const float*>(lds + buf * L::BUF) + 4 * h * L::XS + gs * 32 * MuShape<KP>::NJT + jt * 32 + l32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = xs[(8 * (r >> 2) + (r & 3)) * L::XS];
     }
@@ -381,15 +401,17 @@ struct MuCoop {
             for (int p = 0; p < 2; ++p)
                 a1[ks][p] = __builtin_bit_cast(mu_bf16x8, *reinterpret_cast<const u32x4*>(b + ((rs * 2 + p) * 32 + l32) * L::A1ROW + (16 * ks + 8 * h) * 2));
     }
-    __device__ __forceinline__ void read_a2(int buf, int rs, int l32, int h, int c, mu_bf16x8 (&a2c)[KP == 16 ? 1 : 2]) const
+    __device__ __forceinline__ void read_a2(int buf, int rs, int l32, int h, int c, mu_bf16x8 (&a2c)[MuShape<KP>::NA2]) const
     {
         const unsigned char* b = lds + buf * L::BUF + L::X_BYTES + L::A1_BYTES;
         if constexpr (KP == 16)
             a2c[0] = __builtin_bit_cast(mu_bf16x8, *reinterpret_cast<const u32x4*>(b + ((rs * 2 + (l32 >> 4)) * 16 + (l32 & 15)) * L::A2ROW + (16 * c + 8 * h) * 2));
         else {
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-                a2c[p] = __builtin_bit_cast(mu_bf16x8, *reinterpret_cast<const u32x4*>(b + ((rs * 2 + p) * 32 + l32) * L::A2ROW + (16 * c + 8 * h) * 2));
+            for (int mh = 0; mh < MuShape<KP>::NMH; ++mh)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    a2c[2 * mh + p] = __builtin_bit_cast(mu_bf16x8, *reinterpret_cast<const u32x4*>(b + ((rs * 2 + p) * KP + 32 * mh + l32) * L::A2ROW + (16 * c + 8 * h) * 2));
         }
     }
 };
@@ -397,8 +419,8 @@ struct MuCoop {
 // steps [t0, t1): numerators of the wave's two tiles into acc (MODE 0) or the divergence partial into dv (MODE 1)
 template <int KP, int MODE, bool BETA1>
 __device__ __forceinline__ void mu_coop_loop(MuCoop<KP, MODE == 0>& co, bool active, int rs, int gs, int l32, int h,
-                                             const mu_bf16x8 (&b1)[2][KP / 16][2], f32x16 (&acc)[2], f32x16 (&accd)[2],
-                                             double& dv, int t0, int t1)
+                                             const mu_bf16x8 (&b1)[MuShape<KP>::NJT][KP / 16][2], MuAcc<KP> (&acc)[MuShape<KP>::NJT],
+                                             MuAcc<KP> (&accd)[MuShape<KP>::NJT], double& dv, int t0, int t1)
 {
     if (t0 >= t1) return;
     co.gload(t0);
@@ -413,13 +435,13 @@ __device__ __forceinline__ void mu_coop_loop(MuCoop<KP, MODE == 0>& co, bool act
             co.read_a1(buf, rs, l32, h, a1);
             if constexpr (MODE == 0) {
 #pragma unroll
-                for (int jt = 0; jt < 2; ++jt) {
+                for (int jt = 0; jt < MuShape<KP>::NJT; ++jt) {
                     float x[16];
                     co.read_x(buf, gs, jt, l32, h, x);
                     const f32x16 s = mu_product<KP / 16>(a1, b1[jt]);
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        mu_bf16x8 a2c[KP == 16 ? 1 : 2];
+                        mu_bf16x8 a2c[MuShape<KP>::NA2];
                         co.read_a2(buf, rs, l32, h, c, a2c);
                         mu_quotient_accumulate_chunk<KP, BETA1>(acc[jt], accd[jt], s, x, c, a2c);
                     }
@@ -427,7 +449,7 @@ __device__ __forceinline__ void mu_coop_loop(MuCoop<KP, MODE == 0>& co, bool act
             } else {
                 float part = 0.f;
 #pragma unroll
-                for (int jt = 0; jt < 2; ++jt) {
+                for (int jt = 0; jt < MuShape<KP>::NJT; ++jt) {
                     float x[16];
                     co.read_x(buf, gs, jt, l32, h, x);
                     const f32x16 s = mu_product<KP / 16>(a1, b1[jt]);
@@ -459,11 +481,12 @@ __global__ __launch_bounds__(512) void mu_h_coop_kernel(const float* __restrict_
     constexpr int KS = KP / 16;
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rs = wave & 3, gs = wave >> 2;
-    const int slot = blockIdx.z * 4 + rs;
+    using SH = MuShape<KP>;
+    const int rs = wave % SH::RPW, gs = wave / SH::RPW;
+    const int slot = blockIdx.z * SH::RPW + rs;
     const bool active = slot < mb.n;
     const MuSlotDev& sd = mb.s[active ? slot : 0];
-    const int g0 = blockIdx.x * 128 + gs * 64;
+    const int g0 = blockIdx.x * 128 + gs * 32 * SH::NJT;
     const int chunk = blockIdx.y;
     const int ntiles = Np / 32;
     const int rt0 = chunk * tiles_per_chunk, rt1 = min(ntiles, rt0 + tiles_per_chunk);
@@ -473,52 +496,51 @@ __global__ __launch_bounds__(512) void mu_h_coop_kernel(const float* __restrict_
     co.xbase = X; co.xld = (size_t)ldx; co.xbytes = (unsigned long long)(Np + 1) * ldx * 4ull;     // the slack row included
     co.c0 = blockIdx.x * 128;
     {
-        const int ls = blockIdx.z * 4 + (tid >> 7);                  // the restart this thread loads for
+        const int ls = blockIdx.z * SH::RPW + tid / SH::TPR;         // the restart this thread loads for
         co.src_live = ls < mb.n;
         const MuSlotDev& sl = mb.s[co.src_live ? ls : 0];
         co.src = MuCoopSrc{sl.Wp_hi, sl.Wp_lo, sl.Wc_hi, Np};
     }
-    mu_bf16x8 b1[2][KS][2];
+    mu_bf16x8 b1[SH::NJT][KS][2];
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < SH::NJT; ++jt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const size_t o = (size_t)(g0 + 32 * jt + l32) * KP + 16 * ks + 8 * h;
             b1[jt][ks][0] = mu_ld8(sd.Hp_hi + o);
             b1[jt][ks][1] = mu_ld8(sd.Hp_lo + o);
         }
-    f32x16 acc[2];
+    MuAcc<KP> acc[SH::NJT], accd[SH::NJT];
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < SH::NJT; ++jt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
-    f32x16 accd[2];
+        for (int mh = 0; mh < SH::NMH; ++mh)
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accd[jt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[jt].v[mh][r] = 0.f; accd[jt].v[mh][r] = 0.f; }
     double dv = 0.0;
     mu_coop_loop<KP, 0, BETA1>(co, active, rs, gs, l32, h, b1, acc, accd, dv, rt0, rt1);
     if (!active) return;
     // C layout: register r <-> row m = 8 (r / 4) + 4 h + r % 4, column (gene) l32
-    auto store = [&](float* base, const f32x16 (&a)[2]) {
+    auto store = [&](float* base, const MuAcc<KP> (&a)[SH::NJT]) {
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
+        for (int jt = 0; jt < SH::NJT; ++jt) {
             float* pn = base + ((size_t)chunk * Gs + g0 + 32 * jt + l32) * KP;
             if constexpr (KP == 16) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     v4f v;
-                    v.x = a[jt][4 * q + 0] + a[jt][4 * q + 8]; v.y = a[jt][4 * q + 1] + a[jt][4 * q + 9];
-                    v.z = a[jt][4 * q + 2] + a[jt][4 * q + 10]; v.w = a[jt][4 * q + 3] + a[jt][4 * q + 11];
+                    v.x = a[jt].v[0][4 * q + 0] + a[jt].v[0][4 * q + 8]; v.y = a[jt].v[0][4 * q + 1] + a[jt].v[0][4 * q + 9];
+                    v.z = a[jt].v[0][4 * q + 2] + a[jt].v[0][4 * q + 10]; v.w = a[jt].v[0][4 * q + 3] + a[jt].v[0][4 * q + 11];
                     *reinterpret_cast<v4f*>(pn + 8 * q + 4 * h) = v;
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v4f v = {a[jt][4 * q], a[jt][4 * q + 1], a[jt][4 * q + 2], a[jt][4 * q + 3]};
-                    *reinterpret_cast<v4f*>(pn + 8 * q + 4 * h) = v;
-                }
+                for (int mh = 0; mh < SH::NMH; ++mh)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v4f v = {a[jt].v[mh][4 * q], a[jt].v[mh][4 * q + 1], a[jt].v[mh][4 * q + 2], a[jt].v[mh][4 * q + 3]};
+                        *reinterpret_cast<v4f*>(pn + 32 * mh + 8 * q + 4 * h) = v;
+                    }
             }
         }
     };
@@ -535,48 +557,46 @@ __global__ __launch_bounds__(512) void mu_w_coop_kernel(const float* __restrict_
     constexpr int KS = KP / 16;
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rs = wave & 3, gs = wave >> 2;
-    const int slot = blockIdx.z * 4 + rs;
+    using SH = MuShape<KP>;
+    const int rs = wave % SH::RPW, gs = wave / SH::RPW;
+    const int slot = blockIdx.z * SH::RPW + rs;
     const bool active = slot < mb.n;
     const MuSlotDev& sd = mb.s[active ? slot : 0];
-    const int r0 = blockIdx.x * 128 + gs * 64;                       // (ldxt = N_pad is a multiple of 128)
+    const int r0 = blockIdx.x * 128 + gs * 32 * SH::NJT;             // (ldxt = N_pad is a multiple of 128)
 
     MuCoop<KP, MODE == 0> co;
     co.lds = mu_lds; co.tid = tid;
     co.xbase = Xt; co.xld = (size_t)ldxt; co.xbytes = (unsigned long long)Gs * ldxt * 4ull;
     co.c0 = blockIdx.x * 128;
     {
-        const int ls = blockIdx.z * 4 + (tid >> 7);
+        const int ls = blockIdx.z * SH::RPW + tid / SH::TPR;
         co.src_live = ls < mb.n;
         const MuSlotDev& sl = mb.s[co.src_live ? ls : 0];
         co.src = MuCoopSrc{sl.Hp_hi, sl.Hp_lo, sl.Hc_hi, Gs};
     }
-    mu_bf16x8 b1[2][KS][2];
+    mu_bf16x8 b1[SH::NJT][KS][2];
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < SH::NJT; ++jt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const size_t o = (size_t)(r0 + 32 * jt + l32) * KP + 16 * ks + 8 * h;
             b1[jt][ks][0] = mu_ld8(sd.Wp_hi + o);
             b1[jt][ks][1] = mu_ld8(sd.Wp_lo + o);
         }
-    f32x16 acc[2];
+    MuAcc<KP> acc[SH::NJT], accd[SH::NJT];
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < SH::NJT; ++jt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
-    f32x16 accd[2];
+        for (int mh = 0; mh < SH::NMH; ++mh)
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accd[jt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[jt].v[mh][r] = 0.f; accd[jt].v[mh][r] = 0.f; }
     double dv = 0.0;
     mu_coop_loop<KP, MODE, BETA1>(co, active, rs, gs, l32, h, b1, acc, accd, dv, 0, Gs / 32);
     if (!active) return;
     if constexpr (MODE == 1) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dv += __shfl_xor(dv, o, 64);
-        if (lane == 0 && r0 < N) sd.divpart[blockIdx.x * 2 + gs] = dv;          // one partial per 64-cell strip
+        if (lane == 0 && r0 < N) sd.divpart[blockIdx.x * (8 / SH::RPW) + gs] = dv;    // one partial per strip of 32 NJT cells
         return;
     } else {
         mu_w_epilogue<KP, BETA1>(sd, acc, accd, r0, l32, h, N, ldxt, l1, l2);

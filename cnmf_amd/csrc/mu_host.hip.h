@@ -115,7 +115,8 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
     const int Gs = round_up(ctx->G_pad, 128);
     int rc = mu_ensure_xt(ctx, Gs);
     if (rc) return rc;
-    const int nstrips = (N + 63) / 64, ntiles = Np / 32;
+    constexpr int RPW = MuShape<KP>::RPW, SW = 32 * MuShape<KP>::NJT;      // restarts per workgroup, cells per divergence strip
+    const int nstrips = (N + SW - 1) / SW, ntiles = Np / 32;
     const int nchunks = std::min(32, ntiles), tpc = (ntiles + nchunks - 1) / nchunks;
     const int R = (int)std::min<size_t>(MU_MAXSLOTS, jobs.size());
     const float l1W = (float)prm->l1_reg_W, l2W = (float)prm->l2_reg_W;
@@ -239,7 +240,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
     auto divergence = [&](const std::vector<int>& ids, std::vector<double>& err) -> int {
         const MuBatch mb = batch_of(ids);
         if (!update_H) colsum(mb, 0);                 // refit: the iterations do not need the column sums of W
-        mu_w_coop_kernel<KP, 1, BETA1><<<dim3((N + 127) / 128, 1, (mb.n + 3) / 4), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, 0.f, 0.f);
+        mu_w_coop_kernel<KP, 1, BETA1><<<dim3((N + 127) / 128, 1, (mb.n + RPW - 1) / RPW), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, 0.f, 0.f);
         HIP_TRY(ctx, hipGetLastError());
         for (int i = 0; i < mb.n; ++i) {
             HIP_TRY(ctx, hipMemcpyAsync(hdiv.data() + (size_t)i * nstrips, mb.s[i].divpart, (size_t)nstrips * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -307,7 +308,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         if (ids.empty()) { if (next >= jobs.size()) break; else continue; }
         // ---- one iteration of every live slot
         const MuBatch mb = batch_of(ids);
-        const int gz4 = (mb.n + 3) / 4;
+        const int gz4 = (mb.n + RPW - 1) / RPW;
         mu_w_coop_kernel<KP, 0, BETA1><<<dim3((N + 127) / 128, 1, gz4), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, l1W, l2W);
         if (update_H) {
             colsum(mb, 0);
@@ -348,25 +349,28 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
         if (k < 1) { SET_ERR(ctx, "n_components must be >= 1"); return CNMF_EINVAL; }
         if (k > CNMF_MU_KMAX) { SET_ERR(ctx, "n_components=%d > %d is not supported by the multiplicative-update solver on the device", k, CNMF_MU_KMAX); return CNMF_EUNSUPPORTED; }
     }
-    // rank <= 32: batched on the matrix pipe (kernels_mu_mfma.hip.h); the rest below, one by one
+    // batched on the matrix pipe (kernels_mu_mfma.hip.h: padded ranks 16 / 32 / 64); the vector-ALU kernels below, one
+    // restart at a time, serve CNMF_MU_VALU=1 and matrices beyond the 32-bit addressing bound
     std::vector<char> done(n, 0);
     {
         const char* e = getenv("CNMF_MU_VALU");
         // (the matrix-pipe kernels address a 32-row step of X / X^T with 32-bit byte offsets below 2^31 -- the buffer
         //  descriptor's range: 4 * 32 * row length -> up to 2^24 cells or genes)
         if (!(e && atoi(e) != 0) && ctx->N_pad <= (1 << 24) && ctx->G_pad <= (1 << 24)) {
-            std::vector<MuJob> j16, j32;
+            std::vector<MuJob> j16, j32, j64;
             size_t ho = 0, wo = 0;
             for (int r = 0; r < n; ++r) {
                 const int k = kk[r];
                 if (k <= 16) j16.push_back(MuJob{r, k, ho, wo});
                 else if (k <= 32) j32.push_back(MuJob{r, k, ho, wo});
-                if (k <= 32) done[r] = 1;
+                else j64.push_back(MuJob{r, k, ho, wo});
+                done[r] = 1;
                 ho += (size_t)k * G; wo += (size_t)k * N;
             }
 #define MU_BATCH(KP_, B1_, jobs_) mu_batch_mfma<KP_, B1_>(ctx, jobs_, init_mode, seeds, avg, W0, H0, update_H, prm, H_out, W_out, n_iter_out, err_out)
             if (!j16.empty()) { rc = beta == 1 ? MU_BATCH(16, true, j16) : MU_BATCH(16, false, j16); if (rc) return rc; }
             if (!j32.empty()) { rc = beta == 1 ? MU_BATCH(32, true, j32) : MU_BATCH(32, false, j32); if (rc) return rc; }
+            if (!j64.empty()) { rc = beta == 1 ? MU_BATCH(64, true, j64) : MU_BATCH(64, false, j64); if (rc) return rc; }
 #undef MU_BATCH
         }
     }

@@ -159,9 +159,9 @@ int cnmf_nmf_cd_batch_resident(cnmf_ctx* ctx, int n_restarts, const int32_t* k,
  * update_H = 0 is the refit (cnmf.py:776-802 with solver 'mu'): H0 holds the fixed spectra and W
  * starts from avg[r] everywhere (sklearn:_nmf.py:1229-1231); H_out is then ignored.
  * err_out[r] = sqrt(2 * beta-divergence) at the last evaluation.
- * Restarts of rank <= 32 run batched on the matrix pipe, up to 32 per round of launches sharing each
- * pass over X (kernels_mu_mfma.hip.h); a restart's result does not depend on the batch it ran in.
- * Ranks 33..64: Kullback-Leibler only, one restart after the other (CNMF_EUNSUPPORTED for beta = 0).
+ * Restarts run batched on the matrix pipe (padded rank 16 / 32 / 64, both losses), up to 32 per round of
+ * launches sharing each pass over X (kernels_mu_mfma.hip.h); a restart's result does not depend on the
+ * batch it ran in.  Ranks above CNMF_MU_KMAX (64): CNMF_EUNSUPPORTED.
  * The first call builds a resident transposed copy of X (freed with the matrix).                   */
 int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n_restarts, const int32_t* k, int init_mode,
                       const uint32_t* seeds, const double* avg, const float* W0, const float* H0,

@@ -138,7 +138,7 @@ def test_large_rank_refit_and_mu(engine):
     assert int(nm[0]) == n_ref
     R, R_ref = Wm[0].astype(np.float64) @ Hm[0], W_ref @ H_ref
     assert np.abs(R - R_ref).max() <= 2e-3 * np.abs(R_ref).max()
-    # Itakura-Saito above rank 32 (vector-ALU kernels, one restart at a time) -- no longer refused
+    # Itakura-Saito above rank 32 (matrix-pipe kernels at padded rank 64, as Kullback-Leibler)
     Xp = X + 0.05                                              # IS needs strictly positive data
     engine.set_matrix(Xp)
     for k_is in (40, 64):
@@ -154,10 +154,11 @@ def test_large_rank_refit_and_mu(engine):
 
 
 @pytest.mark.parametrize("n,g,k", [(7, 5, 2), (33, 31, 3), (129, 33, 5), (257, 65, 1), (200, 140, 32), (64, 128, 16),
-                                   (300, 150, 17), (131, 257, 9)])
+                                   (300, 150, 17), (131, 257, 9), (300, 150, 33), (161, 257, 48), (257, 129, 64)])
 def test_kl_small_and_ragged_shapes(engine, n, g, k):
     """The Kullback-Leibler solver's matrix-pipe kernels work on 128-wide blocks and 32-deep steps: shapes below and
-    across every one of those sizes, ranks 1 / 16 / 17 / 32 (both register layouts), against the float64 oracle."""
+    across every one of those sizes, ranks 1 / 16 / 17 / 32 / 33 / 48 / 64 (all three register layouts: two restarts
+    per workgroup and two M tiles above rank 32), against the float64 oracle."""
     from oracle import nmf_mu
     X = _x(n, g, seed=n + g)
     engine.set_matrix(X)

@@ -132,3 +132,33 @@ def test_itakura_saito_batch_vs_oracle(engine, X):
     assert int(n1[0]) == int(n_iter[3])
     np.testing.assert_array_equal(H1[0], H[3])
     np.testing.assert_array_equal(W1[0], W[3])
+
+
+def test_mu_ranks_33_to_64_batched_on_the_matrix_pipe(engine, X, monkeypatch):
+    """Ranks 33..64 run on the matrix-pipe kernels at padded rank 64 (two restarts per workgroup, two M tiles of the
+    second product): an odd number of restarts (the last workgroup holds one), results independent of the batch bit
+    for bit, against the oracle, and against the vector-ALU kernels that served these ranks before."""
+    engine.set_matrix(X)
+    ks = [40, 33, 64, 48, 57]
+    seeds = [300 + i for i in range(len(ks))]
+    H, W, n_iter, err = engine.nmf_mu_batch(ks, seeds=seeds, max_iter=60, return_W=True, warn=False)
+    for i in (0, 2, 4):
+        H1, W1, n1, _ = engine.nmf_mu_batch([ks[i]], seeds=[seeds[i]], max_iter=60, return_W=True, warn=False)
+        assert int(n1[0]) == int(n_iter[i])
+        np.testing.assert_array_equal(H1[0], H[i])
+        np.testing.assert_array_equal(W1[0], W[i])
+    for i in (1, 2, 3):
+        W_ref, H_ref, _ = nmf_mu.nmf_mu(X, ks[i], seed=seeds[i], max_iter=int(n_iter[i]), tol=0.0)
+        R, R_ref = W[i].astype(np.float64) @ H[i], W_ref @ H_ref
+        assert np.abs(R - R_ref).max() <= 2e-3 * np.abs(R_ref).max(), ks[i]
+        ref_err = nmf_mu.beta_divergence(X, W_ref, H_ref, 1, square_root=True)
+        assert abs(err[i] - ref_err) <= 2e-3 * ref_err
+    monkeypatch.setenv("CNMF_MU_VALU", "1")
+    Hv, Wv, nv, ev = engine.nmf_mu_batch(ks[:2], seeds=seeds[:2], max_iter=60, return_W=True, warn=False)
+    monkeypatch.delenv("CNMF_MU_VALU")
+    for i in range(2):
+        assert abs(int(nv[i]) - int(n_iter[i])) <= 10
+        if int(nv[i]) == int(n_iter[i]):
+            R, Rv = W[i].astype(np.float64) @ H[i], Wv[i].astype(np.float64) @ Hv[i]
+            assert np.abs(R - Rv).max() <= 3e-3 * np.abs(Rv).max()
+            assert abs(err[i] - ev[i]) <= 2e-3 * ev[i]
