@@ -158,7 +158,7 @@ int cnmf_nmf_cd_batch_resident(cnmf_ctx* ctx, int n_restarts, const int32_t* k,
  * beta: 1 = kullback-leibler, 0 = itakura-saito.  Same packing / init modes as cnmf_nmf_cd_batch.
  * update_H = 0 is the refit (cnmf.py:776-802 with solver 'mu'): H0 holds the fixed spectra and W
  * starts from avg[r] everywhere (sklearn:_nmf.py:1229-1231); H_out is then ignored.
- * err_out[r] = sqrt(2 * beta-divergence) at the last evaluation.
+ * err_out[r] = sqrt(2 * beta-divergence) of the FINAL factors (sklearn's reconstruction_err_).
  * Restarts run batched on the matrix pipe (padded rank 16 / 32 / 64, both losses), up to 32 per round of
  * launches sharing each pass over X (kernels_mu_mfma.hip.h); a restart's result does not depend on the
  * batch it ran in.  Ranks above CNMF_MU_KMAX (64): CNMF_EUNSUPPORTED.

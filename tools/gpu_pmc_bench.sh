@@ -31,8 +31,8 @@ except Exception:
     KC, NSPLIT = 1024, 8
 out_geom={"packed_columns": KC, "splitk_passB": NSPLIT}
 out={"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES (separate passes, --kernel-trace only) around \`bench.py --steps 1 --warmup 0 --restarts-per-k 100 --no-cpu-baseline --no-extras\` (the bench step itself: 900 restarts, wide batch of 1024 packed columns narrowing in the tail) on the default path (CNMF_GEMM3=4: count structure detected -> f16 two-plane kernels), tools/gpu_pmc_bench.sh; mean over all launches of the kernel. FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B/lane reads, LDS-DMA included; Infinity-Cache hits are counted). mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs)."}
-for key, part in (("passA","gemm2h_streamk_kernel"),("passB","gemm2h_kernel"),("sweepW","sweep_kernel<0, false, false>"),("split","split2h_finalize_kernel")):
-    e={"kernel": part}
+for key, part in (("passA","gemm2h_streamk_kernel"),("passB","gemm2h_kernel"),("sweepW","sweep_kernel<0, false, false,"),("split","split2h_finalize_kernel")):
+    e={"kernel": part.rstrip(",")}
     for c in ("FETCH_SIZE","WRITE_SIZE","SQ_VALU_MFMA_BUSY_CYCLES","GRBM_GUI_ACTIVE"):
         m,n=mean(part,c); e[c]=m; e["launches"]=n or e.get("launches",0)
     if e["FETCH_SIZE"] is not None and e["WRITE_SIZE"] is not None:
