@@ -498,7 +498,8 @@ def e2e_wallclock(eng, C, X, ks_all, restarts_per_k, cpu_it_per_s):
                        "(%d ranks, batched) -> consensus(k=%d, density 0.5) incl. TPM spectra / OLS z-scores / final "
                        "usage refit from one CSR upload" % (len(ks_all) * restarts_per_k, len(ks_all), k_cons),
            "stages_s": t, "total_s": sum(t.values()), "restarts": int(len(n_iter)),
-           "restart_iterations": int(n_iter.sum())}
+           "restart_iterations": int(n_iter.sum()),
+           "factorize_host_s": {k: round(float(v), 4) for k, v in (obj.last_factorize_stats.get("host_seconds") or {}).items()}}
     # ---- the CPU reference path beside it
     from oracle import consensus as oc
     c = {}

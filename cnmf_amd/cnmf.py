@@ -38,11 +38,23 @@ def save_df_to_npz(obj, filename):
     np.savez_compressed(filename, data=obj.values, index=obj.index.values, columns=obj.columns.values)
 
 
+_SIBLING_BYTES = 64 << 20
+
+
 def save_df_to_npz_fast(obj, filename):
     """Same container as save_df_to_npz without zlib: used only for the (large) normalised
     matrix, which the reference stores as uncompressed h5ad (cnmf.py:561); zlib over 400 MB
-    costs ~10 s and buys nothing on a scratch file."""
-    np.savez(filename, data=obj.values, index=obj.index.values, columns=obj.columns.values)
+    costs ~10 s and buys nothing on a scratch file.  Above 64 MB the matrix itself goes into a
+    sibling ``<file>.data.npy`` named inside the npz: a zip member costs a CRC-32 pass over
+    every byte (0.6 s per 800 MB, single-threaded), a plain .npy does not -- and the other
+    workers can map it."""
+    data = np.ascontiguousarray(obj.values)
+    if data.nbytes >= _SIBLING_BYTES:
+        sibling = filename + ".data.npy"
+        np.save(sibling, data)
+        np.savez(filename, data_file=np.array(os.path.basename(sibling)), index=obj.index.values, columns=obj.columns.values)
+    else:
+        np.savez(filename, data=data, index=obj.index.values, columns=obj.columns.values)
 
 
 def save_df_to_text(obj, filename):
@@ -53,7 +65,11 @@ def save_df_to_text(obj, filename):
 def load_df_from_npz(filename):
     """cnmf.py:37-40"""
     with np.load(filename, allow_pickle=True) as f:
-        obj = pd.DataFrame(**f)
+        if "data_file" in f.files:               # written by save_df_to_npz_fast: the matrix sits beside the npz
+            data = np.load(os.path.join(os.path.dirname(os.path.abspath(filename)), str(f["data_file"])))
+            obj = pd.DataFrame(data=data, index=f["index"], columns=f["columns"])
+        else:
+            obj = pd.DataFrame(**f)
     return obj
 
 
@@ -107,7 +123,8 @@ class cNMF:
         self.detect_counts = detect_counts      # False: never use the integer-plane GEMMs (Engine.set_count_detection)
         self._engine = engine
         self._engine_key = None
-        self.spectra_cache = {}          # (k, iter) -> spectra ndarray kept from factorize
+        self.spectra_cache = {}          # (k, iter) -> spectra ndarray (k x genes) kept from factorize
+        self._spectra_columns = None     # their gene names
         self.merged_cache = {}           # k -> merged spectra DataFrame kept from combine (skips a reload)
         self._resident_obj = None        # STRONG reference to the matrix object that is resident (identity check:
                                          # while we hold it CPython cannot hand its id() to another object)
@@ -255,6 +272,9 @@ class cNMF:
         self._initialize_dirs()
         self._forget_results()
         save_df_to_npz_fast(norm_counts, self.paths["normalized_counts"])
+        # this process holds what it just wrote: factorize() / consensus() need not read the 8 N G bytes back
+        self._norm_counts_cache = ((self.paths["normalized_counts"], os.path.getmtime(self.paths["normalized_counts"])),
+                                   norm_counts)
         with open(self.paths["nmf_genes_list"], "w") as F:
             F.write("\n".join(map(str, norm_counts.columns)))
         for stale in (self.paths["tpm"], self.paths["tpm_sparse"], self.paths["tpm_sparse_genes"]):
@@ -427,11 +447,15 @@ class cNMF:
             self.last_factorize_stats = dict(eng.last_stats, n_iter=n_iter)
         _t.append(_time.perf_counter())
         xdt = norm_counts.values.dtype if norm_counts.values.dtype in (np.float32, np.float64) else np.float64
+        self._spectra_columns = norm_counts.columns
         for k, it, H in zip(ks, its, H_list):
-            spectra = pd.DataFrame(H.astype(xdt), index=np.arange(1, k + 1), columns=norm_counts.columns)
-            self.spectra_cache[(k, it)] = spectra
+            # kept as plain arrays (k x genes, X's dtype): 900 DataFrames cost more host time than they are worth;
+            # combine_nmf() builds ONE frame per k
+            arr = H.astype(xdt)
+            self.spectra_cache[(k, it)] = arr
             if write_iter_files:
-                save_df_to_npz(spectra, self.paths["iter_spectra"] % (k, it))
+                save_df_to_npz(pd.DataFrame(arr, index=np.arange(1, k + 1), columns=norm_counts.columns),
+                               self.paths["iter_spectra"] % (k, it))
         _t.append(_time.perf_counter())
         self.last_factorize_stats["host_seconds"] = dict(load_inputs=_t[1] - _t[0], upload=_t[2] - _t[1],
                                                          device_call=_t[3] - _t[2], store_results=_t[4] - _t[3])
@@ -452,24 +476,30 @@ class cNMF:
         run_params = load_df_from_npz(self.paths["nmf_replicate_parameters"])
         print("Combining factorizations for k=%d." % k)
         run_params_subset = run_params[run_params.n_components == k].sort_values("iter")
-        combined_spectra = []
-        for i, p in run_params_subset.iterrows():
-            key = (int(p["n_components"]), int(p["iter"]))
+        blocks, labels, columns = [], [], None
+        for kk, itv in zip(run_params_subset["n_components"].values, run_params_subset["iter"].values):
+            key = (int(kk), int(itv))
             current_file = self.paths["iter_spectra"] % key
             if key in self.spectra_cache:
-                spectra = self.spectra_cache[key].copy()
+                block = self.spectra_cache[key]
+                if columns is None:
+                    columns = self._spectra_columns
             elif os.path.exists(current_file):
-                spectra = load_df_from_npz(current_file)
+                df = load_df_from_npz(current_file)
+                block = df.values
+                if columns is None:
+                    columns = df.columns
             else:
                 if not skip_missing_files:
                     print("Missing file: %s, run with skip_missing=True to override" % current_file)
                     raise FileNotFoundError(errno.ENOENT, os.strerror(errno.ENOENT), current_file)
                 print("Missing file: %s. Skipping." % current_file)
                 continue
-            spectra.index = ["iter%d_topic%d" % (p["iter"], t + 1) for t in range(k)]
-            combined_spectra.append(spectra)
-        if len(combined_spectra) > 0:
-            combined_spectra = pd.concat(combined_spectra, axis=0)
+            blocks.append(block)
+            labels.extend("iter%d_topic%d" % (itv, t + 1) for t in range(k))
+        combined_spectra = []
+        if len(blocks) > 0:
+            combined_spectra = pd.DataFrame(np.concatenate(blocks, axis=0), index=labels, columns=columns)
             (save_df_to_npz if self.compress_merged else save_df_to_npz_fast)(combined_spectra, self.paths["merged_spectra"] % k)
             self.merged_cache[k] = (os.path.getmtime(self.paths["merged_spectra"] % k), combined_spectra)
             if remove_individual_iterations:
@@ -648,15 +678,22 @@ class cNMF:
                     rf, _ = eng.nnls_gram(H_prod, Hrf @ Hrf.T, n_features=len(hvgs), **solver_kw)
                 rf_usages = pd.DataFrame(np.asarray(rf, dtype=xdt), index=norm_counts.index, columns=spectra_tpm_rf.index)
 
-        save_df_to_npz(median_spectra, self.paths["consensus_spectra"] % (k, density_threshold_repl))
-        save_df_to_npz(rf_usages, self.paths["consensus_usages"] % (k, density_threshold_repl))
-        save_df_to_text(median_spectra, self.paths["consensus_spectra__txt"] % (k, density_threshold_repl))
-        save_df_to_text(rf_usages, self.paths["consensus_usages__txt"] % (k, density_threshold_repl))
+        # the nine artefacts of cnmf.py:977-985, written side by side: zlib and the float formatting of the two large
+        # tables (usages: cells x k) overlap instead of adding up
+        rep = (k, density_threshold_repl)
+        writes = [(save_df_to_npz, median_spectra, self.paths["consensus_spectra"] % rep),
+                  (save_df_to_npz, rf_usages, self.paths["consensus_usages"] % rep),
+                  (save_df_to_text, median_spectra, self.paths["consensus_spectra__txt"] % rep),
+                  (save_df_to_text, rf_usages, self.paths["consensus_usages__txt"] % rep)]
         if spectra_tpm is not None:
-            save_df_to_npz(spectra_tpm, self.paths["gene_spectra_tpm"] % (k, density_threshold_repl))
-            save_df_to_text(spectra_tpm, self.paths["gene_spectra_tpm__txt"] % (k, density_threshold_repl))
-            save_df_to_npz(usage_coef, self.paths["gene_spectra_score"] % (k, density_threshold_repl))
-            save_df_to_text(usage_coef, self.paths["gene_spectra_score__txt"] % (k, density_threshold_repl))
+            writes += [(save_df_to_npz, spectra_tpm, self.paths["gene_spectra_tpm"] % rep),
+                       (save_df_to_text, spectra_tpm, self.paths["gene_spectra_tpm__txt"] % rep),
+                       (save_df_to_npz, usage_coef, self.paths["gene_spectra_score"] % rep),
+                       (save_df_to_text, usage_coef, self.paths["gene_spectra_score__txt"] % rep)]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            for fut in [pool.submit(fn, obj, path) for fn, obj, path in writes]:
+                fut.result()                                   # a failed write raises here, as it would have inline
         return median_spectra, rf_usages
 
     # ------------------------------------------------------------------ k selection (cnmf.py:1119-1135)

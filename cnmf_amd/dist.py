@@ -153,10 +153,9 @@ def factorize_distributed(obj, rank, world, device=None, gather="rccl", **factor
         p = run_params.loc[idx]
         key = (int(p["n_components"]), int(p["iter"]))
         if key in obj.spectra_cache:
-            df = obj.spectra_cache[key]
-            genes = df.columns
+            genes = obj._spectra_columns
             rows.append((idx, key[0], key[1]))
-            spectra.append(df.values)
+            spectra.append(np.asarray(obj.spectra_cache[key]))
     if genes is None:
         genes = load_df_from_npz(obj.paths["normalized_counts"]).columns
     hdr, blk = pack_local(rows, spectra, len(genes))
@@ -165,5 +164,6 @@ def factorize_distributed(obj, rank, world, device=None, gather="rccl", **factor
     else:
         merged = allgather_spectra(hdr, blk, len(genes), device=device)
     for (k, it), H in merged.items():
-        obj.spectra_cache[(k, it)] = pd.DataFrame(H.astype(np.float64), index=np.arange(1, k + 1), columns=genes)
+        obj.spectra_cache[(k, it)] = H.astype(np.float64)
+    obj._spectra_columns = genes
     return merged
