@@ -156,3 +156,18 @@ def test_kmeans_needs_several_lloyd_batches(engine):
     assert out["kmeans_n_iter"] == 13                      # KMeans(n_clusters=6, n_init=10, random_state=1).n_iter_ on this input
     assert np.array_equal(out["labels"] + 1, ref["kmeans_labels"])
     assert abs(out["inertia"] - ref["inertia"]) <= 1e-9 * ref["inertia"]
+
+
+def test_more_than_8192_kept_spectra_take_the_global_memory_seeding(engine):
+    """9 000 merged spectra: the KNN selection holds 36 values per thread (the 40-value instantiation), 8 850 rows
+    survive the filter -- above the 8 192 the register k-means++ kernel holds -- so the seeding runs from global memory
+    without being forced to; clusters of 1 475 members take the wide median kernel.  All against the oracle."""
+    S, truth = synth.consensus_stress(R=9000, G=48, k=6, n_outliers=150, seed=3)
+    ref = oc.consensus_core(S, np.abs(np.random.RandomState(0).standard_normal((20, 48))), 6, density_threshold=0.5)
+    out = engine.consensus(S, 6, density_threshold=0.5)
+    kept = out["density_filter"]
+    assert kept.sum() == 8850 and np.array_equal(kept, ref["density_filter"])
+    assert np.abs(out["local_density"] - ref["local_density"]).max() < 1e-9
+    assert np.array_equal(out["labels"][kept] + 1, ref["kmeans_labels"])
+    assert np.abs(out["median_spectra"] - ref["median_spectra"]).max() < 1e-12
+    assert abs(out["inertia"] - ref["inertia"]) <= 1e-9 * ref["inertia"]
