@@ -171,3 +171,18 @@ def test_more_than_8192_kept_spectra_take_the_global_memory_seeding(engine):
     assert np.array_equal(out["labels"][kept] + 1, ref["kmeans_labels"])
     assert np.abs(out["median_spectra"] - ref["median_spectra"]).max() < 1e-12
     assert abs(out["inertia"] - ref["inertia"]) <= 1e-9 * ref["inertia"]
+
+
+@pytest.mark.parametrize("R", [1024, 1025, 4097, 8192, 8193])
+def test_kept_row_counts_at_the_edges_of_the_register_kernels(engine, R):
+    """k-means++ holds 1 / 2 / 4 / 8 rows per thread of a 1024-thread workgroup and falls back to global memory above
+    8 192; the KNN selection holds 4 ... 40 values per thread of 256: row counts on both sides of those edges (all rows
+    kept: density_threshold 2.0), labels and medians against the oracle."""
+    S, _ = synth.consensus_stress(R=R, G=24, k=4, n_outliers=0, seed=R)
+    ref = oc.consensus_core(S, np.abs(np.random.RandomState(0).standard_normal((20, 24))), 4, density_threshold=2.0)
+    out = engine.consensus(S, 4, density_threshold=2.0)
+    assert out["density_filter"].all()
+    assert np.abs(out["local_density"] - ref["local_density"]).max() < 1e-9
+    assert np.array_equal(out["labels"] + 1, ref["kmeans_labels"])
+    assert np.abs(out["median_spectra"] - ref["median_spectra"]).max() < 1e-12
+    assert abs(out["inertia"] - ref["inertia"]) <= 1e-9 * ref["inertia"]
