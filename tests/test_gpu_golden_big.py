@@ -134,12 +134,14 @@ def test_C4_count_valued_csr_vs_sklearn_golden(engine):
     assert tuple(g["shape"]) == X.shape and int(g["nnz"][0]) == X.nnz
     assert abs(float(X.data.astype(np.float64).sum()) - float(g["x_checksum"][0])) <= 1e-9 * float(g["x_checksum"][0])
     engine.set_matrix(X)                                       # CSR upload, densified on the device
-    ks = [20] * 13                                             # 13 x 20 = 260 columns: a full 256-column batch + one refill
-    seeds = [21, 22] + list(range(301, 312))
-    for kc in (256, 0):                                        # a 256-column batch with one refill; the default: 512 wide
+    # 13 x 20 = 260 columns: a 256-column batch with one refill, then the default width for that job (512);
+    # 52 x 20 = 1040 columns: the widest batch (1024 columns = four component groups over 782 cell tiles) with one refill
+    for kc, n_rest, width in ((256, 13, 256), (0, 13, 512), (0, 52, 1024)):
+        ks = [20] * n_rest
+        seeds = [21, 22] + list(range(301, 299 + n_rest))
         H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=10, warn=False, kc_max=kc)
         st = engine.last_stats
-        assert st["kc"] == (kc or 512) and st["gemm_mode"] == 4, st       # the count structure was detected: f16 two-plane path
+        assert st["kc"] == width and st["gemm_mode"] == 4, st             # the count structure was detected: f16 two-plane path
         for r, seed in enumerate((21, 22)):
             assert int(n_iter[r]) == 10
             maxabs, relfro = nmf_cd.spectra_error(g["seed%d_H10" % seed], H[r])
