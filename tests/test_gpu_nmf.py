@@ -260,18 +260,20 @@ def test_full_width_batch_matches_oracle_in_every_gemm_mode(engine, monkeypatch,
     assert list(n2) == list(n_iter) and all(np.array_equal(a, b) for a, b in zip(H, H2))
 
 
-@pytest.mark.parametrize("g3mode,kc", [("4", 512), ("4", 768), ("3", 512), ("2", 512)])
+@pytest.mark.parametrize("g3mode,kc", [("4", 512), ("4", 768), ("3", 512), ("2", 512), ("4", 1024), ("5", 512), ("5", 1024)])
 def test_wide_batch_512_columns_matches_oracle(engine, monkeypatch, g3mode, kc):
     """Wide batches (512 / 768 packed columns = 2 / 3 component groups per GEMM pass: the default for jobs of >= 1536
     columns on large matrices): pass A walks its tiles component-group-major, pass B spreads (row tile, group, K split)
     over the XCDs, the cut flags are looked up by (row tile, group) -- every restart against its float64 oracle run, on
     the count path (f16 and bf16 planes) and the general split-operand path; then the tail narrows the batch in steps
     of 256 columns on the same kernels (more restarts than fit at once, all of different length)."""
-    monkeypatch.setenv("CNMF_GEMM3", g3mode)
+    monkeypatch.setenv("CNMF_GEMM3", min(g3mode, "4"))
     X64 = synth.make_config("C1", dtype=np.float64)
-    engine.set_matrix(X64)
     rs = np.random.RandomState(12)
-    n = 150
+    if g3mode == "5":                 # any matrix that is not count-structured: X itself as two f16 planes (128-column groups)
+        X64 = X64 * np.exp(0.5 * rs.standard_normal((X64.shape[0], 1))) + 0.01 * np.abs(rs.standard_normal(X64.shape))
+    engine.set_matrix(X64)
+    n = 150 if kc < 1024 else 200
     ks = [int(k) for k in rs.randint(5, 10, size=n)]
     seeds = [int(s) for s in rs.randint(1, 2**31 - 1, size=n)]
     assert sum(ks) > kc + 256
