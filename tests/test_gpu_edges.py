@@ -49,6 +49,27 @@ def test_ranks_above_64_next_to_small_ones_and_their_refits(engine):
         assert np.abs(R - R_ref).max() <= 2e-3 * max(1.0, np.abs(R_ref).max()), k
     H2, _, n2, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=80, warn=False)
     assert list(n2) == list(n_iter) and all(np.array_equal(a, b) for a, b in zip(H, H2))      # deterministic
+    # big and small ranks side by side on the split-operand kernels (a matrix they take: count-structured C1), in a 256-column
+    # batch and three times over in the widest one (1024 packed columns, four component groups): same answers to rounding
+    from cnmf_amd import synth
+    Xc = synth.make_config("C1", dtype=np.float64)
+    engine.set_matrix(Xc)
+    Hn, _, nn, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=60, warn=False, kc_max=256)
+    assert engine.last_stats["gemm_mode"] == 4, engine.last_stats
+    Hw, _, nw, _ = engine.nmf_batch(ks * 3, seeds=seeds * 3, max_iter=60, warn=False, kc_max=1024)
+    assert engine.last_stats["kc"] == 1024 and engine.last_stats["gemm_mode"] == 4, engine.last_stats
+    for i in range(3 * len(ks)):
+        a, na = Hn[i % len(ks)], int(nn[i % len(ks)])
+        assert abs(int(nw[i]) - na) <= 2, (ks[i % len(ks)], int(nw[i]), na)
+        if int(nw[i]) == na:
+            maxabs, relfro = nmf_cd.spectra_error(a, Hw[i])
+            assert maxabs <= 1e-4 and relfro <= 1e-3, (ks[i % len(ks)], maxabs, relfro)
+    _, Hc_ref, n_ref = nmf_cd.nmf(Xc, 96, seed=seeds[5], max_iter=60)
+    assert abs(int(nn[5]) - n_ref) <= 2
+    if int(nn[5]) == n_ref:
+        maxabs, relfro = nmf_cd.spectra_error(Hc_ref, Hn[5])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (maxabs, relfro)
+    engine.set_matrix(X)
     _, Hr, _ = nmf_cd.nmf(X, 100, seed=3, max_iter=30)
     W_ref, n_ref = nmf_cd.nnls(X, Hr, max_iter=60)
     Wd, nd = engine.nnls(Hr, max_iter=60, warn=False)
