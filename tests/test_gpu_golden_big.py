@@ -92,6 +92,24 @@ def test_C3_long_restarts_vs_sklearn_golden(engine):
         assert maxabs <= lim and relfro <= lim, (k, maxabs, relfro)
         if n_full < 1000:
             assert viol[r] <= 1e-4
+    # (c) the GENERAL path on the same matrix (count detection off: what a Harmony-corrected or TPM-normalised input of
+    #     this size gets -- X itself as two f16 planes with a per-row exponent, gemm_mode 5), at the 50-iteration truncation:
+    #     a 256-column batch, and the widest one (1024 columns = eight 128-column groups of the two-plane kernels)
+    engine.set_count_detection(False)
+    try:
+        engine.set_matrix(X)
+        fk3, fs3 = _fillers(n9=100, n13=10, n7=10, seed=79)
+        for width, kk, ss in ((256, ks, seeds), (1024, ks + fk3, seeds + fs3)):
+            H, _, n_iter, _ = engine.nmf_batch(kk, seeds=ss, max_iter=50, warn=False, kc_max=width)
+            st = engine.last_stats
+            assert st["kc"] == width and st["gemm_mode"] == 5, st
+            for r, k in enumerate(ks3):
+                assert int(n_iter[r]) == 50
+                dev = g["k%d_f32dev50" % k]
+                maxabs, relfro = nmf_cd.spectra_error(g["k%d_H50" % k], H[r])
+                assert maxabs <= max(1e-4, 4 * dev[0]) and relfro <= max(1e-3, 4 * dev[1]), (k, "general", width, maxabs, relfro, dev)
+    finally:
+        engine.set_count_detection(True)
 
 
 def _c4_matrix():
