@@ -162,3 +162,27 @@ def test_mu_ranks_33_to_64_batched_on_the_matrix_pipe(engine, X, monkeypatch):
             R, Rv = W[i].astype(np.float64) @ H[i], Wv[i].astype(np.float64) @ Hv[i]
             assert np.abs(R - Rv).max() <= 3e-3 * np.abs(Rv).max()
             assert abs(err[i] - ev[i]) <= 2e-3 * ev[i]
+
+
+def test_mu_at_scale_vs_oracle(engine):
+    """12 000 cells x 2 000 genes (375 32-cell strips, 16 gene blocks, 94 cell blocks of 128): Kullback-Leibler at ranks
+    9, 20, 40 and 64 -- all three register layouts of the matrix-pipe kernels -- and Itakura-Saito at rank 40, a fixed
+    number of iterations against the float64 oracle."""
+    X = synth.make_config("C3", dtype=np.float64, n_cells=12000)
+    engine.set_matrix(X)
+    ks, seeds = [9, 20, 40, 64], [5, 6, 7, 8]
+    H, W, n_iter, err = engine.nmf_mu_batch(ks, seeds=seeds, max_iter=12, tol=0.0, return_W=True, warn=False)
+    for k, seed, h, w, n, e in zip(ks, seeds, H, W, n_iter, err):
+        W_ref, H_ref, _ = nmf_mu.nmf_mu(X, k, seed=seed, max_iter=12, tol=0.0)
+        assert int(n) == 12
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, h)
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (k, maxabs, relfro)
+        assert np.abs(w - W_ref).max() <= 2e-3 * np.abs(W_ref).max(), k
+        ref_err = nmf_mu.beta_divergence(X, W_ref, H_ref, 1, square_root=True)
+        assert abs(e - ref_err) <= 2e-3 * ref_err, (k, e, ref_err)
+    Xp = X + 1e-3
+    engine.set_matrix(Xp)
+    Hi, Wi, ni, ei = engine.nmf_mu_batch([40], seeds=[9], beta_loss="itakura-saito", max_iter=8, tol=0.0, return_W=True, warn=False)
+    W_ref, H_ref, _ = nmf_mu.nmf_mu(Xp, 40, seed=9, beta_loss="itakura-saito", max_iter=8, tol=0.0)
+    R, R_ref = Wi[0].astype(np.float64) @ Hi[0], W_ref @ H_ref
+    assert np.abs(R - R_ref).max() <= 5e-3 * np.abs(R_ref).max()
