@@ -33,6 +33,62 @@ __global__ __launch_bounds__(256) void block_apply_rinv_kernel(float* __restrict
     }
 }
 
+// Gram matrices of the blocks for LONG vectors (L = cells): gram_rows_kernel walks all L positions of a block in ONE
+// workgroup (1.1 ms at L = 50 000 -- a third of the whole initialisation).  Here the positions are cut into chunks:
+// part[block][chunk][c][c] (float64) from grid (blocks, chunks), then one workgroup per block adds the chunks in order.
+template <int NP>                                    // pairs (a, b) per thread: c * c <= 256 * NP
+__global__ __launch_bounds__(256) void gram_chunk_kernel(const float* __restrict__ V, int ldv, int L,
+                                                         const SlotDesc* __restrict__ blocks, int chunk_len,
+                                                         double* __restrict__ part, int cmax)
+{
+    constexpr int GC = 64;
+    __shared__ float tile[KMAX][GC + 1];
+    const SlotDesc sd = blocks[blockIdx.x];
+    const int c = sd.k, off = sd.off, tid = threadIdx.x;
+    const int g_lo = blockIdx.y * chunk_len, g_hi = min(L, g_lo + chunk_len);
+    double acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) acc[i] = 0.0;
+    for (int g0 = g_lo; g0 < g_hi; g0 += GC) {
+        for (int e = tid; e < c * GC; e += 256) {
+            const int r = e / GC, g = e % GC;
+            tile[r][g] = (g0 + g < g_hi) ? V[(size_t)(off + r) * ldv + g0 + g] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = tid + 256 * i;
+            if (e < c * c) {
+                const int a = e / c, b = e % c;
+                float s = 0.f;
+#pragma unroll 8
+                for (int g = 0; g < GC; ++g) s = fmaf(tile[a][g], tile[b][g], s);
+                acc[i] += (double)s;
+            }
+        }
+        __syncthreads();
+    }
+    double* out = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * cmax * cmax;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int e = tid + 256 * i;
+        if (e < c * c) out[(e / c) * cmax + e % c] = acc[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_chunk_reduce_kernel(const double* __restrict__ part, int nchunks, int cmax,
+                                                                const SlotDesc* __restrict__ blocks,
+                                                                float* __restrict__ gram_out)
+{
+    const int c = blocks[blockIdx.x].k;
+    for (int e = threadIdx.x; e < c * c; e += 256) {
+        const int a = e / c, b = e % c;
+        double s = 0.0;
+        for (int q = 0; q < nchunks; ++q) s += part[((size_t)blockIdx.x * nchunks + q) * cmax * cmax + a * cmax + b];
+        gram_out[(size_t)blockIdx.x * GRAM_SZ + a * GRAM_LD + b] = (float)s;
+    }
+}
+
 }  // namespace cnmf
 
 // transpose = 0: M = X (rows = cells), 1: M = X^T.  Q0 [M_cols][C] row-major (C = sum of widths <= 256);
@@ -66,6 +122,8 @@ extern "C" int cnmf_range_finder(cnmf_ctx* ctx, int transpose, int nblocks, cons
     int* dList = pool.get<int>(nblocks);
     float* dGram = pool.get<float>((size_t)nblocks * GRAM_SZ);
     float* dRinv = pool.get<float>((size_t)nblocks * cmax * cmax);
+    constexpr int GRAM_CHUNKS = 64;
+    double* dGpart = pool.get<double>((size_t)nblocks * GRAM_CHUNKS * cmax * cmax);
     POOL_TRY(ctx, pool);
     std::vector<SlotDesc> blk(nblocks);
     std::vector<int> list(nblocks);
@@ -106,7 +164,17 @@ extern "C" int cnmf_range_finder(cnmf_ctx* ctx, int transpose, int nblocks, cons
     std::vector<float> hg((size_t)nblocks * GRAM_SZ), hr((size_t)nblocks * cmax * cmax);
     // one Cholesky-QR round of every block of V [KC][ld] (L valid positions)
     auto normalise = [&](float* V, int ld, int L) -> int {
-        gram_rows_kernel<<<nblocks, 256, 0, st>>>(V, ld, L, dBlk, dList, dGram, 0.f);
+        if (L >= 8192) {              // long vectors: positions cut into chunks, partial Grams added in chunk order
+            const int chunk_len = round_up((L + GRAM_CHUNKS - 1) / GRAM_CHUNKS, 64);
+            const int nch = (L + chunk_len - 1) / chunk_len;
+            const dim3 gg(nblocks, nch);
+            if (cmax <= 32) gram_chunk_kernel<4><<<gg, 256, 0, st>>>(V, ld, L, dBlk, chunk_len, dGpart, cmax);
+            else if (cmax <= 64) gram_chunk_kernel<16><<<gg, 256, 0, st>>>(V, ld, L, dBlk, chunk_len, dGpart, cmax);
+            else gram_chunk_kernel<64><<<gg, 256, 0, st>>>(V, ld, L, dBlk, chunk_len, dGpart, cmax);
+            gram_chunk_reduce_kernel<<<nblocks, 256, 0, st>>>(dGpart, nch, cmax, dBlk, dGram);
+        } else {
+            gram_rows_kernel<<<nblocks, 256, 0, st>>>(V, ld, L, dBlk, dList, dGram, 0.f);
+        }
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(hg.data(), dGram, hg.size() * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));

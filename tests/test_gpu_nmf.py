@@ -418,6 +418,19 @@ def test_x_matmul_vs_numpy(engine):
         assert np.abs(engine.x_matmul(Q2, trans=True) - ref2).max() <= 2e-6 * np.abs(ref2).max() * np.sqrt(X.shape[0])
 
 
+def test_nndsvd_long_matrix_takes_the_chunked_gram(engine):
+    """9 000 cells: the Cholesky-QR normaliser of the range finder forms its Gram matrices from 64 chunks of positions
+    (vectors of 8 192 positions and more) -- every restart of a group against scikit-learn's _initialize_nmf."""
+    from sklearn.decomposition._nmf import _initialize_nmf
+    X = synth.make_config("C1", dtype=np.float64, n_cells=9000)
+    engine.set_matrix(X)
+    ks, seeds = [5, 9, 13, 30], [3, 14, 15, 92]
+    for (k, seed), (Wb, Hb) in zip(zip(ks, seeds), engine.nndsvd_init_batch(ks, seeds)):
+        W_ref, H_ref = _initialize_nmf(X, k, init="nndsvd", random_state=seed)
+        assert np.abs(Wb - W_ref).max() <= 1e-3 * np.abs(W_ref).max(), (k, seed)
+        assert np.abs(Hb - H_ref).max() <= 1e-3 * np.abs(H_ref).max(), (k, seed)
+
+
 @pytest.mark.parametrize("shape", ["tall", "wide"])
 def test_nndsvd_init_matches_sklearn(engine, shape):
     """`--init nndsvd` (cnmf.py:1252): randomized-SVD products on the device, factorizations on the host."""
