@@ -41,15 +41,16 @@ def save_df_to_npz(obj, filename):
 _SIBLING_BYTES = 64 << 20
 
 
-def save_df_to_npz_fast(obj, filename):
+def save_df_to_npz_fast(obj, filename, sibling_ok=False):
     """Same container as save_df_to_npz without zlib: used only for the (large) normalised
     matrix, which the reference stores as uncompressed h5ad (cnmf.py:561); zlib over 400 MB
-    costs ~10 s and buys nothing on a scratch file.  Above 64 MB the matrix itself goes into a
+    costs ~10 s and buys nothing on a scratch file.  With ``sibling_ok`` (the normalised matrix only: a file the
+    reference never reads as npz) a matrix above 64 MB goes into a
     sibling ``<file>.data.npy`` named inside the npz: a zip member costs a CRC-32 pass over
     every byte (0.6 s per 800 MB, single-threaded), a plain .npy does not -- and the other
     workers can map it."""
     data = np.ascontiguousarray(obj.values)
-    if data.nbytes >= _SIBLING_BYTES:
+    if sibling_ok and data.nbytes >= _SIBLING_BYTES:
         sibling = filename + ".data.npy"
         np.save(sibling, data)
         np.savez(filename, data_file=np.array(os.path.basename(sibling)), index=obj.index.values, columns=obj.columns.values)
@@ -271,7 +272,7 @@ class cNMF:
                             % (zerocells.sum(), ", ".join(map(str, examples[:4]))))
         self._initialize_dirs()
         self._forget_results()
-        save_df_to_npz_fast(norm_counts, self.paths["normalized_counts"])
+        save_df_to_npz_fast(norm_counts, self.paths["normalized_counts"], sibling_ok=True)
         # this process holds what it just wrote: factorize() / consensus() need not read the 8 N G bytes back
         self._norm_counts_cache = ((self.paths["normalized_counts"], os.path.getmtime(self.paths["normalized_counts"])),
                                    norm_counts)

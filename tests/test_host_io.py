@@ -16,12 +16,15 @@ def test_npz_round_trip_small_and_with_sibling(tmp_path, monkeypatch):
     for name, limit in (("small.df.npz", 1 << 40), ("big.df.npz", 1)):
         monkeypatch.setattr(m, "_SIBLING_BYTES", limit)
         path = str(tmp_path / name)
-        m.save_df_to_npz_fast(df, path)
+        m.save_df_to_npz_fast(df, path, sibling_ok=True)
         got = m.load_df_from_npz(path)
         assert np.array_equal(got.values, df.values)
         assert list(got.index) == list(df.index) and list(got.columns) == list(df.columns)
     assert (tmp_path / "big.df.npz.data.npy").exists() and not (tmp_path / "small.df.npz.data.npy").exists()
     with np.load(str(tmp_path / "small.df.npz"), allow_pickle=True) as f:          # the reference's own container (cnmf.py:31-32)
+        assert sorted(f.files) == ["columns", "data", "index"]
+    m.save_df_to_npz_fast(df, str(tmp_path / "merged.df.npz"))                     # merged spectra: always the reference's form
+    with np.load(str(tmp_path / "merged.df.npz"), allow_pickle=True) as f:
         assert sorted(f.files) == ["columns", "data", "index"]
 
 
