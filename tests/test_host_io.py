@@ -35,3 +35,22 @@ def test_compressed_container_is_the_reference_one(tmp_path):
     with np.load(path, allow_pickle=True) as f:
         assert sorted(f.files) == ["columns", "data", "index"]
         assert np.array_equal(f["data"], df.values)
+
+
+def test_sparse_tpm_statistics_match_get_mean_var(tmp_path):
+    """prepare_from_matrix with a sparse TPM matrix: __mean / __std of tpm_stats as the reference's get_mean_var computes
+    them for sparse input (cnmf.py:126-134: mean, E[x^2] - mean^2, population), duplicates in the input summed first."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(2)
+    dense = rs.gamma(0.5, 2.0, (60, 9)) * (rs.uniform(size=(60, 9)) < 0.4)
+    coo = sp.coo_matrix(dense)
+    dup = sp.coo_matrix((np.concatenate([coo.data * 0.25, coo.data * 0.75]), (np.concatenate([coo.row, coo.row]), np.concatenate([coo.col, coo.col]))), shape=dense.shape)
+    X = _frame(60, 5)
+    obj = m.cNMF(output_dir=str(tmp_path), name="s")
+    obj.prepare_from_matrix(X, components=[3], n_iter=2, seed=1, tpm=(dup, ["t%d" % j for j in range(9)]))
+    stats = m.load_df_from_npz(obj.paths["tpm_stats"])
+    mean = dense.mean(axis=0)
+    std = np.sqrt((dense * dense).mean(axis=0) - mean ** 2)
+    assert np.allclose(stats["__mean"].values, mean, rtol=1e-12, atol=0)
+    assert np.allclose(stats["__std"].values, std, rtol=1e-10, atol=0)
+    assert list(stats.index) == ["t%d" % j for j in range(9)]
