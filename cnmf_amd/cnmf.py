@@ -287,7 +287,9 @@ class cNMF:
             import scipy.sparse as sp
             mat, genes = tpm
             mat = sp.csr_matrix(mat)
-            mat.sum_duplicates()
+            if not mat.has_canonical_format:                   # (never in place on the caller's arrays)
+                mat = mat.copy()
+                mat.sum_duplicates()
             sp.save_npz(self.paths["tpm_sparse"], mat, compressed=False)
             with open(self.paths["tpm_sparse_genes"], "w") as F:
                 F.write("\n".join(map(str, genes)))
