@@ -199,6 +199,7 @@ class cNMF:
         self._resident_obj = None
         self._engine_key = None
         self._norm_counts_cache = (None, None)
+        self._tpm_sparse_cache = None
 
     def _load_norm_counts(self):
         """The normalised matrix file, kept in memory between the stages of one process."""
@@ -293,6 +294,9 @@ class cNMF:
             sp.save_npz(self.paths["tpm_sparse"], mat, compressed=False)
             with open(self.paths["tpm_sparse_genes"], "w") as F:
                 F.write("\n".join(map(str, genes)))
+            # (this process holds what it just wrote: consensus() need not read and CRC-check it back)
+            self._tpm_sparse_cache = ((self.paths["tpm_sparse"], os.path.getmtime(self.paths["tpm_sparse"])),
+                                      mat, pd.Index([str(g) for g in genes]))
             # column mean and E[x^2] in float64 as two weighted bin counts over the stored entries (row-major order, like
             # the sparse sums of get_mean_var; 3-10 x faster than .mean() / .multiply().mean() on a 50 000 x 2 000 matrix)
             d64 = mat.data.astype(np.float64)
@@ -638,8 +642,13 @@ class cNMF:
             #   final refit    -> usages on tpm[:, hvgs] / std as a product with the resident matrix
             if have_sparse:
                 import scipy.sparse as sp
-                tpm_x = sp.load_npz(self.paths["tpm_sparse"]).tocsr()
-                tpm_genes = pd.Index(open(self.paths["tpm_sparse_genes"]).read().split("\n"))
+                key = (self.paths["tpm_sparse"], os.path.getmtime(self.paths["tpm_sparse"]))
+                cached = getattr(self, "_tpm_sparse_cache", None)
+                if cached is not None and cached[0] == key:
+                    tpm_x, tpm_genes = cached[1], cached[2]
+                else:
+                    tpm_x = sp.load_npz(self.paths["tpm_sparse"]).tocsr()
+                    tpm_genes = pd.Index(open(self.paths["tpm_sparse_genes"]).read().split("\n"))
             else:
                 tpm = load_df_from_npz(self.paths["tpm"])
                 tpm_x, tpm_genes = tpm.values, tpm.columns
