@@ -59,8 +59,21 @@ def save_df_to_npz_fast(obj, filename, sibling_ok=False):
 
 
 def save_df_to_text(obj, filename):
-    """cnmf.py:34-35"""
-    obj.to_csv(filename, sep="\t")
+    """cnmf.py:34-35: ``obj.to_csv(filename, sep='\\t')``.  All-float64 frames with plain labels (the usages: cells x k)
+    are formatted here -- the same bytes (shortest round-trip repr per value, like pandas' float -> str), a quarter of the
+    time; anything else (other dtypes, missing values, labels that would need quoting) goes through pandas."""
+    vals = obj.values
+    labels = [str(c) for c in obj.columns] + [str(i) for i in obj.index]
+    plain = (isinstance(obj, pd.DataFrame) and vals.ndim == 2 and vals.dtype == np.float64 and obj.index.nlevels == 1
+             and obj.columns.nlevels == 1 and obj.index.name is None and obj.columns.name is None and vals.size > 0
+             and np.isfinite(vals).all() and not any(ch in lab for lab in labels for ch in "\t\n\r\"") and "" not in labels)
+    if not plain:
+        obj.to_csv(filename, sep="\t")
+        return
+    ncol = vals.shape[1]
+    body = "\n".join("%s\t%s" % (lab, "\t".join(map(repr, row))) for lab, row in zip(labels[ncol:], vals.tolist()))
+    with open(filename, "w", newline="") as F:
+        F.write("\t".join([""] + labels[:ncol]) + "\n" + body + "\n")
 
 
 def load_df_from_npz(filename):

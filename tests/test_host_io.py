@@ -54,3 +54,25 @@ def test_sparse_tpm_statistics_match_get_mean_var(tmp_path):
     assert np.allclose(stats["__mean"].values, mean, rtol=1e-12, atol=0)
     assert np.allclose(stats["__std"].values, std, rtol=1e-10, atol=0)
     assert list(stats.index) == ["t%d" % j for j in range(9)]
+
+
+def test_text_writer_is_byte_identical_to_pandas(tmp_path):
+    """save_df_to_text (cnmf.py:34-35) formats all-float64 frames itself: the bytes must be those of
+    ``DataFrame.to_csv(sep='\\t')`` -- values across the whole double range, integer and string labels -- and every
+    frame it does not take (float32, NaN, labels with a tab or a quote, named index) must go through pandas unchanged."""
+    rs = np.random.RandomState(4)
+    v = rs.gamma(0.3, 1.0, (400, 7)) * np.exp(9 * rs.standard_normal((400, 7)))
+    v[0, 0], v[1, 1], v[2, 2], v[3, 3], v[4, 4], v[5, 5], v[6, 6] = 0.0, 5e-324, 1e22, 123456789.0, 1e16, 0.1, -2.5e-7
+    frames = {
+        "usages": pd.DataFrame(v, index=["cell_%d" % i for i in range(400)], columns=np.arange(1, 8)),
+        "spectra": pd.DataFrame(v.T.copy(), index=np.arange(1, 8), columns=["g%d" % j for j in range(400)]),
+        "f32": pd.DataFrame(v.astype(np.float32), index=["c%d" % i for i in range(400)], columns=np.arange(1, 8)),
+        "nan": pd.DataFrame(np.where(v > 100, np.nan, v), index=["c%d" % i for i in range(400)], columns=np.arange(1, 8)),
+        "tab": pd.DataFrame(v[:3], index=["a\tb", 'q"x', "plain"], columns=np.arange(1, 8)),
+        "named": pd.DataFrame(v[:3], index=pd.Index(["a", "b", "c"], name="cell"), columns=np.arange(1, 8)),
+    }
+    for name, df in frames.items():
+        got, ref = str(tmp_path / (name + ".got.txt")), str(tmp_path / (name + ".ref.txt"))
+        m.save_df_to_text(df, got)
+        df.to_csv(ref, sep="\t")
+        assert open(got, "rb").read() == open(ref, "rb").read(), name
