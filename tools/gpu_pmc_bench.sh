@@ -14,6 +14,9 @@ cd $R
 python - <<PY
 import csv, glob, collections, os, json
 R=os.environ['GRAFT_REPO_ROOT']
+XPLANES=int(os.environ.get('PMC_XPLANES','1'))       # 1: the count path's integer plane; 2: a general matrix as two f16 planes (CNMF_NO_COUNTS=1)
+NOTE=os.environ.get('PMC_NOTE','')
+OUTNAME=os.environ.get('PMC_OUT','pmc_traffic.json')
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(R+'/gpurun_out/pmcb/*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
@@ -40,7 +43,7 @@ for key, part in (("passA","gemm2h_streamk_kernel"),("passB","gemm2h_kernel"),("
     if e["SQ_VALU_MFMA_BUSY_CYCLES"] and e["GRBM_GUI_ACTIVE"]:
         e["mfma_busy_frac"]=e["SQ_VALU_MFMA_BUSY_CYCLES"]/(1024*e["GRBM_GUI_ACTIVE"]/8)
     out[key]=e
-xplane = N_pad*G_pad*2
+xplane = N_pad*G_pad*2*XPLANES
 out["algorithmic_bytes_per_launch"]={
   "passA": xplane + KC*G_pad*4 + KC*N_pad*4,
   "passB": xplane + KC*N_pad*4 + NSPLIT*KC*G_pad*4,
@@ -49,7 +52,8 @@ import sys; sys.path.insert(0, R)
 from bench import source_hashes
 out['kernel_source_sha256']=source_hashes()
 out['geometry']=out_geom
-json.dump(out, open(R+'/gpurun_out/pmc_traffic.json','w'), indent=1)
+if NOTE: out['_source'] = NOTE + ' -- ' + out['_source']
+json.dump(out, open(R+'/gpurun_out/'+OUTNAME,'w'), indent=1)
 print(json.dumps({k:(v if not isinstance(v,dict) else {kk:vv for kk,vv in v.items() if kk in('hbm_bytes_per_launch','mfma_busy_frac','launches')}) for k,v in out.items() if k!='_source'}, indent=1))
 PY
 # the raw per-dispatch counter CSVs (hundreds of MB at 5000+ launches per kernel) stay on the GPU box
