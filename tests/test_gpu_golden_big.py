@@ -94,7 +94,7 @@ def test_C3_long_restarts_vs_sklearn_golden(engine):
             assert viol[r] <= 1e-4
     # (c) the GENERAL path on the same matrix (count detection off: what a Harmony-corrected or TPM-normalised input of
     #     this size gets -- X itself as two f16 planes with a per-row exponent, gemm_mode 5), at the 50-iteration truncation:
-    #     a 256-column batch, and the widest one (1024 columns = eight 128-column groups of the two-plane kernels)
+    #     a 256-column batch, and the widest one (1024 columns = four component groups of the two-plane kernels)
     engine.set_count_detection(False)
     try:
         engine.set_matrix(X)

@@ -270,7 +270,7 @@ def test_wide_batch_512_columns_matches_oracle(engine, monkeypatch, g3mode, kc):
     monkeypatch.setenv("CNMF_GEMM3", min(g3mode, "4"))
     X64 = synth.make_config("C1", dtype=np.float64)
     rs = np.random.RandomState(12)
-    if g3mode == "5":                 # any matrix that is not count-structured: X itself as two f16 planes (128-column groups)
+    if g3mode == "5":                 # any matrix that is not count-structured: X itself as two f16 planes
         X64 = X64 * np.exp(0.5 * rs.standard_normal((X64.shape[0], 1))) + 0.01 * np.abs(rs.standard_normal(X64.shape))
     engine.set_matrix(X64)
     n = 150 if kc < 1024 else 200
