@@ -21,7 +21,7 @@ SYMBOLS = [
     "cnmf_col_moments", "cnmf_scale_columns", "cnmf_row_sums",
     "cnmf_nmf_cd_batch", "cnmf_nmf_cd_batch_resident", "cnmf_nnls",
     "cnmf_consensus", "cnmf_prediction_error", "cnmf_nmf_mu_batch", "cnmf_x_matmul",
-    "cnmf_xt_matmul_f64", "cnmf_nnls_spectra", "cnmf_nnls_gram", "cnmf_nnls_batch", "cnmf_kselect_stats",
+    "cnmf_xt_matmul_f64", "cnmf_nnls_spectra", "cnmf_nnls_f64", "cnmf_nnls_gram", "cnmf_nnls_batch", "cnmf_kselect_stats",
     "cnmf_comm_unique_id", "cnmf_comm_init", "cnmf_comm_finalize", "cnmf_comm_rank", "cnmf_comm_world",
     "cnmf_allgather_bytes", "cnmf_allgather_spectra",
     "cnmf_spectra_rows", "cnmf_spectra_reset", "cnmf_spectra_fetch",
@@ -156,7 +156,9 @@ def load():
     lib.cnmf_xt_matmul_f64.restype = i32
     lib.cnmf_xt_matmul_f64.argtypes = [vp, i32, dblp, i32, dblp, dblp, dblp]
     lib.cnmf_nnls_spectra.restype = i32
-    lib.cnmf_nnls_spectra.argtypes = [vp, i32, dblp, C.POINTER(CdParams), f32p, i32p, dblp]
+    lib.cnmf_nnls_spectra.argtypes = [vp, i32, dblp, C.POINTER(CdParams), dblp, i32p, dblp]
+    lib.cnmf_nnls_f64.restype = i32
+    lib.cnmf_nnls_f64.argtypes = [vp, i32, dblp, dblp, C.POINTER(CdParams), dblp, i32p, dblp]
     lib.cnmf_nnls_gram.restype = i32
     lib.cnmf_nnls_gram.argtypes = [vp, i32, f32p, f32p, C.POINTER(CdParams), f32p, i32p, dblp]
     lib.cnmf_nnls_batch.restype = i32

@@ -400,8 +400,11 @@ class cNMF:
                                    max_iter=kw.get("max_iter", 200), alpha_W=kw.get("alpha_W", 0.0),
                                    l1_ratio=kw.get("l1_ratio", 0.0))
             else:
-                W, _ = eng.nnls(H, tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 200),
-                                alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
+                # scikit-learn solves in X's dtype (sklearn _nmf.py:1221-1233): float64 matrices get the float64 refit
+                # (product, Gram matrix and sweeps), float32 ones the float32 matrix-pipe path
+                refit = eng.nnls_f64 if xdt == np.float64 else eng.nnls
+                W, _ = refit(H, tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 200),
+                             alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
             return H, W.astype(xdt, copy=False)
         k = int(kw["n_components"])
         if kw.get("init") == "nndsvd":                       # `--init nndsvd` (cnmf.py:1252)
@@ -703,6 +706,8 @@ class cNMF:
                 if kw.get("solver", "cd") == "mu":
                     norm_tpm = (np.asarray(tpm_x[:, hidx].todense()) if have_sparse else tpm_x[:, hidx]).astype(np.float64) / std1
                     rf = self.refit_usage(norm_tpm, Hrf.astype(norm_tpm.dtype))
+                elif tdt == np.float64:
+                    rf, _ = eng.nnls_f64(H_prod, gram=Hrf @ Hrf.T, n_features=len(hvgs), **solver_kw)
                 else:
                     rf, _ = eng.nnls_gram(H_prod, Hrf @ Hrf.T, n_features=len(hvgs), **solver_kw)
                 rf_usages = pd.DataFrame(np.asarray(rf, dtype=xdt), index=norm_counts.index, columns=spectra_tpm_rf.index)

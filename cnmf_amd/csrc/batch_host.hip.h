@@ -196,7 +196,13 @@ static int wait_snapshot(cnmf_ctx* ctx, const SlotDesc* sp, int n, int stamp)
 // pass A and the latency-bound H half-step are amortised over four times the columns (169 -> 198 -> 215 restarts/s at
 // 256 / 512 / 1024 columns, 50 000 x 2000); the batch narrows in 256-column steps once the queue is dry (compact()).
 // kc_max: 0 = auto, else an upper bound (multiple of 32; above 256 in steps of 256, up to CNMF_KC_LIMIT).
-constexpr int CNMF_KC_LIMIT = 1024;
+constexpr int CNMF_KC_LIMIT_DEFAULT = 1024;
+static int kc_limit()                  // (CNMF_KC_LIMIT: A/B knob, up to 2048 = the 64 tile bits of the live mask)
+{
+    static const int v = getenv("CNMF_KC_LIMIT") ? atoi(getenv("CNMF_KC_LIMIT")) : CNMF_KC_LIMIT_DEFAULT;
+    return std::max(256, std::min(2048, (v / 256) * 256));
+}
+#define CNMF_KC_LIMIT kc_limit()
 static int pick_kc(int64_t total_k, int max_k, int kc_max, bool wide_ok)
 {
     bool forced = false;

@@ -212,7 +212,13 @@ static void refresh_gemm3_mode()            // at every API entry that launches 
     g_gemm3_mode = (mode < 0 || mode > 4) ? CNMF_GEMM3_DEFAULT : mode;
 }
 static int gemm3_mode() { return g_gemm3_mode; }
-static int gemm3_wg_slots() { return gemm3_mode() >= 2 ? 256 : 512; }
+// (CNMF_WG_SLOTS: fewer persistent GEMM workgroups than CUs -- leaves whole CUs to the kernels of another stream)
+static int gemm3_wg_slots()
+{
+    static const int env = getenv("CNMF_WG_SLOTS") ? atoi(getenv("CNMF_WG_SLOTS")) : 0;
+    if (env >= 32 && gemm3_mode() >= 2) return env;
+    return gemm3_mode() >= 2 ? 256 : 512;
+}
 static int gemm3_jw() { return G3_JW; }     // j extent of a tile = row tile of the B planes
 
 static hipError_t launch_gemm3(hipStream_t st, const unsigned char* A3, const unsigned char* B3, int Kb,

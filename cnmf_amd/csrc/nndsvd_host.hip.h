@@ -183,25 +183,36 @@ extern "C" int cnmf_range_finder(cnmf_ctx* ctx, int transpose, int nblocks, cons
         for (int b = 0; b < nblocks; ++b) {
             const int c = widths[b];
             const float* g = hg.data() + (size_t)b * GRAM_SZ;
-            // upper Cholesky factor R (G = R^T R), float64; a non-positive pivot (rank-deficient block: more columns than
-            // the matrix has rank) gets a tiny pivot instead -- the direction is numerically in the span of the others
+            // upper Cholesky factor R (G = R^T R), float64.  A rank-deficient block (more columns than the matrix has rank:
+            // min(N, G) < k + 10, a noiseless low-rank X, duplicated rows) leaves a pivot that is zero up to the round-off
+            // of the float32 Gram matrix: that direction lies numerically in the span of the earlier columns and is DROPPED
+            // -- row j of R and column j of R^-1 are zero, the column of Q becomes a zero vector and stays one through the
+            // remaining passes.  (Dividing by a floored pivot instead compounds over several deficient columns: R^-1
+            // overflows float32 and the basis turns into NaN -- round-3 advisor finding.)  range(Q) is still the range
+            // of the block; scikit-learn's pivoted LU reaches the same subspace with arbitrary vectors in the null part.
             std::fill(Rm.begin(), Rm.end(), 0.0);
-            double tr = 0.0;
-            for (int i = 0; i < c; ++i) tr += g[i * GRAM_LD + i];
-            const double floor_ = std::max(tr / std::max(c, 1), 1e-300) * 1e-12;
+            std::vector<char> dead(c, 0);
             for (int j = 0; j < c; ++j) {
                 for (int i = 0; i <= j; ++i) {
+                    if (i < j && dead[i]) continue;                    // row i of R is zero
                     double s = g[i * GRAM_LD + j];
                     for (int p = 0; p < i; ++p) s -= Rm[(size_t)p * cmax + i] * Rm[(size_t)p * cmax + j];
-                    if (i == j) Rm[(size_t)j * cmax + j] = std::sqrt(std::max(s, floor_));
-                    else Rm[(size_t)i * cmax + j] = s / Rm[(size_t)i * cmax + i];
+                    if (i == j) {
+                        // the residual of column j against its own squared norm: below ~10 x the round-off of the Gram
+                        // entries (products in float32) it carries no direction
+                        const double own = (double)g[j * GRAM_LD + j];
+                        if (!(s > own * 1e-6) || !(s > 1e-300) || !std::isfinite(s)) dead[j] = 1;
+                        else Rm[(size_t)j * cmax + j] = std::sqrt(s);
+                    } else Rm[(size_t)i * cmax + j] = s / Rm[(size_t)i * cmax + i];
                 }
             }
-            // inverse of the upper-triangular R by back substitution, column by column
+            // inverse of the upper-triangular R by back substitution, column by column (dead rows / columns stay zero)
             std::fill(Ri.begin(), Ri.end(), 0.0);
             for (int j = 0; j < c; ++j) {
+                if (dead[j]) continue;
                 Ri[(size_t)j * cmax + j] = 1.0 / Rm[(size_t)j * cmax + j];
                 for (int i = j - 1; i >= 0; --i) {
+                    if (dead[i]) continue;
                     double s = 0.0;
                     for (int p = i + 1; p <= j; ++p) s += Rm[(size_t)i * cmax + p] * Ri[(size_t)p * cmax + j];
                     Ri[(size_t)i * cmax + j] = -s / Rm[(size_t)i * cmax + i];

@@ -2,7 +2,8 @@
 //
 //   cnmf_xt_matmul_f64   W^T . X  (optionally W^T . zscore(X)) in float64 -- the X^T Y accumulation of
 //                        efficient_ols_all_cols (cnmf.py:55-125) and the product behind refit_spectra
-//   cnmf_nnls_spectra    NNLS for the SPECTRA with the usages fixed: cNMF.refit_spectra (cnmf.py:805-820) without
+//   cnmf_nnls_f64        one usage refit in float64 (product, Gram and sweeps), optional caller-supplied Gram
+//   cnmf_nnls_spectra    NNLS (float64) for the SPECTRA with the usages fixed: cNMF.refit_spectra (cnmf.py:805-820) without
 //                        uploading the transposed matrix -- min_H ||X - W H||, H >= 0 is a coordinate descent over
 //                        the GENE rows of H^T whose constant product is W^T.X (a pass over the resident matrix)
 //   cnmf_nnls_gram       cnmf_nnls with the Gram matrix given by the caller (the final usage refit on the
@@ -89,6 +90,97 @@ __global__ void set_gram_kernel(const float* __restrict__ g, int k, float* __res
     }
 }
 
+
+// ---- float64 NNLS (round 4).  The reference runs scikit-learn in the dtype of the matrix it is handed; with float64
+// inputs (norm_counts / TPM as the reference writes them) the consensus tail -- rf_usages -> refit_spectra on the TPM
+// matrix, values up to 1e5 TPM units -- is pinned by the reference's own test to sum(diff^2) < 1e-4
+// (/root/reference/tests/test_reproducibility.py:96-115), i.e. ~1e-9 relative: float32 sweeps cannot deliver that.
+// These kernels restate _update_cdnmf_fast (sklearn/decomposition/_cdnmf_fast.pyx:8-38) in float64 for ONE refit at
+// a time (they run once per consensus call; N.G.k float64 FMAs, milliseconds).
+
+// P[t][i] = sum_g X[i][g] * H[t][g]  (component-major [k][ldp], float64 accumulation; one wave per row of X)
+template <int KT>
+__global__ __launch_bounds__(256) void xht_f64_kernel(const float* __restrict__ X, int ldx, int N, int G,
+                                                      const double* __restrict__ H, int k, double* __restrict__ P, int ldp)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    double acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) acc[t] = 0.0;
+    for (int g = lane; g < G; g += 64) {
+        const double x = (double)X[(size_t)row * ldx + g];
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+            if (t < k) acc[t] = fma(x, H[(size_t)t * G + g], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        if (t < k) {
+            double v = acc[t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) P[(size_t)t * ldp + row] = v;
+        }
+    }
+}
+
+struct Nnls64State { int iter; int done; double viol_init; double viol_last; };
+
+// one coordinate-descent sweep over the L rows (lane per row; the row's k entries of V [k][ld] live in an LDS strip,
+// the Gram matrix [k][k] (l2 already on its diagonal) is read with wave-uniform loads); p = P - l1 as sklearn folds it
+// (sklearn/decomposition/_nmf.py:396-397).  Per-workgroup violation partials, summed in block order by the decide kernel.
+__global__ __launch_bounds__(64) void nnls_sweep_f64_kernel(double* __restrict__ V, const double* __restrict__ P, int ld,
+                                                            int L, int k, const double* __restrict__ gram, double l1,
+                                                            double* __restrict__ viol_part,
+                                                            const Nnls64State* __restrict__ state)
+{
+    if (state->done) return;
+    extern __shared__ double nnls_ws[];                    // [k][64]
+    const int tid = threadIdx.x, row = blockIdx.x * 64 + tid;
+    const bool live = row < L;
+    const int rowc = min(row, L - 1);
+    for (int t = 0; t < k; ++t) nnls_ws[t * 64 + tid] = live ? V[(size_t)t * ld + rowc] : 0.0;
+    double viol = 0.0;
+    for (int t = 0; t < k; ++t) {
+        double grad = -(P[(size_t)t * ld + rowc] - l1);
+        const double* gt = gram + (size_t)t * k;
+        for (int r = 0; r < k; ++r) grad = fma(gt[r], nnls_ws[r * 64 + tid], grad);
+        const double wt = nnls_ws[t * 64 + tid];
+        const double pg = (wt == 0.0) ? fmin(0.0, grad) : grad;
+        if (live) viol += fabs(pg);
+        const double hess = gt[t];
+        if (hess != 0.0) nnls_ws[t * 64 + tid] = fmax(wt - grad / hess, 0.0);
+    }
+    if (live) for (int t = 0; t < k; ++t) V[(size_t)t * ld + row] = nnls_ws[t * 64 + tid];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) viol += __shfl_xor(viol, o, 64);
+    if (tid == 0) viol_part[blockIdx.x] = viol;
+}
+
+// the stopping rule of _fit_coordinate_descent with update_H=False (sklearn/decomposition/_nmf.py:496-521)
+__global__ __launch_bounds__(64) void nnls_decide_f64_kernel(const double* __restrict__ viol_part, int nparts, double tol,
+                                                             int max_iter, Nnls64State* __restrict__ state)
+{
+    if (threadIdx.x != 0 || state->done) return;
+    double v = 0.0;
+    for (int p = 0; p < nparts; ++p) v += viol_part[p];
+    const int it = state->iter + 1;
+    state->iter = it;
+    if (it == 1) state->viol_init = v;
+    bool done = false;
+    if (state->viol_init == 0.0) { done = true; state->viol_last = 0.0; }
+    else { state->viol_last = v / state->viol_init; if (state->viol_last <= tol) done = true; }
+    if (it >= max_iter) done = true;
+    if (done) state->done = 1;
+}
+
+// [k][ld] component-major float64 (first L of each row) -> [L][k] row-major
+__global__ void cm_to_rows_f64_kernel(const double* __restrict__ V, int ld, int L, int k, double* __restrict__ out)
+{
+    const int c = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < k && i < L) out[(size_t)i * k + c] = V[(size_t)c * ld + i];
+}
 }  // namespace cnmf
 
 // d_out [k][G] (device, float64) = W^T . z(X)
@@ -198,8 +290,53 @@ static int install_nnls_slots(cnmf_ctx* ctx, int n, const int32_t* ks)
     return CNMF_OK;
 }
 
+// ------------------------------------------------------------------ float64 refits
+// dV [k][ld] (zeros on entry: sklearn _nmf.py:1232-1233 starts the solved factor from 0), dP [k][ld] the constant product,
+// dGram [k][k] float64 with the l2 term on its diagonal.  Sweeps until sklearn's rule stops them, polled every 8.
+static int nnls_f64_loop(cnmf_ctx* ctx, DevPool& pool, double* dV, const double* dP, int ld, int L, int k,
+                         const double* dGram, const cnmf_cd_params* prm, int32_t* n_iter_out, double* viol_out)
+{
+    using namespace cnmf;
+    hipStream_t st = ctx->stream;
+    const int nblk = (L + 63) / 64;
+    double* dviol = pool.get<double>(nblk);
+    Nnls64State* dstate = pool.get<Nnls64State>(1, true, st);
+    POOL_TRY(ctx, pool);
+    const size_t lds = (size_t)k * 64 * sizeof(double);
+    HIP_TRY(ctx, dyn_lds_optin((const void*)nnls_sweep_f64_kernel, (int)((size_t)KMAX * 64 * sizeof(double))));
+    Nnls64State hs{0, 0, 0.0, 0.0};
+    const int burst = 8;
+    for (int it = 0; it < prm->max_iter && !hs.done; it += burst) {
+        for (int b = 0; b < burst; ++b) {
+            nnls_sweep_f64_kernel<<<nblk, 64, lds, st>>>(dV, dP, ld, L, k, dGram, prm->l1_reg_W, dviol, dstate);
+            nnls_decide_f64_kernel<<<1, 64, 0, st>>>(dviol, nblk, prm->tol, prm->max_iter, dstate);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(&hs, dstate, sizeof hs, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    if (n_iter_out) *n_iter_out = hs.iter;
+    if (viol_out) *viol_out = hs.viol_last;
+    return CNMF_OK;
+}
+
+// Gram matrix A^T A of a row-major [rows][k] float64 matrix (or A A^T of [k][cols] when `by_rows`), on the host:
+// k x k, summed in index order like a plain loop
+static void host_gram_f64(const double* A, size_t rows, int k, bool by_rows, double l2, std::vector<double>& g)
+{
+    g.assign((size_t)k * k, 0.0);
+    for (int a = 0; a < k; ++a)
+        for (int b = a; b < k; ++b) {
+            double s = 0.0;
+            if (by_rows) for (size_t i = 0; i < rows; ++i) s += A[(size_t)a * rows + i] * A[(size_t)b * rows + i];
+            else for (size_t i = 0; i < rows; ++i) s += A[i * k + a] * A[i * k + b];
+            g[(size_t)a * k + b] = g[(size_t)b * k + a] = s;
+        }
+    for (int a = 0; a < k; ++a) g[(size_t)a * k + a] += l2;
+}
+
 // ------------------------------------------------------------------ refit_spectra (cnmf.py:805-820)
-extern "C" int cnmf_nnls_spectra(cnmf_ctx* ctx, int k, const double* W, const cnmf_cd_params* prm, float* H_out,
+extern "C" int cnmf_nnls_spectra(cnmf_ctx* ctx, int k, const double* W, const cnmf_cd_params* prm, double* H_out,
                                  int32_t* n_iter_out, double* viol_out)
 {
     using namespace cnmf;
@@ -210,47 +347,66 @@ extern "C" int cnmf_nnls_spectra(cnmf_ctx* ctx, int k, const double* W, const cn
     if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int N = (int)ctx->N, G = (int)ctx->G;
-    const int KC = k <= 32 ? 32 : (k <= 64 ? 64 : 128);
-    rc = ensure_batch(ctx, KC, k, k);
-    if (rc) return rc;
     hipStream_t st = ctx->stream;
     DevPool pool;
     double* dW = pool.get<double>((size_t)N * k);
-    double* dXtW = pool.get<double>((size_t)k * G);
-    float* dgram = pool.get<float>((size_t)k * k);
-    float* dH = pool.get<float>((size_t)k * G);
+    double* dXtW = pool.get<double>((size_t)k * G);          // [k][G]: the constant product, component-major over genes
+    double* dH = pool.get<double>((size_t)k * G, true, st);  // the solved factor, from zero
+    double* dgram = pool.get<double>((size_t)k * k);
     POOL_TRY(ctx, pool);
     HIP_TRY(ctx, hipMemcpyAsync(dW, W, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, st));
     // constant product W^T.X (float64 accumulation) and Gram W^T.W (float64 on the host: k x k)
     rc = xtw_f64_device(ctx, pool, dW, k, 0, nullptr, nullptr, dXtW);
     if (rc) return rc;
-    std::vector<float> g((size_t)k * k);
-    for (int a = 0; a < k; ++a)
-        for (int b = a; b < k; ++b) {
-            double s = 0.0;
-            for (int i = 0; i < N; ++i) s += W[(size_t)i * k + a] * W[(size_t)i * k + b];
-            g[(size_t)a * k + b] = g[(size_t)b * k + a] = (float)s;
-        }
-    HIP_TRY(ctx, hipMemcpyAsync(dgram, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    // slot 0: H rows start from zero (sklearn _nmf.py:1232-1233 for the transposed problem)
-    dim3 gc((ctx->G_pad + 255) / 256, KC);
-    clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, 0, KC);
-    clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->XtW, ctx->G_pad, ctx->G_pad, 0, KC);
-    dim3 gf((G + 255) / 256, k);
-    f64_to_rows_kernel<<<gf, 256, 0, st>>>(dXtW, G, ctx->XtW, ctx->G_pad, 0, k);
-    set_gram_kernel<<<(k * k + 255) / 256, 256, 0, st>>>(dgram, k, ctx->gramW, 0, (float)prm->l2_reg_W);
-    const int32_t ks1[1] = {k};
-    rc = install_nnls_slots(ctx, 1, ks1);
+    std::vector<double> g;
+    host_gram_f64(W, (size_t)N, k, false, prm->l2_reg_W, g);
+    HIP_TRY(ctx, hipMemcpyAsync(dgram, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    rc = nnls_f64_loop(ctx, pool, dH, dXtW, G, G, k, dgram, prm, n_iter_out, viol_out);
     if (rc) return rc;
-    rc = nnls_sweep_loop(ctx, 1, ctx->H, ctx->G_pad, G, ctx->XtW, ctx->gramW, (float)prm->l1_reg_W, prm, k, tiers_of(ks1, 1));
-    if (rc) return rc;
-    extract_kernel<<<gf, 256, 0, st>>>(ctx->H, ctx->G_pad, G, 0, k, dH, 0);
-    HIP_TRY(ctx, hipMemcpyAsync(H_out, dH, (size_t)k * G * sizeof(float), hipMemcpyDeviceToHost, st));
-    clear_rows_kernel<<<gc, 256, 0, st>>>(ctx->H, ctx->G_pad, ctx->G_pad, 0, KC);
-    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(H_out, dH, (size_t)k * G * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (n_iter_out) *n_iter_out = ctx->h_snap[0].iter;
-    if (viol_out) *viol_out = ctx->h_snap[0].viol_last;
+    return CNMF_OK;
+}
+
+// ------------------------------------------------------------------ refit_usage in float64 (cnmf.py:776-802)
+// H [k][G] float64 fixed, W [N][k] from zero; gram (nullable) [k][k]: use INSTEAD of H.H^T (the final usage refit of
+// consensus() on the std-scaled HVG columns of the resident TPM matrix, as cnmf_nnls_gram).
+extern "C" int cnmf_nnls_f64(cnmf_ctx* ctx, int k, const double* H, const double* gram, const cnmf_cd_params* prm,
+                             double* W_out, int32_t* n_iter_out, double* viol_out)
+{
+    using namespace cnmf;
+    if (!ctx || !H || !W_out || k < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    int rc = validate_params(ctx, prm);
+    if (rc) return rc;
+    if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int N = (int)ctx->N, G = (int)ctx->G;
+    hipStream_t st = ctx->stream;
+    DevPool pool;
+    double* dHm = pool.get<double>((size_t)k * G);
+    double* dP = pool.get<double>((size_t)k * N);
+    double* dV = pool.get<double>((size_t)k * N, true, st);
+    double* dgram = pool.get<double>((size_t)k * k);
+    double* dOut = pool.get<double>((size_t)N * k);
+    POOL_TRY(ctx, pool);
+    HIP_TRY(ctx, hipMemcpyAsync(dHm, H, (size_t)k * G * sizeof(double), hipMemcpyHostToDevice, st));
+    std::vector<double> g;
+    if (gram) { g.assign(gram, gram + (size_t)k * k); for (int a = 0; a < k; ++a) g[(size_t)a * k + a] += prm->l2_reg_W; }
+    else host_gram_f64(H, (size_t)G, k, true, prm->l2_reg_W, g);
+    HIP_TRY(ctx, hipMemcpyAsync(dgram, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    const unsigned nb = (unsigned)((N + 3) / 4);
+#define CNMF_XHT(KT_) xht_f64_kernel<KT_><<<nb, 256, 0, st>>>(ctx->X, ctx->G_pad, N, G, dHm, k, dP, N)
+    if (k <= 8) CNMF_XHT(8); else if (k <= 16) CNMF_XHT(16); else if (k <= 32) CNMF_XHT(32); else if (k <= 64) CNMF_XHT(64);
+    else CNMF_XHT(128);
+#undef CNMF_XHT
+    HIP_TRY(ctx, hipGetLastError());
+    rc = nnls_f64_loop(ctx, pool, dV, dP, N, N, k, dgram, prm, n_iter_out, viol_out);
+    if (rc) return rc;
+    cm_to_rows_f64_kernel<<<dim3((N + 255) / 256, k), 256, 0, st>>>(dV, N, N, k, dOut);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(W_out, dOut, (size_t)N * k * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
     return CNMF_OK;
 }
 

@@ -475,12 +475,41 @@ class Engine:
         # the transposed problem has G samples and N features: l1_reg_W = N * alpha_W * l1_ratio (sklearn _nmf.py:1254)
         prm = _lib.CdParams(float(tol), int(max_iter), 0, N * alpha_W * l1_ratio, N * alpha_W * (1.0 - l1_ratio),
                             0.0, 0.0, 0, 0)
-        H = np.empty((k, G), dtype=np.float32)
+        H = np.empty((k, G), dtype=np.float64)
         n_iter = C.c_int32(0)
         viol = C.c_double(0.0)
-        self._check(self._lib.cnmf_nnls_spectra(self._ctx, k, W.ctypes.data_as(C.POINTER(C.c_double)), C.byref(prm),
-                                                _fp(H), C.byref(n_iter), C.byref(viol)))
+        dblp = C.POINTER(C.c_double)
+        self._check(self._lib.cnmf_nnls_spectra(self._ctx, k, W.ctypes.data_as(dblp), C.byref(prm),
+                                                H.ctypes.data_as(dblp), C.byref(n_iter), C.byref(viol)))
         return H, int(n_iter.value)
+
+    def nnls_f64(self, H, gram=None, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0, n_features=None, warn=True):
+        """``cnmf_nnls_f64``: the usage refit of :meth:`nnls` with the product ``X @ H.T``, the Gram matrix and the
+        coordinate-descent sweeps in FLOAT64 -- what scikit-learn computes when the reference hands it float64 matrices
+        (the reference's own tolerance on the consensus tail, sum(diff^2) < 1e-4 on TPM-scale values, needs it).
+        ``gram`` (k x k): used instead of ``H @ H.T`` (see :meth:`nnls_gram`).  Returns ``(W [N x k] float64, n_iter)``."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        Hd = np.ascontiguousarray(self._check_H(H, G), dtype=np.float64)
+        k = int(Hd.shape[0])
+        dblp = C.POINTER(C.c_double)
+        gp = None
+        if gram is not None:
+            gd = np.ascontiguousarray(gram, dtype=np.float64)
+            if gd.shape != (k, k):
+                raise ValueError("gram must be (k, k)")
+            gp = gd.ctypes.data_as(dblp)
+        prm = self._params(tol, max_iter, alpha_W, 0.0, l1_ratio, n_features=n_features)
+        W = np.empty((N, k), dtype=np.float64)
+        n_iter = C.c_int32(0)
+        viol = C.c_double(0.0)
+        self._check(self._lib.cnmf_nnls_f64(self._ctx, k, Hd.ctypes.data_as(dblp), gp, C.byref(prm),
+                                            W.ctypes.data_as(dblp), C.byref(n_iter), C.byref(viol)))
+        if warn and tol > 0 and n_iter.value == max_iter:
+            warnings.warn("Maximum number of iterations %d reached. Increase it to improve convergence."
+                          % max_iter, ConvergenceWarning)
+        return W, int(n_iter.value)
 
     def xt_matmul_f64(self, W, mean=None, std=None):
         """``W.T @ X`` in float64, or ``W.T @ ((X - mean) / std)`` when ``mean``/``std`` (length G) are given --

@@ -258,9 +258,17 @@ int cnmf_xt_matmul_f64(cnmf_ctx* ctx, int k, const double* W, int zscore, const 
 /* cNMF.refit_spectra (cnmf.py:805-820 = refit_usage(X.T, usage.T).T, sklearn:_nmf.py:1210-1233): NNLS for the
  * spectra H [k][G] with the usages W [N][k] fixed, H from zero, sklearn's CD stopping rule -- on the resident
  * matrix, without uploading its transpose (the constant product is W^T.X).  The solved factor takes sklearn's
- * "W" role: prm->l1_reg_W / l2_reg_W apply to it.                                                          */
-int cnmf_nnls_spectra(cnmf_ctx* ctx, int k, const double* W, const cnmf_cd_params* prm, float* H_out,
+ * "W" role: prm->l1_reg_W / l2_reg_W apply to it.  Float64 throughout (round 4: product, Gram, sweeps and result):
+ * the reference pins gene_spectra_tpm -- values up to 1e5 TPM units -- to sum(diff^2) < 1e-4
+ * (/root/reference/tests/test_reproducibility.py:96-115).                                                   */
+int cnmf_nnls_spectra(cnmf_ctx* ctx, int k, const double* W, const cnmf_cd_params* prm, double* H_out,
                       int32_t* n_iter_out, double* viol_out);
+/* cNMF.refit_usage (cnmf.py:776-802) in FLOAT64 -- what scikit-learn computes when the reference hands it float64
+ * matrices (the consensus tail: rf_usages feed refit_spectra on the TPM matrix).  H [k][G] fixed, W_out [N][k] from
+ * zero; the product X.H^T, the Gram matrix and the sweeps (sklearn:_cdnmf_fast.pyx:8-38) in float64 over the resident
+ * (float32) matrix.  gram (nullable) [k][k]: used INSTEAD of H.H^T, as in cnmf_nnls_gram below.              */
+int cnmf_nnls_f64(cnmf_ctx* ctx, int k, const double* H, const double* gram, const cnmf_cd_params* prm,
+                  double* W_out, int32_t* n_iter_out, double* viol_out);
 /* cnmf_nnls with a caller-supplied Gram matrix gram[k][k] = H.H^T: the rows H_prod [k][G] only enter the product
  * X.H_prod^T.  Lets the final usage refit of consensus() (cnmf.py:960-975: X = tpm[:, hvgs] / std) run on the
  * resident TPM matrix: H_prod = spectra / std on the HVG columns and 0 elsewhere, gram from the HVG block.    */

@@ -75,21 +75,27 @@ def test_C3_long_restarts_vs_sklearn_golden(engine):
         dev = g["k%d_f32dev50" % k]
         maxabs, relfro = nmf_cd.spectra_error(g["k%d_H50" % k], H[r])
         assert maxabs <= max(1e-4, 4 * dev[0]) and relfro <= max(1e-3, 4 * dev[1]), (k, "wide", maxabs, relfro, dev)
-    # (b) to the stopping rule (tol 1e-4, max_iter 1000): iteration count, objective and spectra.  The OBJECTIVE is a
-    #     stable functional of the trajectory and is held tightly; the spectra of these long ill-conditioned runs to
-    #     5e-3 / 5e-3 (after 400-1000 iterations the float32 drift of (a) has grown accordingly; 2e-2 for the run that
-    #     stops at max_iter without converging) and the iteration count to 5 %.
+    # (b) to the stopping rule (tol 1e-4, max_iter 1000): iteration count, objective and spectra.  Calibrated like (a)
+    #     (round-3 review, weak #2): the golden file records where scikit-learn's OWN float32 path lands relative to its
+    #     float64 path AT THE STOPPING RULE on the same restart (tools/make_golden_big.py c3drift: k = 5: 6e-8 / 5e-7,
+    #     k = 11: 4e-5 / 2e-5, k = 13 -- stops at max_iter without converging -- 7e-4 / 4e-4; the same iteration count as
+    #     float64 in all three).  The device is held to the stated 1e-4 / 1e-3, or to 4 x that float32 drift where float32
+    #     itself cannot do better; the iteration count to max(3, 1 %); the objective -- a stable functional -- to 2e-5.
     H, W, n_iter, viol = engine.nmf_batch(ks, seeds=seeds, warn=False, return_W=True)       # default width: 512 for 316 columns
     assert engine.last_stats["kc"] == 512 and engine.last_stats["gemm_mode"] >= 3
     for r, k in enumerate(ks3):
         n_full = int(g["k%d_seed" % k][2])
-        assert abs(int(n_iter[r]) - n_full) <= max(3, n_full // 20), (k, int(n_iter[r]), n_full)
+        dev = g["k%d_f32devfull" % k]
+        assert int(g["k%d_f32nfull" % k][0]) == n_full                 # (scikit-learn float32 stops where float64 does)
         obj = engine.prediction_error(W[r], H[r])
         obj_ref = float(g["k%d_objfull" % k][0])
-        assert abs(obj - obj_ref) <= 2e-5 * obj_ref, (k, obj, obj_ref)
         maxabs, relfro = nmf_cd.spectra_error(g["k%d_Hfull" % k], H[r])
-        lim = 5e-3 if n_full < 1000 else 2e-2          # (k = 13 has NOT converged at max_iter: a point on a moving path)
-        assert maxabs <= lim and relfro <= lim, (k, maxabs, relfro)
+        print("C3 k=%d at the stopping rule: device n_iter %d (sklearn %d), spectra maxabs %.2e relfro %.2e "
+              "(sklearn float32 vs float64: %.2e %.2e), objective rel. diff %.1e"
+              % (k, int(n_iter[r]), n_full, maxabs, relfro, dev[0], dev[1], abs(obj - obj_ref) / obj_ref))
+        assert abs(int(n_iter[r]) - n_full) <= max(3, n_full // 100), (k, int(n_iter[r]), n_full)
+        assert abs(obj - obj_ref) <= 2e-5 * obj_ref, (k, obj, obj_ref)
+        assert maxabs <= max(1e-4, 4 * dev[0]) and relfro <= max(1e-3, 4 * dev[1]), (k, maxabs, relfro, dev)
         if n_full < 1000:
             assert viol[r] <= 1e-4
     # (c) the GENERAL path on the same matrix (count detection off: what a Harmony-corrected or TPM-normalised input of

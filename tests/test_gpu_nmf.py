@@ -457,3 +457,30 @@ def test_nndsvd_init_matches_sklearn(engine, shape):
         assert Wb.shape == W_ref.shape and Hb.shape == H_ref.shape
         assert np.abs(Wb - W_ref).max() <= 1e-3 * np.abs(W_ref).max(), (k, seed)
         assert np.abs(Hb - H_ref).max() <= 1e-3 * np.abs(H_ref).max(), (k, seed)
+
+
+@pytest.mark.parametrize("case", ["few_cells", "low_rank", "duplicated_rows"])
+def test_nndsvd_rank_deficient_blocks(engine, case):
+    """rank(X) < k + 10: the Cholesky-QR normaliser of the device range finder meets pivots that are zero up to round-off
+    (round-3 advisor finding: a floored pivot compounded over several deficient columns overflowed R^-1 to inf / NaN and
+    factorize aborted where scikit-learn's pivoted LU succeeds).  The dependent directions are dropped; every component
+    scikit-learn determines (singular value > 0, i.e. up to rank(X)) comes out as scikit-learn's."""
+    from sklearn.decomposition._nmf import _initialize_nmf
+    rs = np.random.RandomState(5)
+    if case == "few_cells":                      # min(N, G) = 12 < k + 10 = 18
+        X, k, rank = rs.gamma(0.6, 1.0, size=(12, 200)), 8, 12
+    elif case == "low_rank":                     # noiseless rank-5 matrix, k + 10 = 14 columns
+        X, k, rank = rs.gamma(1.0, 1.0, size=(300, 5)) @ rs.gamma(1.0, 1.0, size=(5, 200)), 4, 5
+    else:                                        # 40 distinct cells, each 10 times
+        X, k, rank = np.repeat(rs.gamma(0.6, 1.0, size=(40, 150)), 10, axis=0), 35, 40
+    engine.set_matrix(X)
+    W0, H0 = engine.nndsvd_init(k, random_state=7)
+    assert np.isfinite(W0).all() and np.isfinite(H0).all()
+    W_ref, H_ref = _initialize_nmf(X, k, init="nndsvd", random_state=7)
+    assert W0.shape == W_ref.shape and H0.shape == H_ref.shape
+    assert k <= rank
+    assert np.abs(W0 - W_ref).max() <= 2e-3 * np.abs(W_ref).max()
+    assert np.abs(H0 - H_ref).max() <= 2e-3 * np.abs(H_ref).max()
+    # and the restart from it runs (the failure mode was a ValueError out of the host SVD)
+    H, _, n_iter, _ = engine.nmf_batch([k], W0=[W0], H0=[H0])
+    assert np.isfinite(H[0]).all() and n_iter[0] >= 1

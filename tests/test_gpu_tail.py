@@ -28,8 +28,9 @@ def _tail_on_device(engine, g, k, thr, sparse):
     X = g["norm_counts"]
     out = engine.consensus(g["merged_k%d" % k], k, density_threshold=thr)
     engine.set_matrix(X)
-    rf, _ = engine.nnls(out["median_spectra"])
-    rf = rf.astype(np.float64)
+    # the reference's matrices are float64 here, so scikit-learn refits in float64: the float64 device refit
+    # (cnmf_nnls_f64; the float32 matrix-pipe refit is what float32 inputs get -- tests/test_gpu_nmf.py)
+    rf, _ = engine.nnls_f64(out["median_spectra"])
     norm = rf / rf.sum(axis=1, keepdims=True)
     order = np.argsort(-norm.sum(axis=0), kind="stable")                    # cnmf.py:939-946
     rf, norm, med = rf[:, order], norm[:, order], out["median_spectra"][order]
@@ -47,7 +48,7 @@ def _tail_on_device(engine, g, k, thr, sparse):
     srf = spectra_tpm[:, hidx].astype(np.float64) / g["tpm_stats"][hidx, 1]
     H_prod = np.zeros((k, tpm.shape[1]))
     H_prod[:, hidx] = srf / std1
-    usages, _ = engine.nnls_gram(H_prod, srf @ srf.T)
+    usages, _ = engine.nnls_f64(H_prod, gram=srf @ srf.T)
     return med, usages, spectra_tpm, coef
 
 
@@ -55,10 +56,17 @@ def _tail_on_device(engine, g, k, thr, sparse):
 @pytest.mark.parametrize("k,thr", [(5, 0.5), (4, 2.0)])
 def test_consensus_tail_golden_reference(engine, g, k, thr, sparse):
     med, usages, spectra_tpm, coef = _tail_on_device(engine, g, k, thr, sparse)
-    assert ((med - g["consensus_spectra_k%d" % k]) ** 2).sum() < TOLERANCE
-    assert ((usages - g["consensus_usages_k%d" % k]) ** 2).sum() < TOLERANCE
-    assert ((spectra_tpm - g["gene_spectra_tpm_k%d" % k]) ** 2).sum() < TOLERANCE * 1e6      # TPM units (x 1e6)
-    assert ((coef - g["gene_spectra_score_k%d" % k]) ** 2).sum() < TOLERANCE
+    # every artefact at the REFERENCE's bar (tests/test_reproducibility.py:12,96-115: sum of squared differences < 1e-4),
+    # gene_spectra_tpm (TPM units, values up to 5e4) included -- round 3 held it to 1e-4 x 1e6 because the refits ran
+    # in float32; the measured values are printed (pytest -s) and land in the assertion message
+    err = {"consensus_spectra": ((med - g["consensus_spectra_k%d" % k]) ** 2).sum(),
+           "consensus_usages": ((usages - g["consensus_usages_k%d" % k]) ** 2).sum(),
+           "gene_spectra_tpm": ((spectra_tpm - g["gene_spectra_tpm_k%d" % k]) ** 2).sum(),
+           "gene_spectra_score": ((coef - g["gene_spectra_score_k%d" % k]) ** 2).sum()}
+    print("consensus tail k=%d thr=%s sparse=%s: sum of squared differences vs the reference's files: %s"
+          % (k, thr, sparse, {a: float("%.3g" % b) for a, b in err.items()}))
+    for name, e in err.items():
+        assert e < TOLERANCE, (name, e)
 
 
 def test_xt_matmul_f64_and_nnls_spectra_vs_numpy(engine):
@@ -76,10 +84,21 @@ def test_xt_matmul_f64_and_nnls_spectra_vs_numpy(engine):
     out = engine.xt_matmul_f64(W, mean=m_dev, std=np.sqrt(v_dev))
     assert np.abs(out - ref).max() <= 1e-9 * np.abs(ref).max()
     # refit_spectra = refit_usage(X.T, usage.T).T (cnmf.py:805-820) against the float64 oracle on the transposed matrix
+    # (float64 on the device too: same iteration count, agreement to round-off)
     H_ref, n_ref = nmf_cd.nnls(X64.T, W.T)
     H, n = engine.nnls_spectra(W)
-    assert abs(n - n_ref) <= 2
-    assert np.abs(H.T - H_ref).max() <= 1e-3 * np.abs(H_ref).max()
+    assert H.dtype == np.float64 and abs(n - n_ref) <= 1
+    assert np.abs(H.T - H_ref).max() <= 1e-10 * np.abs(H_ref).max()
+    # the float64 usage refit against the oracle, with and without a penalty and with a caller-supplied Gram matrix
+    Hs = np.abs(rs.standard_normal((7, 333)))
+    for alpha in (0.0, 0.05):
+        W_ref, n_ref = nmf_cd.nnls(X64, Hs, alpha_W=alpha, l1_ratio=0.3)
+        Wd, n = engine.nnls_f64(Hs, alpha_W=alpha, l1_ratio=0.3)
+        assert Wd.dtype == np.float64 and abs(n - n_ref) <= 1, (alpha, n, n_ref)
+        assert np.abs(Wd - W_ref).max() <= 1e-10 * np.abs(W_ref).max(), alpha
+    Wg, ng = engine.nnls_f64(Hs, gram=Hs @ Hs.T)
+    W0, n0 = engine.nnls_f64(Hs)
+    assert ng == n0 and np.abs(Wg - W0).max() <= 1e-12 * np.abs(W0).max()
 
 
 def test_nnls_batch_equals_single_refits(engine, g):
@@ -136,7 +155,9 @@ def test_mirror_class_consensus_from_reference_merged_spectra(engine, g, tmp_pat
         assert ((med.values - g["consensus_spectra_k%d" % k]) ** 2).sum() < TOLERANCE
         assert ((usages.values - g["consensus_usages_k%d" % k]) ** 2).sum() < TOLERANCE
         tpm_sp = load_df_from_npz(obj.paths["gene_spectra_tpm"] % (k, rep)).values
-        assert ((tpm_sp - g["gene_spectra_tpm_k%d" % k]) ** 2).sum() < TOLERANCE * 1e6
+        e_tpm = ((tpm_sp - g["gene_spectra_tpm_k%d" % k]) ** 2).sum()
+        print("mirror class k=%d: gene_spectra_tpm sum of squared differences %.3g" % (k, e_tpm))
+        assert e_tpm < TOLERANCE, e_tpm
         score = load_df_from_npz(obj.paths["gene_spectra_score"] % (k, rep)).values
         assert ((score - g["gene_spectra_score_k%d" % k]) ** 2).sum() < TOLERANCE
         # the density cache is reused on the second call (same neighbourhood) and refreshed when it changes
