@@ -20,7 +20,7 @@ SYMBOLS = [
     "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_set_count_detection", "cnmf_get_shape", "cnmf_get_matrix",
     "cnmf_col_moments", "cnmf_scale_columns", "cnmf_row_sums",
     "cnmf_nmf_cd_batch", "cnmf_nmf_cd_batch_resident", "cnmf_nnls",
-    "cnmf_consensus", "cnmf_prediction_error", "cnmf_nmf_mu_batch", "cnmf_x_matmul",
+    "cnmf_consensus", "cnmf_pairwise_distances", "cnmf_prediction_error", "cnmf_nmf_mu_batch", "cnmf_x_matmul",
     "cnmf_xt_matmul_f64", "cnmf_nnls_spectra", "cnmf_nnls_f64", "cnmf_nnls_gram", "cnmf_nnls_batch", "cnmf_kselect_stats",
     "cnmf_comm_unique_id", "cnmf_comm_init", "cnmf_comm_finalize", "cnmf_comm_rank", "cnmf_comm_world",
     "cnmf_allgather_bytes", "cnmf_allgather_spectra",
@@ -142,6 +142,8 @@ def load():
                                       C.POINTER(CdParams), f32p, f32p, i32p, dblp]
     lib.cnmf_nnls.restype = i32
     lib.cnmf_nnls.argtypes = [vp, i32, f32p, C.POINTER(CdParams), f32p, i32p, dblp]
+    lib.cnmf_pairwise_distances.restype = i32
+    lib.cnmf_pairwise_distances.argtypes = [vp, dblp, i32, i32, i32p, i32, dblp, dblp]
     lib.cnmf_consensus.restype = i32
     lib.cnmf_consensus.argtypes = [vp, dblp, i32, i32, C.POINTER(ConsensusParams), dblp,
                                    dblp, i32p, i32p, dblp, dblp, dblp]

@@ -339,6 +339,66 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     return CNMF_OK;
 }
 
+// All-pairs Euclidean distances of the rows AS GIVEN (sklearn.metrics.euclidean_distances(X), cnmf.py:891 / :988) and /
+// or the mean silhouette coefficient of a labelling of them (sklearn.metrics.silhouette_score(X, labels,
+// metric='euclidean'), cnmf.py:923) in float64 -- the two scikit-learn calls of the reference's consensus body that are
+// not k-means, as entry points of their own (INTEGRATION.md Option B: no consensus run behind a distance matrix, no
+// scikit-learn behind a silhouette).  dist_out (nullable) [R][R]; labels (nullable) [R] with values 0..k-1 and
+// silhouette_out (nullable) go together.
+extern "C" int cnmf_pairwise_distances(cnmf_ctx* ctx, const double* rows, int R, int G, const int32_t* labels, int k,
+                                       double* dist_out, double* silhouette_out)
+{
+    using namespace cnmf;
+    if (!ctx || !rows || R < 1 || G < 1 || (!dist_out && !silhouette_out)) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    if (silhouette_out && (!labels || k < 2 || k > KM_CID || k >= R)) {
+        SET_ERR(ctx, "Number of labels is %d. Valid values are 2 to n_samples - 1 (inclusive)", k); return CNMF_EINVAL;
+    }
+    CONS_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    Arena& pool = ctx->cons_ws;
+    pool.reset();
+    struct Trim { Arena& a; ~Trim() { if (a.total() > Arena::keep_limit) a.release(); } } trim{pool};
+    const int ld = round_up(G, 16), Rp = round_up(R, 64);
+    double* dS = pool.get<double>((size_t)R * G);
+    double* dL2 = pool.get<double>((size_t)Rp * ld, true, st);
+    double* dsq = pool.get<double>(Rp, true, st);
+    double* dD = pool.get<double>((size_t)Rp * Rp);
+    if (pool.err) { SET_ERR(ctx, "device allocation failed (distance matrix)"); return CNMF_ENOMEM; }
+    CONS_TRY(hipMemcpyAsync(dS, rows, (size_t)R * G * sizeof(double), hipMemcpyHostToDevice, st));
+    copy_rows_sq_kernel<<<R, 256, 0, st>>>(dS, R, G, dL2, ld, dsq);
+    const int nt = Rp / 64;
+    dist_sym_kernel<<<nt * (nt + 1) / 2, 256, 0, st>>>(dL2, ld, ld, dsq, R, dD, Rp);
+    CONS_TRY(hipGetLastError());
+    if (dist_out)
+        CONS_TRY(hipMemcpy2DAsync(dist_out, (size_t)R * sizeof(double), dD, (size_t)Rp * sizeof(double),
+                                  (size_t)R * sizeof(double), R, hipMemcpyDeviceToHost, st));
+    if (silhouette_out) {
+        std::vector<int> ints((size_t)3 * R + k + 1);
+        int* rowid = ints.data(), *order = rowid + R, *lab = order + R, *seg = lab + R;
+        for (int j = 0; j <= k; ++j) seg[j] = 0;
+        for (int q = 0; q < R; ++q) {
+            if (labels[q] < 0 || labels[q] >= k) { SET_ERR(ctx, "label %d of row %d outside 0..%d", (int)labels[q], q, k - 1); return CNMF_EINVAL; }
+            rowid[q] = q; lab[q] = labels[q]; seg[labels[q] + 1]++;
+        }
+        for (int j = 0; j < k; ++j) seg[j + 1] += seg[j];
+        { std::vector<int> pos(seg, seg + k); for (int q = 0; q < R; ++q) order[pos[labels[q]]++] = q; }
+        int* dints = pool.get<int>(ints.size());
+        double* dsil = pool.get<double>(R);
+        double* dsum = pool.get<double>(1);
+        if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+        CONS_TRY(hipMemcpyAsync(dints, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        silhouette_kernel<<<R, 256, 0, st>>>(dD, Rp, dints, dints + R, dints + 3 * R, dints + 2 * R, R, k, dsil);
+        sum_kernel<<<1, 256, 0, st>>>(dsil, R, dsum);
+        CONS_TRY(hipGetLastError());
+        double sum = 0.0;
+        CONS_TRY(hipMemcpyAsync(&sum, dsum, sizeof(double), hipMemcpyDeviceToHost, st));
+        CONS_TRY(hipStreamSynchronize(st));
+        *silhouette_out = sum / R;
+    }
+    CONS_TRY(hipStreamSynchronize(st));
+    return CNMF_OK;
+}
+
 // Replaces the dense residual of cnmf.py:926-930: sum((X - W.H)^2) with X the resident matrix.
 extern "C" int cnmf_prediction_error(cnmf_ctx* ctx, int k, const double* W, const double* H, double* err_out)
 {

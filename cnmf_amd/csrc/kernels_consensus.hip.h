@@ -220,6 +220,23 @@ __global__ __launch_bounds__(256) void l2_rows_kernel(const double* __restrict__
     if (threadIdx.x == 0) sq[r] = s2;
 }
 
+// the same without the normalisation (cnmf_pairwise_distances: euclidean_distances of the rows as they are)
+__global__ __launch_bounds__(256) void copy_rows_sq_kernel(const double* __restrict__ S, int R, int G,
+                                                           double* __restrict__ out, int ld,
+                                                           double* __restrict__ sq)
+{
+    __shared__ double red[4];
+    const int r = blockIdx.x;
+    double s2 = 0.0;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        const double v = S[(size_t)r * G + g];
+        out[(size_t)r * ld + g] = v;
+        s2 += v * v;
+    }
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) sq[r] = s2;
+}
+
 // density[i] = (sum of the m smallest entries of row i) / n      (m = n+1, self distance 0 included)
 // Exact selection by bisection on the IEEE bit pattern (non-negative doubles order like uint64).
 // Fallback for more than 20 480 merged spectra: the ~64 selection passes re-read the row from global memory (it stays

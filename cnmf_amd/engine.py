@@ -771,6 +771,33 @@ class Engine:
             out["topics_dist"] = dist
         return out
 
+    def pairwise_distances(self, rows, labels=None, return_dist=True):
+        """``cnmf_pairwise_distances``: ``sklearn.metrics.euclidean_distances(rows)`` (cnmf.py:891, 988) and / or
+        ``silhouette_score(rows, labels, metric='euclidean')`` (cnmf.py:923) on the device in float64, rows as given.
+        Returns ``(D or None, silhouette or None)``."""
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        if rows.ndim != 2:
+            raise ValueError("rows must be 2-D")
+        R, G = rows.shape
+        dblp = C.POINTER(C.c_double)
+        D = np.empty((R, R), dtype=np.float64) if return_dist else None
+        sil, lp, k = None, None, 0
+        if labels is not None:
+            lab = np.asarray(labels)
+            if lab.shape != (R,):
+                raise ValueError("labels must have one entry per row")
+            uniq, inv = np.unique(lab, return_inverse=True)          # LabelEncoder, sklearn metrics/cluster/_unsupervised.py
+            k = len(uniq)
+            if not 1 < k < R:
+                raise ValueError("Number of labels is %d. Valid values are 2 to n_samples - 1 (inclusive)" % k)
+            inv = np.ascontiguousarray(inv, dtype=np.int32)
+            lp = inv.ctypes.data_as(C.POINTER(C.c_int32))
+            sil = C.c_double(0.0)
+        self._check(self._lib.cnmf_pairwise_distances(self._ctx, rows.ctypes.data_as(dblp), R, G, lp, k,
+                                                      D.ctypes.data_as(dblp) if return_dist else None,
+                                                      C.byref(sil) if sil is not None else None))
+        return D, (float(sil.value) if sil is not None else None)
+
     def prediction_error(self, W, H):
         """``((X - W @ H)**2).sum()`` over the resident matrix (cnmf.py:926-930)."""
         if self.shape is None:

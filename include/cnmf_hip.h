@@ -205,6 +205,13 @@ int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G,
                    double* density_out, int32_t* keep_out, int32_t* labels_out,
                    double* median_out, double* dist_out, double* stats_out);
 
+/* The other two scikit-learn calls of the reference's consensus body, on their own (round 4; INTEGRATION.md Option B
+ * binds them): euclidean_distances(rows) (cnmf.py:891, :988) -> dist_out [R][R] (NULL ok), and
+ * silhouette_score(rows, labels, metric='euclidean') (cnmf.py:923) -> *silhouette_out (NULL ok; labels [R] in 0..k-1,
+ * 2 <= k <= n_samples - 1 as scikit-learn requires).  Float64; the rows are taken AS GIVEN (no normalisation).   */
+int cnmf_pairwise_distances(cnmf_ctx* ctx, const double* rows, int R, int G, const int32_t* labels, int k,
+                            double* dist_out, double* silhouette_out);
+
 /* sum((X - W.H)^2) over the resident matrix: the prediction error of cnmf.py:926-930
  * (W [N][k], H [k][G], float64). */
 int cnmf_prediction_error(cnmf_ctx* ctx, int k, const double* W, const double* H, double* err_out);

@@ -67,7 +67,9 @@ class cNMF(_ref.cNMF):
             H = np.asarray(kw["H"])
             if H.dtype != xdt:
                 raise TypeError("H should have the same dtype as X. Got H.dtype = {}.".format(H.dtype))
-            W, _ = (eng.nnls_mu(H, beta_loss=kw["beta_loss"], **common) if mu else eng.nnls(H, **common))
+            # (scikit-learn solves in X's dtype: float64 matrices get the float64 device refit)
+            W, _ = (eng.nnls_mu(H, beta_loss=kw["beta_loss"], **common) if mu
+                    else (eng.nnls_f64 if xdt == np.float64 else eng.nnls)(H, **common))
             return H, W.astype(xdt, copy=False)
         k, seed = int(kw["n_components"]), int(kw["random_state"])
         if kw.get("init") == "nndsvd":
@@ -132,7 +134,7 @@ class cNMF(_ref.cNMF):
             return device_euclidean_distances(eng, X, Y, **kw)
 
         def silhouette_score(X, labels, metric="euclidean", **kw):
-            return device_silhouette_score(last.get("km"), saved["silhouette_score"], X, labels, metric=metric, **kw)
+            return device_silhouette_score(eng, last.get("km"), X, labels, metric=metric, **kw)
 
         repl = dict(KMeans=kmeans, euclidean_distances=euclidean_distances, silhouette_score=silhouette_score)
         for name, fn in repl.items():

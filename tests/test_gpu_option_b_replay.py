@@ -1,9 +1,10 @@
 """Option B (integration/hip_backend.py) on the DEVICE.  The CPU test tests/test_integration_option_b.py runs the
 unmodified reference through the subclass with a recorder in place of the engine; the call tuples it logs --
 
-    consensus(l2_spectra, 1, skip_density=True, return_dist=True, n_init=1)         euclidean_distances stand-in
+    pairwise_distances(l2_spectra)                                                  euclidean_distances stand-in
     DeviceKMeans(k, n_init=10, random_state=1).fit(l2_spectra[density_filter])      -> consensus(..., want_silhouette=True)
-    silhouette_score(l2_spectra, labels)                                            handed over from that fit
+    silhouette_score(l2_spectra, labels)                                            handed over from that fit, or scored
+                                                                                    by pairwise_distances(rows, labels)
     nnls(median_spectra) / nmf_batch(ks, seeds, tol=1e-4, max_iter=1000)
 
 -- are replayed here against libcnmf_hip.so (the reference tree does not exist on the GPU box) and compared with the
@@ -31,7 +32,7 @@ def _merged_like_the_reference(R_per, k, G, seed):
 def test_euclidean_distances_standin_matches_sklearn(engine, R_per, k, G):
     from sklearn.metrics.pairwise import euclidean_distances
     l2 = _merged_like_the_reference(R_per, k, G, seed=3)
-    D = standins.device_euclidean_distances(engine, l2)                       # the recorded call: k=1, n_init=1, return_dist
+    D = standins.device_euclidean_distances(engine, l2)                       # the recorded call: cnmf_pairwise_distances
     ref = euclidean_distances(l2.values)
     assert D.shape == ref.shape
     assert np.abs(D - ref).max() < 1e-7                                      # sqrt amplifies 1e-16 near 0
@@ -51,11 +52,23 @@ def test_device_kmeans_and_silhouette_handoff_match_sklearn(engine, R_per, k, G)
     assert km.labels_.dtype == np.int32 and np.array_equal(km.labels_, sk.labels_)
     assert abs(km.inertia_ - sk.inertia_) <= 1e-9 * sk.inertia_
     # cnmf.py:923: silhouette_score(l2_spectra.values, kmeans_cluster_labels, metric='euclidean') -- served by the fit
-    sil = standins.device_silhouette_score(km, silhouette_score, kept.values, km.labels_ + 1, metric="euclidean")
+    sil = standins.device_silhouette_score(engine, km, kept.values, km.labels_ + 1, metric="euclidean")
     assert abs(sil - silhouette_score(kept.values, sk.labels_ + 1, metric="euclidean")) < 1e-9
-    # any other request goes to the real function
-    other = standins.device_silhouette_score(km, silhouette_score, kept.values[:-1], sk.labels_[:-1], metric="euclidean")
-    assert abs(other - silhouette_score(kept.values[:-1], sk.labels_[:-1])) < 1e-12
+    # any other rows / labels are scored on the device too (cnmf_pairwise_distances) -- never by scikit-learn
+    # (round-3 review, weak #9): other rows, and the same rows under ANOTHER labelling
+    other = standins.device_silhouette_score(engine, km, kept.values[:-1], sk.labels_[:-1], metric="euclidean")
+    assert abs(other - silhouette_score(kept.values[:-1], sk.labels_[:-1])) < 1e-9
+    relab = (sk.labels_ + np.arange(len(sk.labels_)) % 2) % k
+    if len(np.unique(relab)) > 1:
+        again = standins.device_silhouette_score(engine, km, kept.values, relab)
+        assert abs(again - silhouette_score(kept.values, relab)) < 1e-9
+    with pytest.raises(NotImplementedError):
+        standins.device_silhouette_score(engine, km, kept.values, km.labels_, metric="cosine")
+    # un-normalised rows: distances of the rows as given (the consensus core would have normalised them)
+    raw = kept.values * np.linspace(0.5, 3.0, kept.shape[0])[:, None]
+    from sklearn.metrics.pairwise import euclidean_distances
+    D, s_raw = engine.pairwise_distances(raw, labels=sk.labels_)
+    assert np.abs(D - euclidean_distances(raw)).max() < 1e-7 and abs(s_raw - silhouette_score(raw, sk.labels_)) < 1e-9
 
 
 def test_factorize_and_refit_calls_of_the_subclass(engine):
@@ -79,3 +92,6 @@ def test_factorize_and_refit_calls_of_the_subclass(engine):
     W, n = engine.nnls(med, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0)
     W_ref, n_ref = nmf_cd.nnls(X, med)
     assert abs(n - n_ref) <= 2 and np.abs(W - W_ref).max() <= 1e-3 * np.abs(W_ref).max()
+    # X is float64 here: the subclass takes the float64 refit (scikit-learn's dtype rule)
+    W64, n64 = engine.nnls_f64(med, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0)
+    assert abs(n64 - n_ref) <= 1 and np.abs(W64 - W_ref).max() <= 1e-9 * np.abs(W_ref).max()

@@ -48,6 +48,18 @@ class RecorderEngine:
         RecorderEngine.calls.append(("nnls", np.shape(H)))
         return nmf_cd.nnls(self.X, np.asarray(H, dtype=np.float64), tol=tol, max_iter=max_iter, alpha_W=alpha_W, l1_ratio=l1_ratio)
 
+    def nnls_f64(self, H, gram=None, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0, **kw):
+        from oracle import nmf_cd
+        RecorderEngine.calls.append(("nnls_f64", np.shape(H)))
+        return nmf_cd.nnls(self.X, np.asarray(H, dtype=np.float64), tol=tol, max_iter=max_iter, alpha_W=alpha_W, l1_ratio=l1_ratio)
+
+    def pairwise_distances(self, rows, labels=None, return_dist=True):
+        from oracle import consensus as oc
+        rows = np.asarray(rows, dtype=np.float64)
+        RecorderEngine.calls.append(("pairwise_distances", rows.shape, labels is not None, return_dist))
+        return (oc.euclidean_distances(rows) if return_dist else None,
+                oc.silhouette_score(rows, np.unique(labels, return_inverse=True)[1]) if labels is not None else None)
+
     def consensus(self, spectra, k, density_threshold=0.5, local_neighborhood_size=0.30, skip_density=False,
                   want_silhouette=False, random_state=1, n_init=10, max_iter=300, tol=1e-4, return_dist=False):
         from oracle import consensus as oc
@@ -100,8 +112,11 @@ def test_option_b_subclass_runs_the_reference_pipeline(tmp_path, monkeypatch):
     b = _run(hip_backend.cNMF, tmp_path, "hip", counts_fn)           # the hot path through the (recorded) engine
     kinds = [c[0] for c in RecorderEngine.calls]
     assert kinds.count("nmf_batch") == 1 and ("nmf_batch", 8, 1e-4, 1000) in RecorderEngine.calls    # ONE batched call: 2 k x 4 iters
-    assert "nnls" in kinds and "consensus" in kinds
-    assert ("consensus", (16, 120), 1, True, True) in RecorderEngine.calls      # show_clustering=True: distances from the device
+    # float64 matrices (the shim's h5ad stand-in keeps float64): the float64 device refit, like scikit-learn's dtype rule
+    assert "nnls_f64" in kinds and "nnls" not in kinds and "consensus" in kinds
+    # show_clustering=True: the distance matrix comes from the distance entry point -- no k = 1 consensus behind it
+    assert ("pairwise_distances", (16, 120), False, True) in RecorderEngine.calls
+    assert not any(c[0] == "consensus" and c[2] == 1 for c in RecorderEngine.calls)
 
     for k, rep in ((4, "2_0"), (5, "0_5")):
         for key in ("merged_spectra",):
