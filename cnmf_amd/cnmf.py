@@ -487,6 +487,27 @@ class cNMF:
         self.last_factorize_stats["host_seconds"] = dict(load_inputs=_t[1] - _t[0], upload=_t[2] - _t[1],
                                                          device_call=_t[3] - _t[2], store_results=_t[4] - _t[3])
 
+    def factorize_multi_gpu(self, n_gpus=None, skip_completed_runs=False, gather="rccl", **kw):
+        """``factorize`` on ``n_gpus`` GPUs of this node, one process per GPU, and the gather: afterwards the merged
+        spectra files of every k exist, as after ``factorize`` + ``combine`` (cnmf_amd/dist.py::factorize_multi_gpu)."""
+        from . import dist
+        return dist.factorize_multi_gpu(self, n_gpus=n_gpus, skip_completed_runs=skip_completed_runs, gather=gather, **kw)
+
+    def factorize_multi_process(self, total_workers, skip_completed_runs=False):
+        """The reference's entry point (cnmf.py:677-689): ``total_workers`` worker processes, each running
+        ``factorize(worker_i, total_workers)`` and writing its per-iteration files -- here one worker per GPU
+        (``total_workers`` must not exceed the GPUs of the node), gathered through the files like the reference;
+        ``combine()`` stays the caller's next step, as in the reference."""
+        from . import _lib
+        n_dev = int(_lib.load().cnmf_device_count())
+        if int(total_workers) > max(n_dev, 1):
+            raise ValueError("total_workers=%d exceeds the %d GPU(s) of this node (one worker process per GPU)"
+                             % (int(total_workers), n_dev))
+        from . import dist
+        argv_obj = self
+        return dist.factorize_multi_gpu(argv_obj, n_gpus=int(total_workers), skip_completed_runs=skip_completed_runs,
+                                        gather="files")
+
     # ------------------------------------------------------------------ combine (cnmf.py:462-483, 748-773)
     def combine(self, components=None, skip_missing_files=False):
         if type(components) is int:
@@ -511,11 +532,21 @@ class cNMF:
                 block = self.spectra_cache[key]
                 if columns is None:
                     columns = self._spectra_columns
+                elif block.shape[1] != len(columns):
+                    raise ValueError("restart %r in memory has %d genes, the other restarts of k=%d have %d"
+                                     % (key, block.shape[1], k, len(columns)))
             elif os.path.exists(current_file):
                 df = load_df_from_npz(current_file)
-                block = df.values
                 if columns is None:
                     columns = df.columns
+                elif not (len(df.columns) == len(columns) and (np.asarray(df.columns) == np.asarray(columns)).all()):
+                    # (a stale file of another gene selection in the same output directory; the reference's pd.concat
+                    #  would have aligned by name and padded with NaN -- here the blocks are stacked as arrays)
+                    if set(df.columns) != set(columns):
+                        raise ValueError("%s holds spectra over a different gene set than the other restarts of k=%d "
+                                         "(stale file of an earlier prepare?)" % (current_file, k))
+                    df = df.loc[:, list(columns)]
+                block = df.values
             else:
                 if not skip_missing_files:
                     print("Missing file: %s, run with skip_missing=True to override" % current_file)

@@ -15,7 +15,19 @@ config, i.e. latency- not bandwidth-bound on xGMI).  Two transports, same packin
   the CPU tests); torch is plumbing there (process group + collective), nothing numeric.
 
 After the gather every k's consensus is independent again.
+
+Round 4 -- the N-rank launcher lives here, in the product (``launch_ranks`` / ``factorize_multi_gpu`` /
+``python -m cnmf_amd.dist worker ...``): the counterpart of the reference's ``factorize_multi_process``
+(cnmf.py:677-689, ``factorize_mp_signature`` :254-262: a multiprocessing Pool of workers, each running
+``factorize(worker_i, total_workers)``).  One process per GPU, file rendezvous, one all-gather, rank 0 combines; the
+launcher polls every rank, names the stage a dead rank reached, and kills exactly the processes it started.
 """
+import json
+import os
+import subprocess
+import sys
+import time
+
 import numpy as np
 
 
@@ -167,3 +179,233 @@ def factorize_distributed(obj, rank, world, device=None, gather="rccl", **factor
         obj.spectra_cache[(k, it)] = H.astype(np.float64)
     obj._spectra_columns = genes
     return merged
+
+
+# ------------------------------------------------------------------------------------------ the N-rank launcher
+class RankFailure(RuntimeError):
+    """A rank of a multi-process launch died (or the launch timed out); the message names rank, exit code, the stage
+    every rank had reached and the tail of the failing rank's stderr."""
+
+
+_STAGES = ("spawned", "imported", "engine", "rendezvous", "comm_ready", "factorize", "gathered", "combined", "done")
+
+
+def _stage_path(run_dir, rank):
+    return os.path.join(run_dir, "rank%d.stage" % rank)
+
+
+def mark_stage(stage):
+    """Called by a rank: record how far it got (one small file per rank under CNMF_LAUNCH_DIR; a no-op outside a
+    launch) -- what the launcher quotes when a rank dies, e.g. "rank 3 died at 'engine'; ranks 0-2 were waiting in
+    'rendezvous'": a rank that never reaches ``ncclCommInitRank`` would otherwise leave the others inside it for ever."""
+    d = os.environ.get("CNMF_LAUNCH_DIR")
+    if not d:
+        return
+    try:
+        with open(_stage_path(d, int(os.environ.get("RANK", "0"))), "w") as f:
+            f.write(stage)
+    except OSError:
+        pass
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(argv, n, env=None, timeout=None, poll=0.1, capture_stdout=True):
+    """Start ``n`` processes running ``argv`` -- rank r with RANK / LOCAL_RANK = r, WORLD_SIZE = n, a private launch
+    directory (CNMF_LAUNCH_DIR: stage files, stderr logs, the RCCL id file CNMF_RCCL_ID_FILE) -- and wait for all of them.
+    Returns rank 0's stdout (bytes).  If any rank exits non-zero, or ``timeout`` seconds pass, every process started
+    here (exactly those PIDs) is killed and ``RankFailure`` says which rank failed, where each rank was, and why."""
+    import tempfile
+    run_dir = tempfile.mkdtemp(prefix="cnmf_launch_")
+    port = _free_port()
+    base = dict(os.environ if env is None else env)
+    procs, logs = [], []
+    out0 = b""
+    failure = None
+    t0 = time.time()
+    try:
+        for r in range(n):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                     MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CNMF_LAUNCH_DIR=run_dir,
+                     CNMF_RCCL_ID_FILE=os.path.join(run_dir, "rccl_id"),
+                     HSA_ENABLE_IPC_MODE_LEGACY=base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            log = open(os.path.join(run_dir, "rank%d.stderr" % r), "wb")
+            logs.append(log)
+            with open(_stage_path(run_dir, r), "w") as f:
+                f.write("spawned")
+            procs.append(subprocess.Popen(list(argv), env=e, stdout=subprocess.PIPE if (r == 0 and capture_stdout) else log,
+                                          stderr=log))
+        import selectors
+        sel = selectors.DefaultSelector()
+        open_out = capture_stdout
+        if open_out:
+            sel.register(procs[0].stdout, selectors.EVENT_READ)
+        while True:
+            if open_out:
+                for key, _ in sel.select(timeout=poll):
+                    chunk = os.read(key.fileobj.fileno(), 65536)
+                    if chunk:
+                        out0 += chunk
+                    else:
+                        sel.unregister(key.fileobj)
+                        open_out = False
+            else:
+                time.sleep(poll)
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failure = ("exit", bad[0][0], bad[0][1])
+                break
+            if all(c == 0 for c in codes) and not open_out:
+                break
+            if timeout is not None and time.time() - t0 > timeout:
+                failure = ("timeout", None, None)
+                break
+    finally:
+        if failure is not None:
+            time.sleep(0.5)                               # let the failing rank's message reach its log
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                  # exactly the PIDs started here
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        for log in logs:
+            log.close()
+    stages = []
+    for r in range(n):
+        try:
+            stages.append(open(_stage_path(run_dir, r)).read().strip())
+        except OSError:
+            stages.append("?")
+    if failure is not None:
+        kind, r, code = failure
+        def tail(rr):
+            try:
+                return open(os.path.join(run_dir, "rank%d.stderr" % rr), "rb").read()[-2000:].decode(errors="replace")
+            except OSError:
+                return ""
+        where = ", ".join("rank %d: %r" % (i, st) for i, st in enumerate(stages))
+        if kind == "exit":
+            msg = ("rank %d of %d exited with code %d at stage %r -- the launch was stopped and the other ranks killed "
+                   "(they would have waited for it inside the collective for ever).  Stages reached: %s.\n--- stderr of "
+                   "rank %d ---\n%s" % (r, n, code, stages[r], where, r, tail(r)))
+        else:
+            slow = min(range(n), key=lambda i: _STAGES.index(stages[i]) if stages[i] in _STAGES else -1)
+            msg = ("no result after %.0f s -- the launch was stopped and all ranks killed.  Stages reached: %s.\n--- stderr "
+                   "of rank %d ---\n%s" % (timeout, where, slow, tail(slow)))
+        _rmtree_quiet(run_dir)
+        raise RankFailure(msg)
+    _rmtree_quiet(run_dir)
+    return out0
+
+
+def _rmtree_quiet(d):
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def _load_factory(spec):
+    """"module:callable" -> the callable (the engine factory of a worker: ``factory(local_rank) -> engine``)."""
+    import importlib
+    mod, _, fn = spec.partition(":")
+    return getattr(importlib.import_module(mod), fn)
+
+
+def factorize_multi_gpu(obj, n_gpus=None, skip_completed_runs=False, gather="rccl", write_iter_files=True,
+                        timeout=None, engine_factory=None, python=None):
+    """The mirror of the reference's ``cNMF.factorize_multi_process(total_workers)`` (cnmf.py:677-689) for GPUs: spawn
+    ``n_gpus`` processes (default: every visible GPU), rank r on GPU r running ``factorize(worker_i=r,
+    total_workers=n_gpus)`` -- the reference's own shard, ``worker_filter`` (cnmf.py:52-53) -- then
+
+    * ``gather="rccl"`` (default): ONE all-gather of the spectra through the library's communicator (file rendezvous of
+      the 128-byte id, ``ncclCommInitRank``, ``cnmf_allgather_spectra``); rank 0 writes the merged-spectra files
+      (``combine``), so the parent finds what ``combine()`` would have produced;
+    * ``gather="files"``: the reference's own gather -- every rank writes its per-iteration files, the parent combines
+      from them (``combine()``); no collective at all.
+
+    ``write_iter_files``: keep the reference's per-iteration files too (always on for ``gather="files"``).
+    ``engine_factory`` ("module:callable", test hook): what a worker calls instead of ``Engine(local_rank)``.
+    Raises :class:`RankFailure` when a rank dies or ``timeout`` (seconds) passes.  Multi-GPU execution of the RCCL path
+    has not been measured on hardware yet."""
+    if n_gpus is None:
+        from . import _lib
+        n_gpus = max(1, int(_lib.load().cnmf_device_count()))
+    if gather not in ("rccl", "files"):
+        raise ValueError("gather must be 'rccl' or 'files'")
+    argv = [python or sys.executable, "-m", "cnmf_amd.dist", "worker", "--output-dir", obj.output_dir, "--name", obj.name,
+            "--gather", gather]
+    if skip_completed_runs:
+        argv.append("--skip-completed-runs")
+    if not write_iter_files and gather != "files":
+        argv.append("--no-iter-files")
+    if engine_factory:
+        argv += ["--engine-factory", engine_factory]
+    if not getattr(obj, "detect_counts", True):
+        argv.append("--no-count-detection")
+    env = dict(os.environ)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    out = launch_ranks(argv, int(n_gpus), env=env, timeout=timeout)
+    report = [json.loads(ln) for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if gather == "files":
+        obj.combine()
+    obj.merged_cache.clear()                              # the merged files were (re)written by another process
+    return report[-1] if report else {}
+
+
+def _worker_main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m cnmf_amd.dist")
+    ap.add_argument("mode", choices=("worker",))
+    ap.add_argument("--output-dir", required=True)
+    ap.add_argument("--name", required=True)
+    ap.add_argument("--gather", choices=("rccl", "files"), default="rccl")
+    ap.add_argument("--skip-completed-runs", action="store_true")
+    ap.add_argument("--no-iter-files", action="store_true")
+    ap.add_argument("--no-count-detection", action="store_true")
+    ap.add_argument("--engine-factory", default=None)
+    ap.add_argument("--rendezvous-timeout", type=float, default=300.0)
+    a = ap.parse_args(argv)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    mark_stage("imported")
+    from .cnmf import cNMF
+    engine = _load_factory(a.engine_factory)(local) if a.engine_factory else None
+    obj = cNMF(output_dir=a.output_dir, name=a.name, device=local, engine=engine, detect_counts=not a.no_count_detection)
+    eng = obj.engine                                       # creates the device context: fails loudly without a GPU
+    mark_stage("engine")
+    t0 = time.time()
+    if a.gather == "rccl":
+        mark_stage("rendezvous")
+        id_file = os.environ.get("CNMF_RCCL_ID_FILE") or os.path.join(a.output_dir, a.name, "cnmf_tmp", "rccl_id")
+        comm_bootstrap_file(eng, rank, world, id_file, timeout=a.rendezvous_timeout)
+        mark_stage("comm_ready")
+        mark_stage("factorize")
+        merged = factorize_distributed(obj, rank, world, gather="rccl", skip_completed_runs=a.skip_completed_runs,
+                                       write_iter_files=not a.no_iter_files)
+        mark_stage("gathered")
+        n_total = len(merged)
+        if rank == 0:
+            obj.combine(skip_missing_files=a.skip_completed_runs)
+            mark_stage("combined")
+    else:
+        mark_stage("factorize")
+        obj.factorize(worker_i=rank, total_workers=world, skip_completed_runs=a.skip_completed_runs, write_iter_files=True)
+        n_total = len(obj.last_factorize_jobs)
+    if rank == 0:
+        sys.stdout.write(json.dumps({"world": world, "gather": a.gather, "restarts_seen_by_rank0": int(n_total),
+                                     "rank0_seconds": time.time() - t0}) + "\n")
+        sys.stdout.flush()
+    mark_stage("done")
+
+
+if __name__ == "__main__":
+    _worker_main()

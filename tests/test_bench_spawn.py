@@ -26,7 +26,9 @@ def test_gpus_n_spawns_n_ranks_and_relays_one_json_line():
     assert len(lines) == 1                                   # exactly ONE JSON line on stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 4 and d["rank"] == 0 and d["local_rank"] == 0 and d["spawned"] == "1"
-    assert d["id_file"].startswith("/tmp/cnmf_rccl_id.") and not os.path.exists(d["id_file"])
+    # the RCCL id travels through a file in the launch's private directory, which is gone afterwards
+    assert os.path.basename(d["id_file"]) == "rccl_id" and "cnmf_launch_" in d["id_file"]
+    assert not os.path.exists(os.path.dirname(d["id_file"]))
     assert d["master"].startswith("127.0.0.1:")
     assert "torch" not in p.stderr.lower()
 

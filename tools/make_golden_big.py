@@ -96,6 +96,24 @@ def make_c3_drift():
     np.savez_compressed(path, **out)
 
 
+def make_c3_nndsvd():
+    """scikit-learn's init='nndsvd' (_initialize_nmf, sklearn/decomposition/_nmf.py:316-354) at the FULL C3 size
+    (50 000 x 2000; round-3 review: the device NNDSVD was only tested up to 9 000 cells): H0 in full, W0 on every 97th
+    cell plus its column sums and sums of squares over ALL cells."""
+    from sklearn.decomposition._nmf import _initialize_nmf
+    X = synth.make_config("C3", dtype=np.float32).astype(np.float64)
+    out = {"x_checksum": np.array([X.sum(), (X * X).sum()])}
+    for k, seed in ((9, 14), (13, 3)):
+        t0 = time.time()
+        W0, H0 = _initialize_nmf(X, k, init="nndsvd", random_state=seed)
+        print("C3 nndsvd k=%d seed=%d (%.0f s)" % (k, seed, time.time() - t0), flush=True)
+        out["k%d_seed" % k] = np.array([seed], dtype=np.int64)
+        out["k%d_H0" % k] = H0
+        out["k%d_W0_rows" % k] = W0[::97]
+        out["k%d_W0_colsum" % k] = np.array([W0.sum(axis=0), (W0 * W0).sum(axis=0)])
+    np.savez_compressed(os.path.join(OUT, "ref_c3_nndsvd.npz"), **out)
+
+
 def make_c4():
     X = c4_matrix()
     out = {"shape": np.array(X.shape), "x_checksum": np.array([float(X.data.astype(np.float64).sum())])}
@@ -140,3 +158,5 @@ if __name__ == "__main__":
         make_c3()
     if "c3" in which or "c3drift" in which:
         make_c3_drift()
+    if "c3" in which or "c3nndsvd" in which:
+        make_c3_nndsvd()
