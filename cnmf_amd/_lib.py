@@ -24,7 +24,8 @@ SYMBOLS = [
     "cnmf_xt_matmul_f64", "cnmf_nnls_spectra", "cnmf_nnls_f64", "cnmf_nnls_gram", "cnmf_nnls_batch", "cnmf_kselect_stats",
     "cnmf_comm_unique_id", "cnmf_comm_init", "cnmf_comm_finalize", "cnmf_comm_rank", "cnmf_comm_world",
     "cnmf_allgather_bytes", "cnmf_allgather_spectra",
-    "cnmf_spectra_rows", "cnmf_spectra_reset", "cnmf_spectra_fetch",
+    "cnmf_spectra_rows", "cnmf_spectra_reset", "cnmf_spectra_fetch", "cnmf_spectra_genes", "cnmf_spectra_append",
+    "cnmf_consensus_store", "cnmf_kselect_stats_store",
     "cnmf_range_finder", "cnmf_debug_stream", "cnmf_debug_gemm", "cnmf_debug_gemm3", "cnmf_debug_gemm3c", "cnmf_debug_gemm2h", "cnmf_debug_standard_normal",
 ]
 
@@ -185,6 +186,17 @@ def load():
     lib.cnmf_allgather_spectra.argtypes = [vp, f32p, i64, i64, i64, f32p]
     lib.cnmf_spectra_rows.restype = i64
     lib.cnmf_spectra_rows.argtypes = [vp]
+    lib.cnmf_spectra_append.restype = i32
+    lib.cnmf_spectra_append.argtypes = [vp, f32p, i64, i64]
+    lib.cnmf_spectra_genes.restype = i64
+    lib.cnmf_spectra_genes.argtypes = [vp]
+    i64p = C.POINTER(C.c_int64)
+    lib.cnmf_consensus_store.restype = i32
+    lib.cnmf_consensus_store.argtypes = [vp, i64p, i32, i32, C.POINTER(ConsensusParams), dblp,
+                                         dblp, i32p, i32p, dblp, dblp, dblp]
+    lib.cnmf_kselect_stats_store.restype = i32
+    lib.cnmf_kselect_stats_store.argtypes = [vp, i32, i32p, i32p, i64p, C.POINTER(ConsensusParams), dblp,
+                                             C.POINTER(CdParams), dblp, dblp, dblp, i32p]
     lib.cnmf_spectra_reset.restype = i32
     lib.cnmf_spectra_reset.argtypes = [vp]
     lib.cnmf_spectra_fetch.restype = i32

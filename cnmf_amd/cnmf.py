@@ -140,6 +140,7 @@ class cNMF:
         self.spectra_cache = {}          # (k, iter) -> spectra ndarray (k x genes) kept from factorize
         self._spectra_columns = None     # their gene names
         self.merged_cache = {}           # k -> merged spectra DataFrame kept from combine (skips a reload)
+        self._store_rows = {}            # (k, iter) -> (first row in the engine's resident spectra store, store generation)
         self._resident_obj = None        # STRONG reference to the matrix object that is resident (identity check:
                                          # while we hold it CPython cannot hand its id() to another object)
         self.compress_merged = compress_merged
@@ -209,6 +210,9 @@ class cNMF:
         """A new prepare invalidates everything derived from the previous matrix / ledger."""
         self.spectra_cache.clear()
         self.merged_cache.clear()
+        self._store_rows = {}
+        if self._engine is not None and hasattr(self._engine, "spectra_reset"):
+            self._engine.spectra_reset()
         self._resident_obj = None
         self._engine_key = None
         self._norm_counts_cache = (None, None)
@@ -470,8 +474,14 @@ class cNMF:
             H_list, _, n_iter, _ = eng.nmf_mu_batch(ks, beta_loss=_nmf_kwargs["beta_loss"], **init_kw, **common)
             self.last_factorize_stats = dict(n_iter=n_iter)
         else:
-            H_list, _, n_iter, _ = eng.nmf_batch(ks, kc_max=kc_max, **init_kw, **common)
+            # the spectra also stay in the engine's device store: k selection and consensus of THIS process take their
+            # merged spectra from there (no 80 MB upload per consensus call; round-3 review, next #9)
+            keep = hasattr(eng, "spectra_fetch")
+            H_list, _, n_iter, _ = eng.nmf_batch(ks, kc_max=kc_max, resident="keep" if keep else False, **init_kw, **common)
             self.last_factorize_stats = dict(eng.last_stats, n_iter=n_iter)
+            if keep:
+                for k, it, off in zip(ks, its, eng.last_store_offsets):
+                    self._store_rows[(k, it)] = (int(off), eng.last_store_gen)
         _t.append(_time.perf_counter())
         xdt = norm_counts.values.dtype if norm_counts.values.dtype in (np.float32, np.float64) else np.float64
         self._spectra_columns = norm_counts.columns
@@ -582,6 +592,29 @@ class cNMF:
     def refit_spectra(self, X, usage):
         return self.refit_usage(X.T, usage.T).T
 
+    def _merged_store_rows(self, k, merged_index, eng):
+        """Row indices into ``eng``'s resident spectra store for the merged spectra of ``k`` (labels iter%d_topic%d), or
+        None when any of them is not there (another process ran it, the store was reset, the merged file was not written
+        by this process's combine)."""
+        cached = self.merged_cache.get(k)
+        if (cached is None or eng is not self._engine or not self._store_rows or not hasattr(eng, "store_gen")
+                or cached[0] != os.path.getmtime(self.paths["merged_spectra"] % k)):
+            return None
+        rows = np.empty(len(merged_index), dtype=np.int64)
+        pos = 0
+        while pos < len(merged_index):
+            label = merged_index[pos]
+            try:
+                it = int(label[4:label.index("_topic")])
+            except (ValueError, TypeError):
+                return None
+            ent = self._store_rows.get((k, it))
+            if ent is None or ent[1] != eng.store_gen or pos + k > len(merged_index) or merged_index[pos + k - 1] != "iter%d_topic%d" % (it, k):
+                return None
+            rows[pos:pos + k] = ent[0] + np.arange(k)
+            pos += k
+        return rows
+
     # ------------------------------------------------------------------ consensus (cnmf.py:823-985)
     def consensus(self, k, density_threshold=0.5, local_neighborhood_size=0.30, show_clustering=True,
                   build_ref=True, skip_density_and_return_after_stats=False, close_clustergram_fig=False,
@@ -631,15 +664,19 @@ class cNMF:
             keep = cached_density < density_threshold          # strict <, cnmf.py:903
             if keep.sum() == 0:
                 raise RuntimeError("Zero components remain after density filtering. Consider increasing density threshold")
-            sub = eng.consensus(merged_spectra.values[keep], k, skip_density=True, want_silhouette=False,
-                                return_dist=False)
+            srows = self._merged_store_rows(k, merged_spectra.index, eng)
+            sub = eng.consensus(None if srows is not None else merged_spectra.values[keep], k, skip_density=True,
+                                want_silhouette=False, return_dist=False,
+                                **({"store_rows": srows[keep]} if srows is not None else {}))
             labels = -np.ones(R, dtype=np.int32)
             labels[keep] = sub["labels"]
             out = dict(sub, local_density=cached_density, density_filter=keep, labels=labels)
             if show_clustering:
                 out["topics_dist"] = None      # like the reference with a cached density (cnmf.py:886, 988-990)
         else:
-            out = eng.consensus(merged_spectra.values, k, density_threshold=density_threshold,
+            srows = self._merged_store_rows(k, merged_spectra.index, eng)
+            out = eng.consensus(None if srows is not None else merged_spectra.values, k, density_threshold=density_threshold,
+                                **({"store_rows": srows} if srows is not None else {}),
                                 local_neighborhood_size=local_neighborhood_size,
                                 skip_density=skip_density_and_return_after_stats,
                                 want_silhouette=skip_density_and_return_after_stats,
@@ -773,18 +810,25 @@ class cNMF:
         ks = sorted(set(int(k) for k in run_params.n_components))
         kw = yaml.load(open(self.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
         if batched and kw.get("solver", "cd") == "cd":
-            merged = {}
-            for k in ks:
-                cached = self.merged_cache.get(k)
-                if cached is not None and cached[0] == os.path.getmtime(self.paths["merged_spectra"] % k):
-                    merged[k] = cached[1].values
-                else:
-                    merged[k] = load_df_from_npz(self.paths["merged_spectra"] % k).values
             nc_key = ("norm_counts", self.paths["normalized_counts"], os.path.getmtime(self.paths["normalized_counts"]))
             eng = self._get_engine(norm_counts.values, nc_key)
             self._resident_obj = norm_counts
-            res = eng.kselect_stats(merged, nnls_tol=kw.get("tol", 1e-4), nnls_max_iter=kw.get("max_iter", 1000),
-                                    alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
+            merged, srows = {}, {}
+            for k in ks:
+                cached = self.merged_cache.get(k)
+                if cached is not None and cached[0] == os.path.getmtime(self.paths["merged_spectra"] % k):
+                    rows = self._merged_store_rows(k, cached[1].index, eng)
+                    if rows is not None:
+                        srows[k] = rows
+                    merged[k] = cached[1].values
+                else:
+                    merged[k] = load_df_from_npz(self.paths["merged_spectra"] % k).values
+            solver_kw = dict(nnls_tol=kw.get("tol", 1e-4), nnls_max_iter=kw.get("max_iter", 1000),
+                             alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
+            if len(srows) == len(ks):          # every k still sits in the device store of this process: no upload at all
+                res = eng.kselect_stats(None, store_rows_by_k=srows, **solver_kw)
+            else:
+                res = eng.kselect_stats(merged, **solver_kw)
             stats = pd.DataFrame([[k, 0.5, res[k]["silhouette"], res[k]["prediction_error"]] for k in ks],
                                  columns=["k", "local_density_threshold", "silhouette", "prediction_error"])
             stats["k"] = stats["k"].astype(float)

@@ -327,6 +327,12 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     EventPool events;
     float* d_Hres = nullptr; float* d_Wres = nullptr;
     if (resident) {
+        if (ctx->spectra_rows && ctx->spectra_G != G) {
+            SET_ERR(ctx, "the resident store holds spectra over %lld genes, this matrix has %d: cnmf_spectra_reset first",
+                    (long long)ctx->spectra_G, G);
+            return CNMF_ESTATE;
+        }
+        ctx->spectra_G = G;
         const size_t need = (ctx->spectra_rows + (size_t)total_k) * G;
         if (need > ctx->spectra_cap) {
             float* nb = nullptr;
@@ -382,6 +388,13 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     // CNMF_QUEUE=rank restores the plain descending-rank order (A/B).
     std::vector<int> order(n);
     const bool queue_by_rank = getenv("CNMF_QUEUE") && !strcmp(getenv("CNMF_QUEUE"), "rank");
+    // round 4: what earlier calls on this matrix learned (mean iterations per rank, same tol / max_iter) orders the queue
+    // from the start -- a k-selection sweep, a second factorize with more restarts, the steps of a benchmark do not have to
+    // re-learn that k = 13 runs 1000 iterations and k = 9 runs 37.  CNMF_NO_PRIOR=1: A/B.
+    static const bool no_prior = getenv("CNMF_NO_PRIOR") != nullptr;
+    const bool have_prior = !no_prior && ctx->iter_prior.size() == (size_t)KMAX + 1 && ctx->prior_tol == prm->tol &&
+                            ctx->prior_max_iter == prm->max_iter;
+    auto prior_of = [&](int k) { return have_prior ? ctx->iter_prior[k] : 0.0; };
     if (queue_by_rank) {
         for (int r = 0; r < n; ++r) order[r] = r;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kk[a] > kk[b]; });
@@ -392,6 +405,11 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         for (size_t j = 0; pos < (size_t)n; ++j)
             for (int k = KMAX; k >= 1; --k)
                 if (j < by_k[k].size()) order[pos++] = by_k[k][j];
+        if (have_prior)            // ranks never seen count as longest (sampled first), the others by their learned mean
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                const double ea = prior_of(kk[a]) > 0 ? prior_of(kk[a]) : 1e30, eb = prior_of(kk[b]) > 0 ? prior_of(kk[b]) : 1e30;
+                return ea > eb;
+            });
     }
     std::vector<int64_t> k_iters(KMAX + 1, 0), k_done(KMAX + 1, 0);     // learned per rank: sum of n_iter, restarts retired
     int last_resort_done = 0;
@@ -800,7 +818,19 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             std::vector<int> rest;
             rest.reserve(n_pending);
             for (size_t pi = next; pi < order.size(); ++pi) if (order[pi] >= 0) rest.push_back(order[pi]);
-            auto expect = [&](int r) { const int k = kk[r]; return k_done[k] ? (double)k_iters[k] / (double)k_done[k] : 1e30; };
+            // expected iterations of a rank: mean over the restarts that have STARTED -- the finished ones with their count,
+            // the ones in flight with their age (a lower bound).  Counting only the finished ones is biased low while it
+            // matters most: of a rank whose restarts take 300 or 1000 iterations the 300s retire first.  An earlier call's
+            // mean (prior) enters as four pseudo-observations.
+            std::vector<double> fly_age(KMAX + 1, 0.0); std::vector<int> fly_n(KMAX + 1, 0);
+            for (int s2 = 0; s2 < nslots; ++s2)
+                if (hs[s2].state) { fly_age[hs[s2].k] += (double)(it - hs[s2].installed_at); fly_n[hs[s2].k] += 1; }
+            auto expect = [&](int r) {
+                const int k = kk[r];
+                double num = (double)k_iters[k] + fly_age[k], den = (double)k_done[k] + fly_n[k];
+                if (prior_of(k) > 0) { num += 4.0 * prior_of(k); den += 4.0; }
+                return den > 0 ? num / den : 1e30;
+            };
             std::stable_sort(rest.begin(), rest.end(), [&](int a, int b) {
                 const double ea = expect(a), eb = expect(b);
                 return ea != eb ? ea > eb : kk[a] > kk[b];
@@ -902,6 +932,16 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         HIP_TRY(ctx, hipMemcpyAsync(W_out, d_Wres, woff[n] * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (resident) ctx->spectra_rows += (size_t)total_k;
+    {   // remember the mean iteration count per rank for the next call on this matrix
+        if (ctx->iter_prior.size() != (size_t)KMAX + 1 || ctx->prior_tol != prm->tol || ctx->prior_max_iter != prm->max_iter)
+            ctx->iter_prior.assign((size_t)KMAX + 1, 0.0);
+        ctx->prior_tol = prm->tol; ctx->prior_max_iter = prm->max_iter;
+        for (int k = 1; k <= KMAX; ++k)
+            if (k_done[k]) {
+                const double m = (double)k_iters[k] / (double)k_done[k];
+                ctx->iter_prior[k] = (k_done[k] >= 4 || ctx->iter_prior[k] <= 0) ? m : 0.5 * (m + ctx->iter_prior[k]);
+            }
+    }
     if (stats) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, ev_begin, ev_end);

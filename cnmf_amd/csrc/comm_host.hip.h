@@ -152,10 +152,46 @@ extern "C" int cnmf_allgather_bytes(cnmf_ctx* ctx, const void* send, int64_t nby
 
 extern "C" int64_t cnmf_spectra_rows(const cnmf_ctx* ctx) { return ctx ? (int64_t)ctx->spectra_rows : 0; }
 
+extern "C" int64_t cnmf_spectra_genes(const cnmf_ctx* ctx) { return ctx ? ctx->spectra_G : 0; }
+
 extern "C" int cnmf_spectra_reset(cnmf_ctx* ctx)
 {
     if (!ctx) return CNMF_EINVAL;
     ctx->spectra_rows = 0;
+    return CNMF_OK;
+}
+
+// rows [n][G] float32 appended behind what the store holds: merged spectra that did not come out of a resident batch of
+// this context (read from the reference's files, gathered from other GPUs) -- uploaded ONCE, then every cnmf_consensus_store
+// call (other k, other density thresholds) works from the device
+extern "C" int cnmf_spectra_append(cnmf_ctx* ctx, const float* rows, int64_t n_rows, int64_t n_genes)
+{
+    if (!ctx || !rows || n_rows < 0 || n_genes < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    if (ctx->spectra_rows && ctx->spectra_G != n_genes) {
+        SET_ERR(ctx, "the resident store holds spectra over %lld genes, not %lld: cnmf_spectra_reset first",
+                (long long)ctx->spectra_G, (long long)n_genes);
+        return CNMF_ESTATE;
+    }
+    if (n_rows == 0) return CNMF_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t need = (ctx->spectra_rows + (size_t)n_rows) * (size_t)n_genes;
+    if (need > ctx->spectra_cap) {
+        float* nb = nullptr;
+        const size_t cap = std::max(need, ctx->spectra_cap * 2);
+        HIP_TRY(ctx, hipMalloc(&nb, cap * sizeof(float)));
+        hipError_t ce = hipSuccess;
+        if (ctx->spectra_rows)
+            ce = hipMemcpyAsync(nb, ctx->spectra, ctx->spectra_rows * (size_t)n_genes * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
+        if (ce != hipSuccess) { hipFree(nb); HIP_TRY(ctx, ce); }
+        hipFree(ctx->spectra);
+        ctx->spectra = nb; ctx->spectra_cap = cap;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->spectra + ctx->spectra_rows * (size_t)n_genes, rows, (size_t)n_rows * n_genes * sizeof(float),
+                                hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->spectra_G = n_genes;
+    ctx->spectra_rows += (size_t)n_rows;
     return CNMF_OK;
 }
 
@@ -165,7 +201,7 @@ extern "C" int cnmf_spectra_fetch(cnmf_ctx* ctx, float* out)
     if (!ctx->spectra_rows) return CNMF_OK;
     if (!out) { SET_ERR(ctx, "out is NULL"); return CNMF_EINVAL; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->spectra, ctx->spectra_rows * (size_t)ctx->G * sizeof(float),
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->spectra, ctx->spectra_rows * (size_t)ctx->spectra_G * sizeof(float),
                                 hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CNMF_OK;
@@ -177,9 +213,9 @@ extern "C" int cnmf_allgather_spectra(cnmf_ctx* ctx, const float* local, int64_t
     if (!ctx) return CNMF_EINVAL;
     if (rows_local < 0 || rows_max < rows_local || n_genes <= 0 || !out) { SET_ERR(ctx, "bad sizes / out is NULL"); return CNMF_EINVAL; }
     if (!local) {   // the context's resident store (filled by cnmf_nmf_cd_batch_resident)
-        if ((int64_t)ctx->spectra_rows != rows_local || ctx->G != n_genes) {
+        if ((int64_t)ctx->spectra_rows != rows_local || ctx->spectra_G != n_genes) {
             SET_ERR(ctx, "resident store holds %lld rows x %lld genes, caller said %lld x %lld",
-                    (long long)ctx->spectra_rows, (long long)ctx->G, (long long)rows_local, (long long)n_genes);
+                    (long long)ctx->spectra_rows, (long long)ctx->spectra_G, (long long)rows_local, (long long)n_genes);
             return CNMF_EINVAL;
         }
     }

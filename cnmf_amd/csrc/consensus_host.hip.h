@@ -53,13 +53,21 @@ static inline int first_center_index(int n, double u)
         }                                                                                       \
     } while (0)
 
-extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G,
-                              const cnmf_consensus_params* prm, const double* uniforms,
-                              double* density_out, int32_t* keep_out, int32_t* labels_out,
-                              double* median_out, double* dist_out, double* stats_out)
+// `spectra` (host, float64 [R][G]) or -- round 4 -- `store_rows` [R]: row indices into the context's RESIDENT spectra store
+// (float32, filled by cnmf_nmf_cd_batch_resident): the merged spectra of a k are gathered and widened on the device, no
+// upload (80 MB of float64 at 5 000 x 2 000: 1.5 of the 4.4 ms of the round-3 call).
+static int consensus_impl(cnmf_ctx* ctx, const double* spectra, const int64_t* store_rows, int R, int G,
+                          const cnmf_consensus_params* prm, const double* uniforms,
+                          double* density_out, int32_t* keep_out, int32_t* labels_out,
+                          double* median_out, double* dist_out, double* stats_out)
 {
     using namespace cnmf;
-    if (!ctx || !spectra || !prm || !labels_out || !median_out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    if (!ctx || (!spectra && !store_rows) || !prm || !labels_out || !median_out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    if (store_rows) {
+        if ((int64_t)G != ctx->spectra_G) { SET_ERR(ctx, "the resident store holds spectra over %lld genes, not %d", (long long)ctx->spectra_G, G); return CNMF_EINVAL; }
+        for (int r = 0; r < R; ++r)
+            if (store_rows[r] < 0 || (size_t)store_rows[r] >= ctx->spectra_rows) { SET_ERR(ctx, "store row %lld outside 0..%lld", (long long)store_rows[r], (long long)ctx->spectra_rows - 1); return CNMF_EINVAL; }
+    }
     const int k = prm->k;
     if (R < 1 || G < 1 || k < 1 || k > R) { SET_ERR(ctx, "bad shape R=%d G=%d k=%d", R, G, k); return CNMF_EINVAL; }
     if (k > KM_CID) { SET_ERR(ctx, "k=%d > %d clusters is not supported", k, KM_CID); return CNMF_EUNSUPPORTED; }
@@ -95,7 +103,14 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     double* dL2 = pool.get<double>((size_t)Rp * ld, true, st);
     double* dsq = pool.get<double>(Rp, true, st);
     if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
-    CONS_TRY(hipMemcpyAsync(dS, spectra, (size_t)R * G * sizeof(double), hipMemcpyHostToDevice, st));
+    if (store_rows) {
+        long long* drows = pool.get<long long>(R);
+        if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+        CONS_TRY(hipMemcpyAsync(drows, store_rows, (size_t)R * sizeof(long long), hipMemcpyHostToDevice, st));
+        gather_store_rows_kernel<<<dim3((G + 255) / 256, R), 256, 0, st>>>(ctx->spectra, G, drows, dS);
+    } else {
+        CONS_TRY(hipMemcpyAsync(dS, spectra, (size_t)R * G * sizeof(double), hipMemcpyHostToDevice, st));
+    }
     l2_rows_kernel<<<R, 256, 0, st>>>(dS, R, G, dL2, ld, dsq);
     lap("alloc + upload + l2");
 
@@ -337,6 +352,24 @@ extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G
     CONS_TRY(hipStreamSynchronize(st));
     if (stats_out) { stats_out[0] = Rk; stats_out[1] = best_inertia; stats_out[2] = sil / Rk; stats_out[3] = best_iter; }
     return CNMF_OK;
+}
+
+extern "C" int cnmf_consensus(cnmf_ctx* ctx, const double* spectra, int R, int G,
+                              const cnmf_consensus_params* prm, const double* uniforms,
+                              double* density_out, int32_t* keep_out, int32_t* labels_out,
+                              double* median_out, double* dist_out, double* stats_out)
+{
+    if (!spectra) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    return consensus_impl(ctx, spectra, nullptr, R, G, prm, uniforms, density_out, keep_out, labels_out, median_out, dist_out, stats_out);
+}
+
+extern "C" int cnmf_consensus_store(cnmf_ctx* ctx, const int64_t* store_rows, int R, int G,
+                                    const cnmf_consensus_params* prm, const double* uniforms,
+                                    double* density_out, int32_t* keep_out, int32_t* labels_out,
+                                    double* median_out, double* dist_out, double* stats_out)
+{
+    if (!store_rows) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    return consensus_impl(ctx, nullptr, store_rows, R, G, prm, uniforms, density_out, keep_out, labels_out, median_out, dist_out, stats_out);
 }
 
 // All-pairs Euclidean distances of the rows AS GIVEN (sklearn.metrics.euclidean_distances(X), cnmf.py:891 / :988) and /

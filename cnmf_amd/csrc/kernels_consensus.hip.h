@@ -220,6 +220,14 @@ __global__ __launch_bounds__(256) void l2_rows_kernel(const double* __restrict__
     if (threadIdx.x == 0) sq[r] = s2;
 }
 
+// out[r][:] = (double) store[rows[r]][:]   (merged spectra of one k out of the resident float32 store; grid (G / 256, R))
+__global__ __launch_bounds__(256) void gather_store_rows_kernel(const float* __restrict__ store, int G,
+                                                                const long long* __restrict__ rows, double* __restrict__ out)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (g < G) out[(size_t)r * G + g] = (double)store[(size_t)rows[r] * G + g];
+}
+
 // the same without the normalisation (cnmf_pairwise_distances: euclidean_distances of the rows as they are)
 __global__ __launch_bounds__(256) void copy_rows_sq_kernel(const double* __restrict__ S, int R, int G,
                                                            double* __restrict__ out, int ld,

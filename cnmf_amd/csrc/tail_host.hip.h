@@ -543,12 +543,12 @@ extern "C" int cnmf_nnls_gram(cnmf_ctx* ctx, int k, const float* H_prod, const f
 }
 
 // ------------------------------------------------------------------ k selection (cnmf.py:1119-1135, 922-936)
-extern "C" int cnmf_kselect_stats(cnmf_ctx* ctx, int n, const int32_t* ks, const int32_t* R, const double* spectra,
-                                  const cnmf_consensus_params* cprm, const double* uniforms,
-                                  const cnmf_cd_params* prm, double* silhouette_out, double* pred_err_out,
-                                  double* median_out, int32_t* nnls_iter_out)
+static int kselect_impl(cnmf_ctx* ctx, int n, const int32_t* ks, const int32_t* R, const double* spectra,
+                        const int64_t* store_rows, const cnmf_consensus_params* cprm, const double* uniforms,
+                        const cnmf_cd_params* prm, double* silhouette_out, double* pred_err_out,
+                        double* median_out, int32_t* nnls_iter_out)
 {
-    if (!ctx || !ks || !R || !spectra || !cprm || !uniforms || !silhouette_out || !pred_err_out || n < 1) {
+    if (!ctx || !ks || !R || (!spectra && !store_rows) || !cprm || !uniforms || !silhouette_out || !pred_err_out || n < 1) {
         SET_ERR(ctx, "null argument"); return CNMF_EINVAL;
     }
     if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
@@ -564,8 +564,9 @@ extern "C" int cnmf_kselect_stats(cnmf_ctx* ctx, int n, const int32_t* ks, const
         std::vector<int32_t> keep(R[i]), labels(R[i]);
         std::vector<double> dens(R[i]);
         double stats[4];
-        int rc = cnmf_consensus(ctx, spectra + soff * G, R[i], G, &cprm[i], uniforms + uoff, dens.data(), keep.data(),
-                                labels.data(), med.data() + moff * G, nullptr, stats);
+        int rc = consensus_impl(ctx, spectra ? spectra + soff * G : nullptr, store_rows ? store_rows + soff : nullptr, R[i], G,
+                                &cprm[i], uniforms + uoff, dens.data(), keep.data(), labels.data(), med.data() + moff * G,
+                                nullptr, stats);
         if (rc) return rc;
         silhouette_out[i] = stats[2];
         const int n_init = cprm[i].n_init > 0 ? cprm[i].n_init : 10;
@@ -579,4 +580,23 @@ extern "C" int cnmf_kselect_stats(cnmf_ctx* ctx, int n, const int32_t* ks, const
     for (size_t i = 0; i < med.size(); ++i) medf[i] = (float)med[i];
     if (median_out) memcpy(median_out, med.data(), med.size() * sizeof(double));
     return nnls_batch_impl(ctx, n, ks, medf.data(), nullptr, prm, nullptr, nnls_iter_out, nullptr, pred_err_out, med.data());
+}
+
+extern "C" int cnmf_kselect_stats(cnmf_ctx* ctx, int n, const int32_t* ks, const int32_t* R, const double* spectra,
+                                  const cnmf_consensus_params* cprm, const double* uniforms,
+                                  const cnmf_cd_params* prm, double* silhouette_out, double* pred_err_out,
+                                  double* median_out, int32_t* nnls_iter_out)
+{
+    if (!spectra) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    return kselect_impl(ctx, n, ks, R, spectra, nullptr, cprm, uniforms, prm, silhouette_out, pred_err_out, median_out, nnls_iter_out);
+}
+
+// the same with the merged spectra of every k taken from the RESIDENT store (store_rows: sum R[i] row indices, k by k)
+extern "C" int cnmf_kselect_stats_store(cnmf_ctx* ctx, int n, const int32_t* ks, const int32_t* R, const int64_t* store_rows,
+                                        const cnmf_consensus_params* cprm, const double* uniforms,
+                                        const cnmf_cd_params* prm, double* silhouette_out, double* pred_err_out,
+                                        double* median_out, int32_t* nnls_iter_out)
+{
+    if (!store_rows) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    return kselect_impl(ctx, n, ks, R, nullptr, store_rows, cprm, uniforms, prm, silhouette_out, pred_err_out, median_out, nnls_iter_out);
 }

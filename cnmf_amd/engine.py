@@ -90,6 +90,9 @@ class Engine:
         self.x_mean = None
         self.x_dtype = None
         self.last_stats = None
+        self.store_gen = 0                 # generation of the resident spectra store (bumped by spectra_reset)
+        self.last_store_offsets = None     # first store row of every restart of the last resident batch
+        self.last_store_gen = -1
         if not detect_counts:
             self.set_count_detection(False)
 
@@ -258,12 +261,24 @@ class Engine:
         viol = np.zeros(max(n, 1), dtype=np.float64)
         stats = _lib.BatchStats()
         if resident:
+            # the spectra stay in the context's device store (appended behind what it holds); resident="keep" also
+            # brings THIS call's rows to the host (ONE copy), and `last_store_offsets` says where each restart sits in the
+            # store -- consensus() / kselect_stats() can then take their merged spectra from the device (store_rows)
+            row0 = self.spectra_rows
             rc = self._lib.cnmf_nmf_cd_batch_resident(self._ctx, n, ks.ctypes.data_as(i32p), mode, seedp,
                                                       avgp, w0p, h0p, C.byref(prm),
                                                       n_iter.ctypes.data_as(i32p), viol.ctypes.data_as(dblp),
                                                       C.byref(stats))
             self._check(rc)
             H_list = W_list = None
+            offs = row0 + np.concatenate([[0], np.cumsum(ks)]).astype(np.int64)
+            self.last_store_offsets = offs[:-1].copy()
+            self.last_store_gen = self.store_gen
+            if resident == "keep":
+                if return_W:
+                    raise ValueError("resident='keep' returns spectra only")
+                allrows = self.spectra_fetch()
+                H_list = [allrows[offs[r]:offs[r + 1]] for r in range(n)]
         else:
             H_out = np.empty((max(tot_k, 1), G), dtype=np.float32)
             W_out = np.empty(max(tot_k, 1) * N, dtype=np.float32) if return_W else None
@@ -535,7 +550,7 @@ class Engine:
         return out
 
     def kselect_stats(self, spectra_by_k, local_neighborhood_size=0.30, random_state=1, n_init=10, max_iter=300,
-                      kmeans_tol=1e-4, nnls_tol=1e-4, nnls_max_iter=1000, alpha_W=0.0, l1_ratio=0.0):
+                      kmeans_tol=1e-4, nnls_tol=1e-4, nnls_max_iter=1000, alpha_W=0.0, l1_ratio=0.0, store_rows_by_k=None):
         """The statistics loop of ``k_selection_plot`` (cnmf.py:1119-1135) in ONE device call: ``spectra_by_k`` maps
         k -> merged spectra (R_k x G).  Every k goes through the stats branch of the consensus (no density filter,
         KMeans, medians, silhouette), the |K| usage refits run batched (one pass over X), the prediction errors are
@@ -544,14 +559,23 @@ class Engine:
         if self.shape is None:
             raise RuntimeError("set_matrix() has not been called")
         N, G = self.shape
-        ks = sorted(int(k) for k in spectra_by_k)
+        # ``store_rows_by_k`` (k -> row indices into the resident spectra store) replaces ``spectra_by_k``: nothing is uploaded
+        src = store_rows_by_k if store_rows_by_k is not None else spectra_by_k
+        ks = sorted(int(k) for k in src)
         n = len(ks)
-        S = [np.ascontiguousarray(spectra_by_k[k], dtype=np.float64) for k in ks]
-        for k, s in zip(ks, S):
-            if s.ndim != 2 or s.shape[1] != G:
-                raise ValueError("spectra for k=%d must be (R, %d)" % (k, G))
-        R = np.ascontiguousarray([s.shape[0] for s in S], dtype=np.int32)
-        Sp = np.ascontiguousarray(np.concatenate(S, axis=0))
+        if store_rows_by_k is not None:
+            if self.spectra_genes != G:
+                raise ValueError("the resident store holds spectra over %d genes, the matrix has %d" % (self.spectra_genes, G))
+            rows = [np.ascontiguousarray(store_rows_by_k[k], dtype=np.int64).ravel() for k in ks]
+            R = np.ascontiguousarray([r.size for r in rows], dtype=np.int32)
+            rows_all = np.ascontiguousarray(np.concatenate(rows))
+        else:
+            S = [np.ascontiguousarray(spectra_by_k[k], dtype=np.float64) for k in ks]
+            for k, s in zip(ks, S):
+                if s.ndim != 2 or s.shape[1] != G:
+                    raise ValueError("spectra for k=%d must be (R, %d)" % (k, G))
+            R = np.ascontiguousarray([s.shape[0] for s in S], dtype=np.int32)
+            Sp = np.ascontiguousarray(np.concatenate(S, axis=0))
         cprm = (_lib.ConsensusParams * n)()
         us = []
         for i, k in enumerate(ks):
@@ -567,10 +591,14 @@ class Engine:
         med = np.zeros((int(ks_a.sum()), G))
         nit = np.zeros(n, dtype=np.int32)
         i32p, dblp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
-        rc = self._lib.cnmf_kselect_stats(self._ctx, n, ks_a.ctypes.data_as(i32p), R.ctypes.data_as(i32p),
-                                          Sp.ctypes.data_as(dblp), cprm, u.ctypes.data_as(dblp), C.byref(prm),
-                                          sil.ctypes.data_as(dblp), err.ctypes.data_as(dblp), med.ctypes.data_as(dblp),
-                                          nit.ctypes.data_as(i32p))
+        outs = (cprm, u.ctypes.data_as(dblp), C.byref(prm), sil.ctypes.data_as(dblp), err.ctypes.data_as(dblp),
+                med.ctypes.data_as(dblp), nit.ctypes.data_as(i32p))
+        if store_rows_by_k is not None:
+            rc = self._lib.cnmf_kselect_stats_store(self._ctx, n, ks_a.ctypes.data_as(i32p), R.ctypes.data_as(i32p),
+                                                    rows_all.ctypes.data_as(C.POINTER(C.c_int64)), *outs)
+        else:
+            rc = self._lib.cnmf_kselect_stats(self._ctx, n, ks_a.ctypes.data_as(i32p), R.ctypes.data_as(i32p),
+                                              Sp.ctypes.data_as(dblp), *outs)
         self._check(rc)
         out, off = {}, 0
         for i, k in enumerate(ks):
@@ -727,17 +755,23 @@ class Engine:
     # ------------------------------------------------------------------ consensus core
     def consensus(self, spectra, k, density_threshold=0.5, local_neighborhood_size=0.30,
                   skip_density=False, want_silhouette=False, random_state=1, n_init=10,
-                  max_iter=300, tol=1e-4, return_dist=False):
+                  max_iter=300, tol=1e-4, return_dist=False, store_rows=None):
         """Numerical core of ``cNMF.consensus`` (cnmf.py:871-916) on the device, float64.
 
-        ``spectra``: the merged per-restart spectra (R x G).  Returns a dict with
+        ``spectra``: the merged per-restart spectra (R x G) -- or ``None`` with ``store_rows`` (R row indices into the
+        context's resident spectra store, see ``nmf_batch(resident="keep")``): the merged spectra are then gathered on
+        the device, nothing is uploaded.  Returns a dict with
         ``local_density`` (R,), ``density_filter`` (R,) bool, ``labels`` (R,) int (0-based,
         -1 = filtered), ``median_spectra`` (k x G, rows sum to 1), ``inertia``,
         ``silhouette`` (if requested), ``topics_dist`` (R x R, if requested)."""
-        S = np.ascontiguousarray(spectra, dtype=np.float64)
-        if S.ndim != 2:
-            raise ValueError("spectra must be 2-D")
-        R, G = S.shape
+        if store_rows is not None:
+            rows = np.ascontiguousarray(store_rows, dtype=np.int64).ravel()
+            R, G = int(rows.size), self.spectra_genes
+        else:
+            S = np.ascontiguousarray(spectra, dtype=np.float64)
+            if S.ndim != 2:
+                raise ValueError("spectra must be 2-D")
+            R, G = S.shape
         k = int(k)
         n_neighbors = int(local_neighborhood_size * R / k)                 # cnmf.py:879
         L = 2 + int(np.log(k))
@@ -753,12 +787,13 @@ class Engine:
         dist = np.zeros((R, R), dtype=np.float64) if return_dist else None
         stats = np.zeros(4, dtype=np.float64)
         dblp, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
-        rc = self._lib.cnmf_consensus(self._ctx, S.ctypes.data_as(dblp), R, G, C.byref(prm),
-                                      u.ctypes.data_as(dblp), dens.ctypes.data_as(dblp),
-                                      keep.ctypes.data_as(i32p), labels.ctypes.data_as(i32p),
-                                      med.ctypes.data_as(dblp),
-                                      dist.ctypes.data_as(dblp) if return_dist else None,
-                                      stats.ctypes.data_as(dblp))
+        tail_args = (R, G, C.byref(prm), u.ctypes.data_as(dblp), dens.ctypes.data_as(dblp),
+                     keep.ctypes.data_as(i32p), labels.ctypes.data_as(i32p), med.ctypes.data_as(dblp),
+                     dist.ctypes.data_as(dblp) if return_dist else None, stats.ctypes.data_as(dblp))
+        if store_rows is not None:
+            rc = self._lib.cnmf_consensus_store(self._ctx, rows.ctypes.data_as(C.POINTER(C.c_int64)), *tail_args)
+        else:
+            rc = self._lib.cnmf_consensus(self._ctx, S.ctypes.data_as(dblp), *tail_args)
         if rc == -4 and b"Zero components remain" in self._lib.cnmf_last_error(self._ctx):
             raise RuntimeError("Zero components remain after density filtering. Consider increasing density threshold")
         self._check(rc)
@@ -874,9 +909,23 @@ class Engine:
 
     def spectra_reset(self):
         self._check(self._lib.cnmf_spectra_reset(self._ctx))
+        self.store_gen += 1                      # row indices handed out before this point are void
+
+    @property
+    def spectra_genes(self):
+        return int(self._lib.cnmf_spectra_genes(self._ctx))
+
+    def spectra_append(self, rows):
+        """Upload ``rows`` (n x G, float32) behind the store's content; returns the index of the first new row."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2:
+            raise ValueError("rows must be 2-D")
+        first = self.spectra_rows
+        self._check(self._lib.cnmf_spectra_append(self._ctx, _fp(rows), rows.shape[0], rows.shape[1]))
+        return first
 
     def spectra_fetch(self):
-        out = np.empty((self.spectra_rows, self.shape[1]), dtype=np.float32)
+        out = np.empty((self.spectra_rows, self.spectra_genes), dtype=np.float32)
         if out.size:
             self._check(self._lib.cnmf_spectra_fetch(self._ctx, _fp(out)))
         return out

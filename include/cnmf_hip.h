@@ -255,6 +255,22 @@ int cnmf_allgather_spectra(cnmf_ctx* ctx, const float* local, int64_t rows_local
 int64_t cnmf_spectra_rows(const cnmf_ctx* ctx);
 int cnmf_spectra_reset(cnmf_ctx* ctx);
 int cnmf_spectra_fetch(cnmf_ctx* ctx, float* out /* [rows][G] */);
+/* gene count of the rows in the store (round 4: the store outlives cnmf_set_matrix -- consensus() alternates between the
+ * normalised counts and the TPM matrix while the spectra keep serving k selection and further consensus calls) */
+int64_t cnmf_spectra_genes(const cnmf_ctx* ctx);
+/* append rows [n_rows][n_genes] (float32) to the store: merged spectra read from the reference's files or gathered from
+ * other GPUs, uploaded once for any number of cnmf_consensus_store calls (other k, other density thresholds)         */
+int cnmf_spectra_append(cnmf_ctx* ctx, const float* rows, int64_t n_rows, int64_t n_genes);
+/* cnmf_consensus / cnmf_kselect_stats with the merged spectra taken from the RESIDENT store instead of a host buffer:
+ * store_rows[r] = row of the store holding merged row r (float32 there, widened to float64 on the device) -- what
+ * combine_nmf (cnmf.py:748-773) would have concatenated, without the trip through the host.                   */
+int cnmf_consensus_store(cnmf_ctx* ctx, const int64_t* store_rows, int R, int G,
+                         const cnmf_consensus_params* params, const double* uniforms,
+                         double* density_out, int32_t* keep_out, int32_t* labels_out,
+                         double* median_out, double* dist_out, double* stats_out);
+int cnmf_kselect_stats_store(cnmf_ctx* ctx, int n, const int32_t* ks, const int32_t* R, const int64_t* store_rows,
+                             const cnmf_consensus_params* cprm, const double* uniforms, const cnmf_cd_params* prm,
+                             double* silhouette_out, double* pred_err_out, double* median_out, int32_t* nnls_iter_out);
 
 /* ---- consensus tail + k selection on the device ------------------------------------------------------------ */
 /* out[k][G] (float64) = W^T . X, or W^T . zscore(X) with z = (x - mean[g]) * inv_std[g]: the X^T Y accumulation of

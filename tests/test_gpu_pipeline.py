@@ -157,3 +157,49 @@ def test_device_normalisation_matches_get_norm_counts(engine, tmp_path):
     for key in obj2.spectra_cache:
         a, b = np.asarray(obj.spectra_cache[key]), np.asarray(obj2.spectra_cache[key])
         assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
+
+
+def test_merged_spectra_served_from_the_device_store(tmp_path, gold, engine):
+    """Round 4: factorize keeps the spectra in the engine's resident store (``nmf_batch(resident="keep")``); k selection and
+    consensus of the same process gather their merged spectra ON THE DEVICE (``cnmf_kselect_stats_store`` /
+    ``cnmf_consensus_store``) instead of uploading them -- with bit-identical results to the upload path, which a fresh
+    object reading the files takes; the store survives the TPM upload in between; a new prepare voids it."""
+    g = gold
+    nc = pd.DataFrame(g["norm_counts"], index=["c%d" % i for i in range(g["norm_counts"].shape[0])], columns=list(g["genes"]))
+    tpm = pd.DataFrame(g["tpm"], index=nc.index, columns=list(g["tpm_genes"]))
+    a = cNMF(output_dir=str(tmp_path), name="dev", engine=engine)
+    a.prepare_from_matrix(nc, components=[4, 5], n_iter=6, seed=14, beta_loss="frobenius", tpm=tpm)
+    engine.spectra_reset()
+    a.factorize()
+    assert engine.spectra_rows == 6 * (4 + 5) and engine.spectra_genes == nc.shape[1]
+    # the store holds exactly what came back to the host
+    store = engine.spectra_fetch()
+    for (k, it), (off, gen) in a._store_rows.items():
+        assert gen == engine.store_gen and np.array_equal(store[off:off + k], a.spectra_cache[(k, it)].astype(np.float32))
+    a.combine()
+    calls = []
+    real_cons, real_ksel = engine.consensus, engine.kselect_stats
+    engine.consensus = lambda *x, **kw: (calls.append(("consensus", kw.get("store_rows") is not None)), real_cons(*x, **kw))[1]
+    engine.kselect_stats = lambda *x, **kw: (calls.append(("kselect", kw.get("store_rows_by_k") is not None)), real_ksel(*x, **kw))[1]
+    try:
+        stats_a = a.k_selection_stats()
+        med_a, use_a = a.consensus(5, density_threshold=0.5)         # uploads the TPM matrix behind the core ...
+        med_a4, _ = a.consensus(4, density_threshold=2.0)            # ... and the store still serves the next k
+        assert calls == [("kselect", True), ("consensus", True), ("consensus", True)], calls
+        # a fresh object on the same directory: merged spectra from the files, uploaded
+        calls.clear()
+        b = cNMF(output_dir=str(tmp_path), name="dev", engine=engine)
+        stats_b = b.k_selection_stats()
+        med_b, use_b = b.consensus(5, density_threshold=0.5)
+        med_b4, _ = b.consensus(4, density_threshold=2.0)
+        assert [c[1] for c in calls] == [False, False, False], calls
+    finally:
+        engine.consensus, engine.kselect_stats = real_cons, real_ksel
+    assert np.array_equal(stats_a.values, stats_b.values)
+    assert np.array_equal(med_a.values, med_b.values) and np.array_equal(use_a.values, use_b.values)
+    assert np.array_equal(med_a4.values, med_b4.values)
+    # a new prepare voids the store rows
+    a.prepare_from_matrix(nc, components=[4], n_iter=2, seed=3, beta_loss="frobenius", tpm=tpm)
+    assert a._store_rows == {} and engine.spectra_rows == 0
+    with pytest.raises(ValueError):
+        engine.consensus(None, 4, store_rows=[0, 1, 2, 3, 4, 5, 6, 7])      # nothing there any more
