@@ -56,9 +56,10 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf
 #   3  : count-structured X = (integers <= 256) x per-gene scale -> ONE integer plane, (ah + am + al)*n, all exact
 #   4  : the same on the f16 pipe (kernels_gemm2h.hip.h): counts <= 2048 in one f16 plane, the factor as TWO f16 planes
 #        with a per-row exponent (within 1 ulp_f32 of the f32 value, exact for 3 in 4), partial products exact
-#   5  : any other X on the f16 pipe: X and the factor both as two f16 planes with a per-row exponent, all four plane
-#        products (the 3 x 3 bf16 scheme of modes 1/2 drops the terms below 2^-18)
-SPLIT_MFMAS_PER_PRODUCT = {1: 6, 2: 6, 3: 3, 4: 2, 5: 4}
+#   5  : any other X on the f16 pipe: X and the factor both as two f16 planes with a per-row exponent; round 4: three of
+#        the four plane products (x_m . f_m <= 2^-22 of the product is not formed; the 3 x 3 bf16 scheme of modes 1/2 drops
+#        the terms below 2^-18); CNMF_G2_GEN4=1 brings the fourth back
+SPLIT_MFMAS_PER_PRODUCT = {1: 6, 2: 6, 3: 3, 4: 2, 5: 4 if os.environ.get("CNMF_G2_GEN4") else 3}
 HBM_PEAK_GBS = 8000.0
 # device sources whose text the committed PMC / ablation profiles describe: a profile taken from other sources is stale
 PROFILED_SOURCES = ("cnmf_amd/csrc/kernels_gemm2h.hip.h", "cnmf_amd/csrc/kernels_sweep.hip.h",
@@ -374,7 +375,7 @@ def consensus_wallclock(eng, with_cpu=True):
 def general_path_step(X, ks_all, by_k, restarts_per_k, event_stride):
     """The same step on a matrix that is NOT count-structured as far as the engine is concerned (count detection off:
     what a Harmony-corrected or TPM-normalised input gets, reference preprocess.py:270-358): X itself as two f16
-    planes with a per-row exponent, 4 MFMAs per f32-class product (gemm_mode 5).  Bounded (restarts_per_k restarts per K)."""
+    planes with a per-row exponent, 3 MFMAs per f32-class product (gemm_mode 5).  Bounded (restarts_per_k restarts per K)."""
     from cnmf_amd.engine import Engine
     N, G = X.shape
     eng = Engine(0, detect_counts=False)
@@ -722,9 +723,9 @@ def main():
             # scheme in f32-equivalent flops is the dense peak / that
             peak = BF16_MFMA_PEAK_TFLOPS / per_product
             if agg["gemm_mode"] == 5:
-                kern = ("gemm2h_streamk_kernel<1, HI> (pass A: X.Ht; X and the factor as 2 f16 planes each, 4 MFMAs per product)"
+                kern = ("gemm2h_streamk_kernel<1, HI> (pass A: X.Ht; X and the factor as 2 f16 planes each, 3 MFMAs per product)"
                         if dom == "A" else
-                        "gemm2h_kernel<1, HI> (pass B: Xt.W; X and the factor as 2 f16 planes each, 4 MFMAs per product)")
+                        "gemm2h_kernel<1, HI> (pass B: Xt.W; X and the factor as 2 f16 planes each, 3 MFMAs per product)")
             elif agg["gemm_mode"] == 4:
                 kern = ("gemm2h_streamk_kernel (pass A: X.Ht; X = one integer f16 plane x per-gene scale, factor = 2 f16 planes)"
                         if dom == "A" else

@@ -56,17 +56,30 @@ def save_df_to_npz_fast(obj, filename, sibling_ok=False):
         np.savez(filename, data_file=np.array(os.path.basename(sibling)), index=obj.index.values, columns=obj.columns.values)
     else:
         np.savez(filename, data=data, index=obj.index.values, columns=obj.columns.values)
+        stale = filename + ".data.npy"                       # (left by an earlier, larger matrix under the same name)
+        if os.path.exists(stale):
+            os.remove(stale)
 
 
 def save_df_to_text(obj, filename):
     """cnmf.py:34-35: ``obj.to_csv(filename, sep='\\t')``.  All-float64 frames with plain labels (the usages: cells x k)
     are formatted here -- the same bytes (shortest round-trip repr per value, like pandas' float -> str), a quarter of the
     time; anything else (other dtypes, missing values, labels that would need quoting) goes through pandas."""
-    vals = obj.values
-    labels = [str(c) for c in obj.columns] + [str(i) for i in obj.index]
-    plain = (isinstance(obj, pd.DataFrame) and vals.ndim == 2 and vals.dtype == np.float64 and obj.index.nlevels == 1
-             and obj.columns.nlevels == 1 and obj.index.name is None and obj.columns.name is None and vals.size > 0
-             and np.isfinite(vals).all() and not any(ch in lab for lab in labels for ch in "\t\n\r\"") and "" not in labels)
+    def _plain_axis(ax):
+        # labels whose str() IS what pandas writes: python str objects or integers, no nulls (None / NaN become '' in
+        # to_csv, timestamps lose their midnight time) -- anything else goes through pandas
+        if ax.nlevels != 1 or ax.name is not None:
+            return False
+        if ax.dtype.kind in "iu":
+            return True
+        return ax.dtype == object and all(type(v) is str for v in ax.values)
+
+    plain = isinstance(obj, pd.DataFrame) and _plain_axis(obj.index) and _plain_axis(obj.columns)
+    if plain:
+        vals = obj.values
+        labels = [str(c) for c in obj.columns] + [str(i) for i in obj.index]
+        plain = (vals.ndim == 2 and vals.dtype == np.float64 and vals.size > 0 and np.isfinite(vals).all()
+                 and not any(ch in lab for lab in labels for ch in "\t\n\r\"") and "" not in labels)
     if not plain:
         obj.to_csv(filename, sep="\t")
         return
@@ -277,7 +290,11 @@ class cNMF:
         """Stand-in for the tail of ``prepare`` (cnmf.py:452-459): persist the already
         normalised cells x HVG matrix (DataFrame or ndarray) and write the restart ledger +
         run parameters exactly as the reference does.  Raises the reference's zero-count
-        error (cnmf.py:551-554)."""
+        error (cnmf.py:551-554).
+
+        The object keeps REFERENCES to ``norm_counts`` and to the arrays of a sparse ``tpm`` (so that factorize / consensus of
+        this process need not read back what was just written: 0.8 GB at 50 000 x 2 000): do not modify them in place
+        afterwards -- the files on disk would no longer be what this process computes on.  Pass copies if you must."""
         if not isinstance(norm_counts, pd.DataFrame):
             norm_counts = pd.DataFrame(np.asarray(norm_counts),
                                        index=["cell%d" % i for i in range(np.shape(norm_counts)[0])],

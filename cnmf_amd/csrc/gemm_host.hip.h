@@ -408,7 +408,7 @@ static int g2_var()
 
 static inline unsigned long long g2_full_mask(int KC) { const int t = KC / 32; return t >= 64 ? ~0ull : ((1ull << t) - 1ull); }
 
-template <int NSUB, bool HI, int VAR = 0, bool PART = false>
+template <int NSUB, bool HI, int VAR = 0, bool PART = false, bool GEN = false>
 static hipError_t launch_gemm2h_t(hipStream_t st, const unsigned char* A2, const unsigned char* B1,
                                   const unsigned char* Bhi, const unsigned int* hiflag, const float* rscale, int Kb,
                                   float* C, int ldc, long long cstride, int KC, int Jpad, int nsplit,
@@ -416,12 +416,12 @@ static hipError_t launch_gemm2h_t(hipStream_t st, const unsigned char* A2, const
 {
     constexpr int lds = g2_lds_bytes(NSUB, HI);
     {
-        if (hipError_t e_ = dyn_lds_optin((const void*)gemm2h_kernel<NSUB, HI, VAR, PART>, lds)) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm2h_kernel<NSUB, HI, VAR, PART, GEN>, lds)) return e_;
     }
     int kb_per = (Kb + nsplit - 1) / nsplit;
     kb_per = ((kb_per + NSUB - 1) / NSUB) * NSUB;            // whole steps
     dim3 grid(Jpad / G3C_JW, KC / G3_MW, (Kb + kb_per - 1) / kb_per);
-    gemm2h_kernel<NSUB, HI, VAR, PART><<<grid, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, kb_per, cscale, livemask);
+    gemm2h_kernel<NSUB, HI, VAR, PART, GEN><<<grid, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, kb_per, cscale, livemask);
     return hipGetLastError();
 }
 
@@ -440,6 +440,11 @@ static hipError_t launch_gemm2h(hipStream_t st, const unsigned char* A2, const u
 {
     // livemask: bit t = the 32 packed columns 32 t .. 32 t + 31 hold a restart that still iterates (all ones: everything)
     const bool part = (livemask & g2_full_mask(KC)) != g2_full_mask(KC);
+    // general matrices (cscale != nullptr: X as two f16 planes) multiply three of the four plane pairs (GEN); CNMF_G2_GEN4=1: all four (A/B)
+    static const bool gen4 = getenv("CNMF_G2_GEN4") != nullptr;
+    if (Bhi && cscale && !gen4)
+        return part ? launch_gemm2h_t<1, true, 0, true, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale, livemask)
+                    : launch_gemm2h_t<1, true, 0, false, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale);
     if (Bhi) return part ? launch_gemm2h_t<1, true, 0, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale, livemask)
                          : launch_gemm2h_t<1, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale);
     if (cscale) return hipErrorInvalidValue;              // a column scale exists only on the two-plane operand path
@@ -459,7 +464,7 @@ static hipError_t launch_gemm2h(hipStream_t st, const unsigned char* A2, const u
 }
 static int gemm2h_nsub(bool hi, int Kb) { return (!hi && g2_nsub() == 2 && Kb % 2 == 0) ? 2 : 1; }
 
-template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false>
+template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false, bool GEN = false>
 static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, const unsigned char* A2,
                                           const unsigned char* B1, const unsigned char* Bhi,
                                           const unsigned int* hiflag, const float* rscale, int Kb, float* C0, float* C1,
@@ -468,10 +473,10 @@ static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, co
 {
     constexpr int lds = g2_lds_bytes(NSUB, HI);
     {
-        if (hipError_t e_ = dyn_lds_optin((const void*)gemm2h_streamk_kernel<NSUB, HI, VAR, NTB, PART>, lds)) return e_;
+        if (hipError_t e_ = dyn_lds_optin((const void*)gemm2h_streamk_kernel<NSUB, HI, VAR, NTB, PART, GEN>, lds)) return e_;
     }
     static const int xmap = getenv("CNMF_G2_XMAP") ? atoi(getenv("CNMF_G2_XMAP")) : 1;      // (0: A/B, the identity order)
-    gemm2h_streamk_kernel<NSUB, HI, VAR, NTB, PART><<<sk.P, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T, xmap, cscale, livemask);
+    gemm2h_streamk_kernel<NSUB, HI, VAR, NTB, PART, GEN><<<sk.P, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T, xmap, cscale, livemask);
     return hipGetLastError();
 }
 
@@ -485,6 +490,12 @@ static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, cons
     // several component groups share every count-plane tile in the L2: no non-temporal loads then (CNMF_G2_NT=1: A/B)
     static const bool force_nt = getenv("CNMF_G2_NT") != nullptr;
     const bool shared = sk.MG > 1 && !force_nt;
+    static const bool gen4 = getenv("CNMF_G2_GEN4") != nullptr;
+    if (Bhi && cscale && !gen4) {          // general matrices: three of the four plane pairs (GEN)
+        if (part) return launch_gemm2h_streamk_t<1, true, 0, false, true, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale, livemask);
+        return shared ? launch_gemm2h_streamk_t<1, true, 0, false, false, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale)
+                      : launch_gemm2h_streamk_t<1, true, 0, true, false, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale);
+    }
     if (Bhi) {
         if (part) return launch_gemm2h_streamk_t<1, true, 0, false, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale, livemask);
         return shared ? launch_gemm2h_streamk_t<1, true, 0, false>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale)

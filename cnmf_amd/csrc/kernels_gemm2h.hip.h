@@ -433,7 +433,11 @@ __device__ __forceinline__ void glds16_asm_nt(const void* gsrc, unsigned lds_dst
 // multiplied and stored -- the tail of a call, when restarts have finished and nothing is left to refill their columns:
 // a wave skips the MFMAs of its dead tiles (wave-uniform scalar branches), so a pass costs what its live columns cost,
 // down to the floor of streaming the count plane.  The operand traffic is unchanged.
-template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false>
+// GEN (round 4, general matrices = X itself as two f16 planes, HI instantiation): the product of the two SMALL planes,
+// x_m . f_m, is not formed -- |x_m| <= 2^-11 |x_h| and |f_m| <= 2^-11 |f_h|, so the term is <= 2^-22 of the product, random
+// in sign, against the 2^-24 rounding of every float32 accumulation step (and 16 x below the 2^-18 the 3 x 3 bf16 planes of
+// rounds 1-2 dropped): 3 MFMAs per product instead of 4.  The count path (HI there = a second EXACT integer plane) keeps all.
+template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false, bool GEN = false>
 __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__ A2, const unsigned char* __restrict__ B1,
                                                const unsigned char* __restrict__ Bhi,
                                                const unsigned int* __restrict__ hiflag,
@@ -533,10 +537,11 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
     acc[m_][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[u_][m_][q_], b_[u_][1], acc[m_][1], 0, 0, 0); }
 #define G2_MFMA4(b_, u_, ma_, mb_)                                                                 \
     G2_MFMA(b_, u_, ma_, 1) G2_MFMA(b_, u_, mb_, 1) G2_MFMA(b_, u_, ma_, 0) G2_MFMA(b_, u_, mb_, 0)
+#define G2_MFMA2H(b_, u_, ma_, mb_) G2_MFMA(b_, u_, ma_, 0) G2_MFMA(b_, u_, mb_, 0)
 #define G2_HALF(ma_, mb_)                                                                          \
     _Pragma("unroll") for (int u = 0; u < NSUB; ++u) {                                             \
         G2_MFMA4(bq, u, ma_, mb_)                                                                  \
-        if (HI) { if (hi_blk[u]) { G2_MFMA4(bh, u, ma_, mb_) } }                                   \
+        if (HI) { if (hi_blk[u]) { if constexpr (GEN) { G2_MFMA2H(bh, u, ma_, mb_) } else { G2_MFMA4(bh, u, ma_, mb_) } } } \
     }
 // "the step after this one has landed; the ones behind it may stay in flight"
 #define G2_WAIT_AHEAD(cnt_)                                                                        \
@@ -669,6 +674,7 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
     if (grp == 0) G3_RAW_BARRIER()
 #undef G2_WAIT_AHEAD
 #undef G2_HALF
+#undef G2_MFMA2H
 #undef G2_MFMA4
 #undef G2_MFMA
 #undef G2_READ
@@ -696,7 +702,7 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
 }
 
 // pass B (and pass A on few tiles): split-K launch, XCD-aware order as gemm3c_kernel.  kb_per is a multiple of NSUB.
-template <int NSUB, bool HI, int VAR = 0, bool PART = false>
+template <int NSUB, bool HI, int VAR = 0, bool PART = false, bool GEN = false>
 __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __restrict__ A2,
                                                      const unsigned char* __restrict__ B1,
                                                      const unsigned char* __restrict__ Bhi,
@@ -720,12 +726,12 @@ __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __rest
     }
     const int kb0 = z * kb_per;
     const int nkb = min(kb_per, Kb - kb0);
-    gemm2h_segment<NSUB, HI, VAR, true, PART>(A2, B1, Bhi, hiflag, rscale, Kb, C + (size_t)z * c_split_stride, ldc, mg * G3_MW,
+    gemm2h_segment<NSUB, HI, VAR, true, PART, GEN>(A2, B1, Bhi, hiflag, rscale, Kb, C + (size_t)z * c_split_stride, ldc, mg * G3_MW,
                                               jt * G3C_JW, kb0, nkb, smem3, cscale, (unsigned)((livemask >> (8 * mg)) & 0xffu));
 }
 
 // pass A: stream-K over persistent workgroups, unit = one step of NSUB blocks (Kb % NSUB == 0)
-template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false>
+template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false, bool GEN = false>
 __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char* __restrict__ A2,
                                                              const unsigned char* __restrict__ B1,
                                                              const unsigned char* __restrict__ Bhi,
@@ -754,7 +760,7 @@ __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char
         const int tile = (int)(u / Ks), ks = (int)(u % Ks);
         const int ke = (int)min((long long)Ks, ks + (u1 - u));
         const int mg = tile / NJ, jt = tile % NJ;
-        gemm2h_segment<NSUB, HI, VAR, NTB, PART>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
+        gemm2h_segment<NSUB, HI, VAR, NTB, PART, GEN>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
                                                  jt * G3C_JW, ks * NSUB, (ke - ks) * NSUB, smem3, cscale,
                                                  (unsigned)((livemask >> (8 * mg)) & 0xffu));
         u += ke - ks;

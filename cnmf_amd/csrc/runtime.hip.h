@@ -12,7 +12,7 @@ struct Arena {
     struct Block { char* p; size_t cap, used; };
     std::vector<Block> blocks;
     hipError_t err = hipSuccess;
-    static constexpr size_t keep_limit = (size_t)8 << 30;
+    static constexpr size_t keep_limit = (size_t)2 << 30;      // (the R x R distance matrix of a large consensus is given back)
     void reset() { err = hipSuccess; for (Block& b : blocks) b.used = 0; }
     size_t total() const { size_t t = 0; for (const Block& b : blocks) t += b.cap; return t; }
     void release() { for (Block& b : blocks) hipFree(b.p); blocks.clear(); }

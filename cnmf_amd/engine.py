@@ -887,7 +887,7 @@ class Engine:
         (``local`` [rows, G], or ``None`` for the context's resident store) zero-padded to
         ``rows_max`` rows.  Returns ``[world, rows_max, G]`` float32."""
         if local is None:
-            rows, G = self.spectra_rows, self.shape[1]
+            rows, G = self.spectra_rows, (self.spectra_genes or self.shape[1])
             lp = None
         else:
             local = np.ascontiguousarray(local, dtype=np.float32)

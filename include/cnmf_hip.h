@@ -188,7 +188,13 @@ int cnmf_nnls(cnmf_ctx* ctx, int k, const float* H /*[k][G]*/, const cnmf_cd_par
  * Outputs: density_out[R] (NULL ok; zeros when skip_density), keep_out[R] 0/1 (NULL ok),
  *   labels_out[R] (0..k-1, -1 for filtered rows), median_out[k][G], dist_out[R][R] (NULL ok),
  *   stats_out[4] = {rows kept, best inertia, silhouette (0 unless want_silhouette), n_iter of best run}.
- * Returns CNMF_ESTATE with the reference's message when the filter removes every row (:905-906). */
+ * Returns CNMF_ESTATE with the reference's message when the filter removes every row (:905-906).
+ * Device memory: the float64 distance matrix is ALWAYS formed (k-means++ reads its squared distances from it, also with
+ * skip_density): 8 R_pad^2 bytes (R_pad = R rounded up to 64: 0.2 GB at R = 5 000, 3.2 GB at R = 20 000) + ~24 R G
+ * bytes of spectra copies; a call that leaves more than 2 GB in the context's workspace releases it on return.
+ * k-means++ takes the squared distance of two rows as (Euclidean distance)^2 of the UNcentred rows where scikit-learn
+ * subtracts the column means first: the same number up to the last bits, so the labels are scikit-learn's except where a
+ * draw falls within rounding of a tie. */
 typedef struct cnmf_consensus_params {
     int    k;
     int    n_neighbors;        /* int(local_neighborhood_size * R / k), cnmf.py:879 */

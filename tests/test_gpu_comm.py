@@ -53,9 +53,18 @@ def test_rccl_communicator_world1_and_resident_store(tmp_path):
             eng.allgather_spectra(None, rows_max=3)                        # rows_max < rows held
         eng.comm_finalize()
         assert eng.comm_world == 1
-        # a new matrix invalidates the store
+        # round 4: the store outlives a change of matrix (consensus() alternates between the normalised counts and the TPM
+        # matrix while the spectra keep serving k selection / further consensus calls) and carries its own gene count;
+        # a batch over ANOTHER gene count refuses to append until the store is reset
         eng.set_matrix(X[:100])
-        assert eng.spectra_rows == 0
+        assert eng.spectra_rows == sum(ks) and eng.spectra_genes == X.shape[1]
+        assert np.array_equal(eng.spectra_fetch(), ref)
+        eng.set_matrix(np.ascontiguousarray(X[:, :300]))
+        with pytest.raises(RuntimeError):
+            eng.nmf_batch([4], seeds=[3], resident=True)
+        eng.spectra_reset()
+        eng.nmf_batch([4], seeds=[3], resident=True)
+        assert eng.spectra_rows == 4 and eng.spectra_genes == 300
 
 
 def _bench(args, env, timeout=900):

@@ -70,6 +70,12 @@ def test_text_writer_is_byte_identical_to_pandas(tmp_path):
         "nan": pd.DataFrame(np.where(v > 100, np.nan, v), index=["c%d" % i for i in range(400)], columns=np.arange(1, 8)),
         "tab": pd.DataFrame(v[:3], index=["a\tb", 'q"x', "plain"], columns=np.arange(1, 8)),
         "named": pd.DataFrame(v[:3], index=pd.Index(["a", "b", "c"], name="cell"), columns=np.arange(1, 8)),
+        # labels whose str() is NOT what pandas writes (round-3 advisor): None / NaN -> '', timestamps drop midnight
+        "none_label": pd.DataFrame(v[:3], index=["a", None, "c"], columns=np.arange(1, 8)),
+        "nan_label": pd.DataFrame(v[:3], index=pd.Index(["a", np.nan, "c"], dtype=object), columns=np.arange(1, 8)),
+        "dates": pd.DataFrame(v[:3], index=pd.date_range("2020-01-01", periods=3), columns=np.arange(1, 8)),
+        "float_labels": pd.DataFrame(v[:3], index=[0.5, 1.0, 2.0], columns=np.arange(1, 8)),
+        "series": pd.Series(v[:5, 0], index=["a", "b", "c", "d", "e"]),
     }
     for name, df in frames.items():
         got, ref = str(tmp_path / (name + ".got.txt")), str(tmp_path / (name + ".ref.txt"))
