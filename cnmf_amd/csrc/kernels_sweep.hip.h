@@ -696,15 +696,24 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, int slot, i
             const int r = e / k, c = e % k;
             const size_t gsz = (size_t)gld * gld;
             const float* gp = gram_part + (size_t)slot * nparts * gsz + r * gld + c;
+            // the partials of up to 32 workgroups are requested together, then added in the order of the plain loop
+            // (s_j += part[4 i + j]; the remainder into s0): this launch is pure latency -- 49 partials fetched four
+            // at a time were twelve dependent round trips (~10 of the launch's 13 us, twice per iteration)
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int pI = 0;
-            for (; pI + 4 <= nparts; pI += 4) {
-                s0 += gp[(size_t)pI * gsz];
-                s1 += gp[(size_t)(pI + 1) * gsz];
-                s2 += gp[(size_t)(pI + 2) * gsz];
-                s3 += gp[(size_t)(pI + 3) * gsz];
+            const int n4 = nparts & ~3;
+            for (int p0 = 0; p0 < nparts; p0 += 32) {
+                float v[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) v[j] = gp[(size_t)min(p0 + j, nparts - 1) * gsz];
+#pragma unroll
+                for (int j = 0; j < 32; j += 4) {
+                    if (p0 + j + 4 <= n4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (p0 + j + q >= n4 && p0 + j + q < nparts) s0 += v[j + q];
+                    }
+                }
             }
-            for (; pI < nparts; ++pI) s0 += gp[(size_t)pI * gsz];
             float s = (s0 + s1) + (s2 + s3);
             if (r == c) s += l2_reg;
             gram_out[(size_t)slot * GRAM_SZ + r * GRAM_LD + c] = s;
