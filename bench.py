@@ -840,6 +840,22 @@ def main():
         if emu:
             out["config"]["emulated_shard"] = {"rank": emu[0], "world": emu[1],
                                                "note": "single GPU running only the shard that rank would own"}
+        if world == 1 and not emu and not args.no_extras and gather_mode == "none":
+            # the same job once more WITH queue hints (what the timed steps learned about the iterations per rank, handed back
+            # explicitly: Engine.set_iteration_hints) -- reported beside the headline, never part of it: the headline steps
+            # each learn their queue order from scratch
+            eng.set_iteration_hints(eng.iteration_means())
+            try:
+                th = time.perf_counter()
+                ks_h, st_h, _ = run_step(args.warmup, False)
+                dt_h = time.perf_counter() - th
+            finally:
+                eng.set_iteration_hints(None)
+            out["with_queue_hints"] = {"restarts_per_s": len(ks_h) / dt_h, "ms_per_step": 1e3 * dt_h,
+                                       "tail_share_of_gpu_time": st_h["tail_ms"] / max(st_h["gpu_ms"], 1e-9),
+                                       "column_utilisation": int(st_h["restart_column_iterations"]) / max(int(st_h["column_iterations"]), 1),
+                                       "note": "one more step of the same job with cnmf_set_iteration_hints(cnmf_get_iteration_means()); "
+                                               "not the headline"}
         if world == 1 and not emu:
             cpu = None
             if not args.no_cpu_baseline:

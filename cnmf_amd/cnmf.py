@@ -159,6 +159,7 @@ class cNMF:
         self.compress_merged = compress_merged
         self.last_factorize_stats = None
         self.last_factorize_jobs = []
+        self.learned_iterations = {}     # rank -> mean outer iterations the last factorize saw (queue hints for the next one)
 
     # ------------------------------------------------------------------ paths (cnmf.py:298-330)
     def _initialize_dirs(self):
@@ -456,7 +457,10 @@ class cNMF:
 
     # ------------------------------------------------------------------ factorize (cnmf.py:692-745)
     def factorize(self, worker_i=0, total_workers=1, skip_completed_runs=False, write_iter_files=True,
-                  kc_max=0):
+                  kc_max=0, iteration_hints=None):
+        """cnmf.py:692-745: ONE batched device call for this worker's ledger rows.  ``iteration_hints`` ({rank: expected
+        outer iterations}, e.g. ``self.learned_iterations`` of an earlier factorize on the same data): the queue starts
+        longest-expected-first (Engine.set_iteration_hints); results then differ from an unhinted call in the last bits."""
         import time as _time
         _t = [_time.perf_counter()]
         run_params = load_df_from_npz(self.paths["nmf_replicate_parameters"])
@@ -494,8 +498,16 @@ class cNMF:
             # the spectra also stay in the engine's device store: k selection and consensus of THIS process take their
             # merged spectra from there (no 80 MB upload per consensus call; round-3 review, next #9)
             keep = hasattr(eng, "spectra_fetch")
-            H_list, _, n_iter, _ = eng.nmf_batch(ks, kc_max=kc_max, resident="keep" if keep else False, **init_kw, **common)
+            if iteration_hints is not None:
+                eng.set_iteration_hints(iteration_hints)
+            try:
+                H_list, _, n_iter, _ = eng.nmf_batch(ks, kc_max=kc_max, resident="keep" if keep else False, **init_kw, **common)
+            finally:
+                if iteration_hints is not None:
+                    eng.set_iteration_hints(None)
             self.last_factorize_stats = dict(eng.last_stats, n_iter=n_iter)
+            if hasattr(eng, "iteration_means"):
+                self.learned_iterations = eng.iteration_means()
             if keep:
                 for k, it, off in zip(ks, its, eng.last_store_offsets):
                     self._store_rows[(k, it)] = (int(off), eng.last_store_gen)

@@ -388,13 +388,13 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     // CNMF_QUEUE=rank restores the plain descending-rank order (A/B).
     std::vector<int> order(n);
     const bool queue_by_rank = getenv("CNMF_QUEUE") && !strcmp(getenv("CNMF_QUEUE"), "rank");
-    // round 4: what earlier calls on this matrix learned (mean iterations per rank, same tol / max_iter) orders the queue
-    // from the start -- a k-selection sweep, a second factorize with more restarts, the steps of a benchmark do not have to
-    // re-learn that k = 13 runs 1000 iterations and k = 9 runs 37.  CNMF_NO_PRIOR=1: A/B.
-    static const bool no_prior = getenv("CNMF_NO_PRIOR") != nullptr;
-    const bool have_prior = !no_prior && ctx->iter_prior.size() == (size_t)KMAX + 1 && ctx->prior_tol == prm->tol &&
-                            ctx->prior_max_iter == prm->max_iter;
-    auto prior_of = [&](int k) { return have_prior ? ctx->iter_prior[k] : 0.0; };
+    // round 4: the caller's iteration hints (cnmf_set_iteration_hints: mean iterations per rank, e.g. what an earlier call
+    // on this matrix learned -- cnmf_get_iteration_means) order the queue from the start: a second factorize with more
+    // restarts, a resumed ledger do not have to re-learn that k = 13 runs 1000 iterations and k = 9 runs 37.  Explicit only:
+    // the order decides the packed columns a restart occupies and with them the last bits of its float32 result
+    // (tests/test_gpu_determinism.py); without hints a call's result depends on its own arguments alone.
+    const bool have_prior = ctx->iter_hint.size() == (size_t)KMAX + 1;
+    auto prior_of = [&](int k) { return have_prior ? ctx->iter_hint[k] : 0.0; };
     if (queue_by_rank) {
         for (int r = 0; r < n; ++r) order[r] = r;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kk[a] > kk[b]; });
@@ -932,15 +932,10 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         HIP_TRY(ctx, hipMemcpyAsync(W_out, d_Wres, woff[n] * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (resident) ctx->spectra_rows += (size_t)total_k;
-    {   // remember the mean iteration count per rank for the next call on this matrix
-        if (ctx->iter_prior.size() != (size_t)KMAX + 1 || ctx->prior_tol != prm->tol || ctx->prior_max_iter != prm->max_iter)
-            ctx->iter_prior.assign((size_t)KMAX + 1, 0.0);
-        ctx->prior_tol = prm->tol; ctx->prior_max_iter = prm->max_iter;
+    {   // the mean iteration count per rank this call saw (cnmf_get_iteration_means)
+        if (ctx->iter_prior.size() != (size_t)KMAX + 1) ctx->iter_prior.assign((size_t)KMAX + 1, 0.0);
         for (int k = 1; k <= KMAX; ++k)
-            if (k_done[k]) {
-                const double m = (double)k_iters[k] / (double)k_done[k];
-                ctx->iter_prior[k] = (k_done[k] >= 4 || ctx->iter_prior[k] <= 0) ? m : 0.5 * (m + ctx->iter_prior[k]);
-            }
+            if (k_done[k]) ctx->iter_prior[k] = (double)k_iters[k] / (double)k_done[k];
     }
     if (stats) {
         float ms = 0.f;
@@ -961,6 +956,29 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             stats->passA_ms += a; stats->passB_ms += b;
             stats->passA_launches++; stats->passB_launches++;
         }
+    }
+    return CNMF_OK;
+}
+
+// mean outer iterations per rank seen by the batch calls on the resident matrix: out[KMAX + 1], 0 = rank not seen
+extern "C" int cnmf_get_iteration_means(cnmf_ctx* ctx, double* out)
+{
+    if (!ctx || !out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    for (int k = 0; k <= KMAX; ++k) out[k] = (ctx->iter_prior.size() == (size_t)KMAX + 1) ? ctx->iter_prior[k] : 0.0;
+    return CNMF_OK;
+}
+
+// expected outer iterations per rank for the queue order of the following batch calls on this matrix (n pairs; n = 0
+// clears them; a new matrix clears them too)
+extern "C" int cnmf_set_iteration_hints(cnmf_ctx* ctx, int n, const int32_t* k, const double* mean_iterations)
+{
+    if (!ctx || n < 0 || (n > 0 && (!k || !mean_iterations))) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
+    ctx->iter_hint.clear();
+    if (n == 0) return CNMF_OK;
+    ctx->iter_hint.assign((size_t)KMAX + 1, 0.0);
+    for (int i = 0; i < n; ++i) {
+        if (k[i] < 1 || k[i] > KMAX || !(mean_iterations[i] >= 0)) { ctx->iter_hint.clear(); SET_ERR(ctx, "bad hint %d", i); return CNMF_EINVAL; }
+        ctx->iter_hint[k[i]] = mean_iterations[i];
     }
     return CNMF_OK;
 }

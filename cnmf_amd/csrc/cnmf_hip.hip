@@ -146,7 +146,7 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     ctx->C1 = ctx->Ct1 = ctx->C1h = ctx->Ct1h = nullptr; ctx->hiA = ctx->hiB = nullptr;
     ctx->d_scale = nullptr; ctx->count_state = 0; ctx->count_fmt = 0;
-    ctx->iter_prior.clear();          // iteration counts learned on another matrix say nothing about this one
+    ctx->iter_prior.clear(); ctx->iter_hint.clear();     // iteration counts of another matrix say nothing about this one
     // (the resident spectra store survives a change of matrix: consensus() alternates between the normalised counts and
     //  the TPM matrix while the spectra of the factorize call keep serving k selection and further consensus calls;
     //  the store carries its own gene count, and a batch over another gene count refuses to append to it)

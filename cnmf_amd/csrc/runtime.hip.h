@@ -85,10 +85,11 @@ struct cnmf_ctx {
     float* spectra = nullptr;
     size_t spectra_cap = 0, spectra_rows = 0;
     int64_t spectra_G = 0;             // gene count of the rows in the store (the matrix they were computed on)
-    // what earlier batch calls on THIS matrix learned about the restarts' length: mean outer iterations per rank (0 = nothing
-    // yet) under (prior_tol, prior_max_iter); the next call's queue starts longest-expected-first instead of learning again
-    std::vector<double> iter_prior;
-    double prior_tol = -1.0; int prior_max_iter = 0;
+    // what the batch calls on THIS matrix learned about the restarts' length: mean outer iterations per rank (0 = nothing
+    // yet; cnmf_get_iteration_means), and the caller's hints for the NEXT calls (cnmf_set_iteration_hints): with hints the
+    // queue starts longest-expected-first instead of learning the order again.  Never applied implicitly: the queue order
+    // decides the packed columns a restart occupies, and its float32 result moves in the last bits with them.
+    std::vector<double> iter_prior, iter_hint;
 
     Arena cons_ws;                    // consensus workspace (consensus_host.hip.h)
     void* cons_pinned = nullptr;      // pinned host block of the consensus calls (k-means state read-backs)

@@ -300,6 +300,23 @@ class Engine:
                           % max_iter, ConvergenceWarning)
         return H_list, W_list, n_iter, viol
 
+    def iteration_means(self):
+        """``{rank: mean outer iterations}`` of the restarts the batch calls on the resident matrix have run so far."""
+        out = np.zeros(_lib.CNMF_KMAX + 1, dtype=np.float64)
+        self._check(self._lib.cnmf_get_iteration_means(self._ctx, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return {int(k): float(v) for k, v in enumerate(out) if v > 0}
+
+    def set_iteration_hints(self, hints=None):
+        """Expected iterations per rank (e.g. :meth:`iteration_means` of an earlier call) for the queue order of the following
+        ``nmf_batch`` calls on this matrix -- longest-expected-first from the start instead of learning the order again;
+        ``None`` clears them.  Explicit by design: the order decides which packed columns a restart occupies, and its
+        float32 result moves in the last bits with its placement."""
+        hints = hints or {}
+        ks = np.ascontiguousarray(sorted(hints), dtype=np.int32)
+        vals = np.ascontiguousarray([hints[int(k)] for k in ks], dtype=np.float64)
+        self._check(self._lib.cnmf_set_iteration_hints(self._ctx, int(ks.size), ks.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                       vals.ctypes.data_as(C.POINTER(C.c_double))))
+
     # ------------------------------------------------------------------ multiplicative update
     _BETA = {"kullback-leibler": 1, "itakura-saito": 0, 1: 1, 0: 0, 1.0: 1, 0.0: 0}
 

@@ -149,6 +149,14 @@ int cnmf_nmf_cd_batch_resident(cnmf_ctx* ctx, int n_restarts, const int32_t* k,
                                const cnmf_cd_params* params,
                                int32_t* n_iter_out, double* viol_out,
                                cnmf_batch_stats* stats);
+/* Queue hints (round 4).  A batch call learns, per rank, the mean number of outer iterations its restarts took
+ * (cnmf_get_iteration_means: out[CNMF_KMAX + 1], 0 = rank not seen on this matrix).  Handing such numbers back with
+ * cnmf_set_iteration_hints makes the FOLLOWING calls on this matrix start their queue longest-expected-first instead of
+ * learning the order again (n = 0 clears the hints; so does a new matrix).  Never implicit: the queue order decides which
+ * packed columns a restart occupies, and its float32 result moves in the last bits (1e-6 relative) with its placement --
+ * without hints a call's result depends on its own arguments alone (bit for bit; tests/test_gpu_determinism.py). */
+int cnmf_get_iteration_means(cnmf_ctx* ctx, double* out);
+int cnmf_set_iteration_hints(cnmf_ctx* ctx, int n, const int32_t* k, const double* mean_iterations);
 
 /* ---- multiplicative-update solver --------------------------------------------------------
  * The reference keeps solver='mu' whenever beta_loss != 'frobenius' (cnmf.py:618-631):

@@ -2,12 +2,12 @@
 double buffering, one barrier per step) and the coordinate-descent batcher must return bit-identical results when the
 same call is repeated -- a missing barrier or a buffer hazard shows up here as a difference.
 
-Round 4: the coordinate-descent scheduler remembers, per matrix, how many iterations the restarts of each rank took and
-starts the next call's queue longest-expected-first.  The queue order decides which packed columns a restart occupies, and
-stream-K cuts a pass-A tile at a position that depends on the tile's place in the walk -- so the float32 summation of a
-product is split differently and a restart's result moves in its last bits (1e-6 relative) with its placement.  What must
-hold, and is tested: the SAME sequence of calls on a fresh context gives the same bits; from the second call on (same
-learned order) repeated calls are bit-identical; the first call differs from them by rounding only."""
+Round 4: queue hints (``Engine.set_iteration_hints``: expected iterations per rank, e.g. what an earlier call learned) make a
+call start its queue longest-expected-first.  The queue order decides which packed columns a restart occupies, and stream-K
+cuts a pass-A tile at a position that depends on the tile's place in the walk -- so the float32 summation of a product is
+split differently and a restart's result moves in its last bits (1e-6 relative) with its placement.  Hence the hints are
+never applied implicitly: repeated identical calls are bit-identical (tested first), with hints they stay bit-identical
+among themselves and differ from the unhinted call by rounding only."""
 import numpy as np
 import pytest
 
@@ -29,21 +29,26 @@ def test_repeated_batches_are_bit_identical(engine):
         Hc, _, nc, _ = engine.nmf_batch(ks * 4, seeds=list(range(500, 500 + 4 * len(ks))), max_iter=50, warn=False)
         return [np.concatenate([a.ravel() for a in part]) for part in (H, W, Hi, Wi, Hc)] + [n.copy(), ni.copy(), nc.copy(), np.asarray(err)]
 
-    first = run()
-    second = run()
-    third = run()
+    ref = run()
     names = ["H kl", "W kl", "H is", "W is", "H cd", "n kl", "n is", "n cd", "err kl"]
-    for name, a, b in zip(names, second, third):                  # same learned queue order: bit for bit
-        np.testing.assert_array_equal(a, b, err_msg=name)
-    for name, a, b in zip(names, first, second):
-        if name == "H cd":                                       # another placement in the packed columns: rounding only
-            assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max(), np.abs(a - b).max()
-        else:                                                    # the multiplicative-update batches do not depend on it
+    for _ in range(2):
+        for name, a, b in zip(names, ref, run()):
             np.testing.assert_array_equal(a, b, err_msg=name)
-    # the same sequence of calls on a FRESH context: the first call's bits again
-    from cnmf_amd.engine import Engine
-    with Engine(0) as fresh:
-        fresh.set_matrix(X)
-        H2, _, n2, _ = fresh.nmf_batch(ks * 4, seeds=list(range(500, 500 + 4 * len(ks))), max_iter=50, warn=False)
-        np.testing.assert_array_equal(np.concatenate([a.ravel() for a in H2]), first[4])
-        np.testing.assert_array_equal(n2, first[7])
+    # with hints: another queue order, another placement -- rounding-level differences in the CD restarts only, and
+    # bit-identical again among hinted calls
+    means = engine.iteration_means()
+    assert set(means) >= set(ks) and all(0 < v <= 50 for v in means.values())
+    engine.set_iteration_hints({k: 1000.0 / k for k in means})          # (an order that is certainly not the default one)
+    try:
+        h1, h2 = run(), run()
+    finally:
+        engine.set_iteration_hints(None)
+    for name, a, b in zip(names, h1, h2):
+        np.testing.assert_array_equal(a, b, err_msg=name)
+    for name, a, b in zip(names, ref, h1):
+        if name == "H cd":
+            assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max(), np.abs(a - b).max()
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=name)
+    for name, a, b in zip(names, ref, run()):                            # hints cleared: the first bits again
+        np.testing.assert_array_equal(a, b, err_msg=name)
