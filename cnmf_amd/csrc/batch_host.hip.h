@@ -9,7 +9,8 @@ static int sweep_max_parts()
     return std::max(1, v);
 }
 static int sweep_chunks(int L) { const int64_t m = 256ll * sweep_max_parts(); return std::max(1, (int)(((int64_t)L + m - 1) / m)); }
-static int sweep_parts(int L) { int c = sweep_chunks(L); return (L + 256 * c - 1) / (256 * c); }
+// partials per slot of a half-step: one per 256-row tile (round 4; the workgroups of a sweep walk sweep_chunks of them)
+static int sweep_parts(int L) { return std::max(1, (L + 255) / 256); }
 
 static int pick_nsplit(const cnmf_ctx* ctx, int KC)
 {
@@ -557,7 +558,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         }
         h3_valid = false;                 // rows of H moved: its planes are stale
         // moved rows of slots that no longer iterate are not swept again: refresh their row maxima here
-        if (use2h) HIP_TRY(ctx, launch_rowmax_part(st, ctx->Wt, ctx->N_pad, N, KC, chunksW * 256, nullptr, partsW, ctx->rmaxW));
+        if (use2h) HIP_TRY(ctx, launch_rowmax_part(st, ctx->Wt, ctx->N_pad, N, KC, 256, nullptr, partsW, ctx->rmaxW));
         return CNMF_OK;
     };
 
@@ -668,7 +669,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             // H3 was produced together with the previous iteration's H finalize; rows installed since then
             // (and the very first iteration) need a split of their own.  Count path: H' = H * d.
             if ((n_new > 0 || !h3_valid) && use2h) {
-                HIP_TRY(ctx, launch_rowmax_part(st, ctx->H, ctx->G_pad, G, KC, chunksH * 256, dsc, partsH, ctx->rmaxH));
+                HIP_TRY(ctx, launch_rowmax_part(st, ctx->H, ctx->G_pad, G, KC, 256, dsc, partsH, ctx->rmaxH));
                 HIP_TRY(ctx, launch_split2h(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, dsc, ctx->rmaxH,
                                             partsH, ctx->iscaleH));
             } else if (n_new > 0 || !h3_valid)

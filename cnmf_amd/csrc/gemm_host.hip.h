@@ -66,7 +66,8 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
                                float* rmax_part = nullptr, const double* rmax_scale = nullptr, bool psum = false,
                                PlaneOut po = PlaneOut{nullptr, nullptr, 0, 0})
 {
-    dim3 grid(parts, nslots);
+    // `parts` = 256-row tiles = partials per slot (round 4); a workgroup walks `chunks` of them
+    dim3 grid((parts + chunks - 1) / chunks, nslots);
     if (po.dst) {
         // the W half-step of the f16 paths, planes written by the sweep itself (ranks <= 64 only: the caller checks)
         if (psum || (rmax_part && rmax_scale) || (tiers & 8)) return hipErrorInvalidValue;
@@ -75,7 +76,7 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
         if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, false, false, true>, (int)sweep_lds_bytes(KSMALL, true))) return e_;
         if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, false, false, true>, (int)sweep_lds_bytes(KSMALL, true))) return e_;
         if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, false, false, true>, (int)sweep_lds_bytes(KSMALL, true))) return e_;
-#define CNMF_SWEEP_PLN(T_) sweep_kernel<T_, false, false, true><<<grid, 256, pl, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kgp, kmax, rmax_part, nullptr, po)
+#define CNMF_SWEEP_PLN(T_) sweep_kernel<T_, false, false, true><<<grid, 256, pl, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, parts, want_gram, kgp, kmax, rmax_part, nullptr, po)
         if (tiers & 1) CNMF_SWEEP_PLN(0);
         if (tiers & 2) CNMF_SWEEP_PLN(1);
         if (tiers & 4) CNMF_SWEEP_PLN(2);
@@ -94,8 +95,8 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
     // rmax_scale != nullptr selects the exact row-maximum report (the H half-step of the f16 plane split).
     const size_t lds = sweep_lds_bytes(kmax);
     const int kg = sweep_kg(kmax);
-#define CNMF_SWEEP(T_, R_) sweep_kernel<T_, R_><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax, rmax_part, rmax_scale)
-#define CNMF_SWEEP_PSUM(T_) sweep_kernel<T_, true, true><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax, rmax_part, rmax_scale)
+#define CNMF_SWEEP(T_, R_) sweep_kernel<T_, R_><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, parts, want_gram, kg, kmax, rmax_part, rmax_scale)
+#define CNMF_SWEEP_PSUM(T_) sweep_kernel<T_, true, true><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, parts, want_gram, kg, kmax, rmax_part, rmax_scale)
     if (psum) {                 // split-K partial planes summed (and column-scaled) inside the sweep: sp = psum_info(...)
         {
             if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, true, true>, (int)sweep_lds_bytes(KSMALL))) return e_;
@@ -119,15 +120,16 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
     if (tiers & 8) {            // ranks 65..128: sweep_big_kernel (+ the Gram of the updated rows as its own launch)
         if (psum) return hipErrorInvalidValue;                 // the caller reduces the split-K planes first
         const size_t blds = sweep_big_lds_bytes();
+        const dim3 gbig(parts, nslots);          // one 256-row tile per workgroup: gridDim.x = the number of partials
         if (rmax_part && rmax_scale) {
             if (hipError_t e_ = dyn_lds_optin((const void*)sweep_big_kernel<true>, (int)blds)) return e_;
-            sweep_big_kernel<true><<<grid, 256, blds, st>>>(V, ldv, L, P, sp, gram, slots, l1, viol_part, chunks, rmax_part, rmax_scale);
+            sweep_big_kernel<true><<<gbig, 256, blds, st>>>(V, ldv, L, P, sp, gram, slots, l1, viol_part, 1, rmax_part, rmax_scale);
         } else {
             if (hipError_t e_ = dyn_lds_optin((const void*)sweep_big_kernel<false>, (int)blds)) return e_;
-            sweep_big_kernel<false><<<grid, 256, blds, st>>>(V, ldv, L, P, sp, gram, slots, l1, viol_part, chunks, nullptr, nullptr);
+            sweep_big_kernel<false><<<gbig, 256, blds, st>>>(V, ldv, L, P, sp, gram, slots, l1, viol_part, 1, nullptr, nullptr);
         }
         if (want_gram)
-            gram_big_kernel<<<grid, 256, 0, st>>>(V, ldv, L, slots, gram_part, chunks, kmax, (rmax_part && !rmax_scale) ? rmax_part : nullptr);
+            gram_big_kernel<<<gbig, 256, 0, st>>>(V, ldv, L, slots, gram_part, 1, kmax, (rmax_part && !rmax_scale) ? rmax_part : nullptr);
     }
     return hipGetLastError();
 }

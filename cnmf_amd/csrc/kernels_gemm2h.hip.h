@@ -107,7 +107,14 @@ __device__ __forceinline__ void split2h_tiled_body(const float* __restrict__ src
     {
         const int row = t % TROWS, qt = t / TROWS;
         float mx = 0.f;
-        for (int p = qt; p < parts; p += NQ) mx = fmaxf(mx, rmax_part[(size_t)(r0 + row) * parts + p]);
+        // (one partial per 256-row tile since round 4: 196 of them at 50 000 cells -- eight requests in flight per pass)
+        for (int p0 = qt; p0 < parts; p0 += 8 * NQ) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (p0 + j * NQ < parts) ? rmax_part[(size_t)(r0 + row) * parts + p0 + j * NQ] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[j]);
+        }
         red[qt][row] = mx;
     }
     __syncthreads();

@@ -83,8 +83,8 @@ struct PlaneOut {
 // Partials are written compactly: entry (r,c) at r*gld + c, gld = largest rank of the batch.
 // RMX: also report the largest updated entry per component (x rmax_scale[row]) EXACTLY, at the price of KP
 // registers (the H half-step: few rows).  Without it (the W half-step: keeps 5 waves per SIMD) the report is the
-// bound  sqrt(sum_rows w^2)  from the diagonal of the workgroup's Gram partial -- at most sqrt(rows per workgroup)
-// = 32 x the true maximum, which the f16 plane split tolerates (kernels_gemm2h.hip.h: 5 bits of exponent slack only
+// bound  sqrt(sum_rows w^2)  from the diagonal of the tile's Gram partial -- at most sqrt(256 rows per tile)
+// = 16 x the true maximum (32 x with the 1024-row partials of round 3), which the f16 plane split tolerates (kernels_gemm2h.hip.h: 5 bits of exponent slack only
 // move the threshold below which tiny entries keep an absolute rather than a relative accuracy).
 // PSUM: the products arrive as `sp.mgroups` split-K partial planes (stride sp.tile_rows * 2^20 + sp.tile_cols floats,
 // see psum_info) that are summed here in split order and scaled by the per-row constant sp.split (reinterpreted as
@@ -94,9 +94,12 @@ __device__ __forceinline__ void sweep_body(
     float* __restrict__ V, int ldv, int L, const float* __restrict__ P, const SplitInfo& sp,
     const float* __restrict__ gram, const SlotDesc& sd, int slot, float l1_reg,
     float* __restrict__ gram_part, double* __restrict__ viol_part,
-    int chunks_per_block, int want_gram, float* lds, int kg, int gld,
+    int chunks_per_block, int n_parts, int want_gram, float* lds, int kg, int gld,
     float* __restrict__ rmax_part, const double* __restrict__ rmax_scale, const PlaneOut& po = PlaneOut{nullptr, nullptr, 0, 0})
 {
+    // round 4: ONE partial (Gram of the updated rows, violation, row-maximum report) per (slot, 256-row tile) -- n_parts =
+    // ceil(L / 256) of them -- instead of one per workgroup: the unit a pass-A workgroup can produce as well when it runs
+    // the W half-step of an uncut tile in its epilogue (kernels_gemm2h.hip.h, fused_w_epilogue).
     constexpr int GMODE = (KP <= 16) ? 0 : ((KP <= 32) ? 1 : 2);
     constexpr int GR = (GMODE == 0) ? 16 : ((GMODE == 1) ? 32 : 64);       // gram tile edge
     const int gs = kg + 4, wstride = kg + 1;
@@ -120,20 +123,24 @@ __device__ __forceinline__ void sweep_body(
     __syncthreads();
 
     f32x16 gacc[GMODE == 2 ? 4 : 1];
-    f32x4 gacc4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gacc[a][r] = 0.f;
-    float viol = 0.f;
-    // largest updated entry per component over this workgroup's rows (x the per-row scale of the f16 plane split,
+    f32x4 gacc4;
+    float viol;
+    // largest updated entry per component over this tile's rows (x the per-row scale of the f16 plane split,
     // kernels_gemm2h.hip.h) -- only when the caller wants it
     float mx[RMX ? KP : 1];
-#pragma unroll
-    for (int c = 0; c < (RMX ? KP : 1); ++c) mx[c] = 0.f;
 
     for (int ch = 0; ch < chunks_per_block; ++ch) {
-        const int row = (blockIdx.x * chunks_per_block + ch) * 256 + tid;
+        const int part = blockIdx.x * chunks_per_block + ch;             // the 256-row tile = the partial this chunk writes
+        if (part >= n_parts) break;
+        gacc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gacc[a][r] = 0.f;
+        viol = 0.f;
+#pragma unroll
+        for (int c = 0; c < (RMX ? KP : 1); ++c) mx[c] = 0.f;
+        const int row = part * 256 + tid;
         const bool live = row < L;
         // stream-K pass A: was this (row tile, component group) cut between two workgroups?
         // A slot spans at most two component groups and a wave's 64 rows lie in one row tile,
@@ -322,60 +329,61 @@ __device__ __forceinline__ void sweep_body(
             }
             __builtin_amdgcn_wave_barrier();                                     // the strip is rewritten by the next chunk
         }
-    }
 
-    // ---- row maxima: wave reduce -> LDS -> one partial per (component, workgroup)
-    if constexpr (RMX) {
-#pragma unroll
-        for (int c = 0; c < KP; ++c) {
-            float v = mx[c];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-            if (lane == 0) rmx[wave * 64 + c] = v;
+        // ---- row maxima: wave reduce -> LDS -> one partial per (component, workgroup)
+        if constexpr (RMX) {
+    #pragma unroll
+            for (int c = 0; c < KP; ++c) {
+                float v = mx[c];
+    #pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+                if (lane == 0) rmx[wave * 64 + c] = v;
+            }
         }
-    }
-    // ---- violation: wave reduce (double) -> block partial
-    double dv = (double)viol;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dv += __shfl_xor(dv, o, 64);
-    if (lane == 0) vred[wave] = dv;
+        // ---- violation: wave reduce (double) -> block partial
+        double dv = (double)viol;
+    #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dv += __shfl_xor(dv, o, 64);
+        if (lane == 0) vred[wave] = dv;
 
-    // ---- gram: sum the 4 waves' accumulators through LDS, write the block partial
-    __syncthreads();
-    float* gred = Wsb;                   // reused as [4][GR][GR+1]   (<= 4*64*(kg+1) floats)
-    if (want_gram) {
-        if constexpr (GMODE == 0) {
-            const int li = lane & 15, q = lane >> 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gred[(wave * GR + 4 * q + r) * (GR + 1) + li] = gacc4[r];
-        } else {
-            const int li = lane & 31, h = lane >> 5;
-#pragma unroll
-            for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = (a >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    gred[(wave * GR + rr) * (GR + 1) + (a & 1) * 32 + li] = gacc[a][r];
-                }
+        // ---- gram: sum the 4 waves' accumulators through LDS, write the tile's partial
+        __syncthreads();
+        float* gred = Wsb;                   // reused as [4][GR][GR+1]   (<= 4*64*(kg+1) floats)
+        if (want_gram) {
+            if constexpr (GMODE == 0) {
+                const int li = lane & 15, q = lane >> 4;
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) gred[(wave * GR + 4 * q + r) * (GR + 1) + li] = gacc4[r];
+            } else {
+                const int li = lane & 31, h = lane >> 5;
+    #pragma unroll
+                for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = (a >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        gred[(wave * GR + rr) * (GR + 1) + (a & 1) * 32 + li] = gacc[a][r];
+                    }
+            }
         }
-    }
-    __syncthreads();
-    if (want_gram) {
-        float* gp = gram_part + ((size_t)slot * gridDim.x + blockIdx.x) * (size_t)(gld * gld);
-        for (int e = tid; e < k * k; e += 256) {
-            const int r = e / k, c = e % k;
-            gp[r * gld + c] = gred[(0 * GR + r) * (GR + 1) + c] + gred[(1 * GR + r) * (GR + 1) + c] +
-                              gred[(2 * GR + r) * (GR + 1) + c] + gred[(3 * GR + r) * (GR + 1) + c];
+        __syncthreads();
+        if (want_gram) {
+            float* gp = gram_part + ((size_t)slot * n_parts + part) * (size_t)(gld * gld);
+            for (int e = tid; e < k * k; e += 256) {
+                const int r = e / k, c = e % k;
+                gp[r * gld + c] = gred[(0 * GR + r) * (GR + 1) + c] + gred[(1 * GR + r) * (GR + 1) + c] +
+                                  gred[(2 * GR + r) * (GR + 1) + c] + gred[(3 * GR + r) * (GR + 1) + c];
+            }
         }
-    }
-    if (tid == 0)
-        viol_part[(size_t)slot * gridDim.x + blockIdx.x] = vred[0] + vred[1] + vred[2] + vred[3];
-    if (rmax_part && tid < k && (RMX || want_gram)) {
-        float v;
-        if constexpr (RMX) v = fmaxf(fmaxf(rmx[tid], rmx[64 + tid]), fmaxf(rmx[128 + tid], rmx[192 + tid]));
-        else v = sqrtf(gred[(0 * GR + tid) * (GR + 1) + tid] + gred[(1 * GR + tid) * (GR + 1) + tid] +
-                       gred[(2 * GR + tid) * (GR + 1) + tid] + gred[(3 * GR + tid) * (GR + 1) + tid]) * 1.0001f;
-        rmax_part[(size_t)(off + tid) * gridDim.x + blockIdx.x] = v;
+        if (tid == 0)
+            viol_part[(size_t)slot * n_parts + part] = vred[0] + vred[1] + vred[2] + vred[3];
+        if (rmax_part && tid < k && (RMX || want_gram)) {
+            float v;
+            if constexpr (RMX) v = fmaxf(fmaxf(rmx[tid], rmx[64 + tid]), fmaxf(rmx[128 + tid], rmx[192 + tid]));
+            else v = sqrtf(gred[(0 * GR + tid) * (GR + 1) + tid] + gred[(1 * GR + tid) * (GR + 1) + tid] +
+                           gred[(2 * GR + tid) * (GR + 1) + tid] + gred[(3 * GR + tid) * (GR + 1) + tid]) * 1.0001f;
+            rmax_part[(size_t)(off + tid) * n_parts + part] = v;
+        }
+        __syncthreads();                 // gred aliases the staging strips of the next chunk
     }
 #undef WS
 #undef GS
@@ -397,8 +405,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 
     float l1_reg,
     float* __restrict__ gram_part,           // [nslots][gridDim.x][32][32]
     double* __restrict__ viol_part,          // [nslots][gridDim.x]
-    int chunks_per_block, int want_gram, int kg, int gld,
-    float* __restrict__ rmax_part = nullptr,     // [KC][gridDim.x] largest updated entry per component and workgroup
+    int chunks_per_block, int n_parts, int want_gram, int kg, int gld,
+    float* __restrict__ rmax_part = nullptr,     // [KC][n_parts] largest updated entry per component and 256-row tile
     const double* __restrict__ rmax_scale = nullptr,
     PlaneOut po = PlaneOut{nullptr, nullptr, 0, 0})
 {
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 
     extern __shared__ __attribute__((aligned(16))) float sweep_lds[];
 #define CNMF_SW(KP_)                                                                              \
         sweep_body<KP_, RMX, PSUM, PLN>(V, ldv, L, P, sp, gram, sd, slot, l1_reg, gram_part, viol_part, \
-                        chunks_per_block, want_gram, sweep_lds, kg, gld, rmax_part, rmax_scale, po);
+                        chunks_per_block, n_parts, want_gram, sweep_lds, kg, gld, rmax_part, rmax_scale, po);
     const int k = sd.k;
     if (TIER == 0) {
         if (k > 16) return;
