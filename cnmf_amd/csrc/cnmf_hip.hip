@@ -39,6 +39,7 @@
 #include "kernels_gemm2h.hip.h"
 #include "kernels_rng.hip.h"
 #include "kernels_sweep.hip.h"
+#include "kernels_fusedw.hip.h"
 
 using namespace cnmf;
 

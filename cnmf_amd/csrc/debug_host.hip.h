@@ -228,7 +228,7 @@ extern "C" int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn,
     float* dA = pool.get<float>((size_t)KC * K);
     float* dB = pool.get<float>((size_t)J * K);
     float* dUnit = pool.get<float>(K);
-    const int bparts = sweep_bound ? (K + 255) / 256 : 1;
+    const int bparts = sweep_bound ? (K + 1023) / 1024 : 1;
     float* dRmax = pool.get<float>((size_t)KC * bparts);
     float* dInv = pool.get<float>(KC);
     unsigned char* dA2 = pool.get<unsigned char>((size_t)KC * Kb * G2_ROWB);
@@ -244,7 +244,7 @@ extern "C" int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn,
     HIP_TRY(ctx, hipMemcpyAsync(dB, Bn, (size_t)J * K * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dUnit, ones.data(), (size_t)K * sizeof(float), hipMemcpyHostToDevice, st));
     if (sweep_bound) {
-        debug_rowbound_part_kernel<<<dim3(bparts, KC / 4), 256, 0, st>>>(dA, K, K, 256, bparts, dRmax);
+        debug_rowbound_part_kernel<<<dim3(bparts, KC / 4), 256, 0, st>>>(dA, K, K, 1024, bparts, dRmax);
         HIP_TRY(ctx, hipGetLastError());
     } else
         HIP_TRY(ctx, launch_rowmax_part(st, dA, K, K, KC, K, nullptr, 1, dRmax));

@@ -66,8 +66,9 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
                                float* rmax_part = nullptr, const double* rmax_scale = nullptr, bool psum = false,
                                PlaneOut po = PlaneOut{nullptr, nullptr, 0, 0})
 {
-    // `parts` = 256-row tiles = partials per slot (round 4); a workgroup walks `chunks` of them
-    dim3 grid((parts + chunks - 1) / chunks, nslots);
+    // `parts` = partials per slot: one per workgroup (chunks x 256 rows each), or -- parts = number of 256-row tiles -- one per
+    // tile (the fused W half-step, sweep_tile_parts()); a workgroup walks `chunks` tiles either way
+    dim3 grid(((L + 255) / 256 + chunks - 1) / chunks, nslots);
     if (po.dst) {
         // the W half-step of the f16 paths, planes written by the sweep itself (ranks <= 64 only: the caller checks)
         if (psum || (rmax_part && rmax_scale) || (tiers & 8)) return hipErrorInvalidValue;
@@ -120,16 +121,17 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
     if (tiers & 8) {            // ranks 65..128: sweep_big_kernel (+ the Gram of the updated rows as its own launch)
         if (psum) return hipErrorInvalidValue;                 // the caller reduces the split-K planes first
         const size_t blds = sweep_big_lds_bytes();
-        const dim3 gbig(parts, nslots);          // one 256-row tile per workgroup: gridDim.x = the number of partials
+        const int bchunks = ((L + 255) / 256 + parts - 1) / parts;      // tiles per workgroup so that gridDim.x = the number of partials
+        const dim3 gbig(parts, nslots);
         if (rmax_part && rmax_scale) {
             if (hipError_t e_ = dyn_lds_optin((const void*)sweep_big_kernel<true>, (int)blds)) return e_;
-            sweep_big_kernel<true><<<gbig, 256, blds, st>>>(V, ldv, L, P, sp, gram, slots, l1, viol_part, 1, rmax_part, rmax_scale);
+            sweep_big_kernel<true><<<gbig, 256, blds, st>>>(V, ldv, L, P, sp, gram, slots, l1, viol_part, bchunks, rmax_part, rmax_scale);
         } else {
             if (hipError_t e_ = dyn_lds_optin((const void*)sweep_big_kernel<false>, (int)blds)) return e_;
-            sweep_big_kernel<false><<<gbig, 256, blds, st>>>(V, ldv, L, P, sp, gram, slots, l1, viol_part, 1, nullptr, nullptr);
+            sweep_big_kernel<false><<<gbig, 256, blds, st>>>(V, ldv, L, P, sp, gram, slots, l1, viol_part, bchunks, nullptr, nullptr);
         }
         if (want_gram)
-            gram_big_kernel<<<gbig, 256, 0, st>>>(V, ldv, L, slots, gram_part, 1, kmax, (rmax_part && !rmax_scale) ? rmax_part : nullptr);
+            gram_big_kernel<<<gbig, 256, 0, st>>>(V, ldv, L, slots, gram_part, bchunks, kmax, (rmax_part && !rmax_scale) ? rmax_part : nullptr);
     }
     return hipGetLastError();
 }
@@ -482,12 +484,40 @@ static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, co
     return hipGetLastError();
 }
 
+// the production pass A of the count path with the W half-step of the uncut tiles in its epilogue (kernels_fusedw.hip.h)
+template <bool NTB>
+static hipError_t launch_gemm2h_streamk_fusedw(hipStream_t st, const StreamK3& sk, const unsigned char* A2,
+                                               const unsigned char* B1, const float* rscale, int Kb, float* C0, float* C1,
+                                               float* C2, int ldc, const FusedW& fw)
+{
+    constexpr int lds = g2_lds_bytes(2, false) > FW_LDS_BYTES ? g2_lds_bytes(2, false) : FW_LDS_BYTES;
+    auto kern = gemm2h_streamk_kernel<2, false, CNMF_G2_VAR_DEFAULT, NTB, false, false, FusedW>;
+    if (hipError_t e_ = dyn_lds_optin((const void*)kern, lds)) return e_;
+    static const int xmap = getenv("CNMF_G2_XMAP") ? atoi(getenv("CNMF_G2_XMAP")) : 1;
+    kern<<<sk.P, 512, lds, st>>>(A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T, xmap, nullptr, ~0ull, fw);
+    return hipGetLastError();
+}
+
 // (the plan `sk` must have been made with unit = gemm2h_nsub(Bhi != nullptr, Kb))
+// can this launch carry the W half-step?  (the production instantiation of the count path only)
+static bool gemm2h_streamk_can_fuse(const StreamK3& sk, const unsigned char* Bhi, const float* cscale, int Kb,
+                                    unsigned long long livemask)
+{
+    const bool part = (livemask & g2_full_mask(sk.MG * G3_MW)) != g2_full_mask(sk.MG * G3_MW);
+    return sk.on && !Bhi && !cscale && !part && gemm2h_nsub(false, Kb) == 2 && g2_var() == CNMF_G2_VAR_DEFAULT;
+}
+
 static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, const unsigned char* A2,
                                         const unsigned char* B1, const unsigned char* Bhi, const unsigned int* hiflag,
                                         const float* rscale, int Kb, float* C0, float* C1, float* C2, int ldc,
-                                        const float* cscale = nullptr, unsigned long long livemask = ~0ull)
+                                        const float* cscale = nullptr, unsigned long long livemask = ~0ull,
+                                        const FusedW* fw = nullptr)
 {
+    if (fw && fw->on && gemm2h_streamk_can_fuse(sk, Bhi, cscale, Kb, livemask)) {
+        static const bool force_nt_f = getenv("CNMF_G2_NT") != nullptr;
+        return (sk.MG > 1 && !force_nt_f) ? launch_gemm2h_streamk_fusedw<false>(st, sk, A2, B1, rscale, Kb, C0, C1, C2, ldc, *fw)
+                                          : launch_gemm2h_streamk_fusedw<true>(st, sk, A2, B1, rscale, Kb, C0, C1, C2, ldc, *fw);
+    }
     const bool part = (livemask & g2_full_mask(sk.MG * G3_MW)) != g2_full_mask(sk.MG * G3_MW);
     // several component groups share every count-plane tile in the L2: no non-temporal loads then (CNMF_G2_NT=1: A/B)
     static const bool force_nt = getenv("CNMF_G2_NT") != nullptr;

@@ -444,14 +444,17 @@ __device__ __forceinline__ void glds16_asm_nt(const void* gsrc, unsigned lds_dst
 // x_m . f_m, is not formed -- |x_m| <= 2^-11 |x_h| and |f_m| <= 2^-11 |f_h|, so the term is <= 2^-22 of the product, random
 // in sign, against the 2^-24 rounding of every float32 accumulation step (and 16 x below the 2^-18 the 3 x 3 bf16 planes of
 // rounds 1-2 dropped): 3 MFMAs per product instead of 4.  The count path (HI there = a second EXACT integer plane) keeps all.
-template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false, bool GEN = false>
+// EPI (round 4): what happens to a WHOLE tile's accumulators instead of the plain store -- the W half-step of the tile's
+// restarts run by the pass-A workgroup itself (kernels_fusedw.hip.h); G2NoEpi: the store below.
+struct G2NoEpi { static constexpr bool enabled = false; };
+template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false, bool GEN = false, class EPI = G2NoEpi>
 __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__ A2, const unsigned char* __restrict__ B1,
                                                const unsigned char* __restrict__ Bhi,
                                                const unsigned int* __restrict__ hiflag,
                                                const float* __restrict__ rscale,
                                                int Kb, float* __restrict__ C, int ldc, int m0, int j0, int kb0,
                                                int nkb, unsigned char* smem, const float* __restrict__ cscale = nullptr,
-                                               unsigned live = 0xffu)
+                                               unsigned live = 0xffu, const EPI* epi = nullptr, bool whole_tile = false)
 {
     constexpr int IMGS = g2_imgs(NSUB);
     constexpr int IMG = g2_img_bytes(NSUB, HI);
@@ -689,6 +692,10 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
 #undef G2_ISSUE
 #undef G2_BLKFLAG
 
+    if constexpr (EPI::enabled) {
+        // a tile computed in one piece: the epilogue takes the accumulators (and stores what it does not consume itself)
+        if (whole_tile && epi->on) { (*epi)(acc, rscale, C, ldc, m0, j0, smem); return; }
+    }
     const int j = j0 + wn * 64 + li;
     // general (not count-structured) X as two f16 planes of x * 2^s_j (x2h_planes_kernel): the per-column exponent is
     // undone here (a power of two: exact); 1 otherwise
@@ -738,7 +745,7 @@ __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __rest
 }
 
 // pass A: stream-K over persistent workgroups, unit = one step of NSUB blocks (Kb % NSUB == 0)
-template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false, bool GEN = false>
+template <int NSUB, bool HI, int VAR = 0, bool NTB = true, bool PART = false, bool GEN = false, class EPI = G2NoEpi>
 __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char* __restrict__ A2,
                                                              const unsigned char* __restrict__ B1,
                                                              const unsigned char* __restrict__ Bhi,
@@ -747,7 +754,7 @@ __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char
                                                              float* __restrict__ C0, float* __restrict__ C1,
                                                              float* __restrict__ C2, int ldc, int MG, int T, int xmap,
                                                              const float* __restrict__ cscale = nullptr,
-                                                             unsigned long long livemask = ~0ull)
+                                                             unsigned long long livemask = ~0ull, EPI epi = EPI{})
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int Ks = Kb / NSUB;                             // steps per tile
@@ -767,9 +774,9 @@ __global__ __launch_bounds__(512) void gemm2h_streamk_kernel(const unsigned char
         const int tile = (int)(u / Ks), ks = (int)(u % Ks);
         const int ke = (int)min((long long)Ks, ks + (u1 - u));
         const int mg = tile / NJ, jt = tile % NJ;
-        gemm2h_segment<NSUB, HI, VAR, NTB, PART, GEN>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
+        gemm2h_segment<NSUB, HI, VAR, NTB, PART, GEN, EPI>(A2, B1, Bhi, hiflag, rscale, Kb, (ks == 0) ? C0 : (ke == Ks ? C1 : C2), ldc, mg * G3_MW,
                                                  jt * G3C_JW, ks * NSUB, (ke - ks) * NSUB, smem3, cscale,
-                                                 (unsigned)((livemask >> (8 * mg)) & 0xffu));
+                                                 (unsigned)((livemask >> (8 * mg)) & 0xffu), &epi, ks == 0 && ke == Ks);
         u += ke - ks;
         G3_WAIT_VM(0);
         __syncthreads();                 // the images are refilled by the next segment's DMA

@@ -59,7 +59,12 @@ struct SplitInfo {                  // further partial planes of a stream-K prod
     const unsigned char* split;     // [tiles] bit 0 = the tile was cut: add plane 1; bit 1 = cut twice: add plane 2 too
     int tile_rows, tile_cols, mgroups;
     const float* plane2 = nullptr;
+    int fused = 0;                  // 1: pass A ran the W half-step of the UNCUT tiles itself for every fusable restart
 };
+
+// Restarts whose W half-step a pass-A workgroup can run in its epilogue (kernels_fusedw.hip.h): the register-resident
+// tier of the sweep, columns inside ONE 128-column half of a 256-column component group.
+__device__ __host__ __forceinline__ bool fusedw_fusable(int off, int k) { return k <= 16 && (off & 127) + k <= 128; }
 
 // PLN (round 3, the W half-step of the f16 paths): the sweep also writes the two f16 planes of the rows it has just
 // updated, in the block-major layout pass B multiplies (kernels_gemm2h.hip.h), scaled by the per-component exponent
@@ -83,8 +88,8 @@ struct PlaneOut {
 // Partials are written compactly: entry (r,c) at r*gld + c, gld = largest rank of the batch.
 // RMX: also report the largest updated entry per component (x rmax_scale[row]) EXACTLY, at the price of KP
 // registers (the H half-step: few rows).  Without it (the W half-step: keeps 5 waves per SIMD) the report is the
-// bound  sqrt(sum_rows w^2)  from the diagonal of the tile's Gram partial -- at most sqrt(256 rows per tile)
-// = 16 x the true maximum (32 x with the 1024-row partials of round 3), which the f16 plane split tolerates (kernels_gemm2h.hip.h: 5 bits of exponent slack only
+// bound  sqrt(sum_rows w^2)  from the diagonal of the workgroup's Gram partial -- at most sqrt(rows per workgroup)
+// = 32 x the true maximum (16 x with per-tile partials), which the f16 plane split tolerates (kernels_gemm2h.hip.h: 5 bits of exponent slack only
 // move the threshold below which tiny entries keep an absolute rather than a relative accuracy).
 // PSUM: the products arrive as `sp.mgroups` split-K partial planes (stride sp.tile_rows * 2^20 + sp.tile_cols floats,
 // see psum_info) that are summed here in split order and scaled by the per-row constant sp.split (reinterpreted as
@@ -97,9 +102,10 @@ __device__ __forceinline__ void sweep_body(
     int chunks_per_block, int n_parts, int want_gram, float* lds, int kg, int gld,
     float* __restrict__ rmax_part, const double* __restrict__ rmax_scale, const PlaneOut& po = PlaneOut{nullptr, nullptr, 0, 0})
 {
-    // round 4: ONE partial (Gram of the updated rows, violation, row-maximum report) per (slot, 256-row tile) -- n_parts =
-    // ceil(L / 256) of them -- instead of one per workgroup: the unit a pass-A workgroup can produce as well when it runs
-    // the W half-step of an uncut tile in its epilogue (kernels_gemm2h.hip.h, fused_w_epilogue).
+    // Partials (Gram of the updated rows, violation, row-maximum report): one per workgroup (n_parts = gridDim.x, the
+    // default), or -- round 4, n_parts > gridDim.x -- ONE PER (slot, 256-row tile), n_parts = ceil(L / 256): the unit a pass-A
+    // workgroup can produce as well when it runs the W half-step of an uncut tile in its epilogue (kernels_fusedw.hip.h,
+    // CNMF_FUSE_A=1).
     constexpr int GMODE = (KP <= 16) ? 0 : ((KP <= 32) ? 1 : 2);
     constexpr int GR = (GMODE == 0) ? 16 : ((GMODE == 1) ? 32 : 64);       // gram tile edge
     const int gs = kg + 4, wstride = kg + 1;
@@ -129,18 +135,25 @@ __device__ __forceinline__ void sweep_body(
     // kernels_gemm2h.hip.h) -- only when the caller wants it
     float mx[RMX ? KP : 1];
 
+    const bool per_tile = n_parts > (int)gridDim.x || (!PSUM && sp.fused != 0);
+    bool fresh = true;                                                   // the accumulators hold nothing yet
     for (int ch = 0; ch < chunks_per_block; ++ch) {
-        const int part = blockIdx.x * chunks_per_block + ch;             // the 256-row tile = the partial this chunk writes
-        if (part >= n_parts) break;
-        gacc4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int tile = blockIdx.x * chunks_per_block + ch;             // the 256-row tile of this chunk
+        if (per_tile && tile >= n_parts) break;
+        const int part = per_tile ? tile : (int)blockIdx.x;              // the partial it is added to
+        const bool emit = per_tile || ch == chunks_per_block - 1;
+        if (fresh) {
+            gacc4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
+            for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gacc[a][r] = 0.f;
-        viol = 0.f;
+                for (int r = 0; r < 16; ++r) gacc[a][r] = 0.f;
+            viol = 0.f;
 #pragma unroll
-        for (int c = 0; c < (RMX ? KP : 1); ++c) mx[c] = 0.f;
-        const int row = part * 256 + tid;
+            for (int c = 0; c < (RMX ? KP : 1); ++c) mx[c] = 0.f;
+        }
+        fresh = emit;
+        const int row = tile * 256 + tid;
         const bool live = row < L;
         // stream-K pass A: was this (row tile, component group) cut between two workgroups?
         // A slot spans at most two component groups and a wave's 64 rows lie in one row tile,
@@ -153,6 +166,9 @@ __device__ __forceinline__ void sweep_body(
             mg_edge = (g0 + 1) * sp.tile_cols;
             cut0 = sp.split[rt * sp.mgroups + g0];
             cut1 = sp.split[rt * sp.mgroups + g1];
+            // this (restart, tile) was swept by the pass-A workgroup that computed the tile (workgroup-uniform; per-tile
+            // partials only: nothing of this chunk is pending in the accumulators)
+            if (sp.fused && cut0 == 0 && fusedw_fusable(off, k)) continue;
         }
         float w[KP], p[KP];
         float dsc = 1.0f;                          // per-row scale of the exact row-maximum report (issued with the loads)
@@ -330,6 +346,7 @@ __device__ __forceinline__ void sweep_body(
             __builtin_amdgcn_wave_barrier();                                     // the strip is rewritten by the next chunk
         }
 
+        if (!emit) continue;                                            // (workgroup-uniform)
         // ---- row maxima: wave reduce -> LDS -> one partial per (component, workgroup)
         if constexpr (RMX) {
     #pragma unroll

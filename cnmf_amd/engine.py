@@ -985,7 +985,7 @@ class Engine:
     def debug_gemm2h(self, A, Bn, nsplit=1, nsub=2, reps=0, sweep_bound=False):
         """A [KC, K] . Bn [J, K]^T through the f16 two-plane count kernel (A >= 0, Bn: integers <= 65535);
         returns (C, ms).  ``sweep_bound=True`` scales the rows of A by the bound the W half-step reports
-        (sqrt(sum w^2) per 256-entry tile) instead of the exact row maximum -- the production pass-B scaling."""
+        (sqrt(sum w^2) per 1024-entry block) instead of the exact row maximum -- the production pass-B scaling."""
         nsub = int(nsub) | (128 if sweep_bound else 0)
         A = np.ascontiguousarray(A, dtype=np.float32)
         Bn = np.ascontiguousarray(Bn, dtype=np.float32)
