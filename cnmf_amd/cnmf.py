@@ -61,6 +61,37 @@ def save_df_to_npz_fast(obj, filename, sibling_ok=False):
             os.remove(stale)
 
 
+def save_csr_fast(filename, mat):
+    """The sparse TPM stand-in (``tpm_sparse``: this package's own scratch container, the reference keeps a tpm.h5ad):
+    scipy's ``save_npz`` layout, except that above 64 MB the three arrays go into sibling ``.npy`` files named inside the
+    npz -- a zip member costs a CRC-32 pass over every byte (0.2 s per 560 MB), a plain .npy does not."""
+    if mat.data.nbytes + mat.indices.nbytes < _SIBLING_BYTES:
+        import scipy.sparse as sp
+        sp.save_npz(filename, mat, compressed=False)
+        for part in ("data", "indices", "indptr"):
+            stale = "%s.%s.npy" % (filename, part)
+            if os.path.exists(stale):
+                os.remove(stale)
+        return
+    names = {}
+    for part in ("data", "indices", "indptr"):
+        sib = "%s.%s.npy" % (filename, part)
+        np.save(sib, getattr(mat, part))
+        names[part + "_file"] = np.array(os.path.basename(sib))
+    np.savez(filename, shape=np.array(mat.shape), format=np.array("csr"), **names)
+
+
+def load_csr(filename):
+    """Reads what save_csr_fast (either form) or scipy's save_npz wrote."""
+    import scipy.sparse as sp
+    with np.load(filename, allow_pickle=False) as f:
+        if "data_file" not in f.files:
+            return sp.load_npz(filename).tocsr()
+        d = os.path.dirname(os.path.abspath(filename))
+        parts = [np.load(os.path.join(d, str(f[part + "_file"]))) for part in ("data", "indices", "indptr")]
+        return sp.csr_matrix(tuple(parts), shape=tuple(int(v) for v in f["shape"]))
+
+
 def save_df_to_text(obj, filename):
     """cnmf.py:34-35: ``obj.to_csv(filename, sep='\\t')``.  All-float64 frames with plain labels (the usages: cells x k)
     are formatted here -- the same bytes (shortest round-trip repr per value, like pandas' float -> str), a quarter of the
@@ -314,7 +345,8 @@ class cNMF:
                                    norm_counts)
         with open(self.paths["nmf_genes_list"], "w") as F:
             F.write("\n".join(map(str, norm_counts.columns)))
-        for stale in (self.paths["tpm"], self.paths["tpm_sparse"], self.paths["tpm_sparse_genes"]):
+        for stale in (self.paths["tpm"], self.paths["tpm_sparse"], self.paths["tpm_sparse_genes"]) + tuple(
+                "%s.%s.npy" % (self.paths["tpm_sparse"], part) for part in ("data", "indices", "indptr")):
             if tpm is not None and os.path.exists(stale):
                 os.remove(stale)
         if tpm is not None and isinstance(tpm, tuple):
@@ -326,7 +358,7 @@ class cNMF:
             if not mat.has_canonical_format:                   # (never in place on the caller's arrays)
                 mat = mat.copy()
                 mat.sum_duplicates()
-            sp.save_npz(self.paths["tpm_sparse"], mat, compressed=False)
+            save_csr_fast(self.paths["tpm_sparse"], mat)
             with open(self.paths["tpm_sparse_genes"], "w") as F:
                 F.write("\n".join(map(str, genes)))
             # (this process holds what it just wrote: consensus() need not read and CRC-check it back)
@@ -760,7 +792,7 @@ class cNMF:
                 if cached is not None and cached[0] == key:
                     tpm_x, tpm_genes = cached[1], cached[2]
                 else:
-                    tpm_x = sp.load_npz(self.paths["tpm_sparse"]).tocsr()
+                    tpm_x = load_csr(self.paths["tpm_sparse"])
                     tpm_genes = pd.Index(open(self.paths["tpm_sparse_genes"]).read().split("\n"))
             else:
                 tpm = load_df_from_npz(self.paths["tpm"])

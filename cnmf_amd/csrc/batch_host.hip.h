@@ -11,7 +11,8 @@ static int sweep_max_parts()
 static int sweep_chunks(int L) { const int64_t m = 256ll * sweep_max_parts(); return std::max(1, (int)(((int64_t)L + m - 1) / m)); }
 // partials per slot of a half-step: one per sweep workgroup (sweep_chunks 256-row tiles each) -- or, with the W half-step
 // inside pass A (CNMF_FUSE_A=1, kernels_fusedw.hip.h), one per 256-row tile: the unit a pass-A workgroup produces too
-static bool sweep_tile_parts() { static const bool v = getenv("CNMF_FUSE_A") && atoi(getenv("CNMF_FUSE_A")) == 1; return v; }
+// (CNMF_FUSE_A=2: per-tile partials WITHOUT the fusion -- the arm the fused path is bit-identical to, tools/fused_ab.py)
+static bool sweep_tile_parts() { static const bool v = getenv("CNMF_FUSE_A") && atoi(getenv("CNMF_FUSE_A")) >= 1; return v; }
 static int sweep_parts(int L)
 {
     if (sweep_tile_parts()) return std::max(1, (L + 255) / 256);
@@ -368,6 +369,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     HIP_TRY(ctx, hipHostMalloc(&fw_host.p, (size_t)RING * FW_INTS * sizeof(int)));
     bool fw_dirty = true;
     int n_fw_upload = 0;
+    int64_t n_fused_passes = 0;
     struct PinnedInts { int* p = nullptr; ~PinnedInts() { if (p) hipHostFree(p); } } repack_host;
     HIP_TRY(ctx, hipHostMalloc(&repack_host.p, (size_t)RING * 3 * KC0 * sizeof(int)));
     int* h_repack = repack_host.p;
@@ -465,7 +467,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     const int gvarB = getenv("CNMF_GEMM_B") ? atoi(getenv("CNMF_GEMM_B")) : 0;
     int64_t restart_iters = 0, column_iters = 0, restart_col_iters = 0;
     const bool dbg = getenv("CNMF_DEBUG") != nullptr;
-    int64_t dbg_it[9] = {0}, dbg_live[9] = {0};
+    int64_t dbg_it[65] = {0}, dbg_live[65] = {0};          // by KC / 32 (up to 2048 packed columns)
     const int wg_slots = getenv("CNMF_SK_WGS") ? atoi(getenv("CNMF_SK_WGS")) : 2 * 256;                    // T-layout pass A: 2 workgroups per CU (73.7 KB LDS each)
     StreamK sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
     if (sk.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
@@ -724,6 +726,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                                     PlaneOut{(unsigned short*)ctx->Wt3, shW[shgen], KbB, G3_MW}};
                     HIP_TRY(ctx, launch_gemm2h_streamk(st, sk3, ctx->H3, xA, xAhi, xAfl, ctx->iscaleH, KbA,
                                                        ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad, csA, livemask, &fw));
+                    n_fused_passes += fused_now ? 1 : 0;
                 }
                 else if (usec)
                     HIP_TRY(ctx, launch_gemm3c_streamk(st, sk3, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->XHt, ctx->XHt1,
@@ -968,8 +971,9 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     }
 
     if (dbg) fprintf(stderr, "[cnmf] %lld defragmentations\n", (long long)n_defrag);
+    if (dbg) fprintf(stderr, "[cnmf] W half-step inside pass A: %lld of %lld iterations\n", (long long)n_fused_passes, (long long)it);
     if (dbg)
-        for (int i = 1; i <= 8; ++i)
+        for (int i = 1; i <= 64; ++i)
             if (dbg_it[i]) fprintf(stderr, "[cnmf] KC=%d: %lld iterations, mean host-live columns %.1f\n", i * 32,
                                    (long long)dbg_it[i], (double)dbg_live[i] / dbg_it[i]);
     HIP_TRY(ctx, hipEventRecord(ev_end, st));

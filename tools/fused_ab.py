@@ -1,5 +1,6 @@
 """A/B of the W half-step inside pass A (kernels_fusedw.hip.h) against the stand-alone sweep: the same batch under
-CNMF_FUSE_A=1 (opt-in: measured slower) and the default in two processes (the switch is read once per process); spectra, usages, iteration
+CNMF_FUSE_A=1 (opt-in: measured slower) and CNMF_FUSE_A=2 (the stand-alone sweep with the same
+per-tile partials -- the default adds its partials per workgroup of four tiles, a different rounding) in two processes (the switch is read once per process); spectra, usages, iteration
 counts and violations must be BIT-IDENTICAL.  `python tools/fused_ab.py child <tag>` runs one arm."""
 import json
 import os
@@ -43,13 +44,15 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "child":
         return child(sys.argv[2])
     res = {}
-    for tag, val in (("fused", "1"), ("plain", "0")):
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "child", tag], env=dict(os.environ, CNMF_FUSE_A=val),
-                           capture_output=True, text=True, timeout=900)
+    for tag, val in (("fused", "1"), ("plain", "2")):       # 2: the stand-alone sweep with the same per-tile partials
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "child", tag],
+                           env=dict(os.environ, CNMF_FUSE_A=val, CNMF_DEBUG="1"), capture_output=True, text=True, timeout=900)
         if p.returncode != 0:
             print(p.stdout[-2000:], p.stderr[-4000:])
             raise SystemExit("arm %s failed" % tag)
         res[tag] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        fused_lines = [ln for ln in p.stderr.splitlines() if "W half-step inside pass A" in ln]
+        res[tag]["fused_iterations"] = int(fused_lines[-1].split(":")[1].split("of")[0]) if fused_lines else -1
         print(res[tag])
     a = np.load(os.path.join(ROOT, "gpurun_out", "fused_ab_fused.npz"))
     b = np.load(os.path.join(ROOT, "gpurun_out", "fused_ab_plain.npz"))
@@ -60,7 +63,9 @@ def main():
         print("%-7s identical: %s  (max abs diff %.3g, max |ref| %.3g, %d of %d differ)"
               % (key, same, md, float(np.abs(b[key]).max()), int((a[key] != b[key]).sum()), a[key].size))
         ok &= same
-    print("FUSED_AB_%s  fused %.3f s  plain %.3f s" % ("IDENTICAL" if ok else "DIFFERENT", res["fused"]["seconds"], res["plain"]["seconds"]))
+    ok &= res["fused"]["fused_iterations"] > 0 and res["plain"]["fused_iterations"] == 0        # the arms really differ
+    print("FUSED_AB_%s  fused %.3f s (%d iterations with the epilogue)  plain %.3f s" % ("IDENTICAL" if ok else "DIFFERENT",
+          res["fused"]["seconds"], res["fused"]["fused_iterations"], res["plain"]["seconds"]))
     for tag in ("fused", "plain"):
         os.remove(os.path.join(ROOT, "gpurun_out", "fused_ab_%s.npz" % tag))
     return 0 if ok else 1
