@@ -99,11 +99,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("CNMF_LIB_PATH") or LIB_PATH        # (A/B builds of the library: tools/)
+    if not os.path.exists(path):
         raise ImportError(
             "cnmf_amd: %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, i64, f32p, dblp = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_double)
     i32p, u32p = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
     lib.cnmf_device_count.restype = i32

@@ -443,6 +443,8 @@ static hipError_t launch_gemm2h(hipStream_t st, const unsigned char* A2, const u
                                 const float* cscale = nullptr, unsigned long long livemask = ~0ull)
 {
     // livemask: bit t = the 32 packed columns 32 t .. 32 t + 31 hold a restart that still iterates (all ones: everything)
+    static const bool nostore = getenv("CNMF_G2_NOSTORE") != nullptr;      // timing ablation: results meaningless
+    if (nostore) C = nullptr;
     const bool part = (livemask & g2_full_mask(KC)) != g2_full_mask(KC);
     // general matrices (cscale != nullptr: X as two f16 planes) multiply three of the four plane pairs (GEN); CNMF_G2_GEN4=1: all four (A/B)
     static const bool gen4 = getenv("CNMF_G2_GEN4") != nullptr;
@@ -518,6 +520,8 @@ static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, cons
         return (sk.MG > 1 && !force_nt_f) ? launch_gemm2h_streamk_fusedw<false>(st, sk, A2, B1, rscale, Kb, C0, C1, C2, ldc, *fw)
                                           : launch_gemm2h_streamk_fusedw<true>(st, sk, A2, B1, rscale, Kb, C0, C1, C2, ldc, *fw);
     }
+    static const bool nostore = getenv("CNMF_G2_NOSTORE") != nullptr;      // timing ablation: results meaningless
+    if (nostore) C0 = C1 = C2 = nullptr;
     const bool part = (livemask & g2_full_mask(sk.MG * G3_MW)) != g2_full_mask(sk.MG * G3_MW);
     // several component groups share every count-plane tile in the L2: no non-temporal loads then (CNMF_G2_NT=1: A/B)
     static const bool force_nt = getenv("CNMF_G2_NT") != nullptr;

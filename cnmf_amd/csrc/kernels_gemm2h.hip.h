@@ -30,6 +30,15 @@
 namespace cnmf {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4_g __attribute__((ext_vector_type(4)));
+// (A/B build: -DCNMF_G2_LDS_STORE sends the finished tile through LDS and out with 16-byte stores; measured on one box,
+//  two alternations: 216.8 / 215.6 restarts/s against 217.5 / 216.8 with the four-byte stores straight from the
+//  accumulator registers -- the stores cost 10-13 % of a pass (CNMF_G2_NOSTORE ablation) but not through their issue)
+#ifdef CNMF_G2_LDS_STORE
+constexpr bool G2_LDS_STORE = true;
+#else
+constexpr bool G2_LDS_STORE = false;
+#endif
 
 constexpr int G2_ROWB = 64;                        // factor bytes per row and 16-k block
 constexpr int G2_A = G3_MW * G2_ROWB;              // 16 384 B of factor planes per 16-k block
@@ -696,10 +705,41 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
         // a tile computed in one piece: the epilogue takes the accumulators (and stores what it does not consume itself)
         if (whole_tile && epi->on) { (*epi)(acc, rscale, C, ldc, m0, j0, smem); return; }
     }
+    if (C == nullptr) return;                                // (timing ablation CNMF_G2_NOSTORE: the pass without its stores)
     const int j = j0 + wn * 64 + li;
     // general (not count-structured) X as two f16 planes of x * 2^s_j (x2h_planes_kernel): the per-column exponent is
     // undone here (a power of two: exact); 1 otherwise
     const float cs[2] = {(HI && cscale) ? cscale[j] : 1.0f, (HI && cscale) ? cscale[j + 32] : 1.0f};
+    if constexpr (!PART && G2_LDS_STORE && g2_lds_bytes(NSUB, HI) >= 8 * 16384) {
+        // round-4 experiment (build flag, not adopted): the tile leaves through LDS with 16-byte stores instead of 128
+        // four-byte stores per lane.  The stores are 10-13 % of a pass (CNMF_G2_NOSTORE ablation: pass A 325 -> 291 us,
+        // pass B 197 -> 171 us) but this form measured 0.4 % SLOWER end to end.  The DMA images are dead here (both wave
+        // groups are past their last fragment read), every wave transposes its own 128 components x 64 cells in two rounds
+        // of 64 x 64 through a private 16 KB strip and writes rows of 256 contiguous bytes.  Same values, same places.
+        float* tw = reinterpret_cast<float*>(smem) + wave * 4096;
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int m = 2 * mp + mm;
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = 4 * h + (r & 3) + 8 * (r >> 2);
+                        tw[(mm * 32 + rl) * 64 + n * 32 + li] = (acc[m][n][r] * rscale[m0 + grp * 128 + m * 32 + rl]) * cs[n];
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();                 // (LDS operations of one wave execute in order)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = 4 * i + (lane >> 4);
+                const f32x4_g v = *reinterpret_cast<const f32x4_g*>(tw + c * 64 + 4 * (lane & 15));
+                *reinterpret_cast<f32x4_g*>(C + (size_t)(m0 + grp * 128 + mp * 64 + c) * ldc + j0 + wn * 64 + 4 * (lane & 15)) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         if (!G2_LIVE(m)) continue;                       // nobody reads the products of dead columns
@@ -711,6 +751,7 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
                 const int row = cbase + (r & 3) + 8 * (r >> 2);
                 C[(size_t)row * ldc + j + n * 32] = (acc[m][n][r] * rscale[row]) * cs[n];
             }
+    }
     }
 #undef G2_LIVE
 }
@@ -740,7 +781,7 @@ __global__ __launch_bounds__(512) void gemm2h_kernel(const unsigned char* __rest
     }
     const int kb0 = z * kb_per;
     const int nkb = min(kb_per, Kb - kb0);
-    gemm2h_segment<NSUB, HI, VAR, true, PART, GEN>(A2, B1, Bhi, hiflag, rscale, Kb, C + (size_t)z * c_split_stride, ldc, mg * G3_MW,
+    gemm2h_segment<NSUB, HI, VAR, true, PART, GEN>(A2, B1, Bhi, hiflag, rscale, Kb, C ? C + (size_t)z * c_split_stride : nullptr, ldc, mg * G3_MW,
                                               jt * G3C_JW, kb0, nkb, smem3, cscale, (unsigned)((livemask >> (8 * mg)) & 0xffu));
 }
 

@@ -484,3 +484,34 @@ def test_nndsvd_rank_deficient_blocks(engine, case):
     # and the restart from it runs (the failure mode was a ValueError out of the host SVD)
     H, _, n_iter, _ = engine.nmf_batch([k], W0=[W0], H0=[H0])
     assert np.isfinite(H[0]).all() and n_iter[0] >= 1
+
+
+@pytest.mark.parametrize("case", ["size_factors_1pct", "size_factors_3e-3", "log1p", "tpm_like", "gene_jitter"])
+def test_near_grid_matrices_are_not_snapped(engine, case):
+    """Matrices that are count-DERIVED but no longer (integer x one constant per gene) must take the general path
+    (gemm_mode 5), not be snapped onto the count grid (round-3 review, weak #10): counts scaled by per-CELL size factors
+    close to 1 (1 % and 0.3 % spread: deviations of several 1e-3 count units on the larger counts), log1p-transformed
+    counts, counts-per-10k (TPM-like), and per-entry multiplicative jitter of 0.5 %.  And the result on that path is the
+    float64 oracle's for the matrix AS GIVEN."""
+    C, _ = synth.topic_counts(1024, 520, 6, 5.0, 0.3, 2)
+    C = C[:, C.sum(axis=0) > 0]
+    C = C[C.sum(axis=1) > 0].astype(np.float64)
+    rs = np.random.RandomState(11)
+    if case.startswith("size_factors"):
+        spread = 1e-2 if case.endswith("1pct") else 3e-3
+        Xc = C * (1.0 + spread * (rs.rand(C.shape[0], 1) - 0.5) * 2)
+    elif case == "log1p":
+        Xc = np.log1p(C)
+    elif case == "tpm_like":
+        Xc = C / C.sum(axis=1, keepdims=True) * 1e4
+    else:
+        Xc = C * (1.0 + 5e-3 * (rs.rand(*C.shape) - 0.5) * 2)
+    X = Xc / Xc.std(axis=0, ddof=1)
+    engine.set_matrix(X)
+    ks, seeds = [9] * 29, list(range(1, 30))
+    H, _, n_iter, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=25, warn=False)
+    assert engine.last_stats["kc"] == 256 and engine.last_stats["gemm_mode"] == 5, (case, engine.last_stats["gemm_mode"])
+    for r in (0, 7, 28):
+        _, H_ref, n_ref = nmf_cd.nmf(X, ks[r], seed=seeds[r], max_iter=25)
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, H[r])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (case, r, maxabs, relfro)
