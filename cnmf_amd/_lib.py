@@ -26,7 +26,7 @@ SYMBOLS = [
     "cnmf_allgather_bytes", "cnmf_allgather_spectra",
     "cnmf_spectra_rows", "cnmf_spectra_reset", "cnmf_spectra_fetch", "cnmf_spectra_genes", "cnmf_spectra_append",
     "cnmf_consensus_store", "cnmf_kselect_stats_store",
-    "cnmf_range_finder", "cnmf_debug_stream", "cnmf_debug_gemm", "cnmf_debug_gemm3", "cnmf_debug_gemm3c", "cnmf_debug_gemm2h", "cnmf_debug_standard_normal",
+    "cnmf_range_finder", "cnmf_format_rows_f64", "cnmf_debug_stream", "cnmf_debug_gemm", "cnmf_debug_gemm3", "cnmf_debug_gemm3c", "cnmf_debug_gemm2h", "cnmf_debug_standard_normal",
 ]
 
 COMM_ID_BYTES = 128
@@ -159,6 +159,8 @@ def load():
     lib.cnmf_x_matmul.argtypes = [vp, i32, f32p, i32, f32p]
     lib.cnmf_debug_stream.restype = i32
     lib.cnmf_debug_stream.argtypes = [vp, i32, C.c_longlong, i32]
+    lib.cnmf_format_rows_f64.restype = i64
+    lib.cnmf_format_rows_f64.argtypes = [dblp, i64, i64, C.c_char, C.c_char_p, i64, C.c_void_p, i64]
     lib.cnmf_range_finder.restype = i32
     lib.cnmf_range_finder.argtypes = [vp, i32, i32, i32p, f32p, i32, f32p, f32p]
     lib.cnmf_xt_matmul_f64.restype = i32

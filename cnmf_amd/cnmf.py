@@ -115,6 +115,23 @@ def save_df_to_text(obj, filename):
         obj.to_csv(filename, sep="\t")
         return
     ncol = vals.shape[1]
+    header = ("\t".join([""] + labels[:ncol]) + "\n").encode("utf-8")
+    try:                                                       # the library's formatter (repr(float) in C++); host code only
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        blob = "\n".join(labels[ncol:]).encode("utf-8")
+        out = np.empty(int(v.size) * 33 + len(blob) + v.shape[0] + 1, dtype=np.uint8)
+        n = lib.cnmf_format_rows_f64(v.ctypes.data_as(C.POINTER(C.c_double)), v.shape[0], v.shape[1], b"\t", blob, len(blob),
+                                     out.ctypes.data_as(C.c_void_p), out.size)
+        if n > 0:
+            with open(filename, "wb") as F:
+                F.write(header)
+                F.write(memoryview(out)[:n])
+            return
+    except (ImportError, OSError, AttributeError):
+        pass
     body = "\n".join("%s\t%s" % (lab, "\t".join(map(repr, row))) for lab, row in zip(labels[ncol:], vals.tolist()))
     with open(filename, "w", newline="") as F:
         F.write("\t".join([""] + labels[:ncol]) + "\n" + body + "\n")

@@ -252,3 +252,4 @@ extern "C" int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* N, int64_t* G)
 
 #include "debug_host.hip.h"
 #include "nndsvd_host.hip.h"
+#include "format_host.hip.h"

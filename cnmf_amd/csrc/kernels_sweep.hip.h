@@ -411,9 +411,11 @@ __device__ __forceinline__ void sweep_body(
 // TIER 0 handles ranks <= 16, TIER 1 ranks 17..32, TIER 2 ranks 33..64: one kernel for all ranks would
 // give the common small-rank case the register allocation of the largest (232 VGPR + 64 AGPR = one
 // wave per SIMD).  The host launches only the tiers present in the batch.
-// (TIER 0 without the exact report is the W half-step of the common ranks: held to 5 waves per SIMD)
+// (TIER 0 without the exact report is the W half-step of the common ranks: held to 5 waves per SIMD -- with the plane
+//  output too since round 4: the per-chunk bookkeeping of the partials had pushed it from 95 to 97 registers = 4 waves,
+//  178 instead of 160 us per 1024-column sweep)
 template <int TIER, bool RMX = false, bool PSUM = false, bool PLN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 && !RMX && !PLN) ? 5 : (TIER == 0 && !RMX ? 4 : 1), 8))) void sweep_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 && !RMX) ? 5 : 1, 8))) void sweep_kernel(
     float* __restrict__ V, int ldv, int L,
     const float* __restrict__ P,             // [KC][ldv] products (split-K already reduced)
     SplitInfo sp,

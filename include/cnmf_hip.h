@@ -325,6 +325,14 @@ int cnmf_kselect_stats(cnmf_ctx* ctx, int n, const int32_t* ks, const int32_t* R
                        const cnmf_consensus_params* cprm, const double* uniforms, const cnmf_cd_params* prm,
                        double* silhouette_out, double* pred_err_out, double* median_out, int32_t* nnls_iter_out);
 
+/* ---- text artefacts (host only, no context) ------------------------------------------------
+ * rows x cols FINITE doubles (row-major) as the reference's DataFrame.to_csv(sep) prints them (cnmf.py:34-35): per row the
+ * label (row_labels: the labels separated by '\n', labels_bytes bytes; NULL: none) and the values, every value as Python's
+ * repr(float), `sep` between the fields, '\n' behind the row.  Returns the bytes written, or -(capacity needed) when `cap`
+ * is too small (33 bytes per value + the labels + one separator per row).                                   */
+int64_t cnmf_format_rows_f64(const double* vals, int64_t rows, int64_t cols, char sep, const char* row_labels,
+                             int64_t labels_bytes, char* out, int64_t cap);
+
 /* ---- diagnostics used by the tests ---------------------------------------------------- */
 /* C[KC][J] = A[KC][K] . B  through the engine's MFMA GEMM; mode 0: B is [J][K] (pass A),
  * mode 1: B is [K][J] (pass B, split-K partials summed in split order).                  */
