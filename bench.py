@@ -310,7 +310,7 @@ def pmc_traffic(key, gemm_mode):
     collected in separate rocprofv3 --pmc passes (tools/gpu_pmc_bench.sh) and committed under
     profiles/ -- counters cannot be read from inside an un-profiled run.  (detail, usable)."""
     name = {0: "r1_pmc_traffic.json", 1: "r1_pmc_traffic_split.json", 2: "r1_pmc_traffic_split.json",
-            3: "r1_pmc_traffic_counts.json", 4: "r3_pmc_traffic_f16.json", 5: "r3_pmc_traffic_general.json"}[gemm_mode]
+            3: "r1_pmc_traffic_counts.json", 4: "r4_pmc_traffic_f16.json", 5: "r4_pmc_traffic_general.json"}[gemm_mode]
     d, verdict = load_profile(name)
     if d is None or key not in d:
         return None, False
@@ -778,11 +778,11 @@ def main():
             # measured ceiling of THIS instruction stream with everything but the MFMAs removed (tools/
             # probe_gemm2h_ablate.py var 7): the matrix pipe on non-zero data at the clock the power budget allows --
             # not a roofline, but the reason `frac` cannot approach 1.  Read from a stamped profile, never a literal.
-            abl, verdict = load_profile("r3_gemm2h_ablation.json")
+            abl, verdict = load_profile("r4_gemm2h_ablation.json")
             if abl and "mfma_only_tflops_issued" in abl:
                 issued = ach * per_product * agg["col_iters"] / max(agg["rc_iters"], 1)
                 roof["mfma_only_ablation"] = {"tflops_issued": abl["mfma_only_tflops_issued"],
-                                              "source": "profiles/r3_gemm2h_ablation.json", "stale": verdict,
+                                              "source": "profiles/r4_gemm2h_ablation.json", "stale": verdict,
                                               "issued_over_mfma_only": (issued / abl["mfma_only_tflops_issued"]) if verdict is None else None}
         if split:
             roof["matrix_pipe"] = {
