@@ -5,8 +5,8 @@ Workload (default, ``config.workload``): the north-star headline shape -- 50 000
 2000 high-variance genes (synthetic gamma-Poisson counts, reference `prepare` scaling,
 cnmf_amd/synth.py "C3"), K in {5..13}.  One STEP = one pass of the hot path over one
 batch of restarts: ``--restarts-per-k`` restarts for every K (default 100 = the north star's
-n_iter -> one step is one whole factorize() job of 900 restarts, streamed through 256
-packed component columns by the slot work-queue), run to sklearn's stopping rule (tol 1e-4, max_iter 1000)
+n_iter -> one step is one whole factorize() job of 900 restarts, streamed through up to 1024
+packed component columns by the slot work-queue; every step learns its queue order from scratch), run to sklearn's stopping rule (tol 1e-4, max_iter 1000)
 with sklearn's init='random' generated on the device from the cNMF ledger seeds
 (master seed 14).  X is resident in HBM before the timed region.
 
@@ -28,12 +28,15 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with extra obje
                   count path, 3 or 6 on the others; f32 MFMA peak on the exact-f32 pipe)
   cpu_baseline -- scikit-learn's non_negative_factorization (the call the reference makes,
                   cnmf.py:672) timed on this box's host cores on a bounded sample.
-  consensus    -- BASELINE config 5 (consensus-only stress) wall-clock, GPU next to the sklearn/pandas calls
+  consensus    -- BASELINE config 5 (consensus-only stress) wall-clock, GPU next to the sklearn/pandas calls; with the
+                  spectra uploaded and with the spectra already resident on the device (as after factorize)
+  with_queue_hints -- the same job once more with the iteration counts per rank that the timed steps learned handed back
+                  explicitly (cnmf_set_iteration_hints): reported beside the headline, never part of it
   general_path -- the same step with count detection OFF (any-X split-operand kernels), bounded
   e2e          -- prepare -> factorize -> combine -> k selection -> consensus(k=9) with the TPM tail, seconds per stage,
-                  next to the CPU reference path (measured stage by stage, factorize extrapolated from the measured
-                  restart-iterations/s)
-(the last four at N = 1 only).
+                  next to the CPU reference path (prepare like for like, k selection and consensus measured, factorize an
+                  extrapolation from the measured restart-iterations/s; no total, no speed-up)
+(the last five at N = 1 only).
 """
 import argparse
 import hashlib

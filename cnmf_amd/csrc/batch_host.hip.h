@@ -881,6 +881,14 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                 if (prior_of(k) > 0) { num += 4.0 * prior_of(k); den += 4.0; }
                 return den > 0 ? num / den : 1e30;
             };
+            if (dbg && n_done % 64 < 8) {
+                fprintf(stderr, "[cnmf] it %lld done %d pending %d expected per rank:", (long long)it, n_done, n_pending);
+                for (int k = 1; k <= KMAX; ++k)
+                    if (k_done[k] + fly_n[k] > 0)
+                        fprintf(stderr, " k%d=%.0f(%lld done, %d fly)", k, ((double)k_iters[k] + fly_age[k]) / ((double)k_done[k] + fly_n[k]),
+                                (long long)k_done[k], fly_n[k]);
+                fprintf(stderr, "\n");
+            }
             std::stable_sort(rest.begin(), rest.end(), [&](int a, int b) {
                 const double ea = expect(a), eb = expect(b);
                 return ea != eb ? ea > eb : kk[a] > kk[b];
