@@ -219,3 +219,59 @@ def test_kl_refit_regularised_and_zero_rows(engine):
     if nr != nr_ref:
         Wr_ref, _ = nmf_mu.nnls_mu(X, Hn, max_iter=int(nr), tol=0.0)
     assert np.abs(Wr - Wr_ref).max() <= 2e-3 * max(1e-6, np.abs(Wr_ref).max())
+
+
+def test_round4_entry_points_at_their_edges(engine):
+    """The round-4 additions of the C ABI at their edges: the float64 refit at rank 100 (the 128-accumulator product
+    kernel) and on a ragged shape; pairwise distances / silhouette with a row count that is not a multiple of the 64-row
+    tiles and with two clusters; queue hints outside the rank range; the spectra store under a wrong gene count; the text
+    formatter's capacity check."""
+    import ctypes as C
+    X = _x(333, 170, seed=4)
+    engine.set_matrix(X)
+    rs = np.random.RandomState(9)
+    # float64 refit, rank 100 and rank 3
+    for k in (100, 3):
+        Hs = np.abs(rs.standard_normal((k, 170)))
+        W_ref, n_ref = nmf_cd.nnls(X.astype(np.float32).astype(np.float64), Hs, max_iter=200)
+        W, n = engine.nnls_f64(Hs, max_iter=200, warn=False)
+        assert abs(n - n_ref) <= 1 and np.abs(W - W_ref).max() <= 1e-8 * max(1.0, np.abs(W_ref).max()), k
+    # distances / silhouette: 101 rows, two clusters
+    from sklearn.metrics import silhouette_score
+    from sklearn.metrics.pairwise import euclidean_distances
+    rows = rs.rand(101, 37)
+    labels = (rs.rand(101) < 0.3).astype(int)
+    D, sil = engine.pairwise_distances(rows, labels=labels)
+    assert np.abs(D - euclidean_distances(rows)).max() < 1e-7 and abs(sil - silhouette_score(rows, labels)) < 1e-9
+    with pytest.raises(ValueError):
+        engine.pairwise_distances(rows, labels=np.zeros(101, dtype=int))              # one label only
+    # queue hints: ranks outside 1..CNMF_KMAX are refused, None clears
+    with pytest.raises(ValueError):
+        engine.set_iteration_hints({0: 10.0})
+    with pytest.raises(ValueError):
+        engine.set_iteration_hints({129: 10.0})
+    engine.set_iteration_hints({5: 40.0, 9: 900.0})
+    H1, _, n1, _ = engine.nmf_batch([5, 9, 5, 9], seeds=[1, 2, 3, 4], max_iter=30, warn=False)
+    engine.set_iteration_hints(None)
+    assert all(np.isfinite(h).all() for h in H1) and len(n1) == 4
+    # the spectra store carries its own gene count
+    engine.spectra_reset()
+    first = engine.spectra_append(np.abs(rs.standard_normal((12, 50))).astype(np.float32))
+    assert first == 0 and engine.spectra_rows == 12 and engine.spectra_genes == 50
+    with pytest.raises(RuntimeError):
+        engine.spectra_append(np.zeros((3, 51), dtype=np.float32))                      # another gene count
+    with pytest.raises(ValueError):
+        engine.consensus(None, 3, store_rows=[0, 1, 2, 3, 4, 99])                       # row outside the store
+    out = engine.consensus(None, 3, store_rows=np.arange(12), skip_density=True)
+    ref = engine.consensus(engine.spectra_fetch().astype(np.float64), 3, skip_density=True)
+    assert np.array_equal(out["labels"], ref["labels"]) and np.array_equal(out["median_spectra"], ref["median_spectra"])
+    engine.spectra_reset()
+    # text formatter: too small a buffer reports the capacity it needs
+    lib = engine._lib
+    v = np.ascontiguousarray(rs.rand(4, 3))
+    small = np.empty(8, dtype=np.uint8)
+    need = lib.cnmf_format_rows_f64(v.ctypes.data_as(C.POINTER(C.c_double)), 4, 3, b"\t", None, 0, small.ctypes.data_as(C.c_void_p), small.size)
+    assert need == -(4 * 3 * 33)
+    big = np.empty(-need, dtype=np.uint8)
+    n = lib.cnmf_format_rows_f64(v.ctypes.data_as(C.POINTER(C.c_double)), 4, 3, b"\t", None, 0, big.ctypes.data_as(C.c_void_p), big.size)
+    assert bytes(big[:n]).decode() == "".join("\t".join(repr(float(x)) for x in row) + "\n" for row in v)
