@@ -94,6 +94,12 @@ static void free_x2(cnmf_ctx* c)
     c->X2h = c->X2m = c->Xt2h = c->Xt2m = nullptr; c->x2sA = c->x2sB = nullptr; c->onesA = c->onesB = nullptr;
 }
 
+static void free_mu_sparse(cnmf_ctx* c)
+{
+    for (int i = 0; i < 2; ++i) { c->spA[i].release(); c->spB[i].release(); }
+    c->x_nnz = -1;
+}
+
 static void free_batch(cnmf_ctx* c)
 {
     hipFree(c->H); hipFree(c->Wt); hipFree(c->XHt); hipFree(c->XHt1); hipFree(c->XHt2); hipFree(c->XtW); hipFree(c->d_split);
@@ -120,7 +126,7 @@ extern "C" void cnmf_destroy(cnmf_ctx* ctx)
     free_batch(ctx);
     cnmf_comm_finalize(ctx);
     hipFree(ctx->X); hipFree(ctx->X3); hipFree(ctx->Xt3); hipFree(ctx->XtF);
-    free_x2(ctx);
+    free_x2(ctx); free_mu_sparse(ctx);
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     hipFree(ctx->stageW); hipFree(ctx->stageH); hipFree(ctx->spectra);
@@ -141,6 +147,7 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     free_batch(ctx);
     hipFree(ctx->X); ctx->X = nullptr;
     hipFree(ctx->XtF); ctx->XtF = nullptr;
+    free_mu_sparse(ctx);
     hipFree(ctx->X3); hipFree(ctx->Xt3); ctx->X3 = ctx->Xt3 = nullptr;
     free_x2(ctx);
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);

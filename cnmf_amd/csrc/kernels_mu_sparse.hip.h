@@ -1,0 +1,244 @@
+// Kullback-Leibler multiplicative updates on the NON-ZEROS of X (round 4).
+//
+// For beta = 1 the quotient X / (WH) vanishes wherever X does, so both half-steps and the divergence only ever touch the
+// stored entries -- what scikit-learn does for scipy.sparse input (sklearn/decomposition/_nmf.py:84-194 `_beta_divergence`
+// with `_special_sparse_dot`, :526-631 `_multiplicative_update_w`, :634-728 `_multiplicative_update_h`), and what cNMF hands
+// it whenever the normalised counts are stored sparse (cnmf.py:618-631).  A real count matrix holds 5-10 % non-zeros.
+//
+// Layout: a blocked, sliced ELL image (`BSell`) of the matrix per orientation.  The OWN side of a half-step (cells for the
+// W update, genes for the H update) is cut in slices of 64 rows = one wavefront, a lane per row, the row's factor in registers;
+// the OTHER side is cut in blocks of BS rows whose factor block (BS x KP float32 = 128 KB) sits in LDS for the whole
+// workgroup.  Entries of (slice, block) are stored position-major -- entry t of the 64 rows side by side, 8 bytes each
+// {row of the other side inside its block, value} -- so a wavefront reads 512 contiguous bytes per step; a slice is padded to
+// its longest row (rows are sorted by their non-zero count first, so the padding stays at a few per cent).  Per entry a lane
+// gathers KP floats from LDS (quads swizzled by the row so that random rows spread over all banks), forms w.h, the quotient
+// and the k-vector update: 2 KP + ~8 vector operations and 4 KP bytes of LDS traffic per non-zero and half-step.
+// Bounds at 200 000 x 2 000, 8 % (32 M non-zeros), KP = 16: LDS gather 2 GB at 85-128 B/clk/CU = 26-40 us, vector ALU
+// ~30 us, entry stream 256 MB -- read from HBM once for ALL restarts in flight: the workgroups of one tile for the restarts
+// of the batch are adjacent in the dispatch order of ONE XCD, so the others hit its L2.
+//
+// Summation order is fixed (entries of a row in storage order, blocks in index order): results are run-to-run identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels_mu.hip.h"
+#include "kernels_mu_mfma.hip.h"
+
+namespace cnmf {
+
+struct BSellDev {
+    int R, C, BS, nblk, nslice;     // own rows, other rows, block size (other side), blocks, slices of 64 own rows
+    const int* perm;                // [nslice * 64]: own row of (slice, lane), -1 = none
+    const long long* off;           // [nslice * nblk]: first entry of (slice, block)
+    const int* len;                 // [nslice * nblk]: entries per lane of (slice, block)
+    const uint2* ent;               // {row of the other side inside its block, float bits}
+};
+
+constexpr int SP_WAVES = 16;                      // slices per workgroup (1024 threads: 4 waves per SIMD, one workgroup per CU)
+constexpr int SP_LDS_BYTES = 128 * 1024;
+constexpr int SP_UNROLL = 2;                      // entries per lane and trip (lengths are padded to it)
+template <int KP> struct SpShape { static constexpr int BS = SP_LDS_BYTES / (KP * 4); };
+
+// ---- build, pass 1: non-zeros of every row of M [R][ld] inside every block of BS columns
+__global__ __launch_bounds__(256) void sp_count_kernel(const float* __restrict__ M, int ld, int R, int C, int BS, int nblk,
+                                                       int* __restrict__ cnt)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* m = M + (size_t)row * ld;
+    for (int b = 0; b < nblk; ++b) {
+        const int c0 = b * BS, c1 = min(C, c0 + BS);
+        int n = 0;
+        for (int c = c0 + lane; c < c1; c += 64) n += (m[c] != 0.f) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+        if (lane == 0) cnt[(size_t)row * nblk + b] = n;
+    }
+}
+
+// ---- build, pass 2: a wavefront per (slice, lane) position walks its row and drops the non-zeros of every block into the
+// position-major entry array (which was zero-filled: {0, 0.0f} is the padding entry -- it adds nothing to any sum)
+__global__ __launch_bounds__(256) void sp_fill_kernel(const float* __restrict__ M, int ld, int C, int BS, int nblk, int npos,
+                                                      const int* __restrict__ perm, const long long* __restrict__ off,
+                                                      uint2* __restrict__ ent)
+{
+    const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pos >= npos) return;
+    const int row = perm[pos];
+    if (row < 0) return;
+    const int s = pos >> 6, l = pos & 63;
+    const float* m = M + (size_t)row * ld;
+    for (int b = 0; b < nblk; ++b) {
+        const int c0 = b * BS, c1 = min(C, c0 + BS);
+        uint2* e = ent + off[(size_t)s * nblk + b] + l;
+        int base = 0;
+        for (int cb = c0; cb < c1; cb += 64) {
+            const int c = cb + lane;
+            const float x = c < c1 ? m[c] : 0.f;
+            const bool nz = x != 0.f;
+            const unsigned long long mask = __ballot(nz);
+            if (nz) {
+                const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+                e[(size_t)idx * 64] = uint2{(unsigned)(c - c0), __float_as_uint(x)};
+            }
+            base += __popcll(mask);
+        }
+    }
+}
+
+// physical quad of logical quad q in LDS row r: rows that share a 256-byte bank line are rotated against each other, and
+// so is every group of such rows, so that the 16 lanes of one ds_read_b128 group (random rows) spread over all 16 quad slots
+template <int KP> __device__ __forceinline__ int sp_quad(int r, int q)
+{
+    constexpr int QPR = KP / 4, RPL = 16 / QPR;           // quads per row; rows per bank line
+    return (q + r / RPL) & (QPR - 1);
+}
+
+// ---- one half-step (MODE 0) or the divergence partials (MODE 1) over the stored entries.
+// side 0: own = W (cells), other = Ht (genes), denominator Hsum;  side 1: own = Ht, other = W, denominator Wsum.
+// grid.x enumerates (XCD, restart, tile): tile = (slice group, block); see the header for the order.
+template <int KP, int MODE>
+__global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatch mb, int side, int ngroups, float l1, float l2,
+                                                              int Rs /* padded own rows: row stride of the partials */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds_raw[];
+    float* lds = reinterpret_cast<float*>(sp_lds_raw);
+    constexpr int QPR = KP / 4;
+    // decode: n -> (xcd, m); m -> (restart, tile / 8); tile = (m / n_restarts) * 8 + xcd
+    const int n = blockIdx.x, xcd = n & 7, m = n >> 3;
+    const int slot = m % mb.n, tile = (m / mb.n) * 8 + xcd;
+    const int ntiles = ngroups * A.nblk;
+    if (tile >= ntiles) return;
+    const int grp = tile % ngroups, blk = tile / ngroups;
+    const MuSlotDev& sd = mb.s[slot];
+    float* own = side ? sd.Ht : sd.W;
+    const float* other = side ? sd.W : sd.Ht;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // stage the other side's block
+    const int o0 = blk * A.BS, nrows = min(A.BS, A.C - o0);
+    for (int e = tid; e < nrows * QPR; e += SP_WAVES * 64) {          // (entries only name rows below nrows)
+        const int r = e / QPR, q = e % QPR;
+        const v4f v = *reinterpret_cast<const v4f*>(other + (size_t)(o0 + r) * KP + q * 4);
+        *reinterpret_cast<v4f*>(lds + (r * QPR + sp_quad<KP>(r, q)) * 4) = v;
+    }
+    __syncthreads();
+    const int s = grp * SP_WAVES + wv;
+    double acc = 0.0;
+    int row = -1;
+    float w[KP], num[KP];
+#pragma unroll
+    for (int c = 0; c < KP; ++c) { w[c] = 0.f; num[c] = 0.f; }
+    if (s < A.nslice) {
+        row = A.perm[(size_t)s * 64 + lane];
+        if (row >= 0) {
+#pragma unroll
+            for (int q = 0; q < QPR; ++q) {
+                const v4f v = *reinterpret_cast<const v4f*>(own + (size_t)row * KP + q * 4);
+                w[q * 4] = v.x; w[q * 4 + 1] = v.y; w[q * 4 + 2] = v.z; w[q * 4 + 3] = v.w;
+            }
+        }
+        // (the builder rounds every length up to a multiple of SP_UNROLL: two gathers in flight per lane)
+        const int L = A.len[(size_t)s * A.nblk + blk];
+        const uint2* ep = A.ent + A.off[(size_t)s * A.nblk + blk] + lane;
+        constexpr int U = SP_UNROLL;
+        uint2 nxt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = L > 0 ? ep[(size_t)u * 64] : uint2{0u, 0u};
+        for (int t = 0; t < L; t += U) {
+            uint2 e[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) e[u] = nxt[u];
+            if (t + U < L) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) nxt[u] = ep[(size_t)(t + U + u) * 64];
+            }
+            float h[U][KP];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = (int)e[u].x;
+#pragma unroll
+                for (int q = 0; q < QPR; ++q) {
+                    const v4f v = *reinterpret_cast<const v4f*>(lds + (r * QPR + sp_quad<KP>(r, q)) * 4);
+                    h[u][q * 4] = v.x; h[u][q * 4 + 1] = v.y; h[u][q * 4 + 2] = v.z; h[u][q * 4 + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float x = __uint_as_float(e[u].y);
+                float wh = 0.f;
+#pragma unroll
+                for (int c = 0; c < KP; ++c) wh = fmaf(w[c], h[u][c], wh);
+                const float whs = fmaxf(wh, MU_EPS);
+                if (MODE == 0) {
+                    const float rr = x * __builtin_amdgcn_rcpf(whs);          // (1 ulp; the matrix-pipe path carries 2^-17)
+#pragma unroll
+                    for (int c = 0; c < KP; ++c) num[c] = fmaf(rr, h[u][c], num[c]);
+                } else if (x > MU_EPS) {
+                    acc += (double)(x * logf(x / whs) - x);
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+        __syncthreads();                                    // (every wave is past the factor block: LDS is free)
+        double* red = reinterpret_cast<double*>(sp_lds_raw);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) red[wv] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int q = 0; q < SP_WAVES; ++q) t += red[q];
+            sd.divpart[tile] = t;
+        }
+        return;
+    }
+    if (row < 0) return;
+    if (A.nblk == 1) {
+        // the whole other side was one block: finish the update here (sklearn _nmf.py:588-631 / :684-728)
+        const float* osum = side ? sd.Wsum : sd.Hsum;
+#pragma unroll
+        for (int c = 0; c < KP; ++c) {
+            float dn = osum[c];
+            if (side && dn == 0.f) dn = 1.0f;
+            if (l1 > 0.f) dn += l1;
+            if (l2 > 0.f) dn += l2 * w[c];
+            if (dn == 0.f) dn = MU_EPS;
+            float v = w[c] * (num[c] / dn);
+            if (side && v < F64_EPS_AS_F32) v = 0.f;
+            w[c] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < QPR; ++q)
+            *reinterpret_cast<v4f*>(own + (size_t)row * KP + q * 4) = v4f{w[q * 4], w[q * 4 + 1], w[q * 4 + 2], w[q * 4 + 3]};
+    } else {
+        float* pp = sd.pnum + ((size_t)blk * Rs + row) * KP;
+#pragma unroll
+        for (int q = 0; q < QPR; ++q)
+            *reinterpret_cast<v4f*>(pp + q * 4) = v4f{num[q * 4], num[q * 4 + 1], num[q * 4 + 2], num[q * 4 + 3]};
+    }
+}
+
+// ---- finish of a half-step whose other side took several blocks: numerators added in block order, then the update
+template <int KP>
+__global__ __launch_bounds__(256) void mu_sp_finish_kernel(MuBatch mb, int side, int R, int Rs, int nblk, float l1, float l2)
+{
+    const MuSlotDev& sd = mb.s[blockIdx.y];
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)R * KP) return;
+    const int c = (int)(e % KP);
+    float* own = side ? sd.Ht : sd.W;
+    float n = 0.f;
+    for (int b = 0; b < nblk; ++b) n += sd.pnum[(size_t)b * Rs * KP + e];
+    float dn = (side ? sd.Wsum : sd.Hsum)[c];
+    if (side && dn == 0.f) dn = 1.0f;                          // sklearn _nmf.py:684-686
+    const float v0 = own[e];
+    if (l1 > 0.f) dn += l1;
+    if (l2 > 0.f) dn += l2 * v0;
+    if (dn == 0.f) dn = MU_EPS;
+    float v = v0 * (n / dn);
+    if (side && v < F64_EPS_AS_F32) v = 0.f;                   // sklearn _nmf.py:868-869
+    own[e] = v;
+}
+
+}  // namespace cnmf

@@ -7,6 +7,7 @@
 #pragma once
 #include "kernels_mu.hip.h"
 #include "kernels_mu_mfma.hip.h"
+#include "kernels_mu_sparse.hip.h"
 
 namespace cnmf {
 
@@ -103,20 +104,121 @@ static int mu_ensure_xt(cnmf_ctx* ctx, int Gs)
     return CNMF_OK;
 }
 
+// ---- Kullback-Leibler on the non-zeros: the blocked sliced-ELL images (kernels_mu_sparse.hip.h) of M [R][ld], C columns
+static int sp_build_image(cnmf_ctx* ctx, const float* M, int ld, int R, int C, int BS, SpImage& im)
+{
+    hipStream_t st = ctx->stream;
+    const int nblk = (C + BS - 1) / BS, nslice = (R + 63) / 64, npos = nslice * 64;
+    DevPool pool;
+    int* dcnt = pool.get<int>((size_t)R * nblk);
+    POOL_TRY(ctx, pool);
+    sp_count_kernel<<<(R + 3) / 4, 256, 0, st>>>(M, ld, R, C, BS, nblk, dcnt);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<int> cnt((size_t)R * nblk);
+    HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), dcnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    // rows by decreasing non-zero count (ties in row order): the rows of a slice are about equally long
+    std::vector<long long> tot(R, 0);
+    for (int r = 0; r < R; ++r) for (int b = 0; b < nblk; ++b) tot[r] += cnt[(size_t)r * nblk + b];
+    std::vector<int> perm(npos, -1);
+    for (int r = 0; r < R; ++r) perm[r] = r;
+    std::stable_sort(perm.begin(), perm.begin() + R, [&](int a, int b) { return tot[a] > tot[b]; });
+    std::vector<int> len((size_t)nslice * nblk);
+    std::vector<long long> off((size_t)nslice * nblk);
+    long long n_ent = 0;
+    for (int s = 0; s < nslice; ++s)
+        for (int b = 0; b < nblk; ++b) {
+            int mx = 0;
+            for (int l = 0; l < 64; ++l) { const int r = perm[(size_t)s * 64 + l]; if (r >= 0) mx = std::max(mx, cnt[(size_t)r * nblk + b]); }
+            mx = round_up(mx, SP_UNROLL);
+            len[(size_t)s * nblk + b] = mx; off[(size_t)s * nblk + b] = n_ent;
+            n_ent += (long long)mx * 64;
+        }
+    im.release();
+    hipError_t e = hipMalloc((void**)&im.perm, perm.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&im.off, off.size() * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&im.len, len.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&im.ent, (size_t)std::max<long long>(n_ent, 64) * sizeof(uint2));
+    if (e == hipSuccess) e = hipMemsetAsync(im.ent, 0, (size_t)std::max<long long>(n_ent, 64) * sizeof(uint2), st);
+    if (e == hipSuccess) e = hipMemcpyAsync(im.perm, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(im.off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(im.len, len.data(), len.size() * sizeof(int), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        sp_fill_kernel<<<(npos + 3) / 4, 256, 0, st>>>(M, ld, C, BS, nblk, npos, im.perm, im.off, (uint2*)im.ent);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);               // the host vectors above are stack objects
+    if (e != hipSuccess) { im.release(); HIP_TRY(ctx, e); }
+    im.R = R; im.C = C; im.BS = BS; im.nblk = nblk; im.nslice = nslice; im.n_ent = (size_t)n_ent;
+    return CNMF_OK;
+}
+
+// Does this call take the non-zero path?  CNMF_MU_SPARSE=0 never, =1 always, otherwise when at most a quarter of X is
+// non-zero (the dense matrix-pipe kernels cost ~0.9 ns per ELEMENT and restart-iteration at k <= 16, these ~3 ns per NON-ZERO).
+static int mu_sparse_prepare(cnmf_ctx* ctx, int KP, bool* use)
+{
+    *use = false;
+    const char* ev = getenv("CNMF_MU_SPARSE");
+    const int mode = ev ? atoi(ev) : -1;
+    if (mode == 0 || (KP != 16 && KP != 32)) return CNMF_OK;
+    const int N = (int)ctx->N, G = (int)ctx->G, idx = KP == 16 ? 0 : 1, BS = SP_LDS_BYTES / (KP * 4);
+    if (ctx->x_nnz < 0) {
+        DevPool pool;
+        int* dcnt = pool.get<int>(N);
+        POOL_TRY(ctx, pool);
+        sp_count_kernel<<<(N + 3) / 4, 256, 0, ctx->stream>>>(ctx->X, ctx->G_pad, N, G, G, 1, dcnt);
+        HIP_TRY(ctx, hipGetLastError());
+        std::vector<int> cnt(N);
+        HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), dcnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        long long nnz = 0;
+        for (int v : cnt) nnz += v;
+        ctx->x_nnz = nnz;
+    }
+    if (mode != 1 && (double)ctx->x_nnz > 0.25 * (double)N * (double)G) return CNMF_OK;
+    int rc = CNMF_OK;
+    if (!ctx->spA[idx].ent) rc = sp_build_image(ctx, ctx->X, ctx->G_pad, N, G, BS, ctx->spA[idx]);
+    if (rc) return rc;
+    if (!ctx->spB[idx].ent) {
+        rc = mu_ensure_xt(ctx, round_up(ctx->G_pad, 128));
+        if (rc) return rc;
+        rc = sp_build_image(ctx, ctx->XtF, ctx->N_pad, G, N, BS, ctx->spB[idx]);
+        if (rc) return rc;
+    }
+    if (getenv("CNMF_DEBUG"))
+        fprintf(stderr, "[cnmf] KL on the non-zeros: %lld of %lld elements (%.1f %%), padded entries A %.3f x, B %.3f x\n",
+                ctx->x_nnz, (long long)N * G, 100.0 * ctx->x_nnz / ((double)N * G),
+                ctx->spA[idx].n_ent / std::max(1.0, (double)ctx->x_nnz), ctx->spB[idx].n_ent / std::max(1.0, (double)ctx->x_nnz));
+    *use = true;
+    return CNMF_OK;
+}
+
 struct MuJob { int restart; int k; size_t hoff, woff; };
 
 template <int KP, bool BETA1>
 static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init_mode, const uint32_t* seeds,
                          const double* avg, const float* W0, const float* H0, int update_H,
-                         const cnmf_cd_params* prm, float* H_out, float* W_out, int32_t* n_iter_out, double* err_out)
+                         const cnmf_cd_params* prm, float* H_out, float* W_out, int32_t* n_iter_out, double* err_out,
+                         bool sparse = false)
 {
     hipStream_t st = ctx->stream;
     const int N = (int)ctx->N, G = (int)ctx->G, ldx = ctx->G_pad, Np = ctx->N_pad;
+    // the non-zero path (Kullback-Leibler, padded ranks 16 / 32): same slots, same schedule, other kernels
+    BSellDev dA{}, dB{};
+    int grpA = 0, grpB = 0, tilesA = 0;
+    if (sparse) {
+        const SpImage &a = ctx->spA[KP == 16 ? 0 : 1], &b = ctx->spB[KP == 16 ? 0 : 1];
+        dA = BSellDev{a.R, a.C, a.BS, a.nblk, a.nslice, a.perm, a.off, a.len, (const uint2*)a.ent};
+        dB = BSellDev{b.R, b.C, b.BS, b.nblk, b.nslice, b.perm, b.off, b.len, (const uint2*)b.ent};
+        grpA = (a.nslice + SP_WAVES - 1) / SP_WAVES; grpB = (b.nslice + SP_WAVES - 1) / SP_WAVES;
+        tilesA = grpA * a.nblk;
+    }
     const int Gs = round_up(ctx->G_pad, 128);
     int rc = mu_ensure_xt(ctx, Gs);
     if (rc) return rc;
     constexpr int RPW = MuShape<KP>::RPW, SW = 32 * MuShape<KP>::NJT;      // restarts per workgroup, cells per divergence strip
-    const int nstrips = (N + SW - 1) / SW, ntiles = Np / 32;
+    const int nstrips = std::max((N + SW - 1) / SW, tilesA), ntiles = Np / 32;
+    const int ndiv = sparse ? tilesA : (N + SW - 1) / SW;                   // divergence partials per slot
     const int nchunks = std::min(32, ntiles), tpc = (ntiles + nchunks - 1) / nchunks;
     const int R = (int)std::min<size_t>(MU_MAXSLOTS, jobs.size());
     const float l1W = (float)prm->l1_reg_W, l2W = (float)prm->l2_reg_W;
@@ -136,7 +238,8 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         d.Hp_hi = pool.get<mu_u16>((size_t)Gs * KP, true, st); d.Hp_lo = pool.get<mu_u16>((size_t)Gs * KP, true, st);
         d.Hc_hi = pool.get<mu_u16>((size_t)2 * Gs * KP, true, st);
         d.Hsum = pool.get<float>(KP, true, st); d.Wsum = pool.get<float>(KP, true, st);
-        d.pnum = pool.get<float>((size_t)nchunks * Gs * KP);
+        d.pnum = sparse ? pool.get<float>(std::max<size_t>(dA.nblk > 1 ? (size_t)dA.nblk * Np : 0, dB.nblk > 1 ? (size_t)dB.nblk * Gs : 0) * KP)
+                        : pool.get<float>((size_t)nchunks * Gs * KP);
         d.pden = BETA1 ? nullptr : pool.get<float>((size_t)nchunks * Gs * KP);
         d.divpart = pool.get<double>(nstrips);
         d.cspart = pool.get<double>((size_t)256 * KP);
@@ -156,6 +259,10 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
             HIP_TRY(ctx, dyn_lds_optin((const void*)mu_h_coop_kernel<KP, BETA1>, coop_lds));
             HIP_TRY(ctx, dyn_lds_optin((const void*)mu_w_coop_kernel<KP, 0, BETA1>, coop_lds));
             HIP_TRY(ctx, dyn_lds_optin((const void*)mu_w_coop_kernel<KP, 1, BETA1>, coop_lds));
+            if constexpr (BETA1 && KP <= 32) {
+                HIP_TRY(ctx, dyn_lds_optin((const void*)mu_sp_kernel<KP, 0>, SP_LDS_BYTES));
+                HIP_TRY(ctx, dyn_lds_optin((const void*)mu_sp_kernel<KP, 1>, SP_LDS_BYTES));
+            }
         }
     }
     auto batch_of = [&](const std::vector<int>& ids) { MuBatch mb; mb.n = (int)ids.size(); for (int i = 0; i < mb.n; ++i) mb.s[i] = slots[ids[i]].d; return mb; };
@@ -240,10 +347,14 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
     auto divergence = [&](const std::vector<int>& ids, std::vector<double>& err) -> int {
         const MuBatch mb = batch_of(ids);
         if (!update_H) colsum(mb, 0);                 // refit: the iterations do not need the column sums of W
-        mu_w_coop_kernel<KP, 1, BETA1><<<dim3((N + 127) / 128, 1, (mb.n + RPW - 1) / RPW), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, 0.f, 0.f);
+        if (sparse) {
+            if constexpr (BETA1 && KP <= 32)
+                mu_sp_kernel<KP, 1><<<(tilesA + 7) / 8 * 8 * mb.n, SP_WAVES * 64, SP_LDS_BYTES, st>>>(dA, mb, 0, grpA, 0.f, 0.f, Np);
+        } else
+            mu_w_coop_kernel<KP, 1, BETA1><<<dim3((N + 127) / 128, 1, (mb.n + RPW - 1) / RPW), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, 0.f, 0.f);
         HIP_TRY(ctx, hipGetLastError());
         for (int i = 0; i < mb.n; ++i) {
-            HIP_TRY(ctx, hipMemcpyAsync(hdiv.data() + (size_t)i * nstrips, mb.s[i].divpart, (size_t)nstrips * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(hdiv.data() + (size_t)i * nstrips, mb.s[i].divpart, (size_t)ndiv * sizeof(double), hipMemcpyDeviceToHost, st));
             HIP_TRY(ctx, hipMemcpyAsync(hsums.data() + (size_t)i * 2 * KP, mb.s[i].Hsum, KP * sizeof(float), hipMemcpyDeviceToHost, st));
             HIP_TRY(ctx, hipMemcpyAsync(hsums.data() + (size_t)i * 2 * KP + KP, mb.s[i].Wsum, KP * sizeof(float), hipMemcpyDeviceToHost, st));
         }
@@ -251,7 +362,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         err.resize(mb.n);
         for (int i = 0; i < mb.n; ++i) {
             double res = 0.0;
-            for (int q = 0; q < nstrips; ++q) res += hdiv[(size_t)i * nstrips + q];
+            for (int q = 0; q < ndiv; ++q) res += hdiv[(size_t)i * nstrips + q];
             if (BETA1) {                                   // + sum(WH) from the column sums
                 double swh = 0.0;
                 for (int c = 0; c < KP; ++c) swh += (double)hsums[(size_t)i * 2 * KP + c] * (double)hsums[(size_t)i * 2 * KP + KP + c];
@@ -309,12 +420,28 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         // ---- one iteration of every live slot
         const MuBatch mb = batch_of(ids);
         const int gz4 = (mb.n + RPW - 1) / RPW;
+        if (sparse) {
+            if constexpr (BETA1 && KP <= 32) {
+                mu_sp_kernel<KP, 0><<<(tilesA + 7) / 8 * 8 * mb.n, SP_WAVES * 64, SP_LDS_BYTES, st>>>(dA, mb, 0, grpA, l1W, l2W, Np);
+                if (dA.nblk > 1)
+                    mu_sp_finish_kernel<KP><<<dim3((unsigned)(((size_t)N * KP + 255) / 256), mb.n), 256, 0, st>>>(mb, 0, N, Np, dA.nblk, l1W, l2W);
+                if (update_H) {
+                    colsum(mb, 0);
+                    const int tilesB = grpB * dB.nblk;
+                    mu_sp_kernel<KP, 0><<<(tilesB + 7) / 8 * 8 * mb.n, SP_WAVES * 64, SP_LDS_BYTES, st>>>(dB, mb, 1, grpB, l1H, l2H, Gs);
+                    if (dB.nblk > 1)
+                        mu_sp_finish_kernel<KP><<<dim3((G * KP + 255) / 256, mb.n), 256, 0, st>>>(mb, 1, G, Gs, dB.nblk, l1H, l2H);
+                    colsum(mb, 1);
+                }
+            }
+        } else {
         mu_w_coop_kernel<KP, 0, BETA1><<<dim3((N + 127) / 128, 1, gz4), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, l1W, l2W);
         if (update_H) {
             colsum(mb, 0);
             mu_h_coop_kernel<KP, BETA1><<<dim3(Gs / 128, nchunks, gz4), 512, coop_lds, st>>>(ctx->X, ldx, Np, Gs, mb, tpc, nchunks);
             mu_h_finish_mfma_kernel<KP, BETA1><<<dim3((Gs * KP + 255) / 256, mb.n), 256, 0, st>>>(mb, G, Gs, nchunks, l1H, l2H);
             colsum(mb, 1);
+        }
         }
         HIP_TRY(ctx, hipGetLastError());
         for (int si : ids) slots[si].it++;
@@ -367,9 +494,13 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
                 done[r] = 1;
                 ho += (size_t)k * G; wo += (size_t)k * N;
             }
-#define MU_BATCH(KP_, B1_, jobs_) mu_batch_mfma<KP_, B1_>(ctx, jobs_, init_mode, seeds, avg, W0, H0, update_H, prm, H_out, W_out, n_iter_out, err_out)
-            if (!j16.empty()) { rc = beta == 1 ? MU_BATCH(16, true, j16) : MU_BATCH(16, false, j16); if (rc) return rc; }
-            if (!j32.empty()) { rc = beta == 1 ? MU_BATCH(32, true, j32) : MU_BATCH(32, false, j32); if (rc) return rc; }
+#define MU_BATCH(KP_, B1_, jobs_, ...) mu_batch_mfma<KP_, B1_>(ctx, jobs_, init_mode, seeds, avg, W0, H0, update_H, prm, H_out, W_out, n_iter_out, err_out, ##__VA_ARGS__)
+            // Kullback-Leibler at padded ranks 16 / 32 on a matrix that is mostly zeros: only the non-zeros are touched
+            bool sp16 = false, sp32 = false;
+            if (beta == 1 && !j16.empty()) { rc = mu_sparse_prepare(ctx, 16, &sp16); if (rc) return rc; }
+            if (beta == 1 && !j32.empty()) { rc = mu_sparse_prepare(ctx, 32, &sp32); if (rc) return rc; }
+            if (!j16.empty()) { rc = beta == 1 ? MU_BATCH(16, true, j16, sp16) : MU_BATCH(16, false, j16); if (rc) return rc; }
+            if (!j32.empty()) { rc = beta == 1 ? MU_BATCH(32, true, j32, sp32) : MU_BATCH(32, false, j32); if (rc) return rc; }
             if (!j64.empty()) { rc = beta == 1 ? MU_BATCH(64, true, j64) : MU_BATCH(64, false, j64); if (rc) return rc; }
 #undef MU_BATCH
         }

@@ -71,6 +71,7 @@ static void invalidate_planes(cnmf_ctx* ctx)
     hipStreamSynchronize(ctx->stream);
     hipFree(ctx->X3); hipFree(ctx->Xt3); hipFree(ctx->XtF);
     ctx->X3 = ctx->Xt3 = nullptr; ctx->XtF = nullptr;
+    free_mu_sparse(ctx);
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     ctx->C1 = ctx->Ct1 = ctx->C1h = ctx->Ct1h = nullptr; ctx->hiA = ctx->hiB = nullptr;

@@ -35,6 +35,14 @@ struct Arena {
     }
 };
 
+// blocked sliced-ELL image of the non-zeros of one orientation of X (kernels_mu_sparse.hip.h); all pointers device memory
+struct SpImage {
+    int R = 0, C = 0, BS = 0, nblk = 0, nslice = 0;
+    int* perm = nullptr; long long* off = nullptr; int* len = nullptr; void* ent = nullptr;
+    size_t n_ent = 0;
+    void release() { hipFree(perm); hipFree(off); hipFree(len); hipFree(ent); *this = SpImage{}; }
+};
+
 struct cnmf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -61,6 +69,10 @@ struct cnmf_ctx {
     unsigned int *onesA = nullptr, *onesB = nullptr;
     float* XtF = nullptr;                          // X^T [round_up(G_pad, 64)][N_pad] float32, built on first use by the
                                                    // Kullback-Leibler solver (kernels_mu_mfma.hip.h)
+    // Kullback-Leibler on the non-zeros (kernels_mu_sparse.hip.h): images for padded ranks 16 and 32, cells x genes (A) and
+    // genes x cells (B); x_nnz = -1 until the first Kullback-Leibler call counted the matrix
+    SpImage spA[2], spB[2];
+    long long x_nnz = -1;
 
     // batch buffers (sized for kc_alloc columns)
     int kc_alloc = 0, nsplit_alloc = 0, nsplitA_alloc = 0, parts_alloc = 0;
