@@ -30,7 +30,7 @@ struct BSellDev {
     const int* perm;                // [nslice * 64]: own row of (slice, lane), -1 = none
     const long long* off;           // [nslice * nblk]: first entry of (slice, block)
     const int* len;                 // [nslice * nblk]: entries per lane of (slice, block)
-    const uint2* ent;               // {row of the other side inside its block, float bits}
+    const uint2* ent;               // {LDS byte offset of the other side's row (quad 0 of the rotated row), float bits}
 };
 
 constexpr int SP_WAVES = 16;                      // slices per workgroup (1024 threads: 4 waves per SIMD, one workgroup per CU)
@@ -57,10 +57,13 @@ __global__ __launch_bounds__(256) void sp_count_kernel(const float* __restrict__
 
 // ---- build, pass 2: a wavefront per (slice, lane) position walks its row and drops the non-zeros of every block into the
 // position-major entry array (which was zero-filled: {0, 0.0f} is the padding entry -- it adds nothing to any sum)
+// An entry names its row of the other side by the LDS byte offset of that row's quad 0 (sp_quad below): row r of a
+// [BS][KP] float block whose quads are rotated by r / (rows per 256-byte bank line).
 __global__ __launch_bounds__(256) void sp_fill_kernel(const float* __restrict__ M, int ld, int C, int BS, int nblk, int npos,
                                                       const int* __restrict__ perm, const long long* __restrict__ off,
-                                                      uint2* __restrict__ ent)
+                                                      uint2* __restrict__ ent, int KP)
 {
+    const unsigned QPR = (unsigned)KP / 4u, RPL = 16u / QPR;
     const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pos >= npos) return;
     const int row = perm[pos];
@@ -78,7 +81,8 @@ __global__ __launch_bounds__(256) void sp_fill_kernel(const float* __restrict__ 
             const unsigned long long mask = __ballot(nz);
             if (nz) {
                 const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-                e[(size_t)idx * 64] = uint2{(unsigned)(c - c0), __float_as_uint(x)};
+                const unsigned r = (unsigned)(c - c0);
+                e[(size_t)idx * 64] = uint2{r * (unsigned)(KP * 4) + (((r / RPL) & (QPR - 1u)) << 4), __float_as_uint(x)};
             }
             base += __popcll(mask);
         }
@@ -92,17 +96,24 @@ template <int KP> __device__ __forceinline__ int sp_quad(int r, int q)
     constexpr int QPR = KP / 4, RPL = 16 / QPR;           // quads per row; rows per bank line
     return (q + r / RPL) & (QPR - 1);
 }
+// (the padding entry {0, 0.0f} names row 0, whose rotation is 0: offset 0 is its quad 0)
 
 // ---- one half-step (MODE 0) or the divergence partials (MODE 1) over the stored entries.
-// side 0: own = W (cells), other = Ht (genes), denominator Hsum;  side 1: own = Ht, other = W, denominator Wsum.
-// grid.x enumerates (XCD, restart, tile): tile = (slice group, block); see the header for the order.
-template <int KP, int MODE>
-__global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatch mb, int side, int ngroups, float l1, float l2,
+// SIDE 0: own = W (cells), other = Ht (genes), denominator Hsum;  SIDE 1: own = Ht, other = W, denominator Wsum.
+// grid.x enumerates (XCD, restart, tile): tile = (slice group, block); see the header for the order.  A workgroup owns
+// SP_WAVES * spw consecutive slices of the (sorted) own side; wave v takes slices v, 2 SP_WAVES - 1 - v, 2 SP_WAVES + v, ...
+// -- a long one with a short one, so the 16 waves of a workgroup (which holds its CU alone: the factor block fills the LDS)
+// finish together.  Measured with one slice per wave on the gene side at 200 000 x 2 000 / 9 %: the workgroup waits for
+// the slice of the 64 most expressed genes while the other 15 waves idle (0.72 entries per clock and CU on average).
+typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
+
+template <int KP, int MODE, int SIDE>
+__global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatch mb, int ngroups, int spw, float l1, float l2,
                                                               int Rs /* padded own rows: row stride of the partials */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds_raw[];
     float* lds = reinterpret_cast<float*>(sp_lds_raw);
-    constexpr int QPR = KP / 4;
+    constexpr int QPR = KP / 4, RPL = 16 / QPR, KH = KP / 2;
     // decode: n -> (xcd, m); m -> (restart, tile / 8); tile = (m / n_restarts) * 8 + xcd
     const int n = blockIdx.x, xcd = n & 7, m = n >> 3;
     const int slot = m % mb.n, tile = (m / mb.n) * 8 + xcd;
@@ -110,8 +121,9 @@ __global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatc
     if (tile >= ntiles) return;
     const int grp = tile % ngroups, blk = tile / ngroups;
     const MuSlotDev& sd = mb.s[slot];
-    float* own = side ? sd.Ht : sd.W;
-    const float* other = side ? sd.W : sd.Ht;
+    float* own = SIDE ? sd.Ht : sd.W;
+    const float* other = SIDE ? sd.W : sd.Ht;
+    const float* osum = SIDE ? sd.Wsum : sd.Hsum;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // stage the other side's block
@@ -122,25 +134,26 @@ __global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatc
         *reinterpret_cast<v4f*>(lds + (r * QPR + sp_quad<KP>(r, q)) * 4) = v;
     }
     __syncthreads();
-    const int s = grp * SP_WAVES + wv;
     double acc = 0.0;
-    int row = -1;
-    float w[KP], num[KP];
+    for (int j = 0; j < spw; ++j) {
+        const int s = (grp * spw + j) * SP_WAVES + ((j & 1) ? SP_WAVES - 1 - wv : wv);
+        if (s >= A.nslice) continue;
+        const int row = A.perm[(size_t)s * 64 + lane];
+        sp_f32x2 w[KH], num[KH];
 #pragma unroll
-    for (int c = 0; c < KP; ++c) { w[c] = 0.f; num[c] = 0.f; }
-    if (s < A.nslice) {
-        row = A.perm[(size_t)s * 64 + lane];
+        for (int c = 0; c < KH; ++c) { w[c] = sp_f32x2{0.f, 0.f}; num[c] = sp_f32x2{0.f, 0.f}; }
         if (row >= 0) {
 #pragma unroll
             for (int q = 0; q < QPR; ++q) {
                 const v4f v = *reinterpret_cast<const v4f*>(own + (size_t)row * KP + q * 4);
-                w[q * 4] = v.x; w[q * 4 + 1] = v.y; w[q * 4 + 2] = v.z; w[q * 4 + 3] = v.w;
+                w[q * 2] = sp_f32x2{v.x, v.y}; w[q * 2 + 1] = sp_f32x2{v.z, v.w};
             }
         }
         // (the builder rounds every length up to a multiple of SP_UNROLL: two gathers in flight per lane)
-        const int L = A.len[(size_t)s * A.nblk + blk];
+        const int L = __builtin_amdgcn_readfirstlane(A.len[(size_t)s * A.nblk + blk]);
         const uint2* ep = A.ent + A.off[(size_t)s * A.nblk + blk] + lane;
         constexpr int U = SP_UNROLL;
+        constexpr unsigned RM = KP * 4 - 1;                                 // byte mask of one row
         uint2 nxt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) nxt[u] = L > 0 ? ep[(size_t)u * 64] : uint2{0u, 0u};
@@ -152,31 +165,62 @@ __global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatc
 #pragma unroll
                 for (int u = 0; u < U; ++u) nxt[u] = ep[(size_t)(t + U + u) * 64];
             }
-            float h[U][KP];
+            sp_f32x2 h[U][KH];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int r = (int)e[u].x;
+                const unsigned a0 = e[u].x;                                 // quad q: same row, (quad 0 + q) modulo the row
 #pragma unroll
                 for (int q = 0; q < QPR; ++q) {
-                    const v4f v = *reinterpret_cast<const v4f*>(lds + (r * QPR + sp_quad<KP>(r, q)) * 4);
-                    h[u][q * 4] = v.x; h[u][q * 4 + 1] = v.y; h[u][q * 4 + 2] = v.z; h[u][q * 4 + 3] = v.w;
+                    const unsigned a = q == 0 ? a0 : ((a0 & ~RM) | ((a0 + 16u * q) & RM));
+                    const v4f v = *reinterpret_cast<const v4f*>(sp_lds_raw + a);
+                    h[u][q * 2] = sp_f32x2{v.x, v.y}; h[u][q * 2 + 1] = sp_f32x2{v.z, v.w};
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float x = __uint_as_float(e[u].y);
-                float wh = 0.f;
+                sp_f32x2 da = w[0] * h[u][0], db = w[1] * h[u][1];         // four partial dot products, packed by two
 #pragma unroll
-                for (int c = 0; c < KP; ++c) wh = fmaf(w[c], h[u][c], wh);
-                const float whs = fmaxf(wh, MU_EPS);
+                for (int c = 2; c < KH; c += 2) {
+                    da = __builtin_elementwise_fma(w[c], h[u][c], da);
+                    db = __builtin_elementwise_fma(w[c + 1], h[u][c + 1], db);
+                }
+                da += db;
+                const float whs = fmaxf(da.x + da.y, MU_EPS);
                 if (MODE == 0) {
                     const float rr = x * __builtin_amdgcn_rcpf(whs);          // (1 ulp; the matrix-pipe path carries 2^-17)
+                    const sp_f32x2 r2 = sp_f32x2{rr, rr};
 #pragma unroll
-                    for (int c = 0; c < KP; ++c) num[c] = fmaf(rr, h[u][c], num[c]);
+                    for (int c = 0; c < KH; ++c) num[c] = __builtin_elementwise_fma(r2, h[u][c], num[c]);
                 } else if (x > MU_EPS) {
                     acc += (double)(x * logf(x / whs) - x);
                 }
             }
+        }
+        if (MODE == 1 || row < 0) continue;
+        if (A.nblk == 1) {
+            // the whole other side was one block: finish the update here (sklearn _nmf.py:588-631 / :684-728)
+            float wv_[KP];
+#pragma unroll
+            for (int c = 0; c < KP; ++c) {
+                const float w0 = (c & 1) ? w[c / 2].y : w[c / 2].x, nm = (c & 1) ? num[c / 2].y : num[c / 2].x;
+                float dn = osum[c];
+                if (SIDE && dn == 0.f) dn = 1.0f;
+                if (l1 > 0.f) dn += l1;
+                if (l2 > 0.f) dn += l2 * w0;
+                if (dn == 0.f) dn = MU_EPS;
+                float v = w0 * (nm / dn);
+                if (SIDE && v < F64_EPS_AS_F32) v = 0.f;
+                wv_[c] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < QPR; ++q)
+                *reinterpret_cast<v4f*>(own + (size_t)row * KP + q * 4) = v4f{wv_[q * 4], wv_[q * 4 + 1], wv_[q * 4 + 2], wv_[q * 4 + 3]};
+        } else {
+            float* pp = sd.pnum + ((size_t)blk * Rs + row) * KP;
+#pragma unroll
+            for (int q = 0; q < QPR; ++q)
+                *reinterpret_cast<v4f*>(pp + q * 4) = v4f{num[q * 2].x, num[q * 2].y, num[q * 2 + 1].x, num[q * 2 + 1].y};
         }
     }
     if (MODE == 1) {
@@ -191,31 +235,6 @@ __global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatc
             for (int q = 0; q < SP_WAVES; ++q) t += red[q];
             sd.divpart[tile] = t;
         }
-        return;
-    }
-    if (row < 0) return;
-    if (A.nblk == 1) {
-        // the whole other side was one block: finish the update here (sklearn _nmf.py:588-631 / :684-728)
-        const float* osum = side ? sd.Wsum : sd.Hsum;
-#pragma unroll
-        for (int c = 0; c < KP; ++c) {
-            float dn = osum[c];
-            if (side && dn == 0.f) dn = 1.0f;
-            if (l1 > 0.f) dn += l1;
-            if (l2 > 0.f) dn += l2 * w[c];
-            if (dn == 0.f) dn = MU_EPS;
-            float v = w[c] * (num[c] / dn);
-            if (side && v < F64_EPS_AS_F32) v = 0.f;
-            w[c] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < QPR; ++q)
-            *reinterpret_cast<v4f*>(own + (size_t)row * KP + q * 4) = v4f{w[q * 4], w[q * 4 + 1], w[q * 4 + 2], w[q * 4 + 3]};
-    } else {
-        float* pp = sd.pnum + ((size_t)blk * Rs + row) * KP;
-#pragma unroll
-        for (int q = 0; q < QPR; ++q)
-            *reinterpret_cast<v4f*>(pp + q * 4) = v4f{num[q * 4], num[q * 4 + 1], num[q * 4 + 2], num[q * 4 + 3]};
     }
 }
 

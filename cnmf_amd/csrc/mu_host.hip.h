@@ -144,7 +144,7 @@ static int sp_build_image(cnmf_ctx* ctx, const float* M, int ld, int R, int C, i
     if (e == hipSuccess) e = hipMemcpyAsync(im.off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(im.len, len.data(), len.size() * sizeof(int), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        sp_fill_kernel<<<(npos + 3) / 4, 256, 0, st>>>(M, ld, C, BS, nblk, npos, im.perm, im.off, (uint2*)im.ent);
+        sp_fill_kernel<<<(npos + 3) / 4, 256, 0, st>>>(M, ld, C, BS, nblk, npos, im.perm, im.off, (uint2*)im.ent, SP_LDS_BYTES / 4 / BS);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);               // the host vectors above are stack objects
@@ -205,12 +205,15 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
     const int N = (int)ctx->N, G = (int)ctx->G, ldx = ctx->G_pad, Np = ctx->N_pad;
     // the non-zero path (Kullback-Leibler, padded ranks 16 / 32): same slots, same schedule, other kernels
     BSellDev dA{}, dB{};
-    int grpA = 0, grpB = 0, tilesA = 0;
+    int grpA = 0, grpB = 0, tilesA = 0, spwB = 1;
     if (sparse) {
         const SpImage &a = ctx->spA[KP == 16 ? 0 : 1], &b = ctx->spB[KP == 16 ? 0 : 1];
         dA = BSellDev{a.R, a.C, a.BS, a.nblk, a.nslice, a.perm, a.off, a.len, (const uint2*)a.ent};
         dB = BSellDev{b.R, b.C, b.BS, b.nblk, b.nslice, b.perm, b.off, b.len, (const uint2*)b.ent};
-        grpA = (a.nslice + SP_WAVES - 1) / SP_WAVES; grpB = (b.nslice + SP_WAVES - 1) / SP_WAVES;
+        // cells: one slice per wave (sorted rows: the slices of a workgroup are equally long); genes: all slices of up to
+        // 8192 genes in ONE workgroup per block of cells, long and short slices paired on the waves
+        spwB = std::max(1, std::min(8, (b.nslice + SP_WAVES - 1) / SP_WAVES));
+        grpA = (a.nslice + SP_WAVES - 1) / SP_WAVES; grpB = (b.nslice + SP_WAVES * spwB - 1) / (SP_WAVES * spwB);
         tilesA = grpA * a.nblk;
     }
     const int Gs = round_up(ctx->G_pad, 128);
@@ -260,8 +263,9 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
             HIP_TRY(ctx, dyn_lds_optin((const void*)mu_w_coop_kernel<KP, 0, BETA1>, coop_lds));
             HIP_TRY(ctx, dyn_lds_optin((const void*)mu_w_coop_kernel<KP, 1, BETA1>, coop_lds));
             if constexpr (BETA1 && KP <= 32) {
-                HIP_TRY(ctx, dyn_lds_optin((const void*)mu_sp_kernel<KP, 0>, SP_LDS_BYTES));
-                HIP_TRY(ctx, dyn_lds_optin((const void*)mu_sp_kernel<KP, 1>, SP_LDS_BYTES));
+                HIP_TRY(ctx, dyn_lds_optin((const void*)mu_sp_kernel<KP, 0, 0>, SP_LDS_BYTES));
+                HIP_TRY(ctx, dyn_lds_optin((const void*)mu_sp_kernel<KP, 0, 1>, SP_LDS_BYTES));
+                HIP_TRY(ctx, dyn_lds_optin((const void*)mu_sp_kernel<KP, 1, 0>, SP_LDS_BYTES));
             }
         }
     }
@@ -349,7 +353,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         if (!update_H) colsum(mb, 0);                 // refit: the iterations do not need the column sums of W
         if (sparse) {
             if constexpr (BETA1 && KP <= 32)
-                mu_sp_kernel<KP, 1><<<(tilesA + 7) / 8 * 8 * mb.n, SP_WAVES * 64, SP_LDS_BYTES, st>>>(dA, mb, 0, grpA, 0.f, 0.f, Np);
+                mu_sp_kernel<KP, 1, 0><<<(tilesA + 7) / 8 * 8 * mb.n, SP_WAVES * 64, SP_LDS_BYTES, st>>>(dA, mb, grpA, 1, 0.f, 0.f, Np);
         } else
             mu_w_coop_kernel<KP, 1, BETA1><<<dim3((N + 127) / 128, 1, (mb.n + RPW - 1) / RPW), 512, coop_lds, st>>>(ctx->XtF, Np, N, Gs, mb, 0.f, 0.f);
         HIP_TRY(ctx, hipGetLastError());
@@ -422,13 +426,13 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         const int gz4 = (mb.n + RPW - 1) / RPW;
         if (sparse) {
             if constexpr (BETA1 && KP <= 32) {
-                mu_sp_kernel<KP, 0><<<(tilesA + 7) / 8 * 8 * mb.n, SP_WAVES * 64, SP_LDS_BYTES, st>>>(dA, mb, 0, grpA, l1W, l2W, Np);
+                mu_sp_kernel<KP, 0, 0><<<(tilesA + 7) / 8 * 8 * mb.n, SP_WAVES * 64, SP_LDS_BYTES, st>>>(dA, mb, grpA, 1, l1W, l2W, Np);
                 if (dA.nblk > 1)
                     mu_sp_finish_kernel<KP><<<dim3((unsigned)(((size_t)N * KP + 255) / 256), mb.n), 256, 0, st>>>(mb, 0, N, Np, dA.nblk, l1W, l2W);
                 if (update_H) {
                     colsum(mb, 0);
                     const int tilesB = grpB * dB.nblk;
-                    mu_sp_kernel<KP, 0><<<(tilesB + 7) / 8 * 8 * mb.n, SP_WAVES * 64, SP_LDS_BYTES, st>>>(dB, mb, 1, grpB, l1H, l2H, Gs);
+                    mu_sp_kernel<KP, 0, 1><<<(tilesB + 7) / 8 * 8 * mb.n, SP_WAVES * 64, SP_LDS_BYTES, st>>>(dB, mb, grpB, spwB, l1H, l2H, Gs);
                     if (dB.nblk > 1)
                         mu_sp_finish_kernel<KP><<<dim3((G * KP + 255) / 256, mb.n), 256, 0, st>>>(mb, 1, G, Gs, dB.nblk, l1H, l2H);
                     colsum(mb, 1);

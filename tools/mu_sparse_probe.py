@@ -10,13 +10,17 @@ from cnmf_amd.engine import Engine
 n_cells = int(os.environ.get("SP_CELLS", "200000"))
 its = int(os.environ.get("MU_ITERS", "30"))
 eng = Engine(0)
-for label, mu_lib in (("library size e^5.2", 5.2), ("library size e^6.8 (bench C4)", 6.8)):
+cases = (("library size e^5.2", 5.2), ("library size e^6.8 (bench C4)", 6.8))
+modes = ("1", "0")
+if os.environ.get("SP_ONLY"):                     # (kernel traces: the real-density matrix on the non-zero path only)
+    cases, modes = cases[:1], ("1",)
+for label, mu_lib in cases:
     C, _ = synth.topic_counts(n_cells, 2000, 20, mu_lib, 0.4, 3)
     X = synth.normalise_like_prepare(C, dtype=np.float32)
     del C
     print("%s: %d x %d, %.1f %% non-zero" % (label, X.shape[0], X.shape[1], 100.0 * (X != 0).mean()), flush=True)
     eng.set_matrix(X)
-    for mode in ("1", "0"):
+    for mode in modes:
         os.environ["CNMF_MU_SPARSE"] = mode
         t = time.perf_counter()
         eng.nmf_mu_batch([5, 20], seeds=[1, 2], max_iter=3, tol=0, warn=False)          # warm up: images / X^T, code objects
