@@ -51,6 +51,7 @@ struct MuSlotDev {                     // one restart in flight (all pointers de
     float* pden;                       // ... and denominators (Itakura-Saito only)
     double* divpart;                   // [nstrips] partial divergences
     double* cspart;                    // [256][KP] column-sum partials
+    int k;                             // rank of the restart (the non-zero path skips the padding quads of a factor row)
 };
 struct MuBatch {
     int n;

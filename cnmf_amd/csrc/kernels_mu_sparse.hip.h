@@ -107,34 +107,16 @@ template <int KP> __device__ __forceinline__ int sp_quad(int r, int q)
 // the slice of the 64 most expressed genes while the other 15 waves idle (0.72 entries per clock and CU on average).
 typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
 
-template <int KP, int MODE, int SIDE>
-__global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatch mb, int ngroups, int spw, float l1, float l2,
-                                                              int Rs /* padded own rows: row stride of the partials */)
+// the slices of one wave, for a restart whose rank fills NQ of the KP / 4 quads of a factor row: the padding quads are
+// neither gathered nor multiplied (they hold zeros and stay zeros)
+template <int KP, int MODE, int SIDE, int NQ>
+__device__ __forceinline__ void sp_slices(const BSellDev& A, const MuSlotDev& sd, const unsigned char* lds_raw, int grp, int blk,
+                                          int spw, int wv, int lane, float l1, float l2, int Rs, double& acc)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds_raw[];
-    float* lds = reinterpret_cast<float*>(sp_lds_raw);
-    constexpr int QPR = KP / 4, RPL = 16 / QPR, KH = KP / 2;
-    // decode: n -> (xcd, m); m -> (restart, tile / 8); tile = (m / n_restarts) * 8 + xcd
-    const int n = blockIdx.x, xcd = n & 7, m = n >> 3;
-    const int slot = m % mb.n, tile = (m / mb.n) * 8 + xcd;
-    const int ntiles = ngroups * A.nblk;
-    if (tile >= ntiles) return;
-    const int grp = tile % ngroups, blk = tile / ngroups;
-    const MuSlotDev& sd = mb.s[slot];
+    constexpr int KH = NQ * 2;
+    constexpr unsigned RM = KP * 4 - 1;                                     // byte mask of one row
     float* own = SIDE ? sd.Ht : sd.W;
-    const float* other = SIDE ? sd.W : sd.Ht;
     const float* osum = SIDE ? sd.Wsum : sd.Hsum;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // stage the other side's block
-    const int o0 = blk * A.BS, nrows = min(A.BS, A.C - o0);
-    for (int e = tid; e < nrows * QPR; e += SP_WAVES * 64) {          // (entries only name rows below nrows)
-        const int r = e / QPR, q = e % QPR;
-        const v4f v = *reinterpret_cast<const v4f*>(other + (size_t)(o0 + r) * KP + q * 4);
-        *reinterpret_cast<v4f*>(lds + (r * QPR + sp_quad<KP>(r, q)) * 4) = v;
-    }
-    __syncthreads();
-    double acc = 0.0;
     for (int j = 0; j < spw; ++j) {
         const int s = (grp * spw + j) * SP_WAVES + ((j & 1) ? SP_WAVES - 1 - wv : wv);
         if (s >= A.nslice) continue;
@@ -144,7 +126,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatc
         for (int c = 0; c < KH; ++c) { w[c] = sp_f32x2{0.f, 0.f}; num[c] = sp_f32x2{0.f, 0.f}; }
         if (row >= 0) {
 #pragma unroll
-            for (int q = 0; q < QPR; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const v4f v = *reinterpret_cast<const v4f*>(own + (size_t)row * KP + q * 4);
                 w[q * 2] = sp_f32x2{v.x, v.y}; w[q * 2 + 1] = sp_f32x2{v.z, v.w};
             }
@@ -152,8 +134,7 @@ __global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatc
         // (the builder rounds every length up to a multiple of SP_UNROLL: two gathers in flight per lane)
         const int L = __builtin_amdgcn_readfirstlane(A.len[(size_t)s * A.nblk + blk]);
         const uint2* ep = A.ent + A.off[(size_t)s * A.nblk + blk] + lane;
-        constexpr int U = SP_UNROLL;
-        constexpr unsigned RM = KP * 4 - 1;                                 // byte mask of one row
+        constexpr int U = NQ > 5 ? 1 : SP_UNROLL;                           // (ranks above 20: one gather in flight, no spills)
         uint2 nxt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) nxt[u] = L > 0 ? ep[(size_t)u * 64] : uint2{0u, 0u};
@@ -170,9 +151,9 @@ __global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatc
             for (int u = 0; u < U; ++u) {
                 const unsigned a0 = e[u].x;                                 // quad q: same row, (quad 0 + q) modulo the row
 #pragma unroll
-                for (int q = 0; q < QPR; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const unsigned a = q == 0 ? a0 : ((a0 & ~RM) | ((a0 + 16u * q) & RM));
-                    const v4f v = *reinterpret_cast<const v4f*>(sp_lds_raw + a);
+                    const v4f v = *reinterpret_cast<const v4f*>(lds_raw + a);
                     h[u][q * 2] = sp_f32x2{v.x, v.y}; h[u][q * 2 + 1] = sp_f32x2{v.z, v.w};
                 }
             }
@@ -200,9 +181,9 @@ __global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatc
         if (MODE == 1 || row < 0) continue;
         if (A.nblk == 1) {
             // the whole other side was one block: finish the update here (sklearn _nmf.py:588-631 / :684-728)
-            float wv_[KP];
+            float wv_[NQ * 4];
 #pragma unroll
-            for (int c = 0; c < KP; ++c) {
+            for (int c = 0; c < NQ * 4; ++c) {
                 const float w0 = (c & 1) ? w[c / 2].y : w[c / 2].x, nm = (c & 1) ? num[c / 2].y : num[c / 2].x;
                 float dn = osum[c];
                 if (SIDE && dn == 0.f) dn = 1.0f;
@@ -214,15 +195,47 @@ __global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatc
                 wv_[c] = v;
             }
 #pragma unroll
-            for (int q = 0; q < QPR; ++q)
+            for (int q = 0; q < NQ; ++q)
                 *reinterpret_cast<v4f*>(own + (size_t)row * KP + q * 4) = v4f{wv_[q * 4], wv_[q * 4 + 1], wv_[q * 4 + 2], wv_[q * 4 + 3]};
         } else {
             float* pp = sd.pnum + ((size_t)blk * Rs + row) * KP;
 #pragma unroll
-            for (int q = 0; q < QPR; ++q)
+            for (int q = 0; q < NQ; ++q)
                 *reinterpret_cast<v4f*>(pp + q * 4) = v4f{num[q * 2].x, num[q * 2].y, num[q * 2 + 1].x, num[q * 2 + 1].y};
         }
     }
+}
+
+template <int KP, int MODE, int SIDE>
+__global__ __launch_bounds__(SP_WAVES * 64) void mu_sp_kernel(BSellDev A, MuBatch mb, int ngroups, int spw, float l1, float l2,
+                                                              int Rs /* padded own rows: row stride of the partials */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds_raw[];
+    float* lds = reinterpret_cast<float*>(sp_lds_raw);
+    constexpr int QPR = KP / 4;
+    // decode: n -> (xcd, m); m -> (restart, tile / 8); tile = (m / n_restarts) * 8 + xcd
+    const int n = blockIdx.x, xcd = n & 7, m = n >> 3;
+    const int slot = m % mb.n, tile = (m / mb.n) * 8 + xcd;
+    const int ntiles = ngroups * A.nblk;
+    if (tile >= ntiles) return;
+    const int grp = tile % ngroups, blk = tile / ngroups;
+    const MuSlotDev& sd = mb.s[slot];
+    const float* other = SIDE ? sd.W : sd.Ht;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = __builtin_amdgcn_readfirstlane(min(QPR, max(1, (sd.k + 3) >> 2)));      // live quads of this restart
+    // stage the other side's block
+    const int o0 = blk * A.BS, nrows = min(A.BS, A.C - o0);
+    for (int e = tid; e < nrows * QPR; e += SP_WAVES * 64) {          // (entries only name rows below nrows)
+        const int r = e / QPR, q = e % QPR;
+        const v4f v = *reinterpret_cast<const v4f*>(other + (size_t)(o0 + r) * KP + q * 4);
+        *reinterpret_cast<v4f*>(lds + (r * QPR + sp_quad<KP>(r, q)) * 4) = v;
+    }
+    __syncthreads();
+    double acc = 0.0;
+#define SP_CASE(NQ_) case NQ_: if constexpr (NQ_ <= QPR) sp_slices<KP, MODE, SIDE, NQ_>(A, sd, sp_lds_raw, grp, blk, spw, wv, lane, l1, l2, Rs, acc); break;
+    switch (nq) { SP_CASE(1) SP_CASE(2) SP_CASE(3) SP_CASE(4) SP_CASE(5) SP_CASE(6) SP_CASE(7) SP_CASE(8) default: break; }
+#undef SP_CASE
     if (MODE == 1) {
         __syncthreads();                                    // (every wave is past the factor block: LDS is free)
         double* red = reinterpret_cast<double*>(sp_lds_raw);
@@ -246,6 +259,7 @@ __global__ __launch_bounds__(256) void mu_sp_finish_kernel(MuBatch mb, int side,
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (size_t)R * KP) return;
     const int c = (int)(e % KP);
+    if (c >= ((sd.k + 3) & ~3)) return;                        // padding quads: never written, stay zero
     float* own = side ? sd.Ht : sd.W;
     float n = 0.f;
     for (int b = 0; b < nblk; ++b) n += sd.pnum[(size_t)b * Rs * KP + e];

@@ -309,7 +309,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
             }
             mu_planes_kernel<KP><<<(int)(((size_t)Np * KP + 255) / 256), 256, 0, st>>>(s.d.W, Np, s.d.Wp_hi, s.d.Wp_lo, s.d.Wc_hi, s.d.Wc_hi + (size_t)Np * KP);
             mu_planes_kernel<KP><<<(Gs * KP + 255) / 256, 256, 0, st>>>(s.d.Ht, Gs, s.d.Hp_hi, s.d.Hp_lo, s.d.Hc_hi, s.d.Hc_hi + (size_t)Gs * KP);
-            s.job = jis[i]; s.it = 0; s.fresh = true; s.err0 = s.prev = s.err = 0.0;
+            s.job = jis[i]; s.it = 0; s.fresh = true; s.err0 = s.prev = s.err = 0.0; s.d.k = k;
         }
         HIP_TRY(ctx, hipGetLastError());
         return CNMF_OK;
