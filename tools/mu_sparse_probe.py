@@ -11,9 +11,14 @@ n_cells = int(os.environ.get("SP_CELLS", "200000"))
 its = int(os.environ.get("MU_ITERS", "30"))
 eng = Engine(0)
 cases = (("library size e^5.2", 5.2), ("library size e^6.8 (bench C4)", 6.8))
-modes = ("1", "0")
-if os.environ.get("SP_ONLY"):                     # (kernel traces: the real-density matrix on the non-zero path only)
-    cases, modes = cases[:1], ("1",)
+modes = tuple(os.environ.get("SP_MODES", "1,0").split(","))
+batches = ([9], [9] * 8, [9] * 32, [5, 6, 7, 8, 9, 10, 11, 12, 13] * 4, [20] * 32)
+if os.environ.get("SP_ONLY"):                     # (kernel traces / counters: the real-density matrix only)
+    cases = cases[:1]
+    if "SP_MODES" not in os.environ:
+        modes = ("1",)
+if os.environ.get("SP_LONG"):                     # (steady state: the per-call set-up amortised like in a real run)
+    batches = ([9] * 32, [5, 6, 7, 8, 9, 10, 11, 12, 13] * 4, [20] * 32)
 for label, mu_lib in cases:
     C, _ = synth.topic_counts(n_cells, 2000, 20, mu_lib, 0.4, 3)
     X = synth.normalise_like_prepare(C, dtype=np.float32)
@@ -25,7 +30,7 @@ for label, mu_lib in cases:
         t = time.perf_counter()
         eng.nmf_mu_batch([5, 20], seeds=[1, 2], max_iter=3, tol=0, warn=False)          # warm up: images / X^T, code objects
         print("  CNMF_MU_SPARSE=%s: first call (images) %.2f s" % (mode, time.perf_counter() - t), flush=True)
-        for ks in ([9], [9] * 8, [9] * 32, [5, 6, 7, 8, 9, 10, 11, 12, 13] * 4, [20] * 32):
+        for ks in batches:
             t = time.perf_counter()
             H, _, n, err = eng.nmf_mu_batch(ks, seeds=list(range(7, 7 + len(ks))), max_iter=its, tol=0, warn=False)
             dt = time.perf_counter() - t
