@@ -89,6 +89,88 @@ __global__ __launch_bounds__(256) void sp_fill_kernel(const float* __restrict__ 
     }
 }
 
+// ---- build, pass 3: the order of a row's entries is free -- choose it so that the gather is (nearly) free of LDS bank
+// conflicts.  A `ds_read_b128` is served in four groups of 16 lanes (MI355X_MICROARCH.md, LDS table); inside a group two
+// lanes collide when their rows agree modulo 16 (the rotation of the quads keeps that a bijection onto the 16 quad slots).
+// In storage order the 16 rows of a step are random: the fullest slot holds 3 of them on average, and the counters showed 62 %
+// of the LDS cycles as conflicts.  Here one thread per (slice, block, lane group) re-orders the 16 entry lists: every
+// step, the lanes (longest row first) take an entry of a residue nobody took yet, the one they hold most of -- a greedy
+// edge colouring of the lanes x residues multigraph, 1.3-1.5 rows on the fullest slot instead of 3 in simulation.  No
+// entry is added or dropped; padding entries (value bits 0) are pointed at a row of a free residue.
+__device__ __constant__ unsigned char SP_LANE_GROUPS[4][16] = {
+    {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+    {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+
+__global__ __launch_bounds__(64) void sp_reorder_kernel(int nslice, int nblk, int C, int BS, int KP,
+                                                        const long long* __restrict__ off, const int* __restrict__ len,
+                                                        uint2* __restrict__ ent, uint2* __restrict__ tmp)
+{
+    __shared__ unsigned char cnt[16][16][64];                          // [lane of the group][residue][thread]: entries left
+    __shared__ unsigned short start[16][16][64];                       // first position of that bucket in the lane's list
+    const long long job = (long long)blockIdx.x * 64 + threadIdx.x;    // (slice, block, group)
+    if (job >= (long long)nslice * nblk * 4) return;
+    const int grp = (int)(job & 3);
+    const long long sb = job >> 2;
+    const int L = len[sb];
+    if (L == 0) return;
+    const int blk = (int)(sb % nblk);
+    const int nrows = min(BS, C - blk * BS);
+    const unsigned rowb = (unsigned)KP * 4u, QPR = (unsigned)KP / 4u, RPL = 16u / QPR;
+    uint2* e0 = ent + off[sb];
+    uint2* t0 = tmp + off[sb];
+    const int tx = threadIdx.x;
+#define c_(i, r) cnt[i][r][tx]
+#define st_(i, r) start[i][r][tx]
+    for (int i = 0; i < 16; ++i) for (int r = 0; r < 16; ++r) c_(i, r) = 0;
+    for (int i = 0; i < 16; ++i) {
+        const uint2* e = e0 + SP_LANE_GROUPS[grp][i];
+        for (int t = 0; t < L; ++t) { const uint2 v = e[(size_t)t * 64]; if (v.y) c_(i, (v.x / rowb) & 15u)++; }
+    }
+    // bucket the lists by residue into tmp (same position-major layout); cnt becomes the fill count again afterwards
+    for (int i = 0; i < 16; ++i) {
+        unsigned short a = 0;
+        for (int r = 0; r < 16; ++r) { st_(i, r) = a; a += c_(i, r); c_(i, r) = 0; }
+        const uint2* e = e0 + SP_LANE_GROUPS[grp][i];
+        uint2* d = t0 + SP_LANE_GROUPS[grp][i];
+        for (int t = 0; t < L; ++t) {
+            const uint2 v = e[(size_t)t * 64];
+            if (!v.y) continue;
+            const unsigned r = (v.x / rowb) & 15u;
+            d[(size_t)(st_(i, r) + c_(i, r)) * 64] = v;
+            c_(i, r)++;
+        }
+    }
+    // the steps
+    for (int t = 0; t < L; ++t) {
+        unsigned taken = 0, idle = 0;
+        for (int i = 0; i < 16; ++i) {
+            int best = -1, bestc = 0, any = -1, anyc = 0;
+            for (int r = 0; r < 16; ++r) {
+                const int v = c_(i, r);
+                if (v > anyc) { anyc = v; any = r; }
+                if (v > bestc && !((taken >> r) & 1u)) { bestc = v; best = r; }
+            }
+            if (any < 0) { idle |= 1u << i; continue; }
+            if (best < 0) best = any;                                   // every residue it holds is taken: a conflict
+            c_(i, best)--;
+            e0[(size_t)t * 64 + SP_LANE_GROUPS[grp][i]] = t0[(size_t)(st_(i, best) + c_(i, best)) * 64 + SP_LANE_GROUPS[grp][i]];
+            taken |= 1u << best;
+        }
+        for (int i = 0; i < 16; ++i) {
+            if (!((idle >> i) & 1u)) continue;
+            unsigned r = 0;                                             // a row of a residue nobody reads in this step
+            for (unsigned q = 0; q < 16; ++q) if (!((taken >> q) & 1u)) { r = q; break; }
+            if ((int)r >= nrows) r = 0;
+            taken |= 1u << r;
+            e0[(size_t)t * 64 + SP_LANE_GROUPS[grp][i]] = uint2{r * rowb + (((r / RPL) & (QPR - 1u)) << 4), 0u};
+        }
+    }
+#undef c_
+#undef st_
+}
+
 // physical quad of logical quad q in LDS row r: rows that share a 256-byte bank line are rotated against each other, and
 // so is every group of such rows, so that the 16 lanes of one ds_read_b128 group (random rows) spread over all 16 quad slots
 template <int KP> __device__ __forceinline__ int sp_quad(int r, int q)

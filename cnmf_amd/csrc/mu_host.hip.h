@@ -147,6 +147,20 @@ static int sp_build_image(cnmf_ctx* ctx, const float* M, int ld, int R, int C, i
         sp_fill_kernel<<<(npos + 3) / 4, 256, 0, st>>>(M, ld, C, BS, nblk, npos, im.perm, im.off, (uint2*)im.ent, SP_LDS_BYTES / 4 / BS);
         e = hipGetLastError();
     }
+    // a conflict-free order of every row's entries (CNMF_SP_ORDER=0: storage order, the A/B reference)
+    const char* eo = getenv("CNMF_SP_ORDER");
+    if (e == hipSuccess && !(eo && atoi(eo) == 0) && n_ent > 0) {
+        uint2* tmp = nullptr;
+        e = hipMalloc((void**)&tmp, (size_t)n_ent * sizeof(uint2));
+        if (e == hipSuccess) {
+            const long long jobs = (long long)nslice * nblk * 4;
+            sp_reorder_kernel<<<(unsigned)((jobs + 63) / 64), 64, 0, st>>>(nslice, nblk, C, BS, SP_LDS_BYTES / 4 / BS, im.off, im.len,
+                                                                          (uint2*)im.ent, tmp);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            hipFree(tmp);
+        }
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);               // the host vectors above are stack objects
     if (e != hipSuccess) { im.release(); HIP_TRY(ctx, e); }
     im.R = R; im.C = C; im.BS = BS; im.nblk = nblk; im.nslice = nslice; im.n_ent = (size_t)n_ent;
@@ -176,6 +190,12 @@ static int mu_sparse_prepare(cnmf_ctx* ctx, int KP, bool* use)
         ctx->x_nnz = nnz;
     }
     if (mode != 1 && (double)ctx->x_nnz > 0.25 * (double)N * (double)G) return CNMF_OK;
+    {
+        // the partial numerators of a half-step whose other side needs several blocks: [blocks][own rows][KP] per slot
+        const double nbA = std::ceil((double)G / BS), nbB = std::ceil((double)N / BS);
+        const double part = 4.0 * KP * MU_MAXSLOTS * std::max(nbA > 1 ? nbA * ctx->N_pad : 0.0, nbB > 1 ? nbB * round_up(ctx->G_pad, 128) : 0.0);
+        if (mode != 1 && part > 64e9) return CNMF_OK;              // (e.g. 10^6 cells x 30 000 genes: stay on the dense kernels)
+    }
     int rc = CNMF_OK;
     if (!ctx->spA[idx].ent) rc = sp_build_image(ctx, ctx->X, ctx->G_pad, N, G, BS, ctx->spA[idx]);
     if (rc) return rc;

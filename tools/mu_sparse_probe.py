@@ -24,8 +24,8 @@ for label, mu_lib in cases:
     X = synth.normalise_like_prepare(C, dtype=np.float32)
     del C
     print("%s: %d x %d, %.1f %% non-zero" % (label, X.shape[0], X.shape[1], 100.0 * (X != 0).mean()), flush=True)
-    eng.set_matrix(X)
     for mode in modes:
+        eng.set_matrix(X)                        # (drops the images: CNMF_SP_ORDER / CNMF_MU_SPARSE are read when they are built)
         os.environ["CNMF_MU_SPARSE"] = mode
         t = time.perf_counter()
         eng.nmf_mu_batch([5, 20], seeds=[1, 2], max_iter=3, tol=0, warn=False)          # warm up: images / X^T, code objects
