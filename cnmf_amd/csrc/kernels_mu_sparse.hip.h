@@ -13,9 +13,9 @@
 // its longest row (rows are sorted by their non-zero count first, so the padding stays at a few per cent).  Per entry a lane
 // gathers KP floats from LDS (quads swizzled by the row so that random rows spread over all banks), forms w.h, the quotient
 // and the k-vector update: 2 KP + ~8 vector operations and 4 KP bytes of LDS traffic per non-zero and half-step.
-// Bounds at 200 000 x 2 000, 8 % (32 M non-zeros), KP = 16: LDS gather 2 GB at 85-128 B/clk/CU = 26-40 us, vector ALU
-// ~30 us, entry stream 256 MB -- read from HBM once for ALL restarts in flight: the workgroups of one tile for the restarts
-// of the batch are adjacent in the dispatch order of ONE XCD, so the others hit its L2.
+// The entry stream (290 MB at 200 000 x 2 000 / 9 %) is read from HBM once for ALL restarts in flight: the workgroups of
+// one tile for the restarts of the batch are adjacent in the dispatch order of ONE XCD, so the others hit its L2.
+// Measured there: 108 us per restart-iteration at ranks up to 13 (dense matrix-pipe kernels: 340), DESIGN.md section 4.
 //
 // Summation order is fixed (entries of a row in storage order, blocks in index order): results are run-to-run identical.
 #pragma once
@@ -35,7 +35,7 @@ struct BSellDev {
 
 constexpr int SP_WAVES = 16;                      // slices per workgroup (1024 threads: 4 waves per SIMD, one workgroup per CU)
 constexpr int SP_LDS_BYTES = 128 * 1024;
-constexpr int SP_UNROLL = 2;                      // entries per lane and trip (lengths are padded to it)
+constexpr int SP_UNROLL = 4;                      // lengths are padded to it: up to four entries per lane and trip
 template <int KP> struct SpShape { static constexpr int BS = SP_LDS_BYTES / (KP * 4); };
 
 // ---- build, pass 1: non-zeros of every row of M [R][ld] inside every block of BS columns
@@ -213,10 +213,10 @@ __device__ __forceinline__ void sp_slices(const BSellDev& A, const MuSlotDev& sd
                 w[q * 2] = sp_f32x2{v.x, v.y}; w[q * 2 + 1] = sp_f32x2{v.z, v.w};
             }
         }
-        // (the builder rounds every length up to a multiple of SP_UNROLL: two gathers in flight per lane)
+        // (the builder rounds every length up to a multiple of SP_UNROLL)
         const int L = __builtin_amdgcn_readfirstlane(A.len[(size_t)s * A.nblk + blk]);
         const uint2* ep = A.ent + A.off[(size_t)s * A.nblk + blk] + lane;
-        constexpr int U = NQ > 5 ? 1 : SP_UNROLL;                           // (ranks above 20: one gather in flight, no spills)
+        constexpr int U = NQ <= 3 ? 4 : (NQ <= 5 ? 2 : 1);                  // gathers in flight per lane (registers: no spills)
         uint2 nxt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) nxt[u] = L > 0 ? ep[(size_t)u * 64] : uint2{0u, 0u};
