@@ -36,7 +36,6 @@ struct BSellDev {
 constexpr int SP_WAVES = 16;                      // slices per workgroup (1024 threads: 4 waves per SIMD, one workgroup per CU)
 constexpr int SP_LDS_BYTES = 128 * 1024;
 constexpr int SP_UNROLL = 4;                      // lengths are padded to it: up to four entries per lane and trip
-template <int KP> struct SpShape { static constexpr int BS = SP_LDS_BYTES / (KP * 4); };
 
 // ---- build, pass 1: non-zeros of every row of M [R][ld] inside every block of BS columns
 __global__ __launch_bounds__(256) void sp_count_kernel(const float* __restrict__ M, int ld, int R, int C, int BS, int nblk,

@@ -35,3 +35,26 @@ def test_mu_refit_equals_sklearn(X):
     W_ref, n_ref = sklearn_ref.refit_usage(X, Hn, beta_loss="kullback-leibler", solver="mu", max_iter=200)
     W, n = nmf_mu.nnls_mu(X, Hn, max_iter=200)
     assert n == n_ref and np.abs(W - W_ref).max() <= 1e-9 * np.abs(W_ref).max()
+
+
+def test_kl_on_scipy_sparse_input_equals_the_dense_restatement():
+    """scikit-learn's Kullback-Leibler updates for scipy.sparse input touch only the stored entries
+    (`_special_sparse_dot`, _nmf.py:84-194, 526-728) -- the path cNMF takes when the normalised counts are stored sparse
+    and the one `kernels_mu_sparse.hip.h` restates on the device.  It is the same mathematics as the dense formulas (the
+    quotient vanishes where X does), so the dense numpy restatement is a valid checker for the device's non-zero path:
+    pinned here on a matrix with ~16 % non-zeros, restarts and a refit."""
+    import scipy.sparse as sp
+    C, _ = synth.topic_counts(400, 300, 6, 4.0, 0.4, 5)
+    Xs = synth.normalise_like_prepare(C, dtype=np.float64)
+    assert (Xs != 0).mean() < 0.2
+    csr = sp.csr_matrix(Xs)
+    for k, seed in ((5, 7), (9, 3)):
+        H_ref, W_ref, n_ref = sklearn_ref.nmf(csr, k, seed, beta_loss="kullback-leibler", solver="mu", max_iter=200)
+        W, H, n = nmf_mu.nmf_mu(Xs, k, seed=seed, max_iter=200)
+        assert n == n_ref
+        assert np.abs(H - H_ref).max() <= 1e-8 * np.abs(H_ref).max()
+        assert np.abs(W - W_ref).max() <= 1e-8 * np.abs(W_ref).max()
+    Hn = H / H.sum(axis=1, keepdims=True)
+    W_ref, n_ref = sklearn_ref.refit_usage(csr, Hn, beta_loss="kullback-leibler", solver="mu", max_iter=200)
+    W, n = nmf_mu.nnls_mu(Xs, Hn, max_iter=200)
+    assert n == n_ref and np.abs(W - W_ref).max() <= 1e-8 * np.abs(W_ref).max()
