@@ -116,3 +116,23 @@ def test_kl_path_selection_and_matrix_change(engine, monkeypatch):
     _, H_ref, _ = nmf_mu.nmf_mu(Xs.astype(np.float64), 4, seed=8, max_iter=int(ns[0]), tol=0.0)
     maxabs, relfro = nmf_cd.spectra_error(H_ref, Hs[0])
     assert maxabs <= 1e-4 and relfro <= 1e-3
+
+
+def test_kl_non_zero_path_through_the_cnmf_callsite(engine, tmp_path):
+    """`cNMF.factorize` with beta_loss='kullback-leibler' on a count matrix at a real matrix's density: the engine counts the
+    non-zeros of what it was handed and takes the non-zero path by itself; the merged spectra equal the oracle's restarts."""
+    from cnmf_amd.cnmf import cNMF, ledger_seeds
+    X = _sparse_counts(1800, 600, 4.6, seed=21)
+    assert (X != 0).mean() < 0.25
+    obj = cNMF(output_dir=str(tmp_path), name="mu_sparse", engine=engine)
+    obj.prepare_from_matrix(X, components=[4, 6], n_iter=2, seed=14, beta_loss="kullback-leibler", max_NMF_iter=120)
+    obj.factorize()
+    led = ledger_seeds([4, 6], 2, 14)
+    X64 = X.astype(np.float64)
+    for k in (4, 6):
+        merged = obj.combine_nmf(k)
+        assert merged.shape == (2 * k, X.shape[1]) and np.isfinite(merged.values).all() and (merged.values >= 0).all()
+        seed = [row[2] for row in led if row[0] == k][0]
+        _, H_ref, _ = nmf_mu.nmf_mu(X64, k, seed=seed, max_iter=120)
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, merged.values[:k])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (k, maxabs, relfro)
