@@ -155,7 +155,6 @@ def factorize_distributed(obj, rank, world, device=None, gather="rccl", **factor
     tests).  The rows exchanged are the ones ``factorize`` actually ran (``obj.last_factorize_jobs``): with
     ``skip_completed_runs=True`` the shard is taken over the INCOMPLETE rows (cnmf.py:729-733), not over the
     whole ledger."""
-    import pandas as pd
     from .cnmf import load_df_from_npz
     run_params = load_df_from_npz(obj.paths["nmf_replicate_parameters"])
     obj.factorize(worker_i=rank, total_workers=world, **factorize_kwargs)

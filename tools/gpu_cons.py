@@ -1,5 +1,5 @@
 """GPU probe: consensus-only stress (BASELINE config 5) wall-clock, GPU vs sklearn/pandas on the host."""
-import os, sys, time, json
+import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cnmf_amd import synth

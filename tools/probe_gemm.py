@@ -2,7 +2,7 @@
 import json
 import os
 import sys
-import time
+
 
 import numpy as np
 

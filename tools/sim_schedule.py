@@ -2,7 +2,7 @@
 (gpurun_out/iters_c3.json from tools/dump_iters.py): queue orders and batch widths for the north-star job and its
 strong-scaling shards.  Cost model per batch iteration (microseconds, measured at C3 on one MI355X, round 3):
 T(256) = 270, T(512) = 450, T(1024) = 800 when the batch is full; the tail narrows in 256-column steps."""
-import json, sys, os
+import json, sys
 import numpy as np
 
 T_FULL = {256: 270.0, 512: 450.0, 768: 640.0, 1024: 800.0}
