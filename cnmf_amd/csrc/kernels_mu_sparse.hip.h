@@ -215,7 +215,7 @@ __device__ __forceinline__ void sp_slices(const BSellDev& A, const MuSlotDev& sd
         // (the builder rounds every length up to a multiple of SP_UNROLL)
         const int L = __builtin_amdgcn_readfirstlane(A.len[(size_t)s * A.nblk + blk]);
         const uint2* ep = A.ent + A.off[(size_t)s * A.nblk + blk] + lane;
-        constexpr int U = NQ <= 3 ? 4 : (NQ <= 5 ? 2 : 1);                  // gathers in flight per lane (registers: no spills)
+        constexpr int U = NQ <= 4 ? 4 : (NQ <= 5 ? 2 : 1);                  // gathers in flight per lane (registers: no spills)
         uint2 nxt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) nxt[u] = L > 0 ? ep[(size_t)u * 64] : uint2{0u, 0u};

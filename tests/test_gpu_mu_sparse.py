@@ -19,6 +19,7 @@ def _sparse_counts(n, g, mu_lib, seed):
 
 @pytest.mark.parametrize("n,g,k", [(3000, 700, 7),       # padded rank 16: genes one block, cells two
                                    (1500, 2300, 12),      # genes two blocks, cells one
+                                   (1200, 900, 16),       # all four quads of a 16-float row live (four gathers in flight)
                                    (2500, 1300, 24),      # padded rank 32 (blocks of 1024): three and two blocks
                                    (130, 70, 3)])         # below one slice group
 def test_kl_on_the_non_zeros_vs_oracle_and_dense_path(engine, monkeypatch, n, g, k):

@@ -17,7 +17,9 @@ if os.environ.get("SP_ONLY"):                     # (kernel traces / counters: t
     cases = cases[:1]
     if "SP_MODES" not in os.environ:
         modes = ("1",)
-if os.environ.get("SP_LONG"):                     # (steady state: the per-call set-up amortised like in a real run)
+if os.environ.get("SP_KS"):                       # e.g. SP_KS=13x32,16x32
+    batches = tuple([int(a)] * int(b) for a, b in (t.split("x") for t in os.environ["SP_KS"].split(",")))
+elif os.environ.get("SP_LONG"):                     # (steady state: the per-call set-up amortised like in a real run)
     batches = ([9] * 32, [5, 6, 7, 8, 9, 10, 11, 12, 13] * 4, [20] * 32)
 for label, mu_lib in cases:
     C, _ = synth.topic_counts(n_cells, 2000, 20, mu_lib, 0.4, 3)
