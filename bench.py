@@ -36,7 +36,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with extra obje
   e2e          -- prepare -> factorize -> combine -> k selection -> consensus(k=9) with the TPM tail, seconds per stage,
                   next to the CPU reference path (prepare like for like, k selection and consensus measured, factorize an
                   extrapolation from the measured restart-iterations/s; no total, no speed-up)
-(the last five at N = 1 only).
+  kl_non_zero_path -- Kullback-Leibler restarts (beta_loss != 'frobenius') on a 50 000 x 2 000 count matrix with a real matrix's
+                  sparsity (9 % non-zero): the non-zero kernels beside the dense matrix-pipe kernels, us per restart-iteration
+(the last six at N = 1 only).
 """
 import argparse
 import hashlib
@@ -83,7 +85,7 @@ def parse():
     ap.add_argument("--event-stride", type=int, default=64,
                     help="HIP events around the two GEMM passes of every n-th iteration (the roofline's launch durations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip general_path and e2e (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip general_path, e2e and kl_non_zero_path (profiling runs)")
     ap.add_argument("--emulate-rank", default=None, metavar="R/W",
                     help="single GPU: run only the shard rank R of a world of W would run in --scaling strong "
                          "(tools/shard_scaling.py: the projected strong-scaling curve from one GPU)")
@@ -417,6 +419,41 @@ def general_path_step(X, ks_all, by_k, restarts_per_k, event_stride):
             "flop_basis": "f32-equivalent flops; peak = bf16 / f16 dense MFMA peak / %d MFMAs per product" % per,
             "column_utilisation": int(st["restart_column_iterations"]) / max(int(st["column_iterations"]), 1),
             "gemm_share_of_gpu_time": (avgA + avgB) * launches / max(st["gpu_ms"], 1e-9)}
+
+
+def kl_non_zero_path(ks_all, n_cells=50000, iters=100):
+    """Kullback-Leibler restarts (the reference's solver for beta_loss != 'frobenius', cnmf.py:618-631) on a count matrix
+    with a real matrix's sparsity (library size e^5.2 over 2 000 genes: ~9 % non-zero): the device touches only the
+    non-zeros (kernels_mu_sparse.hip.h, scikit-learn's scipy.sparse path) -- timed beside the dense matrix-pipe kernels
+    (CNMF_MU_SPARSE=0) on the same matrix.  Bounded: 4 restarts per K, `iters` iterations each, tol = 0."""
+    from cnmf_amd import synth
+    from cnmf_amd.engine import Engine
+    Cs, _ = synth.topic_counts(n_cells, 2000, 20, 5.2, 0.4, 3)
+    Xs = synth.normalise_like_prepare(Cs, dtype=np.float32)
+    del Cs
+    ks = [k for k in ks_all if k <= 32] * 4
+    seeds = list(range(11, 11 + len(ks)))
+    out = {"workload": "%d x %d, %.1f %% non-zero; %d KL restarts, K=%d..%d, %d iterations each"
+                       % (Xs.shape[0], Xs.shape[1], 100.0 * float((Xs != 0).mean()), len(ks), min(ks), max(ks), iters)}
+    eng = Engine(0)
+    old = os.environ.get("CNMF_MU_SPARSE")
+    try:
+        eng.set_matrix(Xs)
+        for label, mode in (("non_zero_path", "1"), ("dense_matrix_pipe", "0")):
+            os.environ["CNMF_MU_SPARSE"] = mode
+            eng.nmf_mu_batch(ks[:2], seeds=seeds[:2], max_iter=3, tol=0, warn=False)        # warm-up: images / X^T, code objects
+            t0 = time.perf_counter()
+            _, _, n_iter, _ = eng.nmf_mu_batch(ks, seeds=seeds, max_iter=iters, tol=0, warn=False)
+            dt = time.perf_counter() - t0
+            out[label] = {"us_per_restart_iteration": 1e6 * dt / float(np.sum(n_iter)), "restart_iterations_per_s": float(np.sum(n_iter)) / dt}
+    finally:
+        if old is None:
+            os.environ.pop("CNMF_MU_SPARSE", None)
+        else:
+            os.environ["CNMF_MU_SPARSE"] = old
+        eng.close()
+    out["speed_up"] = out["dense_matrix_pipe"]["us_per_restart_iteration"] / out["non_zero_path"]["us_per_restart_iteration"]
+    return out
 
 
 def e2e_wallclock(eng, C, X, ks_all, restarts_per_k, cpu_it_per_s):
@@ -875,6 +912,10 @@ def main():
                     out["e2e"] = e2e_wallclock(eng, C, X, ks_all, args.restarts_per_k, cpu["value"] if cpu else None)
                 except Exception as e:
                     out["e2e"] = {"error": repr(e)}
+                try:
+                    out["kl_non_zero_path"] = kl_non_zero_path(ks_all)
+                except Exception as e:
+                    out["kl_non_zero_path"] = {"error": repr(e)}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
     barrier()
