@@ -149,7 +149,7 @@ static int sp_build_image(cnmf_ctx* ctx, const float* M, int ld, int R, int C, i
     }
     // a conflict-free order of every row's entries (CNMF_SP_ORDER=0: storage order, the A/B reference)
     const char* eo = getenv("CNMF_SP_ORDER");
-    if (e == hipSuccess && !(eo && atoi(eo) == 0) && n_ent > 0) {
+    if (e == hipSuccess && !(eo && atoi(eo) == 0) && n_ent > 0 && BS / 16 <= 255) {     // (its per-residue counters are bytes)
         uint2* tmp = nullptr;
         e = hipMalloc((void**)&tmp, (size_t)n_ent * sizeof(uint2));
         if (e == hipSuccess) {
