@@ -20,7 +20,7 @@ SYMBOLS = [
     "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_set_count_detection", "cnmf_get_shape", "cnmf_get_matrix",
     "cnmf_col_moments", "cnmf_scale_columns", "cnmf_row_sums",
     "cnmf_nmf_cd_batch", "cnmf_nmf_cd_batch_resident", "cnmf_get_iteration_means", "cnmf_set_iteration_hints", "cnmf_nnls",
-    "cnmf_consensus", "cnmf_pairwise_distances", "cnmf_prediction_error", "cnmf_nmf_mu_batch", "cnmf_x_matmul",
+    "cnmf_consensus", "cnmf_pairwise_distances", "cnmf_prediction_error", "cnmf_nmf_mu_batch", "cnmf_mu_refit_f64", "cnmf_x_matmul",
     "cnmf_xt_matmul_f64", "cnmf_nnls_spectra", "cnmf_nnls_f64", "cnmf_nnls_gram", "cnmf_nnls_batch", "cnmf_kselect_stats",
     "cnmf_comm_unique_id", "cnmf_comm_init", "cnmf_comm_finalize", "cnmf_comm_rank", "cnmf_comm_world",
     "cnmf_allgather_bytes", "cnmf_allgather_spectra",
@@ -142,6 +142,8 @@ def load():
     lib.cnmf_nmf_mu_batch.restype = i32
     lib.cnmf_nmf_mu_batch.argtypes = [vp, i32, i32p, i32, u32p, dblp, f32p, f32p, i32, i32,
                                       C.POINTER(CdParams), f32p, f32p, i32p, dblp]
+    lib.cnmf_mu_refit_f64.restype = i32
+    lib.cnmf_mu_refit_f64.argtypes = [vp, i32, i32, dblp, dblp, C.c_double, C.POINTER(CdParams), dblp, i32p, dblp]
     lib.cnmf_get_iteration_means.restype = i32
     lib.cnmf_get_iteration_means.argtypes = [vp, dblp]
     lib.cnmf_set_iteration_hints.restype = i32

@@ -466,7 +466,11 @@ class cNMF:
             xdt = Xv.dtype if Xv.dtype in (np.float32, np.float64) else np.dtype(np.float64)
             if H.dtype != xdt:
                 raise TypeError("H should have the same dtype as X. Got H.dtype = {}.".format(H.dtype))
-            if mu:
+            if mu and kw["beta_loss"] in ("kullback-leibler", 1):
+                # float64 on the stored entries, like scikit-learn on the reference's float64 matrices (cnmf.py:534)
+                W, _, _ = eng.mu_refit_f64(H, tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 200),
+                                           alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
+            elif mu:
                 W, _ = eng.nnls_mu(H, beta_loss=kw["beta_loss"], tol=kw.get("tol", 1e-4),
                                    max_iter=kw.get("max_iter", 200), alpha_W=kw.get("alpha_W", 0.0),
                                    l1_ratio=kw.get("l1_ratio", 0.0))
@@ -820,8 +824,15 @@ class cNMF:
             kw = yaml.load(open(self.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
             solver_kw = dict(tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 1000),
                              alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
-            if kw.get("solver", "cd") == "mu":
-                # (the multiplicative-update refit keeps the generic path: transposed upload)
+            mu_tail = kw.get("solver", "cd") == "mu"
+            kl_tail = mu_tail and kw.get("beta_loss") in ("kullback-leibler", 1)
+            if kl_tail:
+                # refit_spectra = the Kullback-Leibler refit of tpm.X^T against usages^T (cnmf.py:805-820): float64 on the
+                # compressed rows of X^T, built on the device from the resident matrix -- no todense(), no transposed upload
+                Wt, _, _ = eng.mu_refit_f64(norm_usages.values.T, transposed=True, **solver_kw)
+                spectra_tpm = Wt.T
+            elif mu_tail:
+                # (Itakura-Saito touches every element: the generic path, transposed upload)
                 spectra_tpm = self.refit_spectra(np.asarray(tpm_x.todense()) if have_sparse else tpm_x.astype(tdt),
                                                  norm_usages.values.astype(tdt))
                 eng = self._get_engine(tpm_x, None)
@@ -849,7 +860,16 @@ class cNMF:
                 Hrf = spectra_tpm_rf.values.astype(np.float64)
                 H_prod = np.zeros((Hrf.shape[0], len(tpm_genes)), dtype=np.float64)
                 H_prod[:, hidx] = Hrf / std1
-                if kw.get("solver", "cd") == "mu":
+                if kl_tail:
+                    # the same refit on tpm[:, hvgs] / std without forming that matrix: the resident TPM's entries divided
+                    # by the gene's std on the fly, the other columns dropped; W0 = sqrt(mean(tpm[:, hvgs] / std) / k)
+                    div = np.zeros(len(tpm_genes))
+                    div[hidx] = std1
+                    H_full = np.zeros((Hrf.shape[0], len(tpm_genes)))
+                    H_full[:, hidx] = Hrf
+                    w0 = float(np.sqrt((mean[hidx] / std1).mean() / Hrf.shape[0]))
+                    rf, _, _ = eng.mu_refit_f64(H_full, col_divisor=div, w_init=w0, n_features=len(hvgs), **solver_kw)
+                elif mu_tail:
                     norm_tpm = (np.asarray(tpm_x[:, hidx].todense()) if have_sparse else tpm_x[:, hidx]).astype(np.float64) / std1
                     rf = self.refit_usage(norm_tpm, Hrf.astype(norm_tpm.dtype))
                 elif tdt == np.float64:

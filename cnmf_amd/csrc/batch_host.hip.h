@@ -9,16 +9,8 @@ static int sweep_max_parts()
     return std::max(1, v);
 }
 static int sweep_chunks(int L) { const int64_t m = 256ll * sweep_max_parts(); return std::max(1, (int)(((int64_t)L + m - 1) / m)); }
-// partials per slot of a half-step: one per sweep workgroup (sweep_chunks 256-row tiles each) -- or, with the W half-step
-// inside pass A (CNMF_FUSE_A=1, kernels_fusedw.hip.h), one per 256-row tile: the unit a pass-A workgroup produces too
-// (CNMF_FUSE_A=2: per-tile partials WITHOUT the fusion -- the arm the fused path is bit-identical to, tools/fused_ab.py)
-static bool sweep_tile_parts() { static const bool v = getenv("CNMF_FUSE_A") && atoi(getenv("CNMF_FUSE_A")) >= 1; return v; }
-static int sweep_parts(int L)
-{
-    if (sweep_tile_parts()) return std::max(1, (L + 255) / 256);
-    const int c = sweep_chunks(L);
-    return (L + 256 * c - 1) / (256 * c);
-}
+// partials per slot of a half-step: one per sweep workgroup (sweep_chunks 256-row tiles each)
+static int sweep_parts(int L) { const int c = sweep_chunks(L); return (L + 256 * c - 1) / (256 * c); }
 
 static int pick_nsplit(const cnmf_ctx* ctx, int KC)
 {
@@ -361,15 +353,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     }
     if (W_out) d_Wres = pool.get<float>(woff[n]);
     int* d_repack = pool.get<int>((size_t)3 * KC0);            // re-packing: column map, moved slot ids, their new offsets
-    // fused W half-step (kernels_fusedw.hip.h): slot lists per 128-column block + the "still needed" row masks per group
-    const int FW_INTS = (KC0 / 128 + 1) * FW_LIST + (KC0 / 256 + 1) * 8;
-    int* d_fw = pool.get<int>((size_t)FW_INTS, true, ctx->stream);
     POOL_TRY(ctx, pool);
-    struct PinnedFw { int* p = nullptr; ~PinnedFw() { if (p) hipHostFree(p); } } fw_host;
-    HIP_TRY(ctx, hipHostMalloc(&fw_host.p, (size_t)RING * FW_INTS * sizeof(int)));
-    bool fw_dirty = true;
-    int n_fw_upload = 0;
-    int64_t n_fused_passes = 0;
     struct PinnedInts { int* p = nullptr; ~PinnedInts() { if (p) hipHostFree(p); } } repack_host;
     HIP_TRY(ctx, hipHostMalloc(&repack_host.p, (size_t)RING * 3 * KC0 * sizeof(int)));
     int* h_repack = repack_host.p;
@@ -577,9 +561,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             }
         }
         h3_valid = false;                 // rows of H moved: its planes are stale
-        fw_dirty = true;                  // ... and the slot lists of the fused W half-step
         // moved rows of slots that no longer iterate are not swept again: refresh their row maxima here
-        if (use2h) HIP_TRY(ctx, launch_rowmax_part(st, ctx->Wt, ctx->N_pad, N, KC, sweep_tile_parts() ? 256 : chunksW * 256, nullptr, partsW, ctx->rmaxW));
+        if (use2h) HIP_TRY(ctx, launch_rowmax_part(st, ctx->Wt, ctx->N_pad, N, KC, chunksW * 256, nullptr, partsW, ctx->rmaxW));
         return CNMF_OK;
     };
 
@@ -619,7 +602,6 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             int s = 0;
             while (s < KC0 && hs[s].state != 0) ++s;
             hs[s].state = 1; hs[s].restart = r; hs[s].off = off; hs[s].k = k; hs[s].installed_at = it;
-            fw_dirty = true;
             nslots = std::max(nslots, s + 1);
             dim3 gI((std::max(N, G) + 255) / 256, k);
             if (init_mode == 0) {
@@ -702,12 +684,11 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
         }
         // pass A : XHt[KC][N] = H_all . X^T                       (sklearn _nmf.py:387)
         SplitInfo spA{nullptr, nullptr, 1, 1, 1};
-        bool fused_now = false;
         if (use3) {
             // H3 was produced together with the previous iteration's H finalize; rows installed since then
             // (and the very first iteration) need a split of their own.  Count path: H' = H * d.
             if ((n_new > 0 || !h3_valid) && use2h) {
-                HIP_TRY(ctx, launch_rowmax_part(st, ctx->H, ctx->G_pad, G, KC, sweep_tile_parts() ? 256 : chunksH * 256, dsc, partsH, ctx->rmaxH));
+                HIP_TRY(ctx, launch_rowmax_part(st, ctx->H, ctx->G_pad, G, KC, chunksH * 256, dsc, partsH, ctx->rmaxH));
                 HIP_TRY(ctx, launch_split2h(st, ctx->H, ctx->G_pad, KC, ctx->G_pad, ctx->H3, G3_MW, dsc, ctx->rmaxH,
                                             partsH, ctx->iscaleH));
             } else if (n_new > 0 || !h3_valid)
@@ -715,44 +696,15 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
             if (time_gemm) hipEventRecord(gev[gev.size() - 4], st);
             if (sk3.on) {
                 if (use2h) {
-                    // the W half-step of the uncut tiles inside pass A (kernels_fusedw.hip.h): restarts of rank <= 16 inside
-                    // one 128-column half of their group, planes written by the sweep (fuseW).  Bit-identical to the
-                    // stand-alone sweep and MEASURED SLOWER (pass A 308 -> 1021 us at 1024 columns for a sweep that shrinks
-                    // from 131 to 72 us: a pass-A workgroup has 8 waves to hide the latency of a sweep unit behind, the
-                    // stand-alone kernel 20 per CU; profiles/r4_fused_w_epilogue.txt): opt-in, CNMF_FUSE_A=1.
-                    static const bool fuse_a_on = getenv("CNMF_FUSE_A") && atoi(getenv("CNMF_FUSE_A")) == 1;
-                    fused_now = fuseW && fuse_a_on && sweep_tile_parts() && gemm2h_streamk_can_fuse(sk3, xAhi, csA, KbA, livemask);
-                    if (fused_now && fw_dirty) {
-                        // slot lists per 128-column block + the rows the stand-alone sweep still needs, from the host's
-                        // slot table (converged-but-not-retired restarts stay listed: the device checks `active`)
-                        int* hl = fw_host.p + (size_t)(n_fw_upload++ % RING) * FW_INTS;
-                        const int nblk = KC / 128;
-                        for (int b = 0; b < nblk; ++b) hl[(size_t)b * FW_LIST] = 0;
-                        unsigned* hn = reinterpret_cast<unsigned*>(hl + (size_t)(KC0 / 128) * FW_LIST);
-                        for (int i = 0; i < (KC0 / 256) * 8; ++i) hn[i] = 0u;
-                        for (int s2 = 0; s2 < nslots; ++s2) {
-                            if (!hs[s2].state) continue;
-                            const int off = hs[s2].off, k = hs[s2].k;
-                            if (fusedw_fusable(off, k)) { int* l = hl + (size_t)(off / 128) * FW_LIST; l[1 + l[0]] = s2; l[0] += 1; }
-                            else for (int c = off; c < off + k; ++c) hn[(c / 256) * 8 + ((c % 256) >> 5)] |= 1u << (c & 31);
-                        }
-                        HIP_TRY(ctx, hipMemcpyAsync(d_fw, hl, (size_t)FW_INTS * sizeof(int), hipMemcpyHostToDevice, st));
-                        fw_dirty = false;
-                    }
-                    const FusedW fw{fused_now ? 1 : 0, ctx->Wt, ctx->N_pad, N, ctx->gramH, ctx->d_slots, d_fw,
-                                    reinterpret_cast<const unsigned*>(d_fw + (size_t)(KC0 / 128) * FW_LIST), l1W,
-                                    ctx->gram_part, ctx->viol_part, ctx->rmaxW, partsW, max_k,
-                                    PlaneOut{(unsigned short*)ctx->Wt3, shW[shgen], KbB, G3_MW}};
                     HIP_TRY(ctx, launch_gemm2h_streamk(st, sk3, ctx->H3, xA, xAhi, xAfl, ctx->iscaleH, KbA,
-                                                       ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad, csA, livemask, &fw));
-                    n_fused_passes += fused_now ? 1 : 0;
+                                                       ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad, csA, livemask));
                 }
                 else if (usec)
                     HIP_TRY(ctx, launch_gemm3c_streamk(st, sk3, ctx->H3, ctx->C1, ctx->C1h, ctx->hiA, ctx->XHt, ctx->XHt1,
                                                        ctx->XHt2, ctx->N_pad));
                 else
                     HIP_TRY(ctx, launch_gemm3_streamk(st, sk3, ctx->H3, ctx->X3, ctx->XHt, ctx->XHt1, ctx->XHt2, ctx->N_pad));
-                spA = SplitInfo{ctx->XHt1, ctx->d_split, jwA, G3_MW, sk3.MG, ctx->XHt2, fused_now ? 1 : 0};
+                spA = SplitInfo{ctx->XHt1, ctx->d_split, jwA, G3_MW, sk3.MG, ctx->XHt2};
             } else if (use2h) {
                 HIP_TRY(ctx, launch_gemm2h(st, ctx->H3, xA, xAhi, xAfl, ctx->iscaleH, KbA, ctx->XHt, ctx->N_pad,
                                            (long long)KC * ctx->N_pad, KC, ctx->N_pad, nsplitA, csA, livemask));
@@ -1002,7 +954,6 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     }
 
     if (dbg) fprintf(stderr, "[cnmf] %lld defragmentations\n", (long long)n_defrag);
-    if (dbg) fprintf(stderr, "[cnmf] W half-step inside pass A: %lld of %lld iterations\n", (long long)n_fused_passes, (long long)it);
     if (dbg)
         for (int i = 1; i <= 64; ++i)
             if (dbg_it[i]) fprintf(stderr, "[cnmf] KC=%d: %lld iterations, mean host-live columns %.1f\n", i * 32,

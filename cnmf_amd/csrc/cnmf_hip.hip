@@ -39,11 +39,11 @@
 #include "kernels_gemm2h.hip.h"
 #include "kernels_rng.hip.h"
 #include "kernels_sweep.hip.h"
-#include "kernels_fusedw.hip.h"
 
 using namespace cnmf;
 
 #include "runtime.hip.h"
+#include "csr_host.hip.h"
 #include "gemm_host.hip.h"
 
 // ------------------------------------------------------------------ lifecycle
@@ -126,7 +126,7 @@ extern "C" void cnmf_destroy(cnmf_ctx* ctx)
     free_batch(ctx);
     cnmf_comm_finalize(ctx);
     hipFree(ctx->X); hipFree(ctx->X3); hipFree(ctx->Xt3); hipFree(ctx->XtF);
-    free_x2(ctx); free_mu_sparse(ctx);
+    free_x2(ctx); free_mu_sparse(ctx); free_csr(ctx);
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     hipFree(ctx->stageW); hipFree(ctx->stageH); hipFree(ctx->spectra);
@@ -147,7 +147,7 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     free_batch(ctx);
     hipFree(ctx->X); ctx->X = nullptr;
     hipFree(ctx->XtF); ctx->XtF = nullptr;
-    free_mu_sparse(ctx);
+    free_mu_sparse(ctx); free_csr(ctx);
     hipFree(ctx->X3); hipFree(ctx->Xt3); ctx->X3 = ctx->Xt3 = nullptr;
     free_x2(ctx);
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
@@ -181,15 +181,21 @@ extern "C" int cnmf_set_matrix(cnmf_ctx* ctx, const float* X, int64_t N, int64_t
     return CNMF_OK;
 }
 
+// *bad |= 1: a row whose columns are not strictly increasing (or a stored zero: the dense image would not list it);
+// *bad |= 2: a column index outside [0, n_cols) -- such an entry is skipped
 __global__ void csr_densify_kernel(const int* __restrict__ indptr, const int* __restrict__ indices,
                                    const float* __restrict__ data, float* __restrict__ X, int ld,
-                                   int n_rows)
+                                   int n_rows, int n_cols, int* __restrict__ bad)
 {
     const int row = blockIdx.x;
     if (row >= n_rows) return;
     const int b = indptr[row], e = indptr[row + 1];
-    for (int p = b + threadIdx.x; p < e; p += blockDim.x)
-        atomicAdd(&X[(size_t)row * ld + indices[p]], data[p]);   // duplicates sum, like .toarray()
+    for (int p = b + threadIdx.x; p < e; p += blockDim.x) {
+        const int c = indices[p];
+        if (c < 0 || c >= n_cols) { atomicOr(bad, 2); continue; }
+        if ((p > b && indices[p - 1] >= c) || data[p] == 0.f) atomicOr(bad, 1);
+        atomicAdd(&X[(size_t)row * ld + c], data[p]);   // duplicates sum, like .toarray()
+    }
 }
 
 extern "C" int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const int32_t* indices,
@@ -202,19 +208,36 @@ extern "C" int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const i
     int rc = alloc_matrix(ctx, N, G);
     if (rc) return rc;
     const int64_t nnz = indptr[N];
+    // the arrays stay on the device (csr_host.hip.h): the paths that walk the stored entries use them as uploaded --
+    // provided every row lists strictly increasing columns (scipy's canonical format); otherwise they are rebuilt from the
+    // dense image on first use (which sums duplicates like .toarray())
     DevPool pool;
-    int* d_ptr = pool.get<int>((size_t)(N + 1));
-    int* d_idx = pool.get<int>((size_t)nnz);
-    float* d_val = pool.get<float>((size_t)nnz);
+    int* d_ptr32 = pool.get<int>((size_t)(N + 1));
+    int* d_bad = pool.get<int>(1, true, ctx->stream);
     POOL_TRY(ctx, pool);
-    HIP_TRY(ctx, hipMemcpyAsync(d_ptr, indptr, (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    if (nnz > 0) {
-        HIP_TRY(ctx, hipMemcpyAsync(d_idx, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(d_val, data, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        csr_densify_kernel<<<(unsigned)N, 64, 0, ctx->stream>>>(d_ptr, d_idx, d_val, ctx->X, ctx->G_pad, (int)N);
-        HIP_TRY(ctx, hipGetLastError());
+    long long* d_ptr = nullptr;
+    int* d_idx = nullptr;
+    float* d_val = nullptr;
+    hipError_t e = hipMalloc((void**)&d_ptr, (size_t)(N + 1) * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_idx, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_val, (size_t)std::max<int64_t>(nnz, 1) * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ptr32, indptr, (size_t)(N + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_idx, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_val, data, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    int bad = 0;
+    if (e == hipSuccess) {
+        cnmf::csr_widen_ptr_kernel<<<(unsigned)((N + 1 + 255) / 256), 256, 0, ctx->stream>>>(d_ptr32, N + 1, d_ptr);
+        if (nnz > 0) {
+            csr_densify_kernel<<<(unsigned)N, 64, 0, ctx->stream>>>(d_ptr32, d_idx, d_val, ctx->X, ctx->G_pad, (int)N, (int)G, d_bad);
+        }
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (e != hipSuccess || bad) { hipFree(d_ptr); hipFree(d_idx); hipFree(d_val); d_ptr = nullptr; }
+    HIP_TRY(ctx, e);
+    if (bad & 2) { SET_ERR(ctx, "column index out of range in the CSR arrays"); return CNMF_EINVAL; }
+    if (d_ptr) { ctx->csr_ptr = d_ptr; ctx->csr_idx = d_idx; ctx->csr_val = d_val; ctx->csr_nnz = nnz; }
     return CNMF_OK;
 }
 
@@ -253,6 +276,7 @@ extern "C" int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* N, int64_t* G)
 
 // ------------------------------------------------------------------ multiplicative-update solver
 #include "mu_host.hip.h"
+#include "mu_refit_host.hip.h"
 #include "comm_host.hip.h"
 #include "normalize_host.hip.h"
 #include "tail_host.hip.h"

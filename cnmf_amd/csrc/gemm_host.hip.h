@@ -66,9 +66,8 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
                                float* rmax_part = nullptr, const double* rmax_scale = nullptr, bool psum = false,
                                PlaneOut po = PlaneOut{nullptr, nullptr, 0, 0})
 {
-    // `parts` = partials per slot: one per workgroup (chunks x 256 rows each), or -- parts = number of 256-row tiles -- one per
-    // tile (the fused W half-step, sweep_tile_parts()); a workgroup walks `chunks` tiles either way
-    dim3 grid(((L + 255) / 256 + chunks - 1) / chunks, nslots);
+    // `parts` = partials per slot = workgroups per slot; a workgroup walks `chunks` 256-row tiles
+    dim3 grid(parts, nslots);
     if (po.dst) {
         // the W half-step of the f16 paths, planes written by the sweep itself (ranks <= 64 only: the caller checks)
         if (psum || (rmax_part && rmax_scale) || (tiers & 8)) return hipErrorInvalidValue;
@@ -77,7 +76,7 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
         if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, false, false, true>, (int)sweep_lds_bytes(KSMALL, true))) return e_;
         if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<1, false, false, true>, (int)sweep_lds_bytes(KSMALL, true))) return e_;
         if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<2, false, false, true>, (int)sweep_lds_bytes(KSMALL, true))) return e_;
-#define CNMF_SWEEP_PLN(T_) sweep_kernel<T_, false, false, true><<<grid, 256, pl, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, parts, want_gram, kgp, kmax, rmax_part, nullptr, po)
+#define CNMF_SWEEP_PLN(T_) sweep_kernel<T_, false, false, true><<<grid, 256, pl, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kgp, kmax, rmax_part, nullptr, po)
         if (tiers & 1) CNMF_SWEEP_PLN(0);
         if (tiers & 2) CNMF_SWEEP_PLN(1);
         if (tiers & 4) CNMF_SWEEP_PLN(2);
@@ -96,8 +95,8 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
     // rmax_scale != nullptr selects the exact row-maximum report (the H half-step of the f16 plane split).
     const size_t lds = sweep_lds_bytes(kmax);
     const int kg = sweep_kg(kmax);
-#define CNMF_SWEEP(T_, R_) sweep_kernel<T_, R_><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, parts, want_gram, kg, kmax, rmax_part, rmax_scale)
-#define CNMF_SWEEP_PSUM(T_) sweep_kernel<T_, true, true><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, parts, want_gram, kg, kmax, rmax_part, rmax_scale)
+#define CNMF_SWEEP(T_, R_) sweep_kernel<T_, R_><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax, rmax_part, rmax_scale)
+#define CNMF_SWEEP_PSUM(T_) sweep_kernel<T_, true, true><<<grid, 256, lds, st>>>(V, ldv, L, P, sp, gram, slots, l1, gram_part, viol_part, chunks, want_gram, kg, kmax, rmax_part, rmax_scale)
     if (psum) {                 // split-K partial planes summed (and column-scaled) inside the sweep: sp = psum_info(...)
         {
             if (hipError_t e_ = dyn_lds_optin((const void*)sweep_kernel<0, true, true>, (int)sweep_lds_bytes(KSMALL))) return e_;
@@ -121,7 +120,7 @@ static hipError_t launch_sweep(hipStream_t st, int nslots, float* V, int ldv, in
     if (tiers & 8) {            // ranks 65..128: sweep_big_kernel (+ the Gram of the updated rows as its own launch)
         if (psum) return hipErrorInvalidValue;                 // the caller reduces the split-K planes first
         const size_t blds = sweep_big_lds_bytes();
-        const int bchunks = ((L + 255) / 256 + parts - 1) / parts;      // tiles per workgroup so that gridDim.x = the number of partials
+        const int bchunks = chunks;
         const dim3 gbig(parts, nslots);
         if (rmax_part && rmax_scale) {
             if (hipError_t e_ = dyn_lds_optin((const void*)sweep_big_kernel<true>, (int)blds)) return e_;
@@ -486,40 +485,12 @@ static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, co
     return hipGetLastError();
 }
 
-// the production pass A of the count path with the W half-step of the uncut tiles in its epilogue (kernels_fusedw.hip.h)
-template <bool NTB>
-static hipError_t launch_gemm2h_streamk_fusedw(hipStream_t st, const StreamK3& sk, const unsigned char* A2,
-                                               const unsigned char* B1, const float* rscale, int Kb, float* C0, float* C1,
-                                               float* C2, int ldc, const FusedW& fw)
-{
-    constexpr int lds = g2_lds_bytes(2, false) > FW_LDS_BYTES ? g2_lds_bytes(2, false) : FW_LDS_BYTES;
-    auto kern = gemm2h_streamk_kernel<2, false, CNMF_G2_VAR_DEFAULT, NTB, false, false, FusedW>;
-    if (hipError_t e_ = dyn_lds_optin((const void*)kern, lds)) return e_;
-    static const int xmap = getenv("CNMF_G2_XMAP") ? atoi(getenv("CNMF_G2_XMAP")) : 1;
-    kern<<<sk.P, 512, lds, st>>>(A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T, xmap, nullptr, ~0ull, fw);
-    return hipGetLastError();
-}
-
 // (the plan `sk` must have been made with unit = gemm2h_nsub(Bhi != nullptr, Kb))
-// can this launch carry the W half-step?  (the production instantiation of the count path only)
-static bool gemm2h_streamk_can_fuse(const StreamK3& sk, const unsigned char* Bhi, const float* cscale, int Kb,
-                                    unsigned long long livemask)
-{
-    const bool part = (livemask & g2_full_mask(sk.MG * G3_MW)) != g2_full_mask(sk.MG * G3_MW);
-    return sk.on && !Bhi && !cscale && !part && gemm2h_nsub(false, Kb) == 2 && g2_var() == CNMF_G2_VAR_DEFAULT;
-}
-
 static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, const unsigned char* A2,
                                         const unsigned char* B1, const unsigned char* Bhi, const unsigned int* hiflag,
                                         const float* rscale, int Kb, float* C0, float* C1, float* C2, int ldc,
-                                        const float* cscale = nullptr, unsigned long long livemask = ~0ull,
-                                        const FusedW* fw = nullptr)
+                                        const float* cscale = nullptr, unsigned long long livemask = ~0ull)
 {
-    if (fw && fw->on && gemm2h_streamk_can_fuse(sk, Bhi, cscale, Kb, livemask)) {
-        static const bool force_nt_f = getenv("CNMF_G2_NT") != nullptr;
-        return (sk.MG > 1 && !force_nt_f) ? launch_gemm2h_streamk_fusedw<false>(st, sk, A2, B1, rscale, Kb, C0, C1, C2, ldc, *fw)
-                                          : launch_gemm2h_streamk_fusedw<true>(st, sk, A2, B1, rscale, Kb, C0, C1, C2, ldc, *fw);
-    }
     static const bool nostore = getenv("CNMF_G2_NOSTORE") != nullptr;      // timing ablation: results meaningless
     if (nostore) C0 = C1 = C2 = nullptr;
     const bool part = (livemask & g2_full_mask(sk.MG * G3_MW)) != g2_full_mask(sk.MG * G3_MW);

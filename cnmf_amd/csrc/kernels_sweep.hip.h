@@ -59,12 +59,7 @@ struct SplitInfo {                  // further partial planes of a stream-K prod
     const unsigned char* split;     // [tiles] bit 0 = the tile was cut: add plane 1; bit 1 = cut twice: add plane 2 too
     int tile_rows, tile_cols, mgroups;
     const float* plane2 = nullptr;
-    int fused = 0;                  // 1: pass A ran the W half-step of the UNCUT tiles itself for every fusable restart
 };
-
-// Restarts whose W half-step a pass-A workgroup can run in its epilogue (kernels_fusedw.hip.h): the register-resident
-// tier of the sweep, columns inside ONE 128-column half of a 256-column component group.
-__device__ __host__ __forceinline__ bool fusedw_fusable(int off, int k) { return k <= 16 && (off & 127) + k <= 128; }
 
 // PLN (round 3, the W half-step of the f16 paths): the sweep also writes the two f16 planes of the rows it has just
 // updated, in the block-major layout pass B multiplies (kernels_gemm2h.hip.h), scaled by the per-component exponent
@@ -89,7 +84,7 @@ struct PlaneOut {
 // RMX: also report the largest updated entry per component (x rmax_scale[row]) EXACTLY, at the price of KP
 // registers (the H half-step: few rows).  Without it (the W half-step: keeps 5 waves per SIMD) the report is the
 // bound  sqrt(sum_rows w^2)  from the diagonal of the workgroup's Gram partial -- at most sqrt(rows per workgroup)
-// = 32 x the true maximum (16 x with per-tile partials), which the f16 plane split tolerates (kernels_gemm2h.hip.h: 5 bits of exponent slack only
+// = 32 x the true maximum, which the f16 plane split tolerates (kernels_gemm2h.hip.h: 5 bits of exponent slack only
 // move the threshold below which tiny entries keep an absolute rather than a relative accuracy).
 // PSUM: the products arrive as `sp.mgroups` split-K partial planes (stride sp.tile_rows * 2^20 + sp.tile_cols floats,
 // see psum_info) that are summed here in split order and scaled by the per-row constant sp.split (reinterpreted as
@@ -99,13 +94,9 @@ __device__ __forceinline__ void sweep_body(
     float* __restrict__ V, int ldv, int L, const float* __restrict__ P, const SplitInfo& sp,
     const float* __restrict__ gram, const SlotDesc& sd, int slot, float l1_reg,
     float* __restrict__ gram_part, double* __restrict__ viol_part,
-    int chunks_per_block, int n_parts, int want_gram, float* lds, int kg, int gld,
+    int chunks_per_block, int want_gram, float* lds, int kg, int gld,
     float* __restrict__ rmax_part, const double* __restrict__ rmax_scale, const PlaneOut& po = PlaneOut{nullptr, nullptr, 0, 0})
 {
-    // Partials (Gram of the updated rows, violation, row-maximum report): one per workgroup (n_parts = gridDim.x, the
-    // default), or -- round 4, n_parts > gridDim.x -- ONE PER (slot, 256-row tile), n_parts = ceil(L / 256): the unit a pass-A
-    // workgroup can produce as well when it runs the W half-step of an uncut tile in its epilogue (kernels_fusedw.hip.h,
-    // CNMF_FUSE_A=1).
     constexpr int GMODE = (KP <= 16) ? 0 : ((KP <= 32) ? 1 : 2);
     constexpr int GR = (GMODE == 0) ? 16 : ((GMODE == 1) ? 32 : 64);       // gram tile edge
     const int gs = kg + 4, wstride = kg + 1;
@@ -129,31 +120,20 @@ __device__ __forceinline__ void sweep_body(
     __syncthreads();
 
     f32x16 gacc[GMODE == 2 ? 4 : 1];
-    f32x4 gacc4;
-    float viol;
-    // largest updated entry per component over this tile's rows (x the per-row scale of the f16 plane split,
+    f32x4 gacc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gacc[a][r] = 0.f;
+    float viol = 0.f;
+    // largest updated entry per component over this workgroup's rows (x the per-row scale of the f16 plane split,
     // kernels_gemm2h.hip.h) -- only when the caller wants it
     float mx[RMX ? KP : 1];
+#pragma unroll
+    for (int c = 0; c < (RMX ? KP : 1); ++c) mx[c] = 0.f;
 
-    const bool per_tile = n_parts > (int)gridDim.x || (!PSUM && sp.fused != 0);
-    bool fresh = true;                                                   // the accumulators hold nothing yet
     for (int ch = 0; ch < chunks_per_block; ++ch) {
-        const int tile = blockIdx.x * chunks_per_block + ch;             // the 256-row tile of this chunk
-        if (per_tile && tile >= n_parts) break;
-        const int part = per_tile ? tile : (int)blockIdx.x;              // the partial it is added to
-        const bool emit = per_tile || ch == chunks_per_block - 1;
-        if (fresh) {
-            gacc4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gacc[a][r] = 0.f;
-            viol = 0.f;
-#pragma unroll
-            for (int c = 0; c < (RMX ? KP : 1); ++c) mx[c] = 0.f;
-        }
-        fresh = emit;
-        const int row = tile * 256 + tid;
+        const int row = (blockIdx.x * chunks_per_block + ch) * 256 + tid;
         const bool live = row < L;
         // stream-K pass A: was this (row tile, component group) cut between two workgroups?
         // A slot spans at most two component groups and a wave's 64 rows lie in one row tile,
@@ -166,9 +146,6 @@ __device__ __forceinline__ void sweep_body(
             mg_edge = (g0 + 1) * sp.tile_cols;
             cut0 = sp.split[rt * sp.mgroups + g0];
             cut1 = sp.split[rt * sp.mgroups + g1];
-            // this (restart, tile) was swept by the pass-A workgroup that computed the tile (workgroup-uniform; per-tile
-            // partials only: nothing of this chunk is pending in the accumulators)
-            if (sp.fused && cut0 == 0 && fusedw_fusable(off, k)) continue;
         }
         float w[KP], p[KP];
         float dsc = 1.0f;                          // per-row scale of the exact row-maximum report (issued with the loads)
@@ -345,62 +322,60 @@ __device__ __forceinline__ void sweep_body(
             }
             __builtin_amdgcn_wave_barrier();                                     // the strip is rewritten by the next chunk
         }
+    }
 
-        if (!emit) continue;                                            // (workgroup-uniform)
-        // ---- row maxima: wave reduce -> LDS -> one partial per (component, workgroup)
-        if constexpr (RMX) {
-    #pragma unroll
-            for (int c = 0; c < KP; ++c) {
-                float v = mx[c];
-    #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-                if (lane == 0) rmx[wave * 64 + c] = v;
-            }
+    // ---- row maxima: wave reduce -> LDS -> one partial per (component, workgroup)
+    if constexpr (RMX) {
+#pragma unroll
+        for (int c = 0; c < KP; ++c) {
+            float v = mx[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+            if (lane == 0) rmx[wave * 64 + c] = v;
         }
-        // ---- violation: wave reduce (double) -> block partial
-        double dv = (double)viol;
-    #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dv += __shfl_xor(dv, o, 64);
-        if (lane == 0) vred[wave] = dv;
+    }
+    // ---- violation: wave reduce (double) -> block partial
+    double dv = (double)viol;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dv += __shfl_xor(dv, o, 64);
+    if (lane == 0) vred[wave] = dv;
 
-        // ---- gram: sum the 4 waves' accumulators through LDS, write the tile's partial
-        __syncthreads();
-        float* gred = Wsb;                   // reused as [4][GR][GR+1]   (<= 4*64*(kg+1) floats)
-        if (want_gram) {
-            if constexpr (GMODE == 0) {
-                const int li = lane & 15, q = lane >> 4;
-    #pragma unroll
-                for (int r = 0; r < 4; ++r) gred[(wave * GR + 4 * q + r) * (GR + 1) + li] = gacc4[r];
-            } else {
-                const int li = lane & 31, h = lane >> 5;
-    #pragma unroll
-                for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
-    #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rr = (a >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        gred[(wave * GR + rr) * (GR + 1) + (a & 1) * 32 + li] = gacc[a][r];
-                    }
-            }
+    // ---- gram: sum the 4 waves' accumulators through LDS, write the block partial
+    __syncthreads();
+    float* gred = Wsb;                   // reused as [4][GR][GR+1]   (<= 4*64*(kg+1) floats)
+    if (want_gram) {
+        if constexpr (GMODE == 0) {
+            const int li = lane & 15, q = lane >> 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gred[(wave * GR + 4 * q + r) * (GR + 1) + li] = gacc4[r];
+        } else {
+            const int li = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int a = 0; a < (GMODE == 2 ? 4 : 1); ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (a >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    gred[(wave * GR + rr) * (GR + 1) + (a & 1) * 32 + li] = gacc[a][r];
+                }
         }
-        __syncthreads();
-        if (want_gram) {
-            float* gp = gram_part + ((size_t)slot * n_parts + part) * (size_t)(gld * gld);
-            for (int e = tid; e < k * k; e += 256) {
-                const int r = e / k, c = e % k;
-                gp[r * gld + c] = gred[(0 * GR + r) * (GR + 1) + c] + gred[(1 * GR + r) * (GR + 1) + c] +
-                                  gred[(2 * GR + r) * (GR + 1) + c] + gred[(3 * GR + r) * (GR + 1) + c];
-            }
+    }
+    __syncthreads();
+    if (want_gram) {
+        float* gp = gram_part + ((size_t)slot * gridDim.x + blockIdx.x) * (size_t)(gld * gld);
+        for (int e = tid; e < k * k; e += 256) {
+            const int r = e / k, c = e % k;
+            gp[r * gld + c] = gred[(0 * GR + r) * (GR + 1) + c] + gred[(1 * GR + r) * (GR + 1) + c] +
+                              gred[(2 * GR + r) * (GR + 1) + c] + gred[(3 * GR + r) * (GR + 1) + c];
         }
-        if (tid == 0)
-            viol_part[(size_t)slot * n_parts + part] = vred[0] + vred[1] + vred[2] + vred[3];
-        if (rmax_part && tid < k && (RMX || want_gram)) {
-            float v;
-            if constexpr (RMX) v = fmaxf(fmaxf(rmx[tid], rmx[64 + tid]), fmaxf(rmx[128 + tid], rmx[192 + tid]));
-            else v = sqrtf(gred[(0 * GR + tid) * (GR + 1) + tid] + gred[(1 * GR + tid) * (GR + 1) + tid] +
-                           gred[(2 * GR + tid) * (GR + 1) + tid] + gred[(3 * GR + tid) * (GR + 1) + tid]) * 1.0001f;
-            rmax_part[(size_t)(off + tid) * n_parts + part] = v;
-        }
-        __syncthreads();                 // gred aliases the staging strips of the next chunk
+    }
+    if (tid == 0)
+        viol_part[(size_t)slot * gridDim.x + blockIdx.x] = vred[0] + vred[1] + vred[2] + vred[3];
+    if (rmax_part && tid < k && (RMX || want_gram)) {
+        float v;
+        if constexpr (RMX) v = fmaxf(fmaxf(rmx[tid], rmx[64 + tid]), fmaxf(rmx[128 + tid], rmx[192 + tid]));
+        else v = sqrtf(gred[(0 * GR + tid) * (GR + 1) + tid] + gred[(1 * GR + tid) * (GR + 1) + tid] +
+                       gred[(2 * GR + tid) * (GR + 1) + tid] + gred[(3 * GR + tid) * (GR + 1) + tid]) * 1.0001f;
+        rmax_part[(size_t)(off + tid) * gridDim.x + blockIdx.x] = v;
     }
 #undef WS
 #undef GS
@@ -411,11 +386,9 @@ __device__ __forceinline__ void sweep_body(
 // TIER 0 handles ranks <= 16, TIER 1 ranks 17..32, TIER 2 ranks 33..64: one kernel for all ranks would
 // give the common small-rank case the register allocation of the largest (232 VGPR + 64 AGPR = one
 // wave per SIMD).  The host launches only the tiers present in the batch.
-// (TIER 0 without the exact report is the W half-step of the common ranks: held to 5 waves per SIMD -- with the plane
-//  output too since round 4: the per-chunk bookkeeping of the partials had pushed it from 95 to 97 registers = 4 waves,
-//  178 instead of 160 us per 1024-column sweep)
+// (TIER 0 without the exact report is the W half-step of the common ranks: held to 5 waves per SIMD)
 template <int TIER, bool RMX = false, bool PSUM = false, bool PLN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 && !RMX) ? 5 : 1, 8))) void sweep_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 && !RMX && !PLN) ? 5 : (TIER == 0 && !RMX ? 4 : 1), 8))) void sweep_kernel(
     float* __restrict__ V, int ldv, int L,
     const float* __restrict__ P,             // [KC][ldv] products (split-K already reduced)
     SplitInfo sp,
@@ -424,8 +397,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 
     float l1_reg,
     float* __restrict__ gram_part,           // [nslots][gridDim.x][32][32]
     double* __restrict__ viol_part,          // [nslots][gridDim.x]
-    int chunks_per_block, int n_parts, int want_gram, int kg, int gld,
-    float* __restrict__ rmax_part = nullptr,     // [KC][n_parts] largest updated entry per component and 256-row tile
+    int chunks_per_block, int want_gram, int kg, int gld,
+    float* __restrict__ rmax_part = nullptr,     // [KC][gridDim.x] largest updated entry per component and workgroup
     const double* __restrict__ rmax_scale = nullptr,
     PlaneOut po = PlaneOut{nullptr, nullptr, 0, 0})
 {
@@ -435,7 +408,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TIER == 0 
     extern __shared__ __attribute__((aligned(16))) float sweep_lds[];
 #define CNMF_SW(KP_)                                                                              \
         sweep_body<KP_, RMX, PSUM, PLN>(V, ldv, L, P, sp, gram, sd, slot, l1_reg, gram_part, viol_part, \
-                        chunks_per_block, n_parts, want_gram, sweep_lds, kg, gld, rmax_part, rmax_scale, po);
+                        chunks_per_block, want_gram, sweep_lds, kg, gld, rmax_part, rmax_scale, po);
     const int k = sd.k;
     if (TIER == 0) {
         if (k > 16) return;

@@ -71,12 +71,12 @@ static void invalidate_planes(cnmf_ctx* ctx)
     hipStreamSynchronize(ctx->stream);
     hipFree(ctx->X3); hipFree(ctx->Xt3); hipFree(ctx->XtF);
     ctx->X3 = ctx->Xt3 = nullptr; ctx->XtF = nullptr;
-    free_mu_sparse(ctx);
+    free_mu_sparse(ctx); free_csr(ctx);
     hipFree(ctx->C1); hipFree(ctx->Ct1); hipFree(ctx->d_scale);
     hipFree(ctx->C1h); hipFree(ctx->Ct1h); hipFree(ctx->hiA); hipFree(ctx->hiB);
     ctx->C1 = ctx->Ct1 = ctx->C1h = ctx->Ct1h = nullptr; ctx->hiA = ctx->hiB = nullptr;
     ctx->d_scale = nullptr; ctx->count_state = 0; ctx->count_fmt = 0;
-    ctx->spectra_rows = 0;
+    // (the resident spectra store outlives a change of the matrix, like in alloc_matrix: it carries its own gene count)
 }
 
 extern "C" int cnmf_col_moments(cnmf_ctx* ctx, double* mean_out, double* ssd_out)

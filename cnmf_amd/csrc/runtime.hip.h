@@ -73,6 +73,12 @@ struct cnmf_ctx {
     // genes x cells (B); x_nnz = -1 until the first Kullback-Leibler call counted the matrix
     SpImage spA[2], spB[2];
     long long x_nnz = -1;
+    // compressed rows of X (cells x genes) and of X^T (genes x cells), csr_host.hip.h: kept from cnmf_set_matrix_csr or
+    // built from the dense matrix on first use; 64-bit row pointers, float32 values like the dense image
+    long long *csr_ptr = nullptr, *csc_ptr = nullptr;
+    int *csr_idx = nullptr, *csc_idx = nullptr;
+    float *csr_val = nullptr, *csc_val = nullptr;
+    long long csr_nnz = -1;
 
     // batch buffers (sized for kc_alloc columns)
     int kc_alloc = 0, nsplit_alloc = 0, nsplitA_alloc = 0, parts_alloc = 0;

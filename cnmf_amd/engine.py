@@ -142,6 +142,9 @@ class Engine:
         import scipy.sparse as sp
         if sp.issparse(X):
             X = X.tocsr()
+            if not X.has_canonical_format:          # (sorted rows without duplicates: the device keeps the arrays as uploaded)
+                X = X.copy()
+                X.sum_duplicates()
             data = X.data
             if not np.isfinite(data).all():
                 raise ValueError("Input X contains NaN or infinity.")
@@ -376,7 +379,9 @@ class Engine:
 
     def nnls_mu(self, H, beta_loss="kullback-leibler", tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0,
                 warn=True):
-        """Refit with fixed H and ``solver='mu'``: W starts from avg everywhere (sklearn _nmf.py:1229-1231)."""
+        """Refit with fixed H and ``solver='mu'``: W starts from avg everywhere (sklearn _nmf.py:1229-1231).
+        Kullback-Leibler: the float64 refit on the stored entries (:meth:`mu_refit_f64`; result cast to float32 like the
+        other refits of this class); Itakura-Saito: the dense float32 matrix-pipe kernels."""
         if self.shape is None:
             raise RuntimeError("set_matrix() has not been called")
         N, G = self.shape
@@ -387,6 +392,9 @@ class Engine:
             raise ValueError("Negative values in data passed to NMF (input H)")
         if H.max() == 0:
             raise ValueError("Array passed to NMF (input H) is full of zeros.")
+        if self._BETA[beta_loss] == 1:
+            W, n, _ = self.mu_refit_f64(H, tol=tol, max_iter=max_iter, alpha_W=alpha_W, l1_ratio=l1_ratio, warn=warn)
+            return W.astype(np.float32), n
         k = int(H.shape[0])
         ks = np.array([k], dtype=np.int32)
         Hf = np.ascontiguousarray(H, dtype=np.float32)
@@ -404,6 +412,55 @@ class Engine:
             warnings.warn("Maximum number of iterations %d reached. Increase it to improve convergence."
                           % max_iter, ConvergenceWarning)
         return W, int(n_iter[0])
+
+    def mu_refit_f64(self, H, transposed=False, col_divisor=None, w_init=None, tol=1e-4, max_iter=1000, alpha_W=0.0,
+                     l1_ratio=0.0, n_features=None, warn=True):
+        """``non_negative_factorization(X, H=H, update_H=False, solver='mu', beta_loss='kullback-leibler')`` in float64 on
+        the stored entries of the resident matrix (cnmf_mu_refit_f64): returns ``(W float64, n_iter, err)``.
+
+        ``transposed=False``: X = the resident cells x genes matrix, ``H`` [k, n_genes], W [n_cells, k] (refit_usage,
+        cnmf.py:776-802).  ``transposed=True``: the problem on X^T -- ``H`` [k, n_cells] (usages^T), W [n_genes, k]
+        (refit_spectra, cnmf.py:805-820) -- on the compressed rows of X^T built on the device.
+        ``col_divisor`` [columns of the walked matrix]: the matrix meant is ``X[:, d != 0] / d[d != 0]`` (the final usage
+        refit on the unit-variance high-variance-gene TPM, cnmf.py:963-972); then ``w_init`` (scikit-learn's
+        sqrt(mean / k) of THAT matrix) must be given and ``n_features`` is its column count (scales the W penalties)."""
+        if self.shape is None:
+            raise RuntimeError("set_matrix() has not been called")
+        N, G = self.shape
+        rows, cols = (G, N) if transposed else (N, G)
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        if H.ndim != 2 or H.shape[1] != cols:
+            raise ValueError("Array with wrong shape passed to NMF (input H). Expected (k, %d), but got %s"
+                             % (cols, (H.shape,)))
+        if not np.isfinite(H).all():
+            raise ValueError("Input H contains NaN or infinity.")
+        if H.min() < 0:
+            raise ValueError("Negative values in data passed to NMF (input H)")
+        if H.max() == 0:
+            raise ValueError("Array passed to NMF (input H) is full of zeros.")
+        k = int(H.shape[0])
+        dblp = C.POINTER(C.c_double)
+        div = None
+        if col_divisor is not None:
+            div = np.ascontiguousarray(col_divisor, dtype=np.float64)
+            if div.shape != (cols,) or w_init is None:
+                raise ValueError("col_divisor needs one entry per column of the walked matrix and an explicit w_init")
+        if w_init is None:
+            w_init = self.init_scale(k)
+        # scikit-learn scales the W penalties by the FEATURE count of the matrix it is given (_nmf.py:1254-1265)
+        feats = cols if n_features is None else int(n_features)
+        l1W, _, l2W, _ = regularization(rows, feats, alpha_W, 0.0, l1_ratio)
+        prm = _lib.CdParams(float(tol), int(max_iter), 0, l1W, l2W, 0.0, 0.0, 0, 0)
+        W = np.empty((rows, k), dtype=np.float64)
+        n_iter = C.c_int32(0)
+        err = C.c_double(0.0)
+        self._check(self._lib.cnmf_mu_refit_f64(self._ctx, 1 if transposed else 0, k, H.ctypes.data_as(dblp),
+                                                div.ctypes.data_as(dblp) if div is not None else None, float(w_init),
+                                                C.byref(prm), W.ctypes.data_as(dblp), C.byref(n_iter), C.byref(err)))
+        if warn and tol > 0 and n_iter.value == max_iter:
+            warnings.warn("Maximum number of iterations %d reached. Increase it to improve convergence."
+                          % max_iter, ConvergenceWarning)
+        return W, int(n_iter.value), float(err.value)
 
     # ------------------------------------------------------------------ NNLS refit
     def nnls(self, H, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0, warn=True):

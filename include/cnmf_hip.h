@@ -97,7 +97,12 @@ int cnmf_set_matrix(cnmf_ctx* ctx, const float* X, int64_t n_cells, int64_t n_ge
  * -- what `norm_counts.X /= std` produces (cnmf.py:540-548) -- with a tolerance of 1e-3 count units and then
  * multiplies the exact integer planes; enabled = 0 keeps every matrix on the general float32-operand path.      */
 int cnmf_set_count_detection(cnmf_ctx* ctx, int enabled);
-/* CSR input (scipy.sparse.csr_matrix of float32, int32 indices/indptr): densify on device. */
+/* CSR input (scipy.sparse.csr_matrix of float32, int32 indices/indptr) -- the reference hands `norm_counts.X` / `tpm.X`
+ * to scikit-learn as stored (cnmf.py:726, 873, 950).  The dense image is formed on the device (duplicates summed like
+ * .toarray()); round 5: the arrays also STAY on the device and serve the paths that walk the stored entries
+ * (cnmf_mu_refit_f64, the non-zero images of cnmf_nmf_mu_batch) -- as uploaded when every row lists strictly increasing
+ * columns without stored zeros (scipy's canonical format), otherwise rebuilt from the dense image on first use.
+ * A column index outside [0, n_genes): CNMF_EINVAL.                                                              */
 int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const int32_t* indices,
                         const float* data, int64_t n_cells, int64_t n_genes);
 int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* n_cells, int64_t* n_genes);
@@ -170,11 +175,35 @@ int cnmf_set_iteration_hints(cnmf_ctx* ctx, int n, const int32_t* k, const doubl
  * Restarts run batched on the matrix pipe (padded rank 16 / 32 / 64, both losses), up to 32 per round of
  * launches sharing each pass over X (kernels_mu_mfma.hip.h); a restart's result does not depend on the
  * batch it ran in.  Ranks above CNMF_MU_KMAX (64): CNMF_EUNSUPPORTED.
- * The first call builds a resident transposed copy of X (freed with the matrix).                   */
+ * The first call builds a resident transposed copy of X (freed with the matrix).
+ * Kullback-Leibler on the NON-ZEROS (round 4, kernels_mu_sparse.hip.h) -- scikit-learn's own route for scipy.sparse input
+ * (sklearn:_nmf.py:192 `_special_sparse_dot`): taken by itself when beta = 1, every rank of the call is <= 32 and at most a
+ * quarter of X is non-zero (counted once per matrix); same mathematics (the quotient vanishes where X does), exact float32
+ * products, another summation order than the dense kernels (results agree to float32 round-off, not bit for bit).
+ * Extra device memory: per padded rank in use (16, 32) two blocked sliced-ELL images, 8 B x non-zeros x 1.0-1.2 each
+ * (round 5: built from the compressed rows of the matrix, csr_host.hip.h -- no dense transposed copy on this path), and per
+ * restart in flight the partial numerators [blocks of the other side][own rows][padded rank] float32.  When those
+ * allocations do not fit the call falls back to the dense kernels.  The environment variable CNMF_MU_SPARSE (read when the
+ * context is created; 0 = never, 1 = always where the rank allows) overrides the density rule.                       */
 int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n_restarts, const int32_t* k, int init_mode,
                       const uint32_t* seeds, const double* avg, const float* W0, const float* H0,
                       int beta, int update_H, const cnmf_cd_params* params,
                       float* H_out, float* W_out, int32_t* n_iter_out, double* err_out);
+
+/* Kullback-Leibler refit in FLOAT64 on the stored entries (round 5, mu_refit_host.hip.h): the three
+ *   non_negative_factorization(X, H=..., update_H=False, solver='mu', beta_loss='kullback-leibler')
+ * calls of a consensus run with the Kullback-Leibler loss (cnmf.py:776-820 via :920, :952, :972) on float64 matrices --
+ * scikit-learn's `_fit_multiplicative_update` with H fixed (sklearn:_nmf.py:731-893, :526-631, :84-194).
+ *   side 0: rows = cells   (refit_usage):   H [k][n_genes],  W_out [n_cells][k]
+ *   side 1: rows = GENES   (refit_spectra = the problem on X^T, cnmf.py:820): H = usages^T [k][n_cells], W_out [n_genes][k];
+ *           walks the compressed rows of X^T built on the device -- no todense(), no transposed upload.
+ * coldiv (NULL ok, [columns of the walked matrix]): x'_ij = x_ij / coldiv[j], coldiv[j] == 0 drops column j -- the final
+ *   usage refit on tpm[:, hvgs] / std (cnmf.py:963-972) against the resident full TPM matrix.
+ * w_init: W starts from this value everywhere (sklearn:_nmf.py:1229-1231: sqrt(X.mean() / k) of the matrix meant).
+ * params: tol, max_iter, l1_reg_W, l2_reg_W.  n_iter_out as scikit-learn counts (a multiple of 10 or max_iter),
+ * err_out = sqrt(2 x divergence) of the final factors.  Ranks above CNMF_MU_KMAX: CNMF_EUNSUPPORTED.             */
+int cnmf_mu_refit_f64(cnmf_ctx* ctx, int side, int k, const double* H, const double* coldiv, double w_init,
+                      const cnmf_cd_params* params, double* W_out, int32_t* n_iter_out, double* err_out);
 
 /* ---- NNLS refit ---------------------------------------------------------------------
  * Replaces cNMF.refit_usage (cnmf.py:776-802): non_negative_factorization(X, H=spectra,

@@ -201,8 +201,10 @@ def silhouette_score(X, labels):
 
 # ------------------------------------------------------------------ the consensus core
 def consensus_core(merged_spectra, X, k, density_threshold=0.5, local_neighborhood_size=0.30,
-                   stats_mode=False, nnls_kwargs=None):
-    """cnmf.py:871-936 on arrays.  Returns a dict with every intermediate."""
+                   stats_mode=False, nnls_kwargs=None, refit=None):
+    """cnmf.py:871-936 on arrays.  Returns a dict with every intermediate.  ``refit(X, H) -> (W, n_iter)``: the
+    ``refit_usage`` solver (default: the coordinate-descent NNLS of a 'frobenius' run; a Kullback-Leibler run refits
+    with ``oracle.nmf_mu.nnls_mu``, cnmf.py:618-631 + 792-798)."""
     S = np.asarray(merged_spectra, dtype=np.float64)
     n_neighbors = int(local_neighborhood_size * S.shape[0] / k)
     l2 = l2_normalise(S)
@@ -220,7 +222,7 @@ def consensus_core(merged_spectra, X, k, density_threshold=0.5, local_neighborho
     labs, med = groupby_median(l2, labels)
     med = (med.T / med.sum(axis=1)).T
     kw = dict(nnls_kwargs or {})
-    W, _ = nmf_cd.nnls(np.asarray(X, dtype=np.float64), med, **kw)
+    W, _ = (refit or nmf_cd.nnls)(np.asarray(X, dtype=np.float64), med, **kw)
     out.update(l2_spectra=l2, kmeans_labels=labels, median_spectra=med, rf_usages=W, inertia=inertia)
     if stats_mode:
         out["silhouette"] = silhouette_score(l2, labels)
@@ -240,16 +242,18 @@ def ols_all_cols(Xd, Y):
     return beta
 
 
-def consensus_tail(core, tpm, tpm_std, hvg_idx, refit_usage=True, normalize_tpm_spectra=False):
+def consensus_tail(core, tpm, tpm_std, hvg_idx, refit_usage=True, normalize_tpm_spectra=False, refit=None):
     """cnmf.py:939-975 on arrays: re-order programmes by total normalised usage, refit
-    spectra on the TPM matrix, z-score OLS spectra, final usage refit on std-scaled HVG TPM."""
+    spectra on the TPM matrix, z-score OLS spectra, final usage refit on std-scaled HVG TPM.
+    ``refit``: as in ``consensus_core``."""
+    refit = refit or nmf_cd.nnls
     rf = core["rf_usages"]
     med = core["median_spectra"]
     norm = rf / rf.sum(axis=1, keepdims=True)
     order = np.argsort(-norm.sum(axis=0), kind="stable")
     rf, norm, med = rf[:, order], norm[:, order], med[order]
     tpm = np.asarray(tpm, dtype=np.float64)
-    Wt, _ = nmf_cd.nnls(tpm.T, norm.T)                       # refit_spectra(tpm.X, norm_usages)
+    Wt, _ = refit(tpm.T, norm.T)                             # refit_spectra(tpm.X, norm_usages)
     spectra_tpm = Wt.T
     if normalize_tpm_spectra:
         spectra_tpm = spectra_tpm / spectra_tpm.sum(axis=1, keepdims=True) * 1e6
@@ -260,5 +264,5 @@ def consensus_tail(core, tpm, tpm_std, hvg_idx, refit_usage=True, normalize_tpm_
         norm_tpm = tpm[:, hvg_idx]
         norm_tpm = norm_tpm / norm_tpm.std(axis=0, ddof=1)
         srf = spectra_tpm[:, hvg_idx] / tpm_std[hvg_idx]
-        out["rf_usages"], _ = nmf_cd.nnls(norm_tpm, srf)
+        out["rf_usages"], _ = refit(norm_tpm, srf)
     return out

@@ -1,0 +1,255 @@
+"""Kullback-Leibler end to end (round 5): the float64 refit on the stored entries (cnmf_mu_refit_f64, csr_host.hip.h) against
+the float64 oracle, and the consensus tail of a Kullback-Leibler run against the artefacts the UNMODIFIED reference wrote
+under ``beta_loss='kullback-leibler'`` (tests/golden/ref_small_kl.npz, tools/make_golden.py --beta-loss kullback-leibler) at
+the reference's own bar -- sum of squared differences < 1e-4 (/root/reference/tests/test_reproducibility.py:96-115) --
+through the C-ABI and through the cNMF mirror class, TPM dense and CSR."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+from cnmf_amd import synth
+from cnmf_amd.cnmf import cNMF, load_df_from_npz, save_df_to_npz
+from oracle import consensus as oc
+from oracle import nmf_cd, nmf_mu
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_small_kl.npz")
+TOLERANCE = 1e-4
+
+
+@pytest.fixture(scope="module")
+def g():
+    return dict(np.load(GOLD, allow_pickle=False))
+
+
+def _counts(n, g_, mu_lib, seed):
+    C, _ = synth.topic_counts(n, g_, 6, mu_lib, 0.4, seed)
+    return synth.normalise_like_prepare(C, dtype=np.float32)
+
+
+def _oracle_refit(X64, H, max_iter, **kw):
+    return nmf_mu.nnls_mu(X64, H, max_iter=max_iter, **kw)
+
+
+@pytest.mark.parametrize("n,g_,k", [(2600, 900, 5),      # padded rank 8
+                                    (1500, 2300, 12),    # 16
+                                    (1200, 700, 20),     # 32
+                                    (900, 500, 40)])     # 64: the factor row read twice
+def test_mu_refit_f64_vs_oracle(engine, n, g_, k):
+    """refit_usage and refit_spectra with solver='mu' / Kullback-Leibler: the same iteration count as the float64 oracle
+    (pinned to scikit-learn, dense and scipy.sparse input: tests/test_oracle_mu.py) and agreement to round-off -- on a
+    dense upload (compressed rows built on the device), on a CSR upload (arrays kept), and on a CSR upload that is not in
+    canonical form (falls back to the rebuilt rows): bit-identical between the three."""
+    X = _counts(n, g_, 4.8, seed=n)
+    n, g_ = X.shape
+    X64 = X.astype(np.float64)
+    rs = np.random.RandomState(k)
+    H = np.abs(rs.standard_normal((k, g_))) * (rs.rand(k, g_) < 0.5)
+    H /= H.sum(axis=1, keepdims=True)
+    U = np.abs(rs.standard_normal((n, k)))
+    U /= U.sum(axis=1, keepdims=True)
+    W_ref, n_ref = _oracle_refit(X64, H, 300)
+    Wt_ref, nt_ref = _oracle_refit(np.ascontiguousarray(X64.T), np.ascontiguousarray(U.T), 300)
+    res = []
+    Xs = sp.csr_matrix(X)
+    for label, M in (("dense", X), ("csr", Xs)):
+        engine.set_matrix(M)
+        W, it, err = engine.mu_refit_f64(H, max_iter=300, warn=False)
+        Wt, itt, errt = engine.mu_refit_f64(U.T, transposed=True, max_iter=300, warn=False)
+        assert W.dtype == np.float64 and it == n_ref and itt == nt_ref, (label, it, n_ref, itt, nt_ref)
+        assert np.abs(W - W_ref).max() <= 1e-9 * np.abs(W_ref).max(), label
+        assert np.abs(Wt - Wt_ref).max() <= 1e-9 * np.abs(Wt_ref).max(), label
+        ref_err = nmf_mu.beta_divergence(X64, W_ref, H, 1, square_root=True)
+        assert abs(err - ref_err) <= 1e-10 * ref_err
+        res.append((W, Wt))
+    np.testing.assert_array_equal(res[0][0], res[1][0])          # the device-built rows ARE the uploaded ones
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    # a CSR upload with unsorted rows and a duplicated entry: the arrays are not kept, same numbers
+    coo = Xs.tocoo()
+    rows = np.concatenate([coo.row[::-1], coo.row[:1]])
+    cols = np.concatenate([coo.col[::-1], coo.col[:1]])
+    vals = np.concatenate([coo.data[::-1], coo.data[:1]]).astype(np.float32)
+    vals[-1] *= 0.5; vals[len(coo.data) - 1] *= 0.5             # the first entry, split in two halves (exact in float32)
+    order = np.argsort(rows, kind="stable")
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+    import ctypes as C
+    ip = C.POINTER(C.c_int32)
+    idx32 = np.ascontiguousarray(cols[order], dtype=np.int32)
+    v32 = np.ascontiguousarray(vals[order], dtype=np.float32)
+    engine._check(engine._lib.cnmf_set_matrix_csr(engine._ctx, indptr.ctypes.data_as(ip), idx32.ctypes.data_as(ip),
+                                                  v32.ctypes.data_as(C.POINTER(C.c_float)), n, g_))
+    engine.shape = (n, g_)
+    np.testing.assert_array_equal(engine.get_matrix(), X)
+    W2, it2, _ = engine.mu_refit_f64(H, max_iter=300, warn=False, w_init=float(np.sqrt(X64.mean() / k)))
+    np.testing.assert_array_equal(W2, res[0][0])
+
+
+def test_mu_refit_f64_penalties_column_subset_and_stopping_rule(engine):
+    X = _counts(1800, 800, 5.0, seed=4)
+    X64 = X.astype(np.float64)
+    n, g_ = X.shape
+    rs = np.random.RandomState(1)
+    k = 7
+    H = np.abs(rs.standard_normal((k, g_)))
+    engine.set_matrix(sp.csr_matrix(X))
+    # l1 / l2 penalties on W (scaled by the feature count like scikit-learn, _nmf.py:1254-1265); max_iter not a multiple of 10
+    for kw in (dict(alpha_W=0.003, l1_ratio=0.0), dict(alpha_W=0.002, l1_ratio=0.7), dict()):
+        for max_iter in (37, 200):
+            W_ref, n_ref = _oracle_refit(X64, H, max_iter, **kw)
+            W, it, _ = engine.mu_refit_f64(H, max_iter=max_iter, warn=False, **kw)
+            assert it == n_ref, (kw, max_iter, it, n_ref)
+            assert np.abs(W - W_ref).max() <= 1e-9 * np.abs(W_ref).max(), (kw, max_iter)
+    # tol = 0: no stopping rule, every iteration runs
+    W_ref, n_ref = _oracle_refit(X64, H, 25, tol=0.0)
+    W, it, _ = engine.mu_refit_f64(H, max_iter=25, tol=0.0, warn=False)
+    assert it == n_ref == 25 and np.abs(W - W_ref).max() <= 1e-9 * np.abs(W_ref).max()
+    # the column subset divided by a per-column constant: tpm[:, hvgs] / std of the final usage refit (cnmf.py:963-972)
+    sel = np.sort(rs.choice(g_, 300, replace=False))
+    std1 = X64[:, sel].std(axis=0, ddof=1)
+    Xsub = X64[:, sel] / std1
+    Hs = np.abs(rs.standard_normal((k, 300)))
+    W_ref, n_ref = _oracle_refit(Xsub, Hs, 200, alpha_W=0.001)
+    div = np.zeros(g_); div[sel] = std1
+    H_full = np.zeros((k, g_)); H_full[:, sel] = Hs
+    W, it, err = engine.mu_refit_f64(H_full, col_divisor=div, w_init=float(np.sqrt(Xsub.mean() / k)), n_features=300,
+                                     max_iter=200, alpha_W=0.001, warn=False)
+    assert it == n_ref and np.abs(W - W_ref).max() <= 1e-9 * np.abs(W_ref).max()
+    assert abs(err - nmf_mu.beta_divergence(Xsub, W_ref, Hs, 1, square_root=True)) <= 1e-9 * err
+    # the refit of the engine's `nnls_mu` call site is this path (float32 result of the float64 solve)
+    W32, it32 = engine.nnls_mu(H, max_iter=200, warn=False)
+    W64, it64, _ = engine.mu_refit_f64(H, max_iter=200, warn=False)
+    assert it32 == it64 and W32.dtype == np.float32 and np.array_equal(W32, W64.astype(np.float32))
+    # input validation like scikit-learn's (_nmf.py:1217-1226)
+    with pytest.raises(ValueError):
+        engine.mu_refit_f64(-H)
+    with pytest.raises(ValueError):
+        engine.mu_refit_f64(np.zeros_like(H))
+    with pytest.raises(ValueError):
+        engine.mu_refit_f64(H[:, :-1])
+    # a scaling of the resident matrix drops the compressed rows with the other derived images
+    engine.set_matrix(X * rs.uniform(0.5, 4.0, size=g_).astype(np.float32))
+    Wa, _, _ = engine.mu_refit_f64(H, max_iter=20, warn=False)
+    std, _ = engine.scale_genes_unit_variance()
+    Wb, _, _ = engine.mu_refit_f64(H, max_iter=20, warn=False)
+    Xn = engine.get_matrix().astype(np.float64)
+    W_ref, _ = _oracle_refit(Xn, H, 20)
+    assert np.abs(Wb - W_ref).max() <= 1e-9 * np.abs(W_ref).max() and np.abs(Wa - Wb).max() > 1e-3 * np.abs(Wb).max()
+
+
+def _kl_tail_on_device(engine, g, k, thr, sparse):
+    X = g["norm_counts"]
+    out = engine.consensus(g["merged_k%d" % k], k, density_threshold=thr)
+    engine.set_matrix(sp.csr_matrix(X) if sparse else X)
+    rf, _, _ = engine.mu_refit_f64(out["median_spectra"], max_iter=1000)                  # cnmf.py:920
+    norm = rf / rf.sum(axis=1, keepdims=True)
+    order = np.argsort(-norm.sum(axis=0), kind="stable")                                # cnmf.py:939-946
+    rf, norm, med = rf[:, order], norm[:, order], out["median_spectra"][order]
+    tpm = g["tpm"]
+    engine.set_matrix(sp.csr_matrix(tpm) if sparse else tpm)                            # ONE upload for the three steps below
+    Wt, _, _ = engine.mu_refit_f64(norm.T, transposed=True, max_iter=1000)              # cnmf.py:952 refit_spectra
+    spectra_tpm = Wt.T
+    mean, pvar = engine.col_mean_var()
+    var = np.where(pvar < 1e-12, 1e-12, pvar)
+    XtY = engine.xt_matmul_f64(rf, mean=mean, std=np.sqrt(var))
+    coef, *_ = np.linalg.lstsq(rf.T @ rf, XtY, rcond=None)
+    hidx = np.array([list(g["tpm_genes"]).index(x) for x in list(g["genes"])])
+    n = tpm.shape[0]
+    std1 = np.sqrt(pvar[hidx] * n / (n - 1.0))
+    srf = spectra_tpm[:, hidx] / g["tpm_stats"][hidx, 1]
+    div = np.zeros(tpm.shape[1]); div[hidx] = std1
+    H_full = np.zeros((k, tpm.shape[1])); H_full[:, hidx] = srf
+    usages, _, _ = engine.mu_refit_f64(H_full, col_divisor=div, w_init=float(np.sqrt((mean[hidx] / std1).mean() / k)),
+                                       n_features=len(hidx), max_iter=1000)             # cnmf.py:972
+    return med, usages, spectra_tpm, coef
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+@pytest.mark.parametrize("k,thr", [(5, 0.5), (4, 2.0)])
+def test_kl_consensus_tail_golden_reference(engine, g, k, thr, sparse):
+    med, usages, spectra_tpm, coef = _kl_tail_on_device(engine, g, k, thr, sparse)
+    err = {"consensus_spectra": ((med - g["consensus_spectra_k%d" % k]) ** 2).sum(),
+           "consensus_usages": ((usages - g["consensus_usages_k%d" % k]) ** 2).sum(),
+           "gene_spectra_tpm": ((spectra_tpm - g["gene_spectra_tpm_k%d" % k]) ** 2).sum(),
+           "gene_spectra_score": ((coef - g["gene_spectra_score_k%d" % k]) ** 2).sum()}
+    print("Kullback-Leibler consensus tail k=%d thr=%s sparse=%s: sum of squared differences vs the reference's files: %s"
+          % (k, thr, sparse, {a: float("%.3g" % b) for a, b in err.items()}))
+    for name, e in err.items():
+        assert e < TOLERANCE, (name, e)
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_mirror_class_kl_consensus_from_reference_merged_spectra(engine, g, tmp_path, sparse):
+    """cNMF.consensus / k_selection_stats of the mirror class under beta_loss='kullback-leibler' on the REFERENCE's merged
+    spectra, TPM dense or sparse: every artefact the reference pins, at its own tolerance; no host todense() of the TPM
+    matrix, no transposed upload (the engine holds ONE matrix at a time: asserted on its shape)."""
+    obj = cNMF(output_dir=str(tmp_path), name="goldkl", engine=engine)
+    nc = pd.DataFrame(g["norm_counts"], index=["c%d" % i for i in range(g["norm_counts"].shape[0])], columns=list(g["genes"]))
+    if sparse:
+        tpm = (sp.csr_matrix(g["tpm"]), list(g["tpm_genes"]))
+    else:
+        tpm = pd.DataFrame(g["tpm"], index=nc.index, columns=list(g["tpm_genes"]))
+    obj.prepare_from_matrix(nc, components=[4, 5, 6], n_iter=12, seed=14, beta_loss="kullback-leibler", tpm=tpm)
+    import yaml
+    kw = yaml.load(open(obj.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
+    assert kw["solver"] == "mu" and kw["beta_loss"] == "kullback-leibler"
+    for k in (4, 5, 6):
+        idx = ["iter%d_topic%d" % (it, t + 1) for it in range(12) for t in range(k)]
+        save_df_to_npz(pd.DataFrame(g["merged_k%d" % k], index=idx, columns=list(g["genes"])), obj.paths["merged_spectra"] % k)
+    stats = obj.k_selection_stats()
+    for row, k in zip(stats.itertuples(), (4, 5, 6)):
+        _, _, sil, err = g["stats_k%d" % k]
+        assert row.k == k and abs(row.silhouette - sil) < 1e-8 and abs(row.prediction_error - err) <= 2e-5 * err
+    for k, thr in ((5, 0.5), (4, 2.0)):
+        med, usages = obj.consensus(k, density_threshold=thr)
+        assert engine.shape == g["tpm"].shape                   # the TPM matrix as stored, not a transposed / dense re-upload
+        rep = str(thr).replace(".", "_")
+        errs = {"consensus_spectra": ((med.values - g["consensus_spectra_k%d" % k]) ** 2).sum(),
+                "consensus_usages": ((usages.values - g["consensus_usages_k%d" % k]) ** 2).sum(),
+                "gene_spectra_tpm": ((load_df_from_npz(obj.paths["gene_spectra_tpm"] % (k, rep)).values
+                                      - g["gene_spectra_tpm_k%d" % k]) ** 2).sum(),
+                "gene_spectra_score": ((load_df_from_npz(obj.paths["gene_spectra_score"] % (k, rep)).values
+                                        - g["gene_spectra_score_k%d" % k]) ** 2).sum()}
+        print("mirror class (Kullback-Leibler) k=%d sparse=%s: %s" % (k, sparse, {a: float("%.3g" % b) for a, b in errs.items()}))
+        for name, e in errs.items():
+            assert e < TOLERANCE, (name, e)
+
+
+def test_kl_pipeline_factorize_to_consensus_vs_reference(engine, g, tmp_path):
+    """prepare_from_matrix -> factorize -> combine -> k_selection_stats -> consensus under beta_loss='kullback-leibler', the
+    restarts on the device's float32 kernels: per restart against the reference's merged spectra, then the consensus
+    artefacts (cnmf.py:977-985) against the reference's files."""
+    obj = cNMF(output_dir=str(tmp_path), name="pkl", engine=engine)
+    nc = pd.DataFrame(g["norm_counts"], index=["c%d" % i for i in range(g["norm_counts"].shape[0])], columns=list(g["genes"]))
+    tpm = pd.DataFrame(g["tpm"], index=nc.index, columns=list(g["tpm_genes"]))
+    obj.prepare_from_matrix(nc, components=[4, 5, 6], n_iter=12, seed=14, beta_loss="kullback-leibler", tpm=tpm)
+    led = load_df_from_npz(obj.paths["nmf_replicate_parameters"])
+    assert np.array_equal(led[["n_components", "iter", "nmf_seed"]].values.astype(np.int64), g["ledger"])
+    obj.factorize()
+    obj.combine()
+    worst = 0.0
+    for k in (4, 5, 6):
+        merged = load_df_from_npz(obj.paths["merged_spectra"] % k)
+        ref = g["merged_k%d" % k]
+        assert merged.shape == ref.shape
+        for it in range(12):
+            maxabs, relfro = nmf_cd.spectra_error(ref[it * k:(it + 1) * k], merged.values[it * k:(it + 1) * k])
+            worst = max(worst, relfro)
+            assert maxabs <= 5e-4 and relfro <= 2e-3, (k, it, maxabs, relfro)
+    print("Kullback-Leibler restarts vs the reference's merged spectra: worst relative Frobenius error %.2e" % worst)
+    stats = obj.k_selection_stats()
+    for row, k in zip(stats.itertuples(), (4, 5, 6)):
+        _, _, sil, err = g["stats_k%d" % k]
+        assert row.k == k and abs(row.silhouette - sil) < 5e-3 and abs(row.prediction_error - err) <= 1e-3 * err
+    for k, thr in ((5, 0.5), (4, 2.0)):
+        med, usages = obj.consensus(k, density_threshold=thr)
+        rep = str(thr).replace(".", "_")
+        assert ((med.values - g["consensus_spectra_k%d" % k]) ** 2).sum() < TOLERANCE
+        assert ((usages.values - g["consensus_usages_k%d" % k]) ** 2).sum() < TOLERANCE * usages.size
+        tpm_sp = load_df_from_npz(obj.paths["gene_spectra_tpm"] % (k, rep)).values
+        ref = g["gene_spectra_tpm_k%d" % k]
+        assert np.abs(tpm_sp - ref).max() <= 2e-3 * np.abs(ref).max()
+        score = load_df_from_npz(obj.paths["gene_spectra_score"] % (k, rep)).values
+        assert np.abs(score - g["gene_spectra_score_k%d" % k]).max() < 5e-3

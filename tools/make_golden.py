@@ -17,6 +17,7 @@ not exist:
      stats_k{K}             [k, threshold, silhouette, prediction_error]     cnmf.py:932-936
 
 Run:  python tools/make_golden.py          (takes ~1 min; needs /root/reference)
+      python tools/make_golden.py --beta-loss kullback-leibler      -> golden/ref_small_kl.npz
 """
 import os
 import shutil
@@ -34,12 +35,14 @@ from cnmf_amd import synth  # noqa: E402
 from oracle import scanpy_shim  # noqa: E402
 
 
-def main():
+def main(beta_loss="frobenius"):
     scanpy_shim.install()
     import cnmf as ref  # the unmodified reference
     from cnmf.cnmf import load_df_from_npz, save_df_to_npz
 
-    out_path = os.path.join(ROOT, "tests", "golden", "ref_small.npz")
+    # round 5: the same pipeline under beta_loss='kullback-leibler' (solver 'mu' for the restarts AND for the three refits
+    # of the consensus tail, cnmf.py:618-631) -> golden/ref_small_kl.npz
+    out_path = os.path.join(ROOT, "tests", "golden", "ref_small.npz" if beta_loss == "frobenius" else "ref_small_kl.npz")
     tmp = tempfile.mkdtemp(prefix="cnmf_golden_")
     try:
         # seeded synthetic counts: 240 cells x 400 genes, 5 programmes
@@ -56,7 +59,7 @@ def main():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             obj.prepare(counts_fn, components=ks, n_iter=12, densify=True, seed=14,
-                        num_highvar_genes=150, beta_loss="frobenius")
+                        num_highvar_genes=150, beta_loss=beta_loss)
             obj.factorize(worker_i=0, total_workers=1)
             obj.combine()
             store = {}
@@ -91,4 +94,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    bl = "frobenius"
+    if "--beta-loss" in sys.argv:
+        bl = sys.argv[sys.argv.index("--beta-loss") + 1]
+    main(bl)

@@ -148,8 +148,62 @@ def make_c4_counts():
     np.savez_compressed(os.path.join(OUT, "ref_c4_counts.npz"), **out)
 
 
+def c4kl_matrix():
+    """BASELINE config 4's shape with the library size of a real 10x matrix (e^5.2 -> ~9 % non-zero): the gamma-Poisson
+    counts of the C4 topic model (200 000 x 2000, K_true = 20, data seed 3) scaled to unit variance per gene like the
+    reference's prepare, handed over as CSR -- the matrix of tools/mu_sparse_probe.py."""
+    C, _ = synth.topic_counts(200_000, 2000, 20, 5.2, 0.4, 3)
+    X = synth.normalise_like_prepare(C, dtype=np.float32)
+    return sp.csr_matrix(X)
+
+
+def _c4kl_one(args):
+    k, seed, T, dtype = args
+    X = c4kl_matrix().astype(dtype)
+    t0 = time.time()
+    H, W, n = sklearn_ref.nmf(X, k, seed, beta_loss="kullback-leibler", solver="mu", max_iter=T)
+    from oracle import nmf_mu
+    err = nmf_mu.beta_divergence(X.astype(np.float64), W.astype(np.float64), H.astype(np.float64), 1, square_root=True)
+    print("C4 KL k=%d seed=%d T=%d %s: n_iter=%d err=%.9g (%.0f s)" % (k, seed, T, np.dtype(dtype).name, n, err,
+                                                                         time.time() - t0), flush=True)
+    return (k, seed, T, np.dtype(dtype).name, H, W[:4096].copy(), W.sum(axis=0), n, err)
+
+
+def make_c4kl():
+    """Round 5 (review item 1a): scikit-learn ON THE CSR count matrix with beta_loss='kullback-leibler' -- the
+    reference's own sparse route (sklearn _nmf.py:192 `_special_sparse_dot`, :526-728 via cnmf.py:672) -- at the size the
+    non-zero kernels were benchmarked at: K = 20 and K = 9, 20 and 100 iterations (the stopping rule left on), float64;
+    and the same in float32 as the calibration of what single precision delivers there."""
+    import multiprocessing as mp
+    X = c4kl_matrix()
+    out = {"shape": np.array(X.shape), "nnz": np.array([X.nnz]),
+           "x_checksum": np.array([float(X.data.astype(np.float64).sum())])}
+    del X
+    jobs = [(k, seed, T, dt) for (k, seed) in ((20, 31), (9, 32)) for T in (20, 100) for dt in (np.float64, np.float32)]
+    with mp.get_context("fork").Pool(4) as pool:
+        res = pool.map(_c4kl_one, jobs, chunksize=1)
+    from oracle import nmf_cd
+    byk = {(k, T, dt): (H, Wh, Ws, n, err) for (k, seed, T, dt, H, Wh, Ws, n, err) in res}
+    for (k, seed) in ((20, 31), (9, 32)):
+        out["k%d_seed" % k] = np.array([seed])
+        for T in (20, 100):
+            H, Wh, Ws, n, err = byk[(k, T, "float64")]
+            H32, _, _, n32, err32 = byk[(k, T, "float32")]
+            out["k%d_H%d" % (k, T)] = H.astype(np.float32)
+            out["k%d_Whead%d" % (k, T)] = Wh.astype(np.float32)
+            out["k%d_Wsum%d" % (k, T)] = Ws
+            out["k%d_n%d" % (k, T)] = np.array([n, n32])
+            out["k%d_err%d" % (k, T)] = np.array([err, err32])
+            out["k%d_f32dev%d" % (k, T)] = np.array(nmf_cd.spectra_error(H, H32))
+            print("k=%d T=%d: n_iter %d (f32 %d), err %.9g, sklearn float32 vs float64 %s" % (k, T, n, n32, err,
+                  out["k%d_f32dev%d" % (k, T)]), flush=True)
+    np.savez_compressed(os.path.join(OUT, "ref_c4_kl.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3", "c4", "c4counts"]
+    if "c4kl" in which:
+        make_c4kl()
     if "c4counts" in which:
         make_c4_counts()
     if "c4" in which:
