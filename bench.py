@@ -437,22 +437,44 @@ def kl_non_zero_path(ks_all, n_cells=50000, iters=100):
                        % (Xs.shape[0], Xs.shape[1], 100.0 * float((Xs != 0).mean()), len(ks), min(ks), max(ks), iters)}
     eng = Engine(0)
     old = os.environ.get("CNMF_MU_SPARSE")
+    results = {}
     try:
         eng.set_matrix(Xs)
         for label, mode in (("non_zero_path", "1"), ("dense_matrix_pipe", "0")):
             os.environ["CNMF_MU_SPARSE"] = mode
             eng.nmf_mu_batch(ks[:2], seeds=seeds[:2], max_iter=3, tol=0, warn=False)        # warm-up: images / X^T, code objects
             t0 = time.perf_counter()
-            _, _, n_iter, _ = eng.nmf_mu_batch(ks, seeds=seeds, max_iter=iters, tol=0, warn=False)
+            H_list, _, n_iter, err = eng.nmf_mu_batch(ks, seeds=seeds, max_iter=iters, tol=0, warn=False)
             dt = time.perf_counter() - t0
             out[label] = {"us_per_restart_iteration": 1e6 * dt / float(np.sum(n_iter)), "restart_iterations_per_s": float(np.sum(n_iter)) / dt}
+            results[label] = (H_list, np.asarray(err))
+        # no speed-up without a correctness check beside it (round-4 review): the two paths must agree restart by restart
+        # (same mathematics, another summation order: float32 round-off over `iters` iterations), and the first restart
+        # is held to the float64 oracle's spectra over 20 iterations (bounded: ~10 s on the host)
+        from oracle import nmf_cd, nmf_mu
+        worst = (0.0, 0.0)
+        for hs, hd in zip(results["non_zero_path"][0], results["dense_matrix_pipe"][0]):
+            ma, rf = nmf_cd.spectra_error(hd.astype(np.float64), hs)
+            worst = (max(worst[0], ma), max(worst[1], rf))
+        derr = float(np.max(np.abs(results["non_zero_path"][1] - results["dense_matrix_pipe"][1]) / results["dense_matrix_pipe"][1]))
+        os.environ["CNMF_MU_SPARSE"] = "1"
+        H20, _, _, _ = eng.nmf_mu_batch(ks[:1], seeds=seeds[:1], max_iter=20, tol=0, warn=False)
+        _, H_ref, _ = nmf_mu.nmf_mu(Xs.astype(np.float64), ks[0], seed=seeds[0], max_iter=20, tol=0.0)
+        oma, orf = nmf_cd.spectra_error(H_ref, H20[0])
+        out["agreement"] = {"non_zero_vs_dense_spectra_maxabs": worst[0], "non_zero_vs_dense_spectra_relfro": worst[1],
+                            "non_zero_vs_dense_divergence_rel": derr,
+                            "non_zero_vs_float64_oracle_20_iterations": {"maxabs": oma, "relfro": orf},
+                            "bars": "spectra 1e-4 / 1e-3 (rows L2-normalised, matched by cosine), divergence 1e-3"}
+        out["agreement"]["ok"] = bool(worst[0] <= 1e-4 and worst[1] <= 1e-3 and derr <= 1e-3 and oma <= 1e-4 and orf <= 1e-3)
     finally:
         if old is None:
             os.environ.pop("CNMF_MU_SPARSE", None)
         else:
             os.environ["CNMF_MU_SPARSE"] = old
         eng.close()
-    out["speed_up"] = out["dense_matrix_pipe"]["us_per_restart_iteration"] / out["non_zero_path"]["us_per_restart_iteration"]
+    # (a speed-up is only reported beside a passed agreement check)
+    out["speed_up"] = (out["dense_matrix_pipe"]["us_per_restart_iteration"] / out["non_zero_path"]["us_per_restart_iteration"]
+                       if out.get("agreement", {}).get("ok") else None)
     return out
 
 

@@ -16,7 +16,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 # every symbol include/cnmf_hip.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
-    "cnmf_device_count", "cnmf_create", "cnmf_destroy", "cnmf_last_error", "cnmf_version",
+    "cnmf_device_count", "cnmf_create", "cnmf_destroy", "cnmf_last_error", "cnmf_reload_env", "cnmf_version",
     "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_set_count_detection", "cnmf_get_shape", "cnmf_get_matrix",
     "cnmf_col_moments", "cnmf_scale_columns", "cnmf_row_sums",
     "cnmf_nmf_cd_batch", "cnmf_nmf_cd_batch_resident", "cnmf_get_iteration_means", "cnmf_set_iteration_hints", "cnmf_nnls",
@@ -24,10 +24,14 @@ SYMBOLS = [
     "cnmf_xt_matmul_f64", "cnmf_nnls_spectra", "cnmf_nnls_f64", "cnmf_nnls_gram", "cnmf_nnls_batch", "cnmf_kselect_stats",
     "cnmf_comm_unique_id", "cnmf_comm_init", "cnmf_comm_finalize", "cnmf_comm_rank", "cnmf_comm_world",
     "cnmf_allgather_bytes", "cnmf_allgather_spectra",
-    "cnmf_spectra_rows", "cnmf_spectra_reset", "cnmf_spectra_fetch", "cnmf_spectra_genes", "cnmf_spectra_append",
+    "cnmf_spectra_rows", "cnmf_spectra_reset", "cnmf_spectra_fetch", "cnmf_spectra_fetch_rows", "cnmf_spectra_genes", "cnmf_spectra_append",
     "cnmf_consensus_store", "cnmf_kselect_stats_store",
-    "cnmf_range_finder", "cnmf_format_rows_f64", "cnmf_debug_stream", "cnmf_debug_gemm", "cnmf_debug_gemm3", "cnmf_debug_gemm3c", "cnmf_debug_gemm2h", "cnmf_debug_standard_normal",
+    "cnmf_range_finder", "cnmf_format_rows_f64",
 ]
+# test hooks (include/cnmf_hip_debug.h): present only in a library built with -DCNMF_DEBUG_ABI -- the in-tree default,
+# because tests/ call them; CNMF_PRODUCT_BUILD=1 in the environment of build() leaves them out
+DEBUG_SYMBOLS = ["cnmf_debug_stream", "cnmf_debug_gemm", "cnmf_debug_gemm3", "cnmf_debug_gemm3c", "cnmf_debug_gemm2h",
+                 "cnmf_debug_standard_normal"]
 
 COMM_ID_BYTES = 128
 
@@ -69,26 +73,29 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + [os.path.join(INCLUDE_DIR, "cnmf_hip.h")]
+    deps = sources() + [os.path.join(INCLUDE_DIR, "cnmf_hip.h"), os.path.join(INCLUDE_DIR, "cnmf_hip_debug.h")]
     return any(os.path.getmtime(s) > t for s in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/cnmf_hip.hip for gfx950 into cnmf_amd/libcnmf_hip.so (in-tree)."""
-    if not force and not needs_build():
+def build(force=False, verbose=False, out=None):
+    """Compile csrc/cnmf_hip.hip for gfx950 into cnmf_amd/libcnmf_hip.so (in-tree).  The diagnostic entry points the tests
+    use (cnmf_debug_*, include/cnmf_hip_debug.h) are compiled in unless CNMF_PRODUCT_BUILD=1 is set."""
+    out = out or LIB_PATH
+    if not force and out == LIB_PATH and not needs_build():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    product = os.environ.get("CNMF_PRODUCT_BUILD", "0") not in ("", "0")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-unused-result",
+           "-Wno-unused-value", "-Wno-unused-result"] + ([] if product else ["-DCNMF_DEBUG_ABI"]) + [
            # MFMA accumulators in plain VGPRs (gfx950 has one unified file): no v_accvgpr moves around the
            # elementwise work between chained MFMAs (kernels_mu_mfma.hip.h)
            "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-           os.path.join(SRC_DIR, "cnmf_hip.hip"), "-o", LIB_PATH + ".tmp"]
+           os.path.join(SRC_DIR, "cnmf_hip.hip"), "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(out + ".tmp", out)
+    return out
 
 
 _lib = None
@@ -114,6 +121,8 @@ def load():
     lib.cnmf_destroy.argtypes = [vp]
     lib.cnmf_last_error.restype = C.c_char_p
     lib.cnmf_last_error.argtypes = [vp]
+    lib.cnmf_reload_env.restype = i32
+    lib.cnmf_reload_env.argtypes = [vp]
     lib.cnmf_version.restype = C.c_char_p
     lib.cnmf_set_matrix.restype = i32
     lib.cnmf_set_matrix.argtypes = [vp, f32p, i64, i64]
@@ -142,6 +151,8 @@ def load():
     lib.cnmf_nmf_mu_batch.restype = i32
     lib.cnmf_nmf_mu_batch.argtypes = [vp, i32, i32p, i32, u32p, dblp, f32p, f32p, i32, i32,
                                       C.POINTER(CdParams), f32p, f32p, i32p, dblp]
+    lib.cnmf_spectra_fetch_rows.restype = i32
+    lib.cnmf_spectra_fetch_rows.argtypes = [vp, i64, i64, f32p]
     lib.cnmf_mu_refit_f64.restype = i32
     lib.cnmf_mu_refit_f64.argtypes = [vp, i32, i32, dblp, dblp, C.c_double, C.POINTER(CdParams), dblp, i32p, dblp]
     lib.cnmf_get_iteration_means.restype = i32
@@ -159,8 +170,6 @@ def load():
     lib.cnmf_prediction_error.argtypes = [vp, i32, dblp, dblp, dblp]
     lib.cnmf_x_matmul.restype = i32
     lib.cnmf_x_matmul.argtypes = [vp, i32, f32p, i32, f32p]
-    lib.cnmf_debug_stream.restype = i32
-    lib.cnmf_debug_stream.argtypes = [vp, i32, C.c_longlong, i32]
     lib.cnmf_format_rows_f64.restype = i64
     lib.cnmf_format_rows_f64.argtypes = [dblp, i64, i64, C.c_char, C.c_char_p, i64, C.c_void_p, i64]
     lib.cnmf_range_finder.restype = i32
@@ -210,15 +219,19 @@ def load():
     lib.cnmf_spectra_reset.argtypes = [vp]
     lib.cnmf_spectra_fetch.restype = i32
     lib.cnmf_spectra_fetch.argtypes = [vp, f32p]
-    lib.cnmf_debug_gemm.restype = i32
-    lib.cnmf_debug_gemm.argtypes = [vp, i32, i32, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
-    lib.cnmf_debug_gemm3.restype = i32
-    lib.cnmf_debug_gemm3.argtypes = [vp, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
-    lib.cnmf_debug_gemm3c.restype = i32
-    lib.cnmf_debug_gemm3c.argtypes = [vp, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
-    lib.cnmf_debug_gemm2h.restype = i32
-    lib.cnmf_debug_gemm2h.argtypes = [vp, f32p, f32p, f32p, i32, i32, i32, i32, i32, dblp, i32]
-    lib.cnmf_debug_standard_normal.restype = i32
-    lib.cnmf_debug_standard_normal.argtypes = [vp, C.c_uint32, i64, dblp]
+    lib.has_debug_abi = all(hasattr(lib, n) for n in DEBUG_SYMBOLS)      # (a product build has none of them)
+    if lib.has_debug_abi:
+        lib.cnmf_debug_stream.restype = i32
+        lib.cnmf_debug_stream.argtypes = [vp, i32, C.c_longlong, i32]
+        lib.cnmf_debug_gemm.restype = i32
+        lib.cnmf_debug_gemm.argtypes = [vp, i32, i32, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
+        lib.cnmf_debug_gemm3.restype = i32
+        lib.cnmf_debug_gemm3.argtypes = [vp, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
+        lib.cnmf_debug_gemm3c.restype = i32
+        lib.cnmf_debug_gemm3c.argtypes = [vp, f32p, f32p, f32p, i32, i32, i32, i32, dblp, i32]
+        lib.cnmf_debug_gemm2h.restype = i32
+        lib.cnmf_debug_gemm2h.argtypes = [vp, f32p, f32p, f32p, i32, i32, i32, i32, i32, dblp, i32]
+        lib.cnmf_debug_standard_normal.restype = i32
+        lib.cnmf_debug_standard_normal.argtypes = [vp, C.c_uint32, i64, dblp]
     _lib = lib
     return lib

@@ -551,6 +551,11 @@ class cNMF:
             # the spectra also stay in the engine's device store: k selection and consensus of THIS process take their
             # merged spectra from there (no 80 MB upload per consensus call; round-3 review, next #9)
             keep = hasattr(eng, "spectra_fetch")
+            if keep and self._store_rows and all(key in set(zip(ks, its)) for key in self._store_rows):
+                # every restart this object keeps in the device store is about to be run again: drop the old rows instead
+                # of appending behind them (a bench loop / a repeated factorize would grow the store by 65 MB per call)
+                eng.spectra_reset()
+                self._store_rows.clear()
             if iteration_hints is not None:
                 eng.set_iteration_hints(iteration_hints)
             try:

@@ -14,7 +14,7 @@ static int sweep_parts(int L) { const int c = sweep_chunks(L); return (L + 256 *
 
 static int pick_nsplit(const cnmf_ctx* ctx, int KC)
 {
-    if (const char* s = getenv("CNMF_NSPLIT")) { int v = atoi(s); if (v > 0) return v; }
+    if (const char* s = ctx_getenv(ctx, "CNMF_NSPLIT")) { int v = atoi(s); if (v > 0) return v; }
     // pass B grid = ceil(G_pad/128) x (KC/128 or 1) x nsplit ; aim at ~2 workgroups per CU
     const int jt = (ctx->G_pad + 127) / 128;
     const int mg = std::max(1, KC / 128);
@@ -34,7 +34,7 @@ static int effective_splits(int Ktot, int nsplit)
 // that ~2 workgroups per CU are in flight; the planes are summed by reduce_splits_kernel.
 static int pick_nsplit_A(const cnmf_ctx* ctx, int KC)
 {
-    if (const char* s = getenv("CNMF_NSPLIT_A")) { int v = atoi(s); if (v > 0) return effective_splits(ctx->G_pad, v); }
+    if (const char* s = ctx_getenv(ctx, "CNMF_NSPLIT_A")) { int v = atoi(s); if (v > 0) return effective_splits(ctx->G_pad, v); }
     const int T = (ctx->N_pad / 128) * std::max(1, KC / 128);
     if (T > 256) return 1;                                  // stream-K territory
     int s = std::max(1, 512 / T);
@@ -204,10 +204,10 @@ static int kc_limit()                  // (CNMF_KC_LIMIT: A/B knob, up to 2048 =
     return std::max(256, std::min(2048, (v / 256) * 256));
 }
 #define CNMF_KC_LIMIT kc_limit()
-static int pick_kc(int64_t total_k, int max_k, int kc_max, bool wide_ok)
+static int pick_kc(const cnmf_ctx* ctx, int64_t total_k, int max_k, int kc_max, bool wide_ok)
 {
     bool forced = false;
-    if (const char* s = getenv("CNMF_KC")) { int v = atoi(s); if (v >= 32) { kc_max = v; forced = true; } }
+    if (const char* s = ctx_getenv(ctx, "CNMF_KC")) { int v = atoi(s); if (v >= 32) { kc_max = v; forced = true; } }
     const bool autosize = kc_max <= 0;
     if (autosize) kc_max = 256;
     kc_max = std::max(32, std::min(CNMF_KC_LIMIT, (kc_max / 32) * 32));
@@ -219,7 +219,7 @@ static int pick_kc(int64_t total_k, int max_k, int kc_max, bool wide_ok)
         // as wide as the job, up to the limit: a job that fits entirely starts every restart at once and the batch
         // narrows behind the ones that finish (compact()); measured and simulated on the iteration counts of the
         // north-star job (tools/sim_schedule.py): 113 restarts run 187 / 172 / 145 restarts/s at 1024 / 512 / 256 columns
-        if (autosize && !getenv("CNMF_NO_WIDE")) kc = (int)std::min<int64_t>(CNMF_KC_LIMIT, round_up(total_k, 256));
+        if (autosize && !ctx_getenv(ctx, "CNMF_NO_WIDE")) kc = (int)std::min<int64_t>(CNMF_KC_LIMIT, round_up(total_k, 256));
         else if (!autosize && kc_max > 256) kc = (int)std::min<int64_t>(kc_max, round_up(total_k, 256));
     }
     (void)forced;
@@ -270,10 +270,10 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     // (wide batches need the whole-tile matrix-pipe kernels and a matrix large enough to be worth them)
     const bool wide_can = gemm3_mode() != 0 && gemm3_enabled(ctx, 512);
     const bool wide_auto = wide_can && (int64_t)ctx->N_pad * ctx->G_pad >= (1ll << 24);
-    int KC = pick_kc(total_k, max_k, prm->kc_max, (prm->kc_max > 256 || getenv("CNMF_KC")) ? wide_can : wide_auto);
+    int KC = pick_kc(ctx, total_k, max_k, prm->kc_max, (prm->kc_max > 256 || ctx_getenv(ctx, "CNMF_KC")) ? wide_can : wide_auto);
     // 65..128 columns of a count-structured matrix: the 256-column integer-plane kernels (half empty) are still
     // faster than 128 columns on the f32 pipe
-    if (KC == 128 && prm->kc_max <= 0 && !getenv("CNMF_KC") && gemm3_mode() >= 3 && gemm3_enabled(ctx, 256) &&
+    if (KC == 128 && prm->kc_max <= 0 && !ctx_getenv(ctx, "CNMF_KC") && gemm3_mode() >= 3 && gemm3_enabled(ctx, 256) &&
         (int64_t)ctx->N_pad * ctx->G_pad >= (1ll << 24)) {
         rc = ensure_counts(ctx);
         if (rc) return rc;
@@ -319,7 +319,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int nsplit3 = use3 ? pick_nsplit3(ctx, KC, jwA) : 1;
     const int nsplit3_first = nsplit3;             // (reported: the tail narrows the batch and re-plans)
     const int fin_y = (max_k * max_k + 255) / 256;       // finalize blocks per slot
-    const int lag_env = getenv("CNMF_LAG") ? atoi(getenv("CNMF_LAG")) : 0;
+    const int lag_env = ctx_getenv(ctx, "CNMF_LAG") ? atoi(ctx_getenv(ctx, "CNMF_LAG")) : 0;
     const int lag = std::max(1, std::min(RING - 2, prm->lag > 0 ? prm->lag : (lag_env > 0 ? lag_env : 2)));
     hipStream_t st = ctx->stream;
 
@@ -388,7 +388,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     //     descending (LPT) -- the short restarts are kept for the end, where they fill the columns the long ones free.
     // CNMF_QUEUE=rank restores the plain descending-rank order (A/B).
     std::vector<int> order(n);
-    const bool queue_by_rank = getenv("CNMF_QUEUE") && !strcmp(getenv("CNMF_QUEUE"), "rank");
+    const bool queue_by_rank = ctx_getenv(ctx, "CNMF_QUEUE") && !strcmp(ctx_getenv(ctx, "CNMF_QUEUE"), "rank");
     // round 4: the caller's iteration hints (cnmf_set_iteration_hints: mean iterations per rank, e.g. what an earlier call
     // on this matrix learned -- cnmf_get_iteration_means) order the queue from the start: a second factorize with more
     // restarts, a resumed ledger do not have to re-learn that k = 13 runs 1000 iterations and k = 9 runs 37.  Explicit only:
@@ -427,13 +427,13 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     int n_active = 0;
     int64_t it = 0;          // batch iterations enqueued so far
     int snap_nslots[RING] = {0};
-    const bool no_defrag = getenv("CNMF_NO_DEFRAG") != nullptr;
-    const bool no_psum = getenv("CNMF_NO_PSUM") != nullptr;          // (A/B knob: keep the separate split-K reduce)
+    const bool no_defrag = ctx_getenv(ctx, "CNMF_NO_DEFRAG") != nullptr;
+    const bool no_psum = ctx_getenv(ctx, "CNMF_NO_PSUM") != nullptr;          // (A/B knob: keep the separate split-K reduce)
     // partial-tile passes in the tail (the f16 kernels skip the MFMAs of 32-column tiles without a live restart, the live
     // restarts dealt evenly to the component groups): built and measured in round 3 -- 183.0 vs 182.2 restarts/s on the
     // 113-restart shard, 216.5 vs 215.7 on the full job: within noise (the skipping variant is ~4 % slower with all tiles
     // live, and a tail pass is bound by streaming the count plane as much as by its MFMAs).  Opt-in: CNMF_PART=1.
-    const bool no_part = getenv("CNMF_PART") == nullptr || getenv("CNMF_NO_PART") != nullptr;
+    const bool no_part = ctx_getenv(ctx, "CNMF_PART") == nullptr || ctx_getenv(ctx, "CNMF_NO_PART") != nullptr;
     int64_t last_tail_repack = -1000;
     int64_t last_defrag = -8, n_defrag = 0;
     bool h3_valid = false;           // H3 holds the planes of the current H (split-operand modes)
@@ -444,19 +444,19 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     HIP_TRY(ctx, hipEventRecord(ev_begin, st));
     // HIP events around the two GEMM passes of every `time_stride`-th iteration (an event record costs
     // ~6 us of queue time: bracketing every launch would take 4 % off the throughput it measures)
-    const int time_stride = !stats ? 0 : (prm->profile > 0 ? prm->profile : (getenv("CNMF_TIME_GEMM") ? 1 : 0));
+    const int time_stride = !stats ? 0 : (prm->profile > 0 ? prm->profile : (ctx_getenv(ctx, "CNMF_TIME_GEMM") ? 1 : 0));
     std::vector<hipEvent_t> gev;   // (a0,a1,b0,b1) per iteration when timing is requested
 
     const int chunksW = sweep_chunks(N), partsW = sweep_parts(N);
     const int chunksH = sweep_chunks(G), partsH = sweep_parts(G);
     const float l1W = (float)prm->l1_reg_W, l2W = (float)prm->l2_reg_W;
     const float l1H = (float)prm->l1_reg_H, l2H = (float)prm->l2_reg_H;
-    const int gvarA = getenv("CNMF_GEMM_A") ? atoi(getenv("CNMF_GEMM_A")) : 0;
-    const int gvarB = getenv("CNMF_GEMM_B") ? atoi(getenv("CNMF_GEMM_B")) : 0;
+    const int gvarA = ctx_getenv(ctx, "CNMF_GEMM_A") ? atoi(ctx_getenv(ctx, "CNMF_GEMM_A")) : 0;
+    const int gvarB = ctx_getenv(ctx, "CNMF_GEMM_B") ? atoi(ctx_getenv(ctx, "CNMF_GEMM_B")) : 0;
     int64_t restart_iters = 0, column_iters = 0, restart_col_iters = 0;
-    const bool dbg = getenv("CNMF_DEBUG") != nullptr;
+    const bool dbg = ctx_getenv(ctx, "CNMF_DEBUG") != nullptr;
     int64_t dbg_it[65] = {0}, dbg_live[65] = {0};          // by KC / 32 (up to 2048 packed columns)
-    const int wg_slots = getenv("CNMF_SK_WGS") ? atoi(getenv("CNMF_SK_WGS")) : 2 * 256;                    // T-layout pass A: 2 workgroups per CU (73.7 KB LDS each)
+    const int wg_slots = ctx_getenv(ctx, "CNMF_SK_WGS") ? atoi(ctx_getenv(ctx, "CNMF_SK_WGS")) : 2 * 256;                    // T-layout pass A: 2 workgroups per CU (73.7 KB LDS each)
     StreamK sk = plan_streamk(KC, ctx->N_pad, ctx->G_pad, wg_slots);
     if (sk.on) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_split, sk.split.data(), sk.split.size(), hipMemcpyHostToDevice, st));
     int nsplitA = (sk.on && gvarA == 0) ? 1 : std::min(pick_nsplit_A(ctx, KC), ctx->nsplitA_alloc);
@@ -877,8 +877,8 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     // ---- step 4: tail compaction -- nothing left to refill with and at most half of the packed
     // columns still iterate: repack the live slots into a narrower batch so the two GEMM passes
     // shrink with the work (their cost is proportional to KC).
-    const bool no_compact = getenv("CNMF_NO_COMPACT") != nullptr;
-    const bool f32_tail = getenv("CNMF_F32_TAIL") != nullptr;      // (A/B knob: compact the count path at 128 / 64 too)
+    const bool no_compact = ctx_getenv(ctx, "CNMF_NO_COMPACT") != nullptr;
+    const bool f32_tail = ctx_getenv(ctx, "CNMF_F32_TAIL") != nullptr;      // (A/B knob: compact the count path at 128 / 64 too)
     auto compact = [&]() -> int {
         if (n_pending == 0 && n_active > 0 && KC > 32 && !no_compact) {
             int live_cols = 0;

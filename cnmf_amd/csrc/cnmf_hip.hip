@@ -33,6 +33,9 @@
 #include <vector>
 
 #include "../../include/cnmf_hip.h"
+#ifdef CNMF_DEBUG_ABI
+#include "../../include/cnmf_hip_debug.h"
+#endif
 #include "kernels_gemm.hip.h"
 #include "kernels_gemm3.hip.h"
 #include "kernels_counts.hip.h"
@@ -78,6 +81,7 @@ extern "C" cnmf_ctx* cnmf_create(int device)
         return nullptr;
     }
     cnmf_ctx* ctx = new cnmf_ctx();
+    ctx_snapshot_env(ctx);
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         SET_ERR((cnmf_ctx*)nullptr, "hipStreamCreate failed");
@@ -85,6 +89,14 @@ extern "C" cnmf_ctx* cnmf_create(int device)
         return nullptr;
     }
     return ctx;
+}
+
+// re-read the CNMF_* environment variables into the context's snapshot (tools and tests that flip a knob between two calls)
+extern "C" int cnmf_reload_env(cnmf_ctx* ctx)
+{
+    if (!ctx) return CNMF_EINVAL;
+    ctx_snapshot_env(ctx);
+    return CNMF_OK;
 }
 
 static void free_x2(cnmf_ctx* c)

@@ -207,6 +207,23 @@ extern "C" int cnmf_spectra_fetch(cnmf_ctx* ctx, float* out)
     return CNMF_OK;
 }
 
+// rows [row0, row0 + n_rows) of the store only (a batch call's own rows: the store may hold earlier calls' too)
+extern "C" int cnmf_spectra_fetch_rows(cnmf_ctx* ctx, int64_t row0, int64_t n_rows, float* out)
+{
+    if (!ctx) return CNMF_EINVAL;
+    if (row0 < 0 || n_rows < 0 || (size_t)(row0 + n_rows) > ctx->spectra_rows) {
+        SET_ERR(ctx, "rows %lld..%lld outside the store's %lld rows", (long long)row0, (long long)(row0 + n_rows), (long long)ctx->spectra_rows);
+        return CNMF_EINVAL;
+    }
+    if (!n_rows) return CNMF_OK;
+    if (!out) { SET_ERR(ctx, "out is NULL"); return CNMF_EINVAL; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->spectra + (size_t)row0 * (size_t)ctx->spectra_G,
+                                (size_t)n_rows * (size_t)ctx->spectra_G * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CNMF_OK;
+}
+
 extern "C" int cnmf_allgather_spectra(cnmf_ctx* ctx, const float* local, int64_t rows_local, int64_t rows_max,
                                       int64_t n_genes, float* out)
 {

@@ -82,7 +82,7 @@ static int consensus_impl(cnmf_ctx* ctx, const double* spectra, const int64_t* s
     if (!prm->skip_density && prm->n_neighbors + 1 > R) { SET_ERR(ctx, "n_neighbors+1 > number of spectra"); return CNMF_EINVAL; }
     CONS_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const bool dbg = getenv("CNMF_DEBUG") != nullptr;
+    const bool dbg = ctx_getenv(ctx, "CNMF_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
     auto lap = [&](const char* what) {
@@ -135,7 +135,7 @@ static int consensus_impl(cnmf_ctx* ctx, const double* spectra, const int64_t* s
         if (pool.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
         const int m_sel = prm->n_neighbors + 1, vpt = (R + 255) / 256;
 #define KNN_REG(V) knn_density_reg_kernel<V><<<R, 256, 0, st>>>(dD, Rp, R, m_sel, prm->n_neighbors, ddens)
-        if (vpt <= 80 && !getenv("CNMF_KNN_GLOBAL")) {   // the row in registers, 4-way search (up to 20 480 merged spectra)
+        if (vpt <= 80 && !ctx_getenv(ctx, "CNMF_KNN_GLOBAL")) {   // the row in registers, 4-way search (up to 20 480 merged spectra)
             if (vpt <= 4) KNN_REG(4); else if (vpt <= 8) KNN_REG(8); else if (vpt <= 16) KNN_REG(16);
             else if (vpt <= 24) KNN_REG(24); else if (vpt <= 40) KNN_REG(40); else KNN_REG(80);
         } else {                      // selection passes over the L2-resident row: any R
@@ -234,7 +234,7 @@ static int consensus_impl(cnmf_ctx* ctx, const double* spectra, const int64_t* s
     CONS_TRY(hipMemcpyAsync(dc0, c0, (size_t)I * sizeof(int), hipMemcpyHostToDevice, st));
     const int pp_vpt = (Rk + 1023) / 1024;
 #define PP_REG(V) pp_fused_reg_kernel<1024, V><<<I, 1024, 0, st>>>(dD, Rp, dkeep, kd, dc0, du, (int)ustride, dcids)
-    if (pp_vpt <= 8 && !getenv("CNMF_PP_GLOBAL")) {       // closest[] in registers: up to 8192 kept spectra
+    if (pp_vpt <= 8 && !ctx_getenv(ctx, "CNMF_PP_GLOBAL")) {       // closest[] in registers: up to 8192 kept spectra
         if (pp_vpt <= 1) PP_REG(1); else if (pp_vpt <= 2) PP_REG(2); else if (pp_vpt <= 4) PP_REG(4); else PP_REG(8);
     } else {
         double* dclosest = pool.get<double>((size_t)I * Rkp);

@@ -39,6 +39,7 @@ extern "C" int cnmf_x_matmul(cnmf_ctx* ctx, int trans, const float* Q, int ncols
     return CNMF_OK;
 }
 
+#ifdef CNMF_DEBUG_ABI          // test hooks (include/cnmf_hip_debug.h): not compiled into a product build
 // ------------------------------------------------------------------ diagnostics
 extern "C" int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float* A, const float* B,
                                float* C, int KC, int K, int J, int nsplit, double* ms_out, int reps)
@@ -352,3 +353,4 @@ extern "C" int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CNMF_OK;
 }
+#endif  // CNMF_DEBUG_ABI

@@ -88,6 +88,56 @@ __global__ __launch_bounds__(256) void sp_fill_kernel(const float* __restrict__ 
     }
 }
 
+// ---- build from the compressed rows (round 5: csr_host.hip.h keeps them from the CSR upload / builds X^T's on the device):
+// the same two passes without touching the N x G dense image.  Rows list ascending columns, so the entries of a block are
+// contiguous and the image comes out IDENTICAL to the one built from the dense matrix.
+__global__ __launch_bounds__(256) void sp_count_csr_kernel(const long long* __restrict__ ptr, const int* __restrict__ idx, int R,
+                                                           int BS, int nblk, int* __restrict__ cnt /* zeroed */)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const long long b = ptr[row], e = ptr[row + 1];
+    if (nblk == 1) { if (lane == 0) cnt[row] = (int)(e - b); return; }
+    // the entries of a block form a run; a lane that sits on a run's LAST entry knows where the run ends:
+    // count(block) = end(block) - end(previous non-empty block), as two integer atomics per run (order-independent)
+    for (long long p = b + lane; p < e; p += 64) {
+        const int blk = idx[p] / BS;
+        const int nxt = (p + 1 < e) ? idx[p + 1] / BS : -1;
+        if (nxt != blk) atomicAdd(&cnt[(size_t)row * nblk + blk], (int)(p - b + 1));
+        if (nxt != blk && nxt >= 0) atomicAdd(&cnt[(size_t)row * nblk + nxt], -(int)(p - b + 1));
+    }
+}
+
+// pre[row][b] = entries of the row in blocks 0 .. b - 1
+__global__ __launch_bounds__(256) void sp_prefix_kernel(const int* __restrict__ cnt, int R, int nblk, int* __restrict__ pre)
+{
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= R) return;
+    int run = 0;
+    for (int b = 0; b < nblk; ++b) { pre[(size_t)row * nblk + b] = run; run += cnt[(size_t)row * nblk + b]; }
+}
+
+__global__ __launch_bounds__(256) void sp_fill_csr_kernel(const long long* __restrict__ ptr, const int* __restrict__ idx,
+                                                          const float* __restrict__ val, int BS, int nblk, int npos,
+                                                          const int* __restrict__ perm, const long long* __restrict__ off,
+                                                          const int* __restrict__ pre, uint2* __restrict__ ent, int KP)
+{
+    const unsigned QPR = (unsigned)KP / 4u, RPL = 16u / QPR;
+    const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pos >= npos) return;
+    const int row = perm[pos];
+    if (row < 0) return;
+    const int s = pos >> 6, l = pos & 63;
+    const long long b = ptr[row], e = ptr[row + 1];
+    for (long long p = b + lane; p < e; p += 64) {
+        const int c = idx[p], blk = c / BS;
+        const unsigned r = (unsigned)(c - blk * BS);
+        const int t = (int)(p - b) - pre[(size_t)row * nblk + blk];
+        ent[off[(size_t)s * nblk + blk] + l + (size_t)t * 64] =
+            uint2{r * (unsigned)(KP * 4) + (((r / RPL) & (QPR - 1u)) << 4), __float_as_uint(val[p])};
+    }
+}
+
 // ---- build, pass 3: the order of a row's entries is free -- choose it so that the gather is (nearly) free of LDS bank
 // conflicts.  A `ds_read_b128` is served in four groups of 16 lanes (MI355X_MICROARCH.md, LDS table); inside a group two
 // lanes collide when their rows agree modulo 16 (the rotation of the quads keeps that a bijection onto the 16 quad slots).

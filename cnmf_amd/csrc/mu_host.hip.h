@@ -104,15 +104,19 @@ static int mu_ensure_xt(cnmf_ctx* ctx, int Gs)
     return CNMF_OK;
 }
 
-// ---- Kullback-Leibler on the non-zeros: the blocked sliced-ELL images (kernels_mu_sparse.hip.h) of M [R][ld], C columns
-static int sp_build_image(cnmf_ctx* ctx, const float* M, int ld, int R, int C, int BS, SpImage& im)
+// ---- Kullback-Leibler on the non-zeros: the blocked sliced-ELL images (kernels_mu_sparse.hip.h) of a matrix of R rows x C
+// columns given as compressed rows (round 5: csr_host.hip.h -- the CSR upload as it came, or X^T's rows built on the device;
+// the N x G dense image and its transposed copy are not touched on this path)
+static int sp_build_image(cnmf_ctx* ctx, const long long* ptr, const int* idx, const float* val, int R, int C, int BS, SpImage& im)
 {
     hipStream_t st = ctx->stream;
     const int nblk = (C + BS - 1) / BS, nslice = (R + 63) / 64, npos = nslice * 64;
     DevPool pool;
-    int* dcnt = pool.get<int>((size_t)R * nblk);
+    int* dcnt = pool.get<int>((size_t)R * nblk, true, st);
+    int* dpre = pool.get<int>((size_t)R * nblk);
     POOL_TRY(ctx, pool);
-    sp_count_kernel<<<(R + 3) / 4, 256, 0, st>>>(M, ld, R, C, BS, nblk, dcnt);
+    sp_count_csr_kernel<<<(R + 3) / 4, 256, 0, st>>>(ptr, idx, R, BS, nblk, dcnt);
+    sp_prefix_kernel<<<(R + 255) / 256, 256, 0, st>>>(dcnt, R, nblk, dpre);
     HIP_TRY(ctx, hipGetLastError());
     std::vector<int> cnt((size_t)R * nblk);
     HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), dcnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -144,11 +148,11 @@ static int sp_build_image(cnmf_ctx* ctx, const float* M, int ld, int R, int C, i
     if (e == hipSuccess) e = hipMemcpyAsync(im.off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(im.len, len.data(), len.size() * sizeof(int), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        sp_fill_kernel<<<(npos + 3) / 4, 256, 0, st>>>(M, ld, C, BS, nblk, npos, im.perm, im.off, (uint2*)im.ent, SP_LDS_BYTES / 4 / BS);
+        sp_fill_csr_kernel<<<(npos + 3) / 4, 256, 0, st>>>(ptr, idx, val, BS, nblk, npos, im.perm, im.off, dpre, (uint2*)im.ent, SP_LDS_BYTES / 4 / BS);
         e = hipGetLastError();
     }
     // a conflict-free order of every row's entries (CNMF_SP_ORDER=0: storage order, the A/B reference)
-    const char* eo = getenv("CNMF_SP_ORDER");
+    const char* eo = ctx_getenv(ctx, "CNMF_SP_ORDER");
     if (e == hipSuccess && !(eo && atoi(eo) == 0) && n_ent > 0 && BS / 16 <= 255) {     // (its per-residue counters are bytes)
         uint2* tmp = nullptr;
         e = hipMalloc((void**)&tmp, (size_t)n_ent * sizeof(uint2));
@@ -162,50 +166,54 @@ static int sp_build_image(cnmf_ctx* ctx, const float* M, int ld, int R, int C, i
         }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);               // the host vectors above are stack objects
-    if (e != hipSuccess) { im.release(); HIP_TRY(ctx, e); }
+    if (e != hipSuccess) {
+        im.release();
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return CNMF_ENOMEM; }      // (the caller falls back to the dense kernels)
+        HIP_TRY(ctx, e);
+    }
     im.R = R; im.C = C; im.BS = BS; im.nblk = nblk; im.nslice = nslice; im.n_ent = (size_t)n_ent;
     return CNMF_OK;
 }
 
 // Does this call take the non-zero path?  CNMF_MU_SPARSE=0 never, =1 always, otherwise when at most a quarter of X is
-// non-zero (the dense matrix-pipe kernels cost ~0.9 ns per ELEMENT and restart-iteration at k <= 16, these ~3 ns per NON-ZERO).
+// non-zero (the dense matrix-pipe kernels cost ~0.9 ns per ELEMENT and restart-iteration at k <= 16, these ~3 ns per NON-ZERO)
+// and its images and partial numerators fit the free device memory (else: the dense kernels, as before round 4).
 static int mu_sparse_prepare(cnmf_ctx* ctx, int KP, bool* use)
 {
     *use = false;
-    const char* ev = getenv("CNMF_MU_SPARSE");
+    const char* ev = ctx_getenv(ctx, "CNMF_MU_SPARSE");
     const int mode = ev ? atoi(ev) : -1;
     if (mode == 0 || (KP != 16 && KP != 32)) return CNMF_OK;
     const int N = (int)ctx->N, G = (int)ctx->G, idx = KP == 16 ? 0 : 1, BS = SP_LDS_BYTES / (KP * 4);
-    if (ctx->x_nnz < 0) {
-        DevPool pool;
-        int* dcnt = pool.get<int>(N);
-        POOL_TRY(ctx, pool);
-        sp_count_kernel<<<(N + 3) / 4, 256, 0, ctx->stream>>>(ctx->X, ctx->G_pad, N, G, G, 1, dcnt);
-        HIP_TRY(ctx, hipGetLastError());
-        std::vector<int> cnt(N);
-        HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), dcnt, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        long long nnz = 0;
-        for (int v : cnt) nnz += v;
-        ctx->x_nnz = nnz;
-    }
+    int rc = ensure_csr(ctx);                                   // (kept from the CSR upload, or two passes over the dense image)
+    if (rc == CNMF_ENOMEM && mode != 1) return CNMF_OK;
+    if (rc) return rc;
+    ctx->x_nnz = ctx->csr_nnz;
     if (mode != 1 && (double)ctx->x_nnz > 0.25 * (double)N * (double)G) return CNMF_OK;
-    {
-        // the partial numerators of a half-step whose other side needs several blocks: [blocks][own rows][KP] per slot
+    if (!ctx->spA[idx].ent || !ctx->spB[idx].ent) {
+        // the partial numerators of a half-step whose other side needs several blocks ([blocks][own rows][KP] per slot), the
+        // two images (8 B per entry, padded: x 1.25 allowed for), X^T's compressed rows and the build's scratch
         const double nbA = std::ceil((double)G / BS), nbB = std::ceil((double)N / BS);
         const double part = 4.0 * KP * MU_MAXSLOTS * std::max(nbA > 1 ? nbA * ctx->N_pad : 0.0, nbB > 1 ? nbB * round_up(ctx->G_pad, 128) : 0.0);
-        if (mode != 1 && part > 64e9) return CNMF_OK;              // (e.g. 10^6 cells x 30 000 genes: stay on the dense kernels)
+        const double need = part + 2.0 * 1.25 * 8.0 * (double)ctx->x_nnz * 2.0 + 8.0 * (double)ctx->x_nnz + 8.0 * ((double)N * nbA + (double)G * nbB);
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        if (mode != 1 && (part > 64e9 || need > 0.9 * (double)free_b)) {
+            if (ctx_getenv(ctx, "CNMF_DEBUG")) fprintf(stderr, "[cnmf] KL on the non-zeros: %.1f GB needed, %.1f GB free -> dense kernels\n", need / 1e9, free_b / 1e9);
+            return CNMF_OK;
+        }
     }
-    int rc = CNMF_OK;
-    if (!ctx->spA[idx].ent) rc = sp_build_image(ctx, ctx->X, ctx->G_pad, N, G, BS, ctx->spA[idx]);
+    if (!ctx->spA[idx].ent) rc = sp_build_image(ctx, ctx->csr_ptr, ctx->csr_idx, ctx->csr_val, N, G, BS, ctx->spA[idx]);
+    if (!rc && !ctx->spB[idx].ent) {
+        rc = ensure_csc(ctx);
+        if (!rc) rc = sp_build_image(ctx, ctx->csc_ptr, ctx->csc_idx, ctx->csc_val, G, N, BS, ctx->spB[idx]);
+    }
+    if (rc == CNMF_ENOMEM && mode != 1) {                       // an allocation failed after all: the dense kernels still work
+        ctx->spA[idx].release(); ctx->spB[idx].release();
+        return CNMF_OK;
+    }
     if (rc) return rc;
-    if (!ctx->spB[idx].ent) {
-        rc = mu_ensure_xt(ctx, round_up(ctx->G_pad, 128));
-        if (rc) return rc;
-        rc = sp_build_image(ctx, ctx->XtF, ctx->N_pad, G, N, BS, ctx->spB[idx]);
-        if (rc) return rc;
-    }
-    if (getenv("CNMF_DEBUG"))
+    if (ctx_getenv(ctx, "CNMF_DEBUG"))
         fprintf(stderr, "[cnmf] KL on the non-zeros: %lld of %lld elements (%.1f %%), padded entries A %.3f x, B %.3f x\n",
                 ctx->x_nnz, (long long)N * G, 100.0 * ctx->x_nnz / ((double)N * G),
                 ctx->spA[idx].n_ent / std::max(1.0, (double)ctx->x_nnz), ctx->spB[idx].n_ent / std::max(1.0, (double)ctx->x_nnz));
@@ -237,7 +245,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         tilesA = grpA * a.nblk;
     }
     const int Gs = round_up(ctx->G_pad, 128);
-    int rc = mu_ensure_xt(ctx, Gs);
+    int rc = sparse ? CNMF_OK : mu_ensure_xt(ctx, Gs);           // (the non-zero path walks its images only)
     if (rc) return rc;
     constexpr int RPW = MuShape<KP>::RPW, SW = 32 * MuShape<KP>::NJT;      // restarts per workgroup, cells per divergence strip
     const int nstrips = std::max((N + SW - 1) / SW, tilesA), ntiles = Np / 32;
@@ -282,7 +290,7 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
             HIP_TRY(ctx, dyn_lds_optin((const void*)mu_h_coop_kernel<KP, BETA1>, coop_lds));
             HIP_TRY(ctx, dyn_lds_optin((const void*)mu_w_coop_kernel<KP, 0, BETA1>, coop_lds));
             HIP_TRY(ctx, dyn_lds_optin((const void*)mu_w_coop_kernel<KP, 1, BETA1>, coop_lds));
-            if constexpr (BETA1 && KP <= 32) {
+            if constexpr (BETA1 && KP <= 32) if (sparse) {
                 HIP_TRY(ctx, dyn_lds_optin((const void*)mu_sp_kernel<KP, 0, 0>, SP_LDS_BYTES));
                 HIP_TRY(ctx, dyn_lds_optin((const void*)mu_sp_kernel<KP, 0, 1>, SP_LDS_BYTES));
                 HIP_TRY(ctx, dyn_lds_optin((const void*)mu_sp_kernel<KP, 1, 0>, SP_LDS_BYTES));
@@ -504,7 +512,7 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
     // restart at a time, serve CNMF_MU_VALU=1 and matrices beyond the 32-bit addressing bound
     std::vector<char> done(n, 0);
     {
-        const char* e = getenv("CNMF_MU_VALU");
+        const char* e = ctx_getenv(ctx, "CNMF_MU_VALU");
         // (the matrix-pipe kernels address a 32-row step of X / X^T with 32-bit byte offsets below 2^31 -- the buffer
         //  descriptor's range: 4 * 32 * row length -> up to 2^24 cells or genes)
         if (!(e && atoi(e) != 0) && ctx->N_pad <= (1 << 24) && ctx->G_pad <= (1 << 24)) {

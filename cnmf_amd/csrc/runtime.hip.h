@@ -1,6 +1,7 @@
 // Context, error plumbing and scope-bound device resources of libcnmf_hip (included by cnmf_hip.hip).
 #pragma once
 
+#include <map>
 static thread_local std::string g_last_error;
 
 struct cnmf_comm;
@@ -47,6 +48,10 @@ struct cnmf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    // the CNMF_* environment variables as they were when the context was created (cnmf_create) or last re-read
+    // (cnmf_reload_env): the host paths of a call consult THIS snapshot (ctx_getenv), not the process environment -- a
+    // knob that steers a numerics-affecting path cannot change between two calls on one context behind the caller's back
+    std::map<std::string, std::string> env;
 
     // data matrix
     int64_t N = 0, G = 0;
@@ -115,6 +120,23 @@ struct cnmf_ctx {
 
     cnmf_comm* comm = nullptr;        // RCCL communicator (comm_host.hip.h); NULL = single GPU
 };
+
+extern char** environ;
+static void ctx_snapshot_env(cnmf_ctx* ctx)
+{
+    ctx->env.clear();
+    for (char** e = environ; e && *e; ++e) {
+        if (strncmp(*e, "CNMF_", 5) != 0) continue;
+        const char* eq = strchr(*e, '=');
+        if (eq) ctx->env[std::string(*e, eq - *e)] = std::string(eq + 1);
+    }
+}
+static const char* ctx_getenv(const cnmf_ctx* ctx, const char* name)
+{
+    if (!ctx) return getenv(name);
+    auto it = ctx->env.find(name);
+    return it == ctx->env.end() ? nullptr : it->second.c_str();
+}
 
 static constexpr int RING = 8;
 #ifndef CNMF_GEMM3_DEFAULT

@@ -260,7 +260,19 @@ def launch_ranks(argv, n, env=None, timeout=None, poll=0.1, capture_stdout=True)
             if bad:
                 failure = ("exit", bad[0][0], bad[0][1])
                 break
-            if all(c == 0 for c in codes) and not open_out:
+            if all(c == 0 for c in codes):
+                if open_out:
+                    # every rank has exited: drain what rank 0 wrote and stop -- a grandchild that inherited the pipe
+                    # must not keep the parent waiting
+                    try:
+                        os.set_blocking(procs[0].stdout.fileno(), False)
+                        while True:
+                            chunk = os.read(procs[0].stdout.fileno(), 65536)
+                            if not chunk:
+                                break
+                            out0 += chunk
+                    except (BlockingIOError, OSError):
+                        pass
                 break
             if timeout is not None and time.time() - t0 > timeout:
                 failure = ("timeout", None, None)
@@ -318,8 +330,11 @@ def _load_factory(spec):
     return getattr(importlib.import_module(mod), fn)
 
 
+DEFAULT_LAUNCH_TIMEOUT = 24 * 3600.0      # a hung rank (ncclCommInitRank, the all-gather) must not block the parent for ever
+
+
 def factorize_multi_gpu(obj, n_gpus=None, skip_completed_runs=False, gather="rccl", write_iter_files=True,
-                        timeout=None, engine_factory=None, python=None):
+                        timeout=DEFAULT_LAUNCH_TIMEOUT, engine_factory=None, python=None):
     """The mirror of the reference's ``cNMF.factorize_multi_process(total_workers)`` (cnmf.py:677-689) for GPUs: spawn
     ``n_gpus`` processes (default: every visible GPU), rank r on GPU r running ``factorize(worker_i=r,
     total_workers=n_gpus)`` -- the reference's own shard, ``worker_filter`` (cnmf.py:52-53) -- then
@@ -332,7 +347,8 @@ def factorize_multi_gpu(obj, n_gpus=None, skip_completed_runs=False, gather="rcc
 
     ``write_iter_files``: keep the reference's per-iteration files too (always on for ``gather="files"``).
     ``engine_factory`` ("module:callable", test hook): what a worker calls instead of ``Engine(local_rank)``.
-    Raises :class:`RankFailure` when a rank dies or ``timeout`` (seconds) passes.  Multi-GPU execution of the RCCL path
+    Raises :class:`RankFailure` when a rank dies or ``timeout`` seconds pass (default: a day -- a rank that hangs without
+    dying is otherwise never detected; ``None`` waits for ever).  Multi-GPU execution of the RCCL path
     has not been measured on hardware yet."""
     if n_gpus is None:
         from . import _lib
@@ -354,6 +370,12 @@ def factorize_multi_gpu(obj, n_gpus=None, skip_completed_runs=False, gather="rcc
     env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
     out = launch_ranks(argv, int(n_gpus), env=env, timeout=timeout)
     report = [json.loads(ln) for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
+    # what the workers wrote supersedes whatever an earlier factorize() of THIS process left in memory (another shard,
+    # another batch placement): combine() must read the files, consensus must not map rows into this process's old store
+    if hasattr(obj, "spectra_cache"):
+        obj.spectra_cache.clear()
+    if hasattr(obj, "_store_rows"):
+        obj._store_rows.clear()
     if gather == "files":
         obj.combine()
     obj.merged_cache.clear()                              # the merged files were (re)written by another process

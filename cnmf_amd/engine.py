@@ -7,6 +7,7 @@ maps status codes to the exception types the reference path raises
 (scikit-learn raises ValueError / TypeError).
 """
 import ctypes as C
+import os
 import warnings
 
 import numpy as np
@@ -86,6 +87,7 @@ class Engine:
         if not self._ctx:
             raise RuntimeError("cnmf_create failed: %s" % self._lib.cnmf_last_error(None).decode())
         self.device = int(device)
+        self._env_snap = self._env_now()
         self.shape = None
         self._x_mean, self._x_mean_src = None, None
         self.x_dtype = None
@@ -104,6 +106,21 @@ class Engine:
         self._check(self._lib.cnmf_set_count_detection(self._ctx, int(bool(enabled))))
 
     # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _env_now():
+        return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("CNMF_")))
+
+    def reload_env(self):
+        """The library reads its ``CNMF_*`` switches once per context (cnmf_create); this re-reads them."""
+        self._check(self._lib.cnmf_reload_env(self._ctx))
+        self._env_snap = self._env_now()
+
+    def _sync_env(self):
+        # host-side convenience (tests and A/B tools flip a switch between two calls of one process): the context's
+        # snapshot follows os.environ when -- and only when -- the process environment has changed since it was taken
+        if self._env_now() != self._env_snap:
+            self.reload_env()
+
     def close(self):
         if getattr(self, "_ctx", None):
             self._lib.cnmf_destroy(self._ctx)
@@ -129,6 +146,7 @@ class Engine:
     def _params(self, tol, max_iter, alpha_W, alpha_H, l1_ratio, kc_max=0, lag=0, profile=0, n_features=None):
         """``n_features``: the feature count sklearn would see (it scales the W penalties, _nmf.py:1254-1265) when the
         solved problem uses a column SUBSET of the resident matrix (nnls_gram)."""
+        self._sync_env()
         N, G = self.shape
         l1W, l1H, l2W, l2H = regularization(N, G if n_features is None else int(n_features), alpha_W, alpha_H, l1_ratio)
         return _lib.CdParams(float(tol), int(max_iter), int(kc_max), l1W, l2W, l1H, l2H, int(lag), int(profile))
@@ -294,8 +312,8 @@ class Engine:
             if resident == "keep":
                 if return_W:
                     raise ValueError("resident='keep' returns spectra only")
-                allrows = self.spectra_fetch()
-                H_list = [allrows[offs[r]:offs[r + 1]] for r in range(n)]
+                mine = self.spectra_fetch(row0, tot_k)            # THIS call's rows only (ONE copy)
+                H_list = [mine[offs[r] - row0:offs[r + 1] - row0] for r in range(n)]
         else:
             H_out = np.empty((max(tot_k, 1), G), dtype=np.float32)
             W_out = np.empty(max(tot_k, 1) * N, dtype=np.float32) if return_W else None
@@ -424,6 +442,7 @@ class Engine:
         ``col_divisor`` [columns of the walked matrix]: the matrix meant is ``X[:, d != 0] / d[d != 0]`` (the final usage
         refit on the unit-variance high-variance-gene TPM, cnmf.py:963-972); then ``w_init`` (scikit-learn's
         sqrt(mean / k) of THAT matrix) must be given and ``n_features`` is its column count (scales the W penalties)."""
+        self._sync_env()
         if self.shape is None:
             raise RuntimeError("set_matrix() has not been called")
         N, G = self.shape
@@ -644,6 +663,7 @@ class Engine:
         KMeans, medians, silhouette), the |K| usage refits run batched (one pass over X), the prediction errors are
         computed with the usages still on the device.  Returns ``{k: dict(silhouette, prediction_error,
         median_spectra, nnls_iter)}``."""
+        self._sync_env()
         if self.shape is None:
             raise RuntimeError("set_matrix() has not been called")
         N, G = self.shape
@@ -852,6 +872,7 @@ class Engine:
         ``local_density`` (R,), ``density_filter`` (R,) bool, ``labels`` (R,) int (0-based,
         -1 = filtered), ``median_spectra`` (k x G, rows sum to 1), ``inertia``,
         ``silhouette`` (if requested), ``topics_dist`` (R x R, if requested)."""
+        self._sync_env()
         if store_rows is not None:
             rows = np.ascontiguousarray(store_rows, dtype=np.int64).ravel()
             R, G = int(rows.size), self.spectra_genes
@@ -898,6 +919,7 @@ class Engine:
         """``cnmf_pairwise_distances``: ``sklearn.metrics.euclidean_distances(rows)`` (cnmf.py:891, 988) and / or
         ``silhouette_score(rows, labels, metric='euclidean')`` (cnmf.py:923) on the device in float64, rows as given.
         Returns ``(D or None, silhouette or None)``."""
+        self._sync_env()
         rows = np.ascontiguousarray(rows, dtype=np.float64)
         if rows.ndim != 2:
             raise ValueError("rows must be 2-D")
@@ -1012,10 +1034,13 @@ class Engine:
         self._check(self._lib.cnmf_spectra_append(self._ctx, _fp(rows), rows.shape[0], rows.shape[1]))
         return first
 
-    def spectra_fetch(self):
-        out = np.empty((self.spectra_rows, self.spectra_genes), dtype=np.float32)
+    def spectra_fetch(self, row0=0, rows=None):
+        """Rows ``[row0, row0 + rows)`` of the resident spectra store on the host (default: all of it)."""
+        total = self.spectra_rows
+        rows = total - int(row0) if rows is None else int(rows)
+        out = np.empty((rows, self.spectra_genes if total else 0), dtype=np.float32)
         if out.size:
-            self._check(self._lib.cnmf_spectra_fetch(self._ctx, _fp(out)))
+            self._check(self._lib.cnmf_spectra_fetch_rows(self._ctx, int(row0), rows, _fp(out)))
         return out
 
     def debug_gemm(self, mode, A, B, variant=0, nsplit=1, reps=0):

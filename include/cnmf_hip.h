@@ -86,6 +86,10 @@ int         cnmf_device_count(void);
 cnmf_ctx*   cnmf_create(int device);           /* NULL on failure; see cnmf_last_error(NULL) */
 void        cnmf_destroy(cnmf_ctx* ctx);
 const char* cnmf_last_error(const cnmf_ctx* ctx);
+/* The CNMF_* environment variables (INTEGRATION.md "Runtime switches") that steer per-call host decisions are read ONCE,
+ * when the context is created, into the context; cnmf_reload_env re-reads them (A/B tools, tests).  A knob therefore
+ * cannot change between two calls on one context unless the caller asks for it.                                   */
+int cnmf_reload_env(cnmf_ctx* ctx);
 const char* cnmf_version(void);
 
 /* ---- data matrix ------------------------------------------------------------------
@@ -298,6 +302,8 @@ int cnmf_allgather_spectra(cnmf_ctx* ctx, const float* local, int64_t rows_local
 int64_t cnmf_spectra_rows(const cnmf_ctx* ctx);
 int cnmf_spectra_reset(cnmf_ctx* ctx);
 int cnmf_spectra_fetch(cnmf_ctx* ctx, float* out /* [rows][G] */);
+/* rows [row0, row0 + n_rows) of the store: what ONE batch call appended (the store may hold earlier calls' rows too) */
+int cnmf_spectra_fetch_rows(cnmf_ctx* ctx, int64_t row0, int64_t n_rows, float* out);
 /* gene count of the rows in the store (round 4: the store outlives cnmf_set_matrix -- consensus() alternates between the
  * normalised counts and the TPM matrix while the spectra keep serving k selection and further consensus calls) */
 int64_t cnmf_spectra_genes(const cnmf_ctx* ctx);
@@ -362,26 +368,6 @@ int cnmf_kselect_stats(cnmf_ctx* ctx, int n, const int32_t* ks, const int32_t* R
 int64_t cnmf_format_rows_f64(const double* vals, int64_t rows, int64_t cols, char sep, const char* row_labels,
                              int64_t labels_bytes, char* out, int64_t cap);
 
-/* ---- diagnostics used by the tests ---------------------------------------------------- */
-/* C[KC][J] = A[KC][K] . B  through the engine's MFMA GEMM; mode 0: B is [J][K] (pass A),
- * mode 1: B is [K][J] (pass B, split-K partials summed in split order).                  */
-int cnmf_debug_gemm(cnmf_ctx* ctx, int mode, int variant, const float* A, const float* B,
-                    float* C, int KC, int K, int J, int nsplit, double* ms_out, int reps);
-/* C[KC][J] = A[KC][K] . B[J][K]^T through the split-operand (3 x bf16 planes, f32-accurate) MFMA
- * path; KC % 256 == 0, K % 16 == 0.                                                        */
-int cnmf_debug_gemm3(cnmf_ctx* ctx, const float* A, const float* B, float* C, int KC, int K, int J,
-                     int nsplit, double* ms_out, int reps);
-/* the same for count-structured data: Bn [J][K] holds non-negative integers <= 256 (ONE bf16 plane),
- * A arbitrary float32 (three planes); 3 exact bf16 MFMAs per product on 256 x 256 tiles.           */
-int cnmf_debug_gemm3c(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, int KC, int K, int J,
-                      int nsplit, double* ms_out, int reps);
-/* the same on the f16 matrix pipe (the default for count-structured data): Bn <= 2048 in ONE f16 plane (a
- * flagged second plane above that), A >= 0 as TWO f16 planes with a per-row exponent; 2 MFMAs per product.
- * KC % 256 == 0, K % 64 == 0; nsub = 16-k sub-blocks per barrier pair (1 | 2); nsub | 128: scale every row of A by
- * the BOUND the W half-step reports (sqrt of the sum of squares over 1024-entry blocks x 1.0001) instead of the exact
- * row maximum -- the production pass-B scaling, for the accuracy tests.                                   */
-int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, int KC, int K, int J,
-                      int nsplit, int nsub, double* ms_out, int reps);
 /* The range finder of sklearn's randomized_svd (utils/extmath.py:287-357) -- the O(N G) part of init='nndsvd'
  * (decomposition/_nmf.py:316-354; `--init nndsvd`, cnmf.py:1252) -- for a GROUP of restarts: `nblocks` blocks of
  * widths[b] = k_b + 10 columns side by side (sum <= 256, each <= CNMF_KMAX).  transpose = 0: M = X; 1: M = X^T
@@ -390,11 +376,8 @@ int cnmf_debug_gemm2h(cnmf_ctx* ctx, const float* A, const float* Bn, float* C, 
  * per block, B_out [C][M_cols] = Q^T M.  The small SVD / sign flip / NNDSVD split stay with the caller.           */
 int cnmf_range_finder(cnmf_ctx* ctx, int transpose, int nblocks, const int32_t* widths, const float* Q0, int n_iter,
                       float* Q_out, float* B_out);
-/* calibration streams of known byte counts for the PMC counters (tools/pmc_calibrate.py): width 1 = a copy with 4 B per
- * lane, 4 = 16 B per lane, 0 = a read-only LDS-DMA stream (global_load_lds_dwordx4); n_floats floats, `reps` launches.  */
-int cnmf_debug_stream(cnmf_ctx* ctx, int width, long long n_floats, int reps);
-/* numpy RandomState(seed).standard_normal(n) reproduced on the device. */
-int cnmf_debug_standard_normal(cnmf_ctx* ctx, uint32_t seed, int64_t n, double* out);
+/* (the diagnostic entry points the tests use -- cnmf_debug_* -- are declared in cnmf_hip_debug.h and exist only in a
+ * library built with -DCNMF_DEBUG_ABI; they are not part of the drop-in boundary) */
 
 #ifdef __cplusplus
 }

@@ -17,19 +17,25 @@ def lib():
     return _lib.load()
 
 
-def header_symbols():
-    src = open(os.path.join(ROOT, "include", "cnmf_hip.h")).read()
+def header_symbols(name="cnmf_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(cnmf_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_header_and_loader_agree():
     assert header_symbols() == sorted(_lib.SYMBOLS)
+    # the diagnostic entry points live in their own header, behind a build flag: none of them in the drop-in boundary
+    assert not [s for s in header_symbols() if s.startswith("cnmf_debug_")]
+    assert header_symbols("cnmf_hip_debug.h") == sorted(_lib.DEBUG_SYMBOLS)
+    assert "#ifdef CNMF_DEBUG_ABI" in open(os.path.join(ROOT, "cnmf_amd", "csrc", "debug_host.hip.h")).read()
 
 
 def test_every_declared_symbol_is_exported(lib):
     missing = [s for s in header_symbols() if not hasattr(lib, s)]
     assert not missing, missing
+    # the in-tree build carries the test hooks (tests/ call them); a product build (CNMF_PRODUCT_BUILD=1) has none
+    assert lib.has_debug_abi and not [s for s in _lib.DEBUG_SYMBOLS if not hasattr(lib, s)]
 
 
 def test_version_and_error_strings(lib):

@@ -68,6 +68,7 @@ def test_mu_refit_f64_vs_oracle(engine, n, g_, k):
     np.testing.assert_array_equal(res[0][0], res[1][0])          # the device-built rows ARE the uploaded ones
     np.testing.assert_array_equal(res[0][1], res[1][1])
     # a CSR upload with unsorted rows and a duplicated entry: the arrays are not kept, same numbers
+    w0 = engine.init_scale(k)                                     # (sqrt(X.mean() / k) in X's dtype, as the two runs above)
     coo = Xs.tocoo()
     rows = np.concatenate([coo.row[::-1], coo.row[:1]])
     cols = np.concatenate([coo.col[::-1], coo.col[:1]])
@@ -83,7 +84,7 @@ def test_mu_refit_f64_vs_oracle(engine, n, g_, k):
                                                   v32.ctypes.data_as(C.POINTER(C.c_float)), n, g_))
     engine.shape = (n, g_)
     np.testing.assert_array_equal(engine.get_matrix(), X)
-    W2, it2, _ = engine.mu_refit_f64(H, max_iter=300, warn=False, w_init=float(np.sqrt(X64.mean() / k)))
+    W2, it2, _ = engine.mu_refit_f64(H, max_iter=300, warn=False, w_init=w0)
     np.testing.assert_array_equal(W2, res[0][0])
 
 

@@ -198,6 +198,15 @@ def test_merged_spectra_served_from_the_device_store(tmp_path, gold, engine):
     assert np.array_equal(stats_a.values, stats_b.values)
     assert np.array_equal(med_a.values, med_b.values) and np.array_equal(use_a.values, use_b.values)
     assert np.array_equal(med_a4.values, med_b4.values)
+    # a repeated factorize of the same ledger replaces its rows instead of appending behind them, and a
+    # batch call brings back its OWN rows only; a resumed worker (other ledger rows) appends
+    first = {key: v.copy() for key, v in a.spectra_cache.items()}
+    a.factorize()
+    assert engine.spectra_rows == 6 * (4 + 5)
+    assert all(np.array_equal(first[key], a.spectra_cache[key]) for key in first)
+    a.factorize(worker_i=0, total_workers=2)                         # a subset of the keys the object holds: appended
+    assert engine.spectra_rows == 6 * (4 + 5) + sum(k for i, (k, it) in enumerate((k, it) for k in (4, 5) for it in range(6)) if i % 2 == 0)
+    np.testing.assert_array_equal(engine.spectra_fetch(5, 3), engine.spectra_fetch()[5:8])
     # a new prepare voids the store rows
     a.prepare_from_matrix(nc, components=[4], n_iter=2, seed=3, beta_loss="frobenius", tpm=tpm)
     assert a._store_rows == {} and engine.spectra_rows == 0
