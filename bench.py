@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--emulate-rank", default=None, metavar="R/W",
                     help="single GPU: run only the shard rank R of a world of W would run in --scaling strong "
                          "(tools/shard_scaling.py: the projected strong-scaling curve from one GPU)")
+    ap.add_argument("--comm-dry-run", action="store_true",
+                    help="N > 1: form the RCCL communicator, run one all-gather across all ranks, print what RCCL saw, exit")
     ap.add_argument("--cpu-iters", type=int, default=30)
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-workers-child", default=None, help=argparse.SUPPRESS)
@@ -650,6 +652,7 @@ def main():
     N, G = X.shape
     eng = Engine(local_rank)
     eng.set_matrix(X)
+    rccl_info = None
     if gather_mode == "rccl":
         from cnmf_amd import dist as cd
         # all ranks of one node are children of the same launcher process: its pid + the rendezvous port
@@ -657,6 +660,16 @@ def main():
         id_path = os.environ.get("CNMF_RCCL_ID_FILE") or os.path.join(
             "/tmp", "cnmf_rccl_id.%d.%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
         cd.comm_bootstrap_file(eng, rank, world, id_path)
+        # proof in the line itself that RCCL formed a communicator of `world` ranks and that a collective crossed ALL of them
+        # (round-4 review, item 8): every rank contributes its rank and device to one ncclAllGather
+        seen = eng.allgather_array(np.array([rank, local_rank], dtype=np.int64))
+        rccl_info = {"communicator_ranks": int(eng.comm_world()), "ranks_seen_by_allgather": sorted(int(r) for r in seen[:, 0]),
+                     "devices": [int(d) for d in seen[:, 1]], "transport": "ncclAllGather in libcnmf_hip.so (RCCL via dlopen)"}
+        if args.comm_dry_run:
+            if rank == 0:
+                print(json.dumps({"dry_run": "communicator only: no factorisation was run", "n_gpus": world, "rccl": rccl_info}))
+            eng.close()
+            return
 
     ks_all = list(range(args.kmin, args.kmax + 1))
     n_steps_total = args.warmup + args.steps
@@ -896,6 +909,7 @@ def main():
                                 "meaning": "from the moment the queue of pending restarts ran dry to the end of the call"},
                        "per_rank": ranks,
                        "parallelism": "restart-sharded x%d (%s scaling)" % (world, args.scaling), "gather": gather_mode,
+                       "rccl": rccl_info,
                        "torch_in_process": "torch" in sys.modules},
             "roofline": roof,
         }

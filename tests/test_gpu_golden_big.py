@@ -27,6 +27,17 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+_C4_CACHE = {}
+
+
+def _c4_counts_csr():
+    """The count-valued C4 matrix (200 000 x 2000, Poisson counts / std) as CSR, built once per test session: the
+    Poisson draws cost a minute of host time."""
+    if "X" not in _C4_CACHE:
+        _C4_CACHE["X"] = sp.csr_matrix(synth.make_config("C4", dtype=np.float32))
+    return _C4_CACHE["X"]
+
+
 def _fillers(n9=20, n13=5, n7=6, seed=77):
     ks = [9] * n9 + [13] * n13 + [7] * n7
     seeds = [int(s) for s in np.random.RandomState(seed).randint(1, 2 ** 31 - 1, size=len(ks))]
@@ -192,7 +203,7 @@ def test_C4_count_valued_csr_vs_sklearn_golden(engine):
     ~3 tiles per persistent stream-K workgroup, a shape no smaller test reaches.  scikit-learn's float64 output after
     10 iterations (tools/make_golden_big.py c4counts) vs the device inside a 260-column batch: 1e-4 / 1e-3."""
     g = np.load(os.path.join(GOLD, "ref_c4_counts.npz"))
-    X = sp.csr_matrix(synth.make_config("C4", dtype=np.float32))
+    X = _c4_counts_csr()
     assert tuple(g["shape"]) == X.shape and int(g["nnz"][0]) == X.nnz
     assert abs(float(X.data.astype(np.float64).sum()) - float(g["x_checksum"][0])) <= 1e-9 * float(g["x_checksum"][0])
     engine.set_matrix(X)                                       # CSR upload, densified on the device
@@ -208,3 +219,38 @@ def test_C4_count_valued_csr_vs_sklearn_golden(engine):
             assert int(n_iter[r]) == 10
             maxabs, relfro = nmf_cd.spectra_error(g["seed%d_H10" % seed], H[r])
             assert maxabs <= 1e-4 and relfro <= 1e-3, (kc, seed, maxabs, relfro)
+
+
+def test_C4_as_BASELINE_states_it_to_the_stopping_rule(engine):
+    """BASELINE config 4 AS WRITTEN: the 200 000-cell CSR matrix, K = 20, the n_iter = 100 ledger (seed 14) run to
+    scikit-learn's stopping rule in ONE device call at the default width (1024 packed columns = 51 restarts in flight over
+    782 cell tiles, refill, the tail narrowing) -- round-4 review, weak #3: C4 was never run past 10 iterations.  On this
+    matrix K = 20 = K_true: every restart stops after 36..55 outer iterations; scikit-learn's float64 output for the
+    shortest and the longest of them (tools/make_golden_big.py c4stop; its own float32 path stops at the same counts,
+    1e-7 / 1e-6 away) vs the device: iteration count exact, spectra 1e-4 / 1e-3, objective 1e-5."""
+    g = np.load(os.path.join(GOLD, "ref_c4_stop.npz"))
+    X = _c4_counts_csr()
+    assert tuple(g["shape"]) == X.shape
+    assert abs(float(X.data.astype(np.float64).sum()) - float(g["x_checksum"][0])) <= 1e-9 * float(g["x_checksum"][0])
+    led = ledger_seeds([20], 100, 14)
+    engine.set_matrix(X)
+    H, _, n_iter, _ = engine.nmf_batch([k for k, _, _ in led], seeds=[int(s) for _, _, s in led], warn=False)
+    st = engine.last_stats
+    assert st["kc"] == 1024 and st["gemm_mode"] == 4, st
+    assert 30 <= int(n_iter.min()) and int(n_iter.max()) <= 70            # (the whole ledger stops where scikit-learn's rows do)
+    for row in (15, 75):
+        seed, it, n_ref, n_ref32 = (int(v) for v in g["row%d_seed" % row])
+        assert int(led[row][2]) == seed and n_ref == n_ref32
+        assert int(n_iter[row]) == n_ref, (row, int(n_iter[row]), n_ref)
+        maxabs, relfro = nmf_cd.spectra_error(g["row%d_H" % row], H[row])
+        print("C4 K=20 ledger row %d: %d iterations (scikit-learn %d), spectra %.2e / %.2e" % (row, n_iter[row], n_ref, maxabs, relfro))
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (row, maxabs, relfro)
+    # the objective of the two restarts (their usages come back too: a second call, the two rows in front of 50 others)
+    rows = [15, 75] + [r for r in range(52) if r not in (15, 75)][:50]
+    H2, W2, n2, _ = engine.nmf_batch([20] * 52, seeds=[int(led[r][2]) for r in rows], warn=False, return_W=True)
+    assert engine.last_stats["kc"] == 1024
+    for i, row in enumerate((15, 75)):
+        assert int(n2[i]) == int(g["row%d_seed" % row][2])
+        obj = engine.prediction_error(W2[i], H2[i])
+        ref = float(g["row%d_obj" % row][0])
+        assert abs(obj - ref) <= 1e-5 * ref, (row, obj, ref)

@@ -229,17 +229,33 @@ def test_kl_pipeline_factorize_to_consensus_vs_reference(engine, g, tmp_path):
     led = load_df_from_npz(obj.paths["nmf_replicate_parameters"])
     assert np.array_equal(led[["n_components", "iter", "nmf_seed"]].values.astype(np.int64), g["ledger"])
     obj.factorize()
+    n_dev = {(int(k), int(it)): int(n) for (k, it, _), n in zip(g["ledger"], obj.last_factorize_stats["n_iter"])}
     obj.combine()
-    worst = 0.0
+    worst, moved = 0.0, 0
+    X64 = g["norm_counts"]
     for k in (4, 5, 6):
         merged = load_df_from_npz(obj.paths["merged_spectra"] % k)
         ref = g["merged_k%d" % k]
         assert merged.shape == ref.shape
         for it in range(12):
-            maxabs, relfro = nmf_cd.spectra_error(ref[it * k:(it + 1) * k], merged.values[it * k:(it + 1) * k])
+            dev = merged.values[it * k:(it + 1) * k]
+            maxabs, relfro = nmf_cd.spectra_error(ref[it * k:(it + 1) * k], dev)
+            if not (maxabs <= 5e-4 and relfro <= 2e-3):
+                # the stopping rule is evaluated every 10 iterations on a float32 divergence: a restart that sits on the
+                # threshold may stop one check earlier or later than scikit-learn's float64 run -- then it is held to the
+                # float64 oracle truncated at the device's own count (the oracle reproduces the reference's merged spectra
+                # to 1e-9: tests/test_golden_reference.py::test_kl_restart_spectra_reproduced)
+                seed = int([s_ for kk, ii, s_ in g["ledger"] if kk == k and ii == it][0])
+                _, _, n_ref = nmf_mu.nmf_mu(X64, k, seed=seed, max_iter=1000)
+                assert n_dev[(k, it)] != n_ref and abs(n_dev[(k, it)] - n_ref) <= 10, (k, it, n_dev[(k, it)], n_ref, maxabs, relfro)
+                _, H_ref, _ = nmf_mu.nmf_mu(X64, k, seed=seed, max_iter=n_dev[(k, it)], tol=0.0)
+                maxabs, relfro = nmf_cd.spectra_error(H_ref, dev)
+                moved += 1
             worst = max(worst, relfro)
             assert maxabs <= 5e-4 and relfro <= 2e-3, (k, it, maxabs, relfro)
-    print("Kullback-Leibler restarts vs the reference's merged spectra: worst relative Frobenius error %.2e" % worst)
+    assert moved <= 3, moved
+    print("Kullback-Leibler restarts vs the reference's merged spectra: worst relative Frobenius error %.2e (%d of 36 stopped one "
+          "check away from scikit-learn's count)" % (worst, moved))
     stats = obj.k_selection_stats()
     for row, k in zip(stats.itertuples(), (4, 5, 6)):
         _, _, sil, err = g["stats_k%d" % k]
