@@ -17,7 +17,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 # every symbol include/cnmf_hip.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
     "cnmf_device_count", "cnmf_create", "cnmf_destroy", "cnmf_last_error", "cnmf_reload_env", "cnmf_version",
-    "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_set_count_detection", "cnmf_get_shape", "cnmf_get_matrix",
+    "cnmf_set_matrix", "cnmf_set_matrix_csr", "cnmf_set_count_detection", "cnmf_get_shape", "cnmf_matrix_images", "cnmf_get_matrix",
     "cnmf_col_moments", "cnmf_scale_columns", "cnmf_row_sums",
     "cnmf_nmf_cd_batch", "cnmf_nmf_cd_batch_resident", "cnmf_get_iteration_means", "cnmf_set_iteration_hints", "cnmf_nnls",
     "cnmf_consensus", "cnmf_pairwise_distances", "cnmf_prediction_error", "cnmf_nmf_mu_batch", "cnmf_mu_refit_f64", "cnmf_x_matmul",
@@ -121,6 +121,8 @@ def load():
     lib.cnmf_destroy.argtypes = [vp]
     lib.cnmf_last_error.restype = C.c_char_p
     lib.cnmf_last_error.argtypes = [vp]
+    lib.cnmf_matrix_images.restype = i32
+    lib.cnmf_matrix_images.argtypes = [vp, i32p]
     lib.cnmf_reload_env.restype = i32
     lib.cnmf_reload_env.argtypes = [vp]
     lib.cnmf_version.restype = C.c_char_p

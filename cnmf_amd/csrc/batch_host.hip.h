@@ -244,7 +244,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
                      double* viol_out, cnmf_batch_stats* stats)
 {
     if (!ctx) { SET_ERR(ctx, "ctx is NULL"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     refresh_gemm3_mode();
     int rc = validate_params(ctx, prm);
     if (rc) return rc;
@@ -1039,7 +1039,7 @@ extern "C" int cnmf_nnls(cnmf_ctx* ctx, int k, const float* Hin, const cnmf_cd_p
                          float* W_out, int32_t* n_iter_out, double* viol_out)
 {
     if (!ctx) { SET_ERR(ctx, "ctx is NULL"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     int rc = validate_params(ctx, prm);
     if (rc) return rc;
     if (!Hin || !W_out || k < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }

@@ -149,7 +149,17 @@ extern "C" void cnmf_destroy(cnmf_ctx* ctx)
 }
 
 // ------------------------------------------------------------------ data matrix
-static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
+static int alloc_dense(cnmf_ctx* ctx)
+{
+    // one extra row of slack: pass B's last 128-gene tile runs past G_pad into the next row
+    // (values that only feed never-stored output columns), so the last row needs a successor
+    const size_t bytes = ((size_t)ctx->N_pad + 1) * ctx->G_pad * sizeof(float);
+    HIP_TRY(ctx, hipMalloc(&ctx->X, bytes));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->X, 0, bytes, ctx->stream));
+    return CNMF_OK;
+}
+
+static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G, bool dense = true)
 {
     if (N <= 0 || G <= 0 || N > (1ll << 30) || G > (1ll << 24)) {
         SET_ERR(ctx, "bad matrix shape %lld x %lld", (long long)N, (long long)G);
@@ -173,12 +183,7 @@ static int alloc_matrix(cnmf_ctx* ctx, int64_t N, int64_t G)
     ctx->N = N; ctx->G = G;
     ctx->N_pad = round_up(N, N >= 512 ? 256 : 128);  // whole 256-wide tiles for the split-operand GEMMs
     ctx->G_pad = round_up(G, G >= 512 ? 256 : 32);
-    // one extra row of slack: pass B's last 128-gene tile runs past G_pad into the next row
-    // (values that only feed never-stored output columns), so the last row needs a successor
-    const size_t bytes = ((size_t)ctx->N_pad + 1) * ctx->G_pad * sizeof(float);
-    HIP_TRY(ctx, hipMalloc(&ctx->X, bytes));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->X, 0, bytes, ctx->stream));
-    return CNMF_OK;
+    return dense ? alloc_dense(ctx) : CNMF_OK;
 }
 
 extern "C" int cnmf_set_matrix(cnmf_ctx* ctx, const float* X, int64_t N, int64_t G)
@@ -195,19 +200,41 @@ extern "C" int cnmf_set_matrix(cnmf_ctx* ctx, const float* X, int64_t N, int64_t
 
 // *bad |= 1: a row whose columns are not strictly increasing (or a stored zero: the dense image would not list it);
 // *bad |= 2: a column index outside [0, n_cols) -- such an entry is skipped
-__global__ void csr_densify_kernel(const int* __restrict__ indptr, const int* __restrict__ indices,
+// X == nullptr: only the checks (the dense image is formed later, when a path asks for it: ensure_dense)
+__global__ void csr_densify_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
                                    const float* __restrict__ data, float* __restrict__ X, int ld,
                                    int n_rows, int n_cols, int* __restrict__ bad)
 {
     const int row = blockIdx.x;
     if (row >= n_rows) return;
-    const int b = indptr[row], e = indptr[row + 1];
-    for (int p = b + threadIdx.x; p < e; p += blockDim.x) {
+    const long long b = indptr[row], e = indptr[row + 1];
+    for (long long p = b + threadIdx.x; p < e; p += blockDim.x) {
         const int c = indices[p];
-        if (c < 0 || c >= n_cols) { atomicOr(bad, 2); continue; }
-        if ((p > b && indices[p - 1] >= c) || data[p] == 0.f) atomicOr(bad, 1);
-        atomicAdd(&X[(size_t)row * ld + c], data[p]);   // duplicates sum, like .toarray()
+        if (c < 0 || c >= n_cols) { if (bad) atomicOr(bad, 2); continue; }
+        if (bad && ((p > b && indices[p - 1] >= c) || data[p] == 0.f)) atomicOr(bad, 1);
+        if (X) atomicAdd(&X[(size_t)row * ld + c], data[p]);   // duplicates sum, like .toarray()
     }
+}
+
+// The dense float32 image of the resident matrix.  A dense upload has it from the start; a CSR upload (canonical rows)
+// keeps only its compressed rows until a path that multiplies the dense matrix asks for it here (round 5: a
+// Kullback-Leibler run on a sparse matrix -- restarts on the non-zero images, float64 refits on the compressed rows --
+// never does: 1.6 GB at 200 000 x 2000 stay unallocated, and so does the transposed copy of the dense solver).
+static int ensure_dense(cnmf_ctx* ctx)
+{
+    if (ctx->X) return CNMF_OK;
+    if (ctx->N <= 0 || !ctx->csr_ptr) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = alloc_dense(ctx);
+    if (rc) return rc;
+    if (ctx->csr_nnz > 0) {
+        csr_densify_kernel<<<(unsigned)ctx->N, 64, 0, ctx->stream>>>(ctx->csr_ptr, ctx->csr_idx, ctx->csr_val, ctx->X, ctx->G_pad,
+                                                                    (int)ctx->N, (int)ctx->G, nullptr);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { hipFree(ctx->X); ctx->X = nullptr; HIP_TRY(ctx, e); }
+    }
+    return CNMF_OK;
 }
 
 extern "C" int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const int32_t* indices,
@@ -217,12 +244,12 @@ extern "C" int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const i
         SET_ERR(ctx, "null argument");
         return CNMF_EINVAL;
     }
-    int rc = alloc_matrix(ctx, N, G);
+    int rc = alloc_matrix(ctx, N, G, false);                     // (no dense image yet: ensure_dense forms it on demand)
     if (rc) return rc;
     const int64_t nnz = indptr[N];
     // the arrays stay on the device (csr_host.hip.h): the paths that walk the stored entries use them as uploaded --
-    // provided every row lists strictly increasing columns (scipy's canonical format); otherwise they are rebuilt from the
-    // dense image on first use (which sums duplicates like .toarray())
+    // provided every row lists strictly increasing columns without stored zeros (scipy's canonical format); otherwise the
+    // dense image is formed at once (duplicates summed like .toarray()) and the compressed rows are rebuilt from it on first use
     DevPool pool;
     int* d_ptr32 = pool.get<int>((size_t)(N + 1));
     int* d_bad = pool.get<int>(1, true, ctx->stream);
@@ -239,17 +266,21 @@ extern "C" int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const i
     int bad = 0;
     if (e == hipSuccess) {
         cnmf::csr_widen_ptr_kernel<<<(unsigned)((N + 1 + 255) / 256), 256, 0, ctx->stream>>>(d_ptr32, N + 1, d_ptr);
-        if (nnz > 0) {
-            csr_densify_kernel<<<(unsigned)N, 64, 0, ctx->stream>>>(d_ptr32, d_idx, d_val, ctx->X, ctx->G_pad, (int)N, (int)G, d_bad);
-        }
+        if (nnz > 0)
+            csr_densify_kernel<<<(unsigned)N, 64, 0, ctx->stream>>>(d_ptr, d_idx, d_val, nullptr, ctx->G_pad, (int)N, (int)G, d_bad);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
-    if (e != hipSuccess || bad) { hipFree(d_ptr); hipFree(d_idx); hipFree(d_val); d_ptr = nullptr; }
+    if (e != hipSuccess || (bad & 2)) { hipFree(d_ptr); hipFree(d_idx); hipFree(d_val); }
     HIP_TRY(ctx, e);
     if (bad & 2) { SET_ERR(ctx, "column index out of range in the CSR arrays"); return CNMF_EINVAL; }
-    if (d_ptr) { ctx->csr_ptr = d_ptr; ctx->csr_idx = d_idx; ctx->csr_val = d_val; ctx->csr_nnz = nnz; }
+    ctx->csr_ptr = d_ptr; ctx->csr_idx = d_idx; ctx->csr_val = d_val; ctx->csr_nnz = nnz;
+    if (bad & 1) {                      // not canonical: the dense image now (sums duplicates), the arrays are dropped
+        rc = ensure_dense(ctx);
+        free_csr(ctx);
+        if (rc) return rc;
+    }
     return CNMF_OK;
 }
 
@@ -278,7 +309,17 @@ extern "C" int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* N, int64_t* G)
     if (!ctx) return CNMF_EINVAL;
     if (N) *N = ctx->N;
     if (G) *G = ctx->G;
-    return ctx->X ? CNMF_OK : CNMF_ESTATE;
+    return (ctx->X || ctx->csr_ptr) ? CNMF_OK : CNMF_ESTATE;
+}
+
+// which images of the matrix are resident (bit 0: dense float32 image, 1: compressed rows of X, 2: compressed rows of X^T,
+// 3: dense X^T copy of the dense multiplicative-update kernels, 4 / 5: non-zero images at padded rank 16 / 32, 6: count planes)
+extern "C" int cnmf_matrix_images(const cnmf_ctx* ctx, int32_t* flags)
+{
+    if (!ctx || !flags) return CNMF_EINVAL;
+    *flags = (ctx->X ? 1 : 0) | (ctx->csr_ptr ? 2 : 0) | (ctx->csc_ptr ? 4 : 0) | (ctx->XtF ? 8 : 0) |
+             ((ctx->spA[0].ent && ctx->spB[0].ent) ? 16 : 0) | ((ctx->spA[1].ent && ctx->spB[1].ent) ? 32 : 0) | (ctx->C1 ? 64 : 0);
+    return CNMF_OK;
 }
 
 #include "batch_host.hip.h"

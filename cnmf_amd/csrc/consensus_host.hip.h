@@ -437,7 +437,7 @@ extern "C" int cnmf_prediction_error(cnmf_ctx* ctx, int k, const double* W, cons
 {
     using namespace cnmf;
     if (!ctx || !W || !H || !err_out || k < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     if (k > KMAX) { SET_ERR(ctx, "k=%d > %d", k, KMAX); return CNMF_EUNSUPPORTED; }
     CONS_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

@@ -138,7 +138,7 @@ static int ensure_csr(cnmf_ctx* ctx)
 {
     using namespace cnmf;
     if (ctx->csr_ptr) return CNMF_OK;
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }       // (neither image: no matrix)
     const int N = (int)ctx->N, G = (int)ctx->G;
     hipStream_t st = ctx->stream;
     long long* ptr = nullptr;

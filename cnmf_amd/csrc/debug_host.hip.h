@@ -6,7 +6,7 @@
 extern "C" int cnmf_x_matmul(cnmf_ctx* ctx, int trans, const float* Q, int ncols, float* out)
 {
     if (!ctx || !Q || !out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     if (ncols < 1 || ncols > 256 || (trans != 0 && trans != 1)) { SET_ERR(ctx, "bad ncols/trans"); return CNMF_EINVAL; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

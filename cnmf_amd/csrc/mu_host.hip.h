@@ -245,7 +245,8 @@ static int mu_batch_mfma(cnmf_ctx* ctx, const std::vector<MuJob>& jobs, int init
         tilesA = grpA * a.nblk;
     }
     const int Gs = round_up(ctx->G_pad, 128);
-    int rc = sparse ? CNMF_OK : mu_ensure_xt(ctx, Gs);           // (the non-zero path walks its images only)
+    int rc = sparse ? CNMF_OK : ensure_dense(ctx);               // (the non-zero path walks its images only)
+    if (!rc && !sparse) rc = mu_ensure_xt(ctx, Gs);
     if (rc) return rc;
     constexpr int RPW = MuShape<KP>::RPW, SW = 32 * MuShape<KP>::NJT;      // restarts per workgroup, cells per divergence strip
     const int nstrips = std::max((N + SW - 1) / SW, tilesA), ntiles = Np / 32;
@@ -490,7 +491,7 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
 {
     using namespace cnmf;
     if (!ctx) { SET_ERR(ctx, "ctx is NULL"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (!ctx->X && !ctx->csr_ptr) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
     int rc = validate_params(ctx, prm);
     if (rc) return rc;
     if (beta != 0 && beta != 1) { SET_ERR(ctx, "beta_loss must be 1 (kullback-leibler) or 0 (itakura-saito)"); return CNMF_EUNSUPPORTED; }
@@ -542,6 +543,7 @@ extern "C" int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int in
         const int k = kk[r];
         if (done[r]) { hoff += (size_t)k * G; woff += (size_t)k * N; continue; }
         const int KP = k <= 8 ? 8 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
+        if (int rcd_ = ensure_dense(ctx)) return rcd_;
         // row chunks of the H half-step / divergence kernels: ~8 waves per SIMD (2048 workgroups), >= 64 rows each
         const int nchunks = std::max(1, std::min(std::max(64, 2048 / std::max(1, (G + 255) / 256)), N / 64));
         const int rpc = (N + nchunks - 1) / nchunks;

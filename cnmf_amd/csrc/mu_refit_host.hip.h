@@ -138,7 +138,7 @@ extern "C" int cnmf_mu_refit_f64(cnmf_ctx* ctx, int side, int k, const double* H
 {
     using namespace cnmf;
     if (!ctx || !H || !prm || !W_out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (!ctx->X && !ctx->csr_ptr) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
     if (k < 1 || k > CNMF_MU_KMAX) { SET_ERR(ctx, "rank %d outside 1..%d (multiplicative updates)", k, CNMF_MU_KMAX); return CNMF_EUNSUPPORTED; }
     if (side != 0 && side != 1) { SET_ERR(ctx, "side must be 0 (rows = cells) or 1 (rows = genes)"); return CNMF_EINVAL; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -98,7 +98,7 @@ extern "C" int cnmf_range_finder(cnmf_ctx* ctx, int transpose, int nblocks, cons
 {
     using namespace cnmf;
     if (!ctx || !widths || !Q0 || !Q_out || !B_out || nblocks < 1 || n_iter < 0) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     int C = 0, cmax = 0;
     for (int b = 0; b < nblocks; ++b) {
         if (widths[b] < 1 || widths[b] > KMAX) { SET_ERR(ctx, "block width %d outside 1..%d", widths[b], KMAX); return CNMF_EUNSUPPORTED; }

@@ -83,7 +83,7 @@ extern "C" int cnmf_col_moments(cnmf_ctx* ctx, double* mean_out, double* ssd_out
 {
     using namespace cnmf;
     if (!ctx || !mean_out || !ssd_out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int N = (int)ctx->N, G = (int)ctx->G, chunks = (N + NORM_ROWS - 1) / NORM_ROWS;
@@ -108,7 +108,7 @@ extern "C" int cnmf_scale_columns(cnmf_ctx* ctx, const double* divisor)
 {
     using namespace cnmf;
     if (!ctx || !divisor) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     const int N = (int)ctx->N, G = (int)ctx->G;
     for (int g = 0; g < G; ++g)
         if (!(divisor[g] > 0.0) || !std::isfinite(divisor[g])) {
@@ -133,7 +133,7 @@ extern "C" int cnmf_row_sums(cnmf_ctx* ctx, double* out)
 {
     using namespace cnmf;
     if (!ctx || !out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int N = (int)ctx->N, G = (int)ctx->G;
@@ -150,7 +150,7 @@ extern "C" int cnmf_row_sums(cnmf_ctx* ctx, double* out)
 extern "C" int cnmf_get_matrix(cnmf_ctx* ctx, float* out)
 {
     if (!ctx || !out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpy2DAsync(out, (size_t)ctx->G * sizeof(float), ctx->X, (size_t)ctx->G_pad * sizeof(float),
                                   (size_t)ctx->G * sizeof(float), (size_t)ctx->N, hipMemcpyDeviceToHost, ctx->stream));

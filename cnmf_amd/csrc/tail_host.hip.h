@@ -214,7 +214,7 @@ extern "C" int cnmf_xt_matmul_f64(cnmf_ctx* ctx, int k, const double* W, int zsc
                                   const double* inv_std, double* out)
 {
     if (!ctx || !W || !out || k < 1 || (zscore && (!mean || !inv_std))) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     if (k > KMAX) { SET_ERR(ctx, "k=%d > %d", k, KMAX); return CNMF_EUNSUPPORTED; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -341,7 +341,7 @@ extern "C" int cnmf_nnls_spectra(cnmf_ctx* ctx, int k, const double* W, const cn
 {
     using namespace cnmf;
     if (!ctx || !W || !H_out || k < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     int rc = validate_params(ctx, prm);
     if (rc) return rc;
     if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
@@ -376,7 +376,7 @@ extern "C" int cnmf_nnls_f64(cnmf_ctx* ctx, int k, const double* H, const double
 {
     using namespace cnmf;
     if (!ctx || !H || !W_out || k < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     int rc = validate_params(ctx, prm);
     if (rc) return rc;
     if (k > KMAX) { SET_ERR(ctx, "n_components=%d > CNMF_KMAX=%d", k, KMAX); return CNMF_EUNSUPPORTED; }
@@ -424,7 +424,7 @@ static int nnls_batch_impl(cnmf_ctx* ctx, int n, const int32_t* ks, const float*
 {
     using namespace cnmf;
     if (!ctx || !ks || !Hin || n < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     int rc = validate_params(ctx, prm);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -551,7 +551,7 @@ static int kselect_impl(cnmf_ctx* ctx, int n, const int32_t* ks, const int32_t* 
     if (!ctx || !ks || !R || (!spectra && !store_rows) || !cprm || !uniforms || !silhouette_out || !pred_err_out || n < 1) {
         SET_ERR(ctx, "null argument"); return CNMF_EINVAL;
     }
-    if (!ctx->X) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     const int G = (int)ctx->G;
     size_t tot_k = 0;
     for (int i = 0; i < n; ++i) tot_k += (size_t)ks[i];

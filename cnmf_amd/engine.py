@@ -196,6 +196,14 @@ class Engine:
         self.shape = (int(X.shape[0]), int(X.shape[1]))
         return self
 
+    def matrix_images(self):
+        """Which images of the matrix the device holds right now (cnmf_matrix_images): a CSR upload keeps its compressed
+        rows and forms the dense float32 image only when a path that multiplies the dense matrix asks for it."""
+        f = C.c_int32(0)
+        self._check(self._lib.cnmf_matrix_images(self._ctx, C.byref(f)))
+        names = ("dense", "csr", "csr_of_transpose", "dense_transpose", "non_zero_images_16", "non_zero_images_32", "count_planes")
+        return {n: bool(f.value >> i & 1) for i, n in enumerate(names)}
+
     def get_matrix(self):
         """The resident matrix back on the host (float32 [n_cells, n_genes])."""
         if self.shape is None:

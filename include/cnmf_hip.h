@@ -110,6 +110,11 @@ int cnmf_set_count_detection(cnmf_ctx* ctx, int enabled);
 int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const int32_t* indices,
                         const float* data, int64_t n_cells, int64_t n_genes);
 int cnmf_get_shape(const cnmf_ctx* ctx, int64_t* n_cells, int64_t* n_genes);
+/* Which images of the matrix are resident right now (round 5): bit 0 the dense float32 image (a CSR upload forms it only when
+ * a path that multiplies the dense matrix asks for it: a Kullback-Leibler run on a sparse matrix never does), bit 1 the
+ * compressed rows of X, bit 2 those of X^T, bit 3 the dense X^T copy of the dense multiplicative-update kernels,
+ * bits 4 / 5 the non-zero images at padded rank 16 / 32, bit 6 the integer count planes of the coordinate-descent path. */
+int cnmf_matrix_images(const cnmf_ctx* ctx, int32_t* flags);
 /* the resident matrix back on the host ([n_cells][n_genes] float32) */
 int cnmf_get_matrix(cnmf_ctx* ctx, float* out);
 

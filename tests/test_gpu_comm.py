@@ -126,6 +126,8 @@ def test_bench_default_multi_gpu_transport_is_the_library_rccl_gather(tmp_path):
                           "--restarts-per-k", "3", "--no-cpu-baseline", "--no-extras"],
                          dict(CNMF_BENCH_FORCE_DIST="1", CNMF_RCCL_ID_FILE=str(tmp_path / "id")))
     assert p.returncode == 0, p.stderr[-3000:]
+    # the line itself says what RCCL saw: a communicator of `world` ranks and one all-gather that crossed all of them
+    assert d["config"]["rccl"]["communicator_ranks"] == 1 and d["config"]["rccl"]["ranks_seen_by_allgather"] == [0]
     assert len(lines) == 1, p.stdout[-2000:]
     assert d["config"]["gather"] == "rccl" and d["n_gpus"] == 1
     assert d["config"]["torch_in_process"] is False            # the launcher's env is all the N > 1 path needs

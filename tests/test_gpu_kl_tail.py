@@ -270,3 +270,43 @@ def test_kl_pipeline_factorize_to_consensus_vs_reference(engine, g, tmp_path):
         assert np.abs(tpm_sp - ref).max() <= 2e-3 * np.abs(ref).max()
         score = load_df_from_npz(obj.paths["gene_spectra_score"] % (k, rep)).values
         assert np.abs(score - g["gene_spectra_score_k%d" % k]).max() < 5e-3
+
+
+def test_sparse_upload_stays_sparse_on_the_kl_route(engine, monkeypatch):
+    """Round-4 review, missing #2: the reference hands scikit-learn the CSR matrix as stored and scikit-learn touches the stored
+    entries only.  A CSR upload keeps its compressed rows; Kullback-Leibler restarts (non-zero images built from them) and
+    the float64 refits never form the dense float32 image nor the dense transposed copy -- a path that multiplies the dense
+    matrix (coordinate descent) forms it on demand, with the same numbers as a dense upload."""
+    X = _counts(3000, 1100, 4.6, seed=12)
+    assert (X != 0).mean() < 0.2
+    Xs = sp.csr_matrix(X)
+    engine.set_matrix(Xs)
+    im = engine.matrix_images()
+    assert im["csr"] and not im["dense"] and not im["dense_transpose"], im
+    H, W, n_iter, err = engine.nmf_mu_batch([7, 20], seeds=[3, 4], max_iter=60, return_W=True, warn=False)
+    rs = np.random.RandomState(0)
+    Wr, _, _ = engine.mu_refit_f64(np.abs(rs.standard_normal((5, X.shape[1]))), max_iter=30, warn=False)
+    Wt, _, _ = engine.mu_refit_f64(np.abs(rs.standard_normal((5, X.shape[0]))), transposed=True, max_iter=30, warn=False)
+    im = engine.matrix_images()
+    assert im["csr"] and im["csr_of_transpose"] and im["non_zero_images_16"] and im["non_zero_images_32"], im
+    assert not im["dense"] and not im["dense_transpose"], im
+    # the same calls on a dense upload of the same matrix: the compressed rows are built on the device, same bits
+    engine.set_matrix(X)
+    assert engine.matrix_images()["dense"] and not engine.matrix_images()["csr"]
+    Hd, Wd, nd, errd = engine.nmf_mu_batch([7, 20], seeds=[3, 4], max_iter=60, return_W=True, warn=False)
+    for a, b in zip(H + W, Hd + Wd):
+        np.testing.assert_array_equal(a, b)
+    assert list(n_iter) == list(nd) and list(err) == list(errd)
+    # coordinate descent on the CSR upload: the dense image appears when asked for, results as on the dense upload
+    Hc_d, _, nc_d, _ = engine.nmf_batch([6], seeds=[9], max_iter=40, warn=False)
+    engine.set_matrix(Xs)
+    assert not engine.matrix_images()["dense"]
+    Hc_s, _, nc_s, _ = engine.nmf_batch([6], seeds=[9], max_iter=40, warn=False)
+    assert engine.matrix_images()["dense"]
+    np.testing.assert_array_equal(Hc_s[0], Hc_d[0])
+    np.testing.assert_array_equal(engine.get_matrix(), X)
+    # Itakura-Saito touches every element: the dense kernels (and their transposed copy) on demand as well
+    engine.set_matrix(Xs)
+    engine.nmf_mu_batch([5], seeds=[3], beta_loss="itakura-saito", max_iter=10, warn=False)
+    im = engine.matrix_images()
+    assert im["dense"] and im["dense_transpose"], im
