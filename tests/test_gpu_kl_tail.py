@@ -281,6 +281,10 @@ def test_sparse_upload_stays_sparse_on_the_kl_route(engine, monkeypatch):
     assert (X != 0).mean() < 0.2
     Xs = sp.csr_matrix(X)
     engine.set_matrix(Xs)
+    # (scipy's sparse mean and numpy's dense mean of a float32 matrix differ in the last bit, and with them scikit-learn's
+    #  init scale sqrt(X.mean() / k): pin it, so that the two uploads below start from identical factors)
+    xm = np.float32(X.mean())
+    engine.x_mean = xm
     im = engine.matrix_images()
     assert im["csr"] and not im["dense"] and not im["dense_transpose"], im
     H, W, n_iter, err = engine.nmf_mu_batch([7, 20], seeds=[3, 4], max_iter=60, return_W=True, warn=False)
@@ -292,6 +296,7 @@ def test_sparse_upload_stays_sparse_on_the_kl_route(engine, monkeypatch):
     assert not im["dense"] and not im["dense_transpose"], im
     # the same calls on a dense upload of the same matrix: the compressed rows are built on the device, same bits
     engine.set_matrix(X)
+    engine.x_mean = xm
     assert engine.matrix_images()["dense"] and not engine.matrix_images()["csr"]
     Hd, Wd, nd, errd = engine.nmf_mu_batch([7, 20], seeds=[3, 4], max_iter=60, return_W=True, warn=False)
     for a, b in zip(H + W, Hd + Wd):
@@ -300,6 +305,7 @@ def test_sparse_upload_stays_sparse_on_the_kl_route(engine, monkeypatch):
     # coordinate descent on the CSR upload: the dense image appears when asked for, results as on the dense upload
     Hc_d, _, nc_d, _ = engine.nmf_batch([6], seeds=[9], max_iter=40, warn=False)
     engine.set_matrix(Xs)
+    engine.x_mean = xm
     assert not engine.matrix_images()["dense"]
     Hc_s, _, nc_s, _ = engine.nmf_batch([6], seeds=[9], max_iter=40, warn=False)
     assert engine.matrix_images()["dense"]

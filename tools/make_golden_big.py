@@ -151,52 +151,75 @@ def make_c4_counts():
 def c4kl_matrix():
     """BASELINE config 4's shape with the library size of a real 10x matrix (e^5.2 -> ~9 % non-zero): the gamma-Poisson
     counts of the C4 topic model (200 000 x 2000, K_true = 20, data seed 3) scaled to unit variance per gene like the
-    reference's prepare, handed over as CSR -- the matrix of tools/mu_sparse_probe.py."""
-    C, _ = synth.topic_counts(200_000, 2000, 20, 5.2, 0.4, 3)
+    reference's prepare, handed over as CSR -- the matrix of tools/mu_sparse_probe.py.  (C4KL_CELLS: a smaller dry run.)"""
+    C, _ = synth.topic_counts(int(os.environ.get("C4KL_CELLS", 200_000)), 2000, 20, 5.2, 0.4, 3)
     X = synth.normalise_like_prepare(C, dtype=np.float32)
     return sp.csr_matrix(X)
 
 
+C4KL_JOBS = [(k, seed, T, dt) for T in (100, 20) for (k, seed) in ((20, 31), (9, 32)) for dt in ("float64", "float32")]
+C4KL_TMP = os.environ.get("C4KL_TMP", "/tmp/work/c4kl_parts")
+
+
 def _c4kl_one(args):
+    """One scikit-learn run on the CSR matrix; its result goes to its own file at once (a long job: nothing is lost when a
+    later one fails)."""
     k, seed, T, dtype = args
+    from oracle import nmf_mu_csr
     X = c4kl_matrix().astype(dtype)
     t0 = time.time()
     H, W, n = sklearn_ref.nmf(X, k, seed, beta_loss="kullback-leibler", solver="mu", max_iter=T)
-    from oracle import nmf_mu
-    err = nmf_mu.beta_divergence(X.astype(np.float64), W.astype(np.float64), H.astype(np.float64), 1, square_root=True)
-    print("C4 KL k=%d seed=%d T=%d %s: n_iter=%d err=%.9g (%.0f s)" % (k, seed, T, np.dtype(dtype).name, n, err,
-                                                                         time.time() - t0), flush=True)
-    return (k, seed, T, np.dtype(dtype).name, H, W[:4096].copy(), W.sum(axis=0), n, err)
+    X64 = X.astype(np.float64)
+    ii, jj = X64.nonzero()
+    err = nmf_mu_csr.kl_divergence(X64, W.astype(np.float64), H.astype(np.float64), ii, jj)
+    print("C4 KL k=%d seed=%d T=%d %s: n_iter=%d err=%.9g (%.0f s)" % (k, seed, T, dtype, n, err, time.time() - t0), flush=True)
+    os.makedirs(C4KL_TMP, exist_ok=True)
+    np.savez(os.path.join(C4KL_TMP, "k%d_T%d_%s.npz" % (k, T, dtype)), H=H, Whead=W[:4096], Wsum=W.sum(axis=0), n=n, err=err)
+    return True
 
 
 def make_c4kl():
     """Round 5 (review item 1a): scikit-learn ON THE CSR count matrix with beta_loss='kullback-leibler' -- the
     reference's own sparse route (sklearn _nmf.py:192 `_special_sparse_dot`, :526-728 via cnmf.py:672) -- at the size the
-    non-zero kernels were benchmarked at: K = 20 and K = 9, 20 and 100 iterations (the stopping rule left on), float64;
-    and the same in float32 as the calibration of what single precision delivers there."""
+    non-zero kernels were benchmarked at: K = 20 and K = 9, 100 and 20 iterations (the stopping rule left on), float64;
+    and the same in float32 as the calibration of what single precision delivers there.  ~45 s per iteration and job."""
     import multiprocessing as mp
     X = c4kl_matrix()
     out = {"shape": np.array(X.shape), "nnz": np.array([X.nnz]),
            "x_checksum": np.array([float(X.data.astype(np.float64).sum())])}
     del X
-    jobs = [(k, seed, T, dt) for (k, seed) in ((20, 31), (9, 32)) for T in (20, 100) for dt in (np.float64, np.float32)]
-    with mp.get_context("fork").Pool(4) as pool:
-        res = pool.map(_c4kl_one, jobs, chunksize=1)
+    todo = [j for j in C4KL_JOBS if not os.path.exists(os.path.join(C4KL_TMP, "k%d_T%d_%s.npz" % (j[0], j[2], j[3])))]
+    if todo:
+        with mp.get_context("fork").Pool(int(os.environ.get("C4KL_PROCS", 4))) as pool:
+            pool.map(_c4kl_one, todo, chunksize=1)
+    merge_c4kl(out)
+
+
+def merge_c4kl(out=None):
+    """ref_c4_kl.npz from whatever per-job files exist (float64 entries require their job; float32 calibration optional)."""
     from oracle import nmf_cd
-    byk = {(k, T, dt): (H, Wh, Ws, n, err) for (k, seed, T, dt, H, Wh, Ws, n, err) in res}
+    if out is None:
+        X = c4kl_matrix()
+        out = {"shape": np.array(X.shape), "nnz": np.array([X.nnz]), "x_checksum": np.array([float(X.data.astype(np.float64).sum())])}
     for (k, seed) in ((20, 31), (9, 32)):
         out["k%d_seed" % k] = np.array([seed])
         for T in (20, 100):
-            H, Wh, Ws, n, err = byk[(k, T, "float64")]
-            H32, _, _, n32, err32 = byk[(k, T, "float32")]
-            out["k%d_H%d" % (k, T)] = H.astype(np.float32)
-            out["k%d_Whead%d" % (k, T)] = Wh.astype(np.float32)
-            out["k%d_Wsum%d" % (k, T)] = Ws
-            out["k%d_n%d" % (k, T)] = np.array([n, n32])
-            out["k%d_err%d" % (k, T)] = np.array([err, err32])
-            out["k%d_f32dev%d" % (k, T)] = np.array(nmf_cd.spectra_error(H, H32))
-            print("k=%d T=%d: n_iter %d (f32 %d), err %.9g, sklearn float32 vs float64 %s" % (k, T, n, n32, err,
-                  out["k%d_f32dev%d" % (k, T)]), flush=True)
+            f64 = os.path.join(C4KL_TMP, "k%d_T%d_float64.npz" % (k, T))
+            if not os.path.exists(f64):
+                continue
+            a = np.load(f64)
+            out["k%d_H%d" % (k, T)] = a["H"].astype(np.float32)
+            out["k%d_Whead%d" % (k, T)] = a["Whead"].astype(np.float32)
+            out["k%d_Wsum%d" % (k, T)] = a["Wsum"]
+            n32, err32, dev = -1, np.nan, (np.nan, np.nan)
+            f32 = os.path.join(C4KL_TMP, "k%d_T%d_float32.npz" % (k, T))
+            if os.path.exists(f32):
+                b = np.load(f32)
+                n32, err32, dev = int(b["n"]), float(b["err"]), nmf_cd.spectra_error(a["H"], b["H"])
+            out["k%d_n%d" % (k, T)] = np.array([int(a["n"]), n32])
+            out["k%d_err%d" % (k, T)] = np.array([float(a["err"]), err32])
+            out["k%d_f32dev%d" % (k, T)] = np.array(dev)
+            print("k=%d T=%d: n_iter %d (f32 %d), err %.9g, sklearn float32 vs float64 %s" % (k, T, int(a["n"]), n32, float(a["err"]), dev), flush=True)
     np.savez_compressed(os.path.join(OUT, "ref_c4_kl.npz"), **out)
 
 
@@ -235,6 +258,8 @@ if __name__ == "__main__":
         make_c4_stop()
     if "c4kl" in which:
         make_c4kl()
+    if "c4klmerge" in which:
+        merge_c4kl()
     if "c4counts" in which:
         make_c4_counts()
     if "c4" in which:
