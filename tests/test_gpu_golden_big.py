@@ -254,3 +254,62 @@ def test_C4_as_BASELINE_states_it_to_the_stopping_rule(engine):
         obj = engine.prediction_error(W2[i], H2[i])
         ref = float(g["row%d_obj" % row][0])
         assert abs(obj - ref) <= 1e-5 * ref, (row, obj, ref)
+
+
+def _c4kl_csr():
+    """The matrix of tools/make_golden_big.py::c4kl_matrix: C4's topic model at a real 10x library size (~9 % non-zero)."""
+    if "KL" not in _C4_CACHE:
+        C, _ = synth.topic_counts(200_000, 2000, 20, 5.2, 0.4, 3)
+        _C4_CACHE["KL"] = sp.csr_matrix(synth.normalise_like_prepare(C, dtype=np.float32))
+    return _C4_CACHE["KL"]
+
+
+def test_C4_kl_non_zero_path_vs_sklearn_on_csr_golden(engine, monkeypatch):
+    """Round-4 review, weak #1 / next #1a: the Kullback-Leibler non-zero kernels at the size they were benchmarked at --
+    200 000 x 2000, 36 M stored entries (98 blocks of cells: their float32 partial numerators summed in block order) --
+    against scikit-learn ITSELF on the CSR matrix (`non_negative_factorization(X_csr, solver='mu',
+    beta_loss='kullback-leibler')`, float64, tools/make_golden_big.py c4kl): K = 20 and K = 9 after 20 and 100
+    iterations.  The path is taken by the density rule (asserted: no dense image is ever formed, and the forced path gives
+    the same bits); spectra 1e-4 / 1e-3 or 4 x scikit-learn's own float32-vs-float64 distance where that is larger, the
+    divergence 1e-3, usages 2e-3; bit identity across batch compositions at this size."""
+    g = np.load(os.path.join(GOLD, "ref_c4_kl.npz"))
+    X = _c4kl_csr()
+    assert tuple(g["shape"]) == X.shape and int(g["nnz"][0]) == X.nnz
+    assert abs(float(X.data.astype(np.float64).sum()) - float(g["x_checksum"][0])) <= 1e-9 * float(g["x_checksum"][0])
+    assert X.nnz < 0.25 * X.shape[0] * X.shape[1]
+    engine.set_matrix(X)
+    cases = [(k, T) for k in (20, 9) for T in (20, 100) if "k%d_H%d" % (k, T) in g.files]
+    assert (20, 20) in cases and len(cases) >= 3, cases            # (what the golden file holds; all four when it is complete)
+    singles = {}
+    for k, T in cases:
+        seed = int(g["k%d_seed" % k][0])
+        H, W, n_iter, err = engine.nmf_mu_batch([k], seeds=[seed], max_iter=T, return_W=True, warn=False)
+        im = engine.matrix_images()
+        assert im["non_zero_images_%d" % (16 if k <= 16 else 32)] and not im["dense"] and not im["dense_transpose"], im
+        n_ref, n_ref32 = (int(v) for v in g["k%d_n%d" % (k, T)])
+        assert int(n_iter[0]) == n_ref, (k, T, int(n_iter[0]), n_ref, n_ref32)
+        maxabs, relfro = nmf_cd.spectra_error(g["k%d_H%d" % (k, T)], H[0])
+        d32 = g["k%d_f32dev%d" % (k, T)]
+        bar = (max(1e-4, 4 * float(np.nan_to_num(d32[0]))), max(1e-3, 4 * float(np.nan_to_num(d32[1]))))
+        ref_err = float(g["k%d_err%d" % (k, T)][0])
+        print("C4 KL k=%d T=%d: %d iterations, spectra %.2e / %.2e (scikit-learn float32: %.2e / %.2e), divergence %.9g vs %.9g"
+              % (k, T, n_iter[0], maxabs, relfro, d32[0], d32[1], err[0], ref_err))
+        assert maxabs <= bar[0] and relfro <= bar[1], (k, T, maxabs, relfro, bar)
+        assert abs(err[0] - ref_err) <= 1e-3 * ref_err
+        Wh = g["k%d_Whead%d" % (k, T)]
+        # (same seed, same initial factors: the components come in the same order)
+        assert np.abs(W[0][:4096] - Wh).max() <= 2e-3 * np.abs(Wh).max()
+        assert np.abs(W[0].sum(axis=0) - g["k%d_Wsum%d" % (k, T)]).max() <= 1e-3 * np.abs(g["k%d_Wsum%d" % (k, T)]).max()
+        singles[(k, T)] = (H[0], W[0], int(n_iter[0]), float(err[0]))
+    # forced == chosen by density; another batch composition (both padded ranks in flight, fillers around) == alone
+    monkeypatch.setenv("CNMF_MU_SPARSE", "1")
+    Hf, Wf, nf, ef = engine.nmf_mu_batch([20], seeds=[int(g["k20_seed"][0])], max_iter=20, return_W=True, warn=False)
+    monkeypatch.delenv("CNMF_MU_SPARSE")
+    np.testing.assert_array_equal(Hf[0], singles[(20, 20)][0]); np.testing.assert_array_equal(Wf[0], singles[(20, 20)][1])
+    ks = [13, 20, 5, 9, 20, 9]
+    seeds = [7, int(g["k20_seed"][0]), 8, int(g["k9_seed"][0]), 9, 10]
+    Hb, Wb, nb, eb = engine.nmf_mu_batch(ks, seeds=seeds, max_iter=20, return_W=True, warn=False)
+    np.testing.assert_array_equal(Hb[1], singles[(20, 20)][0]); np.testing.assert_array_equal(Wb[1], singles[(20, 20)][1])
+    if (9, 20) in singles:
+        np.testing.assert_array_equal(Hb[3], singles[(9, 20)][0]); np.testing.assert_array_equal(Wb[3], singles[(9, 20)][1])
+    assert float(eb[1]) == singles[(20, 20)][3]

@@ -58,3 +58,22 @@ def test_kl_on_scipy_sparse_input_equals_the_dense_restatement():
     W_ref, n_ref = sklearn_ref.refit_usage(csr, Hn, beta_loss="kullback-leibler", solver="mu", max_iter=200)
     W, n = nmf_mu.nnls_mu(Xs, Hn, max_iter=200)
     assert n == n_ref and np.abs(W - W_ref).max() <= 1e-8 * np.abs(W_ref).max()
+
+
+def test_csr_walking_restatement_equals_sklearn_on_csr():
+    """oracle/nmf_mu_csr.py (round 5: scikit-learn's Kullback-Leibler updates on the STORED entries, component by component
+    over flat index arrays -- what generated nothing by itself but checks the full-size golden `ref_c4_kl.npz`, which
+    scikit-learn itself produced) against the live scikit-learn function on CSR input: restarts with and without penalties,
+    iteration counts, the divergence."""
+    import scipy.sparse as sp
+    from oracle import nmf_mu_csr
+    C, _ = synth.topic_counts(900, 500, 6, 4.2, 0.4, 8)
+    Xd = synth.normalise_like_prepare(C, dtype=np.float64)
+    csr = sp.csr_matrix(Xd)
+    for k, seed, kw in ((5, 7, {}), (12, 3, {}), (6, 4, dict(alpha_W=0.001, alpha_H=0.002, l1_ratio=0.5))):
+        H_ref, W_ref, n_ref = sklearn_ref.nmf(csr, k, seed, beta_loss="kullback-leibler", solver="mu", max_iter=200, **kw)
+        W, H, n = nmf_mu_csr.nmf_kl_csr(csr, k, seed, max_iter=200, **kw)
+        assert n == n_ref
+        assert np.abs(H - H_ref).max() <= 1e-9 * np.abs(H_ref).max() and np.abs(W - W_ref).max() <= 1e-9 * np.abs(W_ref).max()
+        ii, jj = csr.nonzero()
+        assert abs(nmf_mu_csr.kl_divergence(csr, W, H, ii, jj) - nmf_mu.beta_divergence(Xd, W, H, 1, square_root=True)) <= 1e-9

@@ -16,7 +16,7 @@ print("general:", d["general_path"].get("restarts_per_s"), "consensus:", d["cons
 print("e2e:", d["e2e"]["stages_s"], d["e2e"]["total_s"], d["e2e"]["cpu_reference"]["stages_s"])
 print("cpu_baseline:", d["cpu_baseline"]["value"], d["cpu_baseline"]["unit"], d["cpu_baseline"].get("cores"))
 P
-PROF_TAG="default path, auto width" RPK=50 PROF_OUT=r4_kernel_stats.txt bash tools/gpu_r3_prof.sh > gpurun_out/r4_prof.log 2>&1; rm -rf gpurun_out/prof
+PROF_TAG="default path, auto width" RPK=50 PROF_OUT=r4_kernel_stats.txt bash tools/gpu_prof.sh > gpurun_out/r4_prof.log 2>&1; rm -rf gpurun_out/prof
 head -12 gpurun_out/r4_kernel_stats.txt | cut -c1-90,111-170
 RPK=50 bash tools/gpu_pmc_bench.sh > gpurun_out/r4_pmc.log 2>&1
 tail -32 gpurun_out/r4_pmc.log | head -28

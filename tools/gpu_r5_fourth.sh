@@ -6,7 +6,7 @@ mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r5_pytest.log 2>&1; echo "pytest rc=$?" | tee gpurun_out/r5_fourth.status
 tail -4 gpurun_out/r5_pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r5_smoke.log 2>&1; echo "smoke rc=$?" | tee -a gpurun_out/r5_fourth.status
-PROF_TAG="default path, auto width" RPK=50 PROF_OUT=r5_kernel_stats.txt bash tools/gpu_r3_prof.sh > gpurun_out/r5_prof.log 2>&1; rm -rf gpurun_out/prof
+PROF_TAG="default path, auto width" RPK=50 PROF_OUT=r5_kernel_stats.txt bash tools/gpu_prof.sh > gpurun_out/r5_prof.log 2>&1; rm -rf gpurun_out/prof
 head -12 gpurun_out/r5_kernel_stats.txt | cut -c1-90,111-170
 RPK=50 PMC_OUT=r5_pmc_traffic.json bash tools/gpu_pmc_bench.sh > gpurun_out/r5_pmc.log 2>&1
 tail -32 gpurun_out/r5_pmc.log | head -28
