@@ -67,6 +67,12 @@ def test_mu_refit_f64_vs_oracle(engine, n, g_, k):
         res.append((W, Wt))
     np.testing.assert_array_equal(res[0][0], res[1][0])          # the device-built rows ARE the uploaded ones
     np.testing.assert_array_equal(res[0][1], res[1][1])
+    # the transpose of the compressed rows is built on the device by a counting sort whose order is fixed by construction:
+    # rebuilt from scratch (a fresh upload each time) it must give the same bits, run after run
+    for _ in range(3):
+        engine.set_matrix(Xs)
+        Wt_again, _, _ = engine.mu_refit_f64(U.T, transposed=True, max_iter=300, warn=False)
+        np.testing.assert_array_equal(Wt_again, res[1][1])
     # a CSR upload with unsorted rows and a duplicated entry: the arrays are not kept, same numbers
     w0 = engine.init_scale(k)                                     # (sqrt(X.mean() / k) in X's dtype, as the two runs above)
     coo = Xs.tocoo()
@@ -316,3 +322,34 @@ def test_sparse_upload_stays_sparse_on_the_kl_route(engine, monkeypatch):
     engine.nmf_mu_batch([5], seeds=[3], beta_loss="itakura-saito", max_iter=10, warn=False)
     im = engine.matrix_images()
     assert im["dense"] and im["dense_transpose"], im
+
+
+def test_mu_refit_f64_ragged_and_empty_rows_and_columns(engine):
+    """Edge shapes of the compressed rows: cells and genes without a single stored entry (a TPM matrix keeps genes nobody
+    expresses), fewer rows than one wavefront group / one transpose chunk, a single column, rank 1 -- against the oracle."""
+    rs = np.random.RandomState(3)
+    for n, g_, k in ((37, 19, 3), (300, 1, 1), (5, 700, 2), (1000, 400, 6)):
+        X = (rs.gamma(1.0, 1.0, size=(n, g_)) * (rs.rand(n, g_) < 0.15)).astype(np.float32)
+        X[rs.choice(n, max(1, n // 7), replace=False)] = 0            # empty cells
+        if g_ > 2:
+            X[:, rs.choice(g_, max(1, g_ // 5), replace=False)] = 0   # empty genes
+        if not X.any():
+            X[0, 0] = 1.0
+        X64 = X.astype(np.float64)
+        H = np.abs(rs.standard_normal((k, g_))) + 0.01
+        U = np.abs(rs.standard_normal((n, k))) + 0.01
+        for M in (X, sp.csr_matrix(X)):
+            engine.set_matrix(M)
+            W_ref, n_ref = _oracle_refit(X64, H, 60)
+            W, it, err = engine.mu_refit_f64(H, max_iter=60, warn=False)
+            assert it == n_ref and np.abs(W - W_ref).max() <= 1e-9 * max(np.abs(W_ref).max(), 1e-300), (n, g_, k)
+            assert not W[~X.any(axis=1)].any()                        # a cell without entries ends at exactly zero usage
+            Wt_ref, nt_ref = _oracle_refit(np.ascontiguousarray(X64.T), np.ascontiguousarray(U.T), 60)
+            Wt, itt, _ = engine.mu_refit_f64(U.T, transposed=True, max_iter=60, warn=False)
+            assert itt == nt_ref and np.abs(Wt - Wt_ref).max() <= 1e-9 * max(np.abs(Wt_ref).max(), 1e-300), (n, g_, k)
+    # an all-zero CSR matrix uploads (no stored entries at all) and refits to zeros
+    Z = sp.csr_matrix((50, 30), dtype=np.float32)
+    engine.set_matrix(Z)
+    engine.x_mean = np.float32(1.0)
+    W, it, err = engine.mu_refit_f64(np.ones((2, 30)), max_iter=20, warn=False)
+    assert not W.any() and err == 0.0
