@@ -656,13 +656,29 @@ def main():
     eng = Engine(local_rank)
     eng.set_matrix(X)
     rccl_info = None
+    gather_fallback = None
     if gather_mode == "rccl":
         from cnmf_amd import dist as cd
         # all ranks of one node are children of the same launcher process: its pid + the rendezvous port
         # name the id file uniquely for this launch
         id_path = os.environ.get("CNMF_RCCL_ID_FILE") or os.path.join(
             "/tmp", "cnmf_rccl_id.%d.%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
-        cd.comm_bootstrap_file(eng, rank, world, id_path)
+        try:
+            cd.comm_bootstrap_file(eng, rank, world, id_path)
+        except Exception as e:
+            # The in-library communicator has never met more than one GPU.  If its first N > 1 init
+            # fails on this node, the run still measures: every rank falls back to torch.distributed (backend nccl = the same
+            # RCCL) -- unless the transport was chosen explicitly -- and the line says so.
+            if world == 1 or os.environ.get("CNMF_GATHER"):
+                raise
+            sys.stderr.write("bench.py: in-library RCCL init failed on rank %d (%r): falling back to torch.distributed\n" % (rank, e))
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl")
+            gather_mode = "torch"
+            gather_fallback = repr(e)
+    if gather_mode == "rccl":
         # proof in the line itself that RCCL formed a communicator of `world` ranks and that a collective crossed ALL of them
         # (round-4 review, item 8): every rank contributes its rank and device to one ncclAllGather
         seen = eng.allgather_array(np.array([rank, local_rank], dtype=np.int64))
@@ -670,7 +686,9 @@ def main():
                      "devices": [int(d) for d in seen[:, 1]], "transport": "ncclAllGather in libcnmf_hip.so (RCCL via dlopen)"}
         if args.comm_dry_run:
             if rank == 0:
-                print(json.dumps({"dry_run": "communicator only: no factorisation was run", "n_gpus": world, "rccl": rccl_info}))
+                os.write(json_fd, (json.dumps({"dry_run": "communicator only: no factorisation was run", "n_gpus": world,
+                                               "rccl": rccl_info}) + "\n").encode())
+            os.close(json_fd)
             eng.close()
             return
 
@@ -916,7 +934,7 @@ def main():
                                 "meaning": "from the moment the queue of pending restarts ran dry to the end of the call"},
                        "per_rank": ranks,
                        "parallelism": "restart-sharded x%d (%s scaling)" % (world, args.scaling), "gather": gather_mode,
-                       "rccl": rccl_info,
+                       "rccl": rccl_info, "gather_fallback": gather_fallback,
                        "torch_in_process": "torch" in sys.modules},
             "roofline": roof,
         }

@@ -132,3 +132,13 @@ def test_bench_default_multi_gpu_transport_is_the_library_rccl_gather(tmp_path):
     assert d["config"]["gather"] == "rccl" and d["n_gpus"] == 1
     assert d["config"]["torch_in_process"] is False            # the launcher's env is all the N > 1 path needs
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 6) < 1e-6
+
+
+def test_bench_comm_dry_run_reports_what_rccl_saw(tmp_path):
+    """`bench.py --comm-dry-run`: everything up to the communicator and one all-gather across its ranks, then a JSON line
+    that says what RCCL saw -- the readiness check for the first real N > 1 run (here at world 1 through the N > 1 code)."""
+    p, lines, d = _bench(["--gpus", "1", "--workload", "C1", "--comm-dry-run"],
+                         dict(CNMF_BENCH_FORCE_DIST="1", CNMF_RCCL_ID_FILE=str(tmp_path / "id")), timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1 and d["n_gpus"] == 1 and "dry_run" in d
+    assert d["rccl"]["communicator_ranks"] == 1 and d["rccl"]["ranks_seen_by_allgather"] == [0] and d["rccl"]["devices"] == [0]
