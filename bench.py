@@ -669,7 +669,7 @@ def main():
             # The in-library communicator has never met more than one GPU.  If its first N > 1 init
             # fails on this node, the run still measures: every rank falls back to torch.distributed (backend nccl = the same
             # RCCL) -- unless the transport was chosen explicitly -- and the line says so.
-            if world == 1 or os.environ.get("CNMF_GATHER"):
+            if world == 1 or os.environ.get("CNMF_GATHER") or os.environ.get("CNMF_BENCH_ONE_GPU"):
                 raise
             sys.stderr.write("bench.py: in-library RCCL init failed on rank %d (%r): falling back to torch.distributed\n" % (rank, e))
             import torch
