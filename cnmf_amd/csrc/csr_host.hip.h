@@ -108,6 +108,75 @@ __global__ __launch_bounds__(64) void csr_tr_fill_kernel(const long long* __rest
     }
 }
 
+
+// ---- the float64 statistics and products of the consensus tail on the compressed rows of X^T (round 5): a wavefront per
+// gene, its stored entries lane-strided, fixed-order butterfly sums -- so that a Kullback-Leibler run's tail (whose refits
+// walk the stored entries already) never needs the dense N x G_all image of the TPM matrix.
+// mean[g] = sum x / N ;  ssd[g] = sum over ALL cells of (x - mean)^2 = sum_stored (x - mean)^2 + (N - stored) mean^2
+__global__ __launch_bounds__(256) void csc_col_moments_kernel(const long long* __restrict__ tptr, const float* __restrict__ tval,
+                                                              int G, int N, double* __restrict__ mean, double* __restrict__ ssd)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= G) return;
+    const long long b = tptr[g], e = tptr[g + 1];
+    double s = 0.0;
+    for (long long p = b + lane; p < e; p += 64) s += (double)tval[p];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const double mu = s / (double)N;
+    double q = 0.0;
+    for (long long p = b + lane; p < e; p += 64) { const double d = (double)tval[p] - mu; q += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (lane == 0) { mean[g] = mu; ssd[g] = q + (double)(N - (e - b)) * mu * mu; }
+}
+
+// column sums of W [N][k] (float64), one workgroup per component, fixed order
+__global__ __launch_bounds__(256) void colsum_f64_kernel(const double* __restrict__ W, int N, int k, double* __restrict__ out)
+{
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) s += W[(size_t)i * k + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[c] = red[0];
+}
+
+// out[t][g] = sum_i W[i][t] z(x_ig),  z(x) = (x - mean[g]) inv_std[g] (zs) or x:  with the zeros of the column folded
+// into the constant term,  = inv_std[g] (sum_stored W[i][t] x_ig - mean[g] wsum[t]).  Components in chunks of 16.
+__global__ __launch_bounds__(256) void csc_xtw_f64_kernel(const long long* __restrict__ tptr, const int* __restrict__ tidx,
+                                                          const float* __restrict__ tval, int G, const double* __restrict__ W,
+                                                          int k, int zs, const double* __restrict__ mean,
+                                                          const double* __restrict__ inv_std, const double* __restrict__ wsum,
+                                                          double* __restrict__ out)
+{
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= G) return;
+    const long long b = tptr[g], e = tptr[g + 1];
+    const double mu = zs ? mean[g] : 0.0, is = zs ? inv_std[g] : 1.0;
+    for (int t0 = 0; t0 < k; t0 += 16) {
+        const int nt = min(16, k - t0);
+        double acc[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = 0.0;
+        for (long long p = b + lane; p < e; p += 64) {
+            const double x = (double)tval[p];
+            const double* w = W + (size_t)tidx[p] * k + t0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) if (t < nt) acc[t] = fma(w[t], x, acc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            double a = acc[t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            if (lane == 0 && t < nt) out[(size_t)(t0 + t) * G + g] = (a - mu * wsum[t0 + t]) * is;
+        }
+    }
+}
+
 }  // namespace cnmf
 
 static void free_csr(cnmf_ctx* c)

@@ -83,6 +83,23 @@ extern "C" int cnmf_col_moments(cnmf_ctx* ctx, double* mean_out, double* ssd_out
 {
     using namespace cnmf;
     if (!ctx || !mean_out || !ssd_out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    if (!ctx->X && ctx->csr_ptr) {
+        // a matrix that lives as compressed rows only (a CSR upload nobody has asked the dense image of): the same
+        // statistics from the stored entries of every column, float64 (round 5)
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (int rc_ = ensure_csc(ctx)) return rc_;
+        const int N_ = (int)ctx->N, G_ = (int)ctx->G;
+        DevPool pool_;
+        double* m_ = pool_.get<double>(G_);
+        double* s_ = pool_.get<double>(G_);
+        POOL_TRY(ctx, pool_);
+        csc_col_moments_kernel<<<(G_ + 3) / 4, 256, 0, ctx->stream>>>(ctx->csc_ptr, ctx->csc_val, G_, N_, m_, s_);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(mean_out, m_, (size_t)G_ * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ssd_out, s_, (size_t)G_ * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return CNMF_OK;
+    }
     if (int rcd_ = ensure_dense(ctx)) return rcd_;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

@@ -214,7 +214,8 @@ extern "C" int cnmf_xt_matmul_f64(cnmf_ctx* ctx, int k, const double* W, int zsc
                                   const double* inv_std, double* out)
 {
     if (!ctx || !W || !out || k < 1 || (zscore && (!mean || !inv_std))) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
-    if (int rcd_ = ensure_dense(ctx)) return rcd_;
+    const bool on_rows = !ctx->X && ctx->csr_ptr;          // compressed rows only (round 5): walk the stored entries of X^T
+    if (!on_rows) { if (int rcd_ = ensure_dense(ctx)) return rcd_; }
     if (k > KMAX) { SET_ERR(ctx, "k=%d > %d", k, KMAX); return CNMF_EUNSUPPORTED; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -224,13 +225,22 @@ extern "C" int cnmf_xt_matmul_f64(cnmf_ctx* ctx, int k, const double* W, int zsc
     double* dmean = zscore ? pool.get<double>(G) : nullptr;
     double* dinv = zscore ? pool.get<double>(G) : nullptr;
     double* dout = pool.get<double>((size_t)k * G);
+    double* dws = on_rows ? pool.get<double>(k) : nullptr;
     POOL_TRY(ctx, pool);
     HIP_TRY(ctx, hipMemcpyAsync(dW, W, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, st));
     if (zscore) {
         HIP_TRY(ctx, hipMemcpyAsync(dmean, mean, (size_t)G * sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(dinv, inv_std, (size_t)G * sizeof(double), hipMemcpyHostToDevice, st));
     }
-    int rc = xtw_f64_device(ctx, pool, dW, k, zscore, dmean, dinv, dout);
+    int rc = CNMF_OK;
+    if (on_rows) {
+        rc = ensure_csc(ctx);
+        if (rc) return rc;
+        cnmf::colsum_f64_kernel<<<k, 256, 0, st>>>(dW, N, k, dws);
+        cnmf::csc_xtw_f64_kernel<<<(G + 3) / 4, 256, 0, st>>>(ctx->csc_ptr, ctx->csc_idx, ctx->csc_val, G, dW, k, zscore, dmean, dinv, dws, dout);
+        HIP_TRY(ctx, hipGetLastError());
+    } else
+        rc = xtw_f64_device(ctx, pool, dW, k, zscore, dmean, dinv, dout);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out, dout, (size_t)k * G * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -329,7 +329,9 @@ int cnmf_kselect_stats_store(cnmf_ctx* ctx, int n, const int32_t* ks, const int3
 /* ---- consensus tail + k selection on the device ------------------------------------------------------------ */
 /* out[k][G] (float64) = W^T . X, or W^T . zscore(X) with z = (x - mean[g]) * inv_std[g]: the X^T Y accumulation of
  * efficient_ols_all_cols(normalize_y=True) (cnmf.py:55-125, called at :958) over the RESIDENT matrix (the TPM matrix,
- * dense or uploaded as CSR) in float64 like the reference.  W is [N][k] float64 (k <= CNMF_KMAX).           */
+ * dense or uploaded as CSR) in float64 like the reference.  W is [N][k] float64 (k <= CNMF_KMAX).  A matrix that lives as
+ * compressed rows only (a CSR upload whose dense image nobody asked for) is walked on its stored entries -- the zeros of
+ * a column folded into the constant term; cnmf_col_moments likewise.                                          */
 int cnmf_xt_matmul_f64(cnmf_ctx* ctx, int k, const double* W, int zscore, const double* mean,
                        const double* inv_std, double* out);
 /* cNMF.refit_spectra (cnmf.py:805-820 = refit_usage(X.T, usage.T).T, sklearn:_nmf.py:1210-1233): NNLS for the

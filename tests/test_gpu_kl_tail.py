@@ -212,6 +212,11 @@ def test_mirror_class_kl_consensus_from_reference_merged_spectra(engine, g, tmp_
     for k, thr in ((5, 0.5), (4, 2.0)):
         med, usages = obj.consensus(k, density_threshold=thr)
         assert engine.shape == g["tpm"].shape                   # the TPM matrix as stored, not a transposed / dense re-upload
+        if sparse:
+            # the whole tail -- refits, gene statistics, the OLS product with z-scoring -- walked the stored entries: the
+            # dense image of the TPM matrix was never formed
+            im = engine.matrix_images()
+            assert im["csr"] and im["csr_of_transpose"] and not im["dense"] and not im["dense_transpose"], im
         rep = str(thr).replace(".", "_")
         errs = {"consensus_spectra": ((med.values - g["consensus_spectra_k%d" % k]) ** 2).sum(),
                 "consensus_usages": ((usages.values - g["consensus_usages_k%d" % k]) ** 2).sum(),
@@ -353,3 +358,30 @@ def test_mu_refit_f64_ragged_and_empty_rows_and_columns(engine):
     engine.x_mean = np.float32(1.0)
     W, it, err = engine.mu_refit_f64(np.ones((2, 30)), max_iter=20, warn=False)
     assert not W.any() and err == 0.0
+
+
+def test_gene_statistics_and_ols_product_on_the_compressed_rows(engine):
+    """`cnmf_col_moments` and `cnmf_xt_matmul_f64` (the gene statistics and the X^T Y accumulation of
+    efficient_ols_all_cols, cnmf.py:55-125) on a matrix that lives as compressed rows only: float64 from the stored entries
+    of every gene (the zeros of a column folded into the constant term) against numpy, and against the dense kernels."""
+    rs = np.random.RandomState(5)
+    X = (rs.gamma(2.0, 3.0, size=(1300, 450)) * (rs.rand(1300, 450) < 0.12)).astype(np.float32)
+    X[:, 7] = 0                                                   # a gene nobody expresses (variance floored by the caller)
+    X64 = X.astype(np.float64)
+    W = np.abs(rs.standard_normal((1300, 21)))                    # (two chunks of 16 components)
+    engine.set_matrix(sp.csr_matrix(X))
+    mean, var = engine.col_mean_var()
+    assert not engine.matrix_images()["dense"]
+    assert np.abs(mean - X64.mean(axis=0)).max() <= 1e-13 * np.abs(X64.mean(axis=0)).max()
+    assert np.abs(var - X64.var(axis=0)).max() <= 1e-12 * X64.var(axis=0).max()
+    v = np.where(var < 1e-12, 1e-12, var)
+    out = engine.xt_matmul_f64(W, mean=mean, std=np.sqrt(v))
+    plain = engine.xt_matmul_f64(W)
+    assert not engine.matrix_images()["dense"]
+    ref = W.T @ ((X64 - X64.mean(axis=0)) / np.sqrt(np.where(X64.var(axis=0) < 1e-12, 1e-12, X64.var(axis=0))))
+    assert np.abs(out - ref).max() <= 1e-9 * np.abs(ref).max()
+    assert np.abs(plain - W.T @ X64).max() <= 1e-12 * np.abs(W.T @ X64).max()
+    engine.set_matrix(X)                                          # the dense kernels on the same matrix
+    mean_d, var_d = engine.col_mean_var()
+    out_d = engine.xt_matmul_f64(W, mean=mean_d, std=np.sqrt(np.where(var_d < 1e-12, 1e-12, var_d)))
+    assert np.abs(mean - mean_d).max() <= 1e-13 * np.abs(mean_d).max() and np.abs(out - out_d).max() <= 1e-9 * np.abs(out_d).max()
