@@ -279,7 +279,7 @@ def test_C4_kl_non_zero_path_vs_sklearn_on_csr_golden(engine, monkeypatch):
     assert X.nnz < 0.25 * X.shape[0] * X.shape[1]
     engine.set_matrix(X)
     cases = [(k, T) for k in (20, 9) for T in (20, 100) if "k%d_H%d" % (k, T) in g.files]
-    assert (20, 20) in cases and (9, 20) in cases, cases          # (the 100-iteration entries when the golden file holds them)
+    assert len(cases) == 4, cases
     singles = {}
     for k, T in cases:
         seed = int(g["k%d_seed" % k][0])
