@@ -68,8 +68,13 @@ class cNMF(_ref.cNMF):
             if H.dtype != xdt:
                 raise TypeError("H should have the same dtype as X. Got H.dtype = {}.".format(H.dtype))
             # (scikit-learn solves in X's dtype: float64 matrices get the float64 device refit)
-            W, _ = (eng.nnls_mu(H, beta_loss=kw["beta_loss"], **common) if mu
-                    else (eng.nnls_f64 if xdt == np.float64 else eng.nnls)(H, **common))
+            if mu and kw["beta_loss"] in ("kullback-leibler", 1):
+                # float64 on the stored entries of the matrix (cnmf_mu_refit_f64), like scikit-learn on float64 input
+                W, _, _ = eng.mu_refit_f64(H, **common)
+            elif mu:
+                W, _ = eng.nnls_mu(H, beta_loss=kw["beta_loss"], **common)
+            else:
+                W, _ = (eng.nnls_f64 if xdt == np.float64 else eng.nnls)(H, **common)
             return H, W.astype(xdt, copy=False)
         k, seed = int(kw["n_components"]), int(kw["random_state"])
         if kw.get("init") == "nndsvd":

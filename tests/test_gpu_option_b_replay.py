@@ -96,3 +96,45 @@ def test_factorize_and_refit_calls_of_the_subclass(engine):
     W64, n64 = engine.nnls_f64(med, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0)
     # (float64 arithmetic on the float32-RESIDENT matrix: what is left is the rounding of X itself, ~1e-8)
     assert abs(n64 - n_ref) <= 1 and np.abs(W64 - W_ref).max() <= 1e-6 * np.abs(W_ref).max()
+
+
+def test_kl_calls_of_option_b_match_live_sklearn_on_csr(engine):
+    """Round 5: under `beta_loss='kullback-leibler'` the reference's `_nmf` (cnmf.py:661-674) reaches scikit-learn with
+    solver='mu' -- restarts through `factorize`, and `refit_usage` / `refit_spectra` with `update_H=False` on float64
+    matrices.  The subclass sends them to `Engine.nmf_mu_batch` / `Engine.mu_refit_f64`; replayed here against the LIVE
+    scikit-learn function on the SAME scipy.sparse matrix (what the reference hands over when the counts are stored sparse):
+    the float64 refits to round-off with identical iteration counts, the float32 restarts at 1e-4 / 1e-3."""
+    import scipy.sparse as sp
+    from sklearn.decomposition import non_negative_factorization
+    C, _ = synth.topic_counts(2200, 800, 6, 4.6, 0.4, 21)
+    Xd = synth.normalise_like_prepare(C, dtype=np.float64)
+    X = sp.csr_matrix(Xd)
+    engine.set_matrix(X)
+    kw = dict(alpha_W=0.0, alpha_H=0.0, l1_ratio=0.0, beta_loss="kullback-leibler", solver="mu", tol=1e-4, max_iter=400,
+              init="random")
+    # refit_usage(X, spectra) and refit_spectra(X, usage) = refit_usage(X.T, usage.T).T  (cnmf.py:792-798, 820)
+    rs = np.random.RandomState(2)
+    spectra = np.abs(rs.standard_normal((7, X.shape[1])))
+    usage = np.abs(rs.standard_normal((X.shape[0], 7)))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        W_ref, _, n_ref = non_negative_factorization(X, **dict(kw, n_components=7, H=spectra, update_H=False))
+        Wt_ref, _, nt_ref = non_negative_factorization(X.T, **dict(kw, n_components=7, H=np.ascontiguousarray(usage.T), update_H=False))
+    W, n, _ = engine.mu_refit_f64(spectra, tol=1e-4, max_iter=400)
+    Wt, nt, _ = engine.mu_refit_f64(usage.T, transposed=True, tol=1e-4, max_iter=400)
+    assert n == n_ref and nt == nt_ref, (n, n_ref, nt, nt_ref)
+    assert np.abs(W - W_ref).max() <= 1e-9 * np.abs(W_ref).max() and np.abs(Wt - Wt_ref).max() <= 1e-9 * np.abs(Wt_ref).max()
+    # restarts: factorize's loop body (cnmf.py:735-741) for two ledger seeds
+    for k, seed in ((6, 1371922286), (9, 815960704)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            W_ref, H_ref, n_ref = non_negative_factorization(X, **dict(kw, n_components=k, random_state=seed))
+        H, _, n_iter, _ = engine.nmf_mu_batch([k], seeds=[seed], max_iter=400, warn=False)
+        assert abs(int(n_iter[0]) - n_ref) <= 10, (k, int(n_iter[0]), n_ref)
+        if int(n_iter[0]) != n_ref:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                _, H_ref, _ = non_negative_factorization(X, **dict(kw, n_components=k, random_state=seed, max_iter=int(n_iter[0]), tol=0.0))
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, H[0])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (k, maxabs, relfro)
