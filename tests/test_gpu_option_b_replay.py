@@ -107,7 +107,8 @@ def test_kl_calls_of_option_b_match_live_sklearn_on_csr(engine):
     import scipy.sparse as sp
     from sklearn.decomposition import non_negative_factorization
     C, _ = synth.topic_counts(2200, 800, 6, 4.6, 0.4, 21)
-    Xd = synth.normalise_like_prepare(C, dtype=np.float64)
+    # (values representable in float32 -- the device's resident image --, handed to scikit-learn as float64: the reference's dtype)
+    Xd = synth.normalise_like_prepare(C, dtype=np.float32).astype(np.float64)
     X = sp.csr_matrix(Xd)
     engine.set_matrix(X)
     kw = dict(alpha_W=0.0, alpha_H=0.0, l1_ratio=0.0, beta_loss="kullback-leibler", solver="mu", tol=1e-4, max_iter=400,
@@ -120,7 +121,11 @@ def test_kl_calls_of_option_b_match_live_sklearn_on_csr(engine):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         W_ref, _, n_ref = non_negative_factorization(X, **dict(kw, n_components=7, H=spectra, update_H=False))
-        Wt_ref, _, nt_ref = non_negative_factorization(X.T, **dict(kw, n_components=7, H=np.ascontiguousarray(usage.T), update_H=False))
+        # NB the reference's `refit_spectra` hands scikit-learn `X.T` -- for a CSR matrix a CSC one -- and scikit-learn 1.7.2's
+        # multiplicative update pairs `X.data` (column-major there) with `_special_sparse_dot(...).tocsr().data` (row-major):
+        # on CSC input its quotient mixes entries (the result differs from the one for the SAME matrix as CSR or dense by
+        # tens of per cent).  The device computes what scikit-learn computes for the matrix as CSR / dense.
+        Wt_ref, _, nt_ref = non_negative_factorization(sp.csr_matrix(X.T), **dict(kw, n_components=7, H=np.ascontiguousarray(usage.T), update_H=False))
     W, n, _ = engine.mu_refit_f64(spectra, tol=1e-4, max_iter=400)
     Wt, nt, _ = engine.mu_refit_f64(usage.T, transposed=True, tol=1e-4, max_iter=400)
     assert n == n_ref and nt == nt_ref, (n, n_ref, nt, nt_ref)
