@@ -175,6 +175,16 @@ def ledger_seeds(ks, n_iter, random_state_seed):
     return [(k, r, nmf_seeds[i]) for i, (k, r) in enumerate(itertools.product(k_list, range(n_iter)))]
 
 
+class SparseFrame:
+    """A cells x genes scipy CSR matrix with its labels -- what the reference holds in ``norm_counts`` (an AnnData with a
+    sparse ``.X``, cnmf.py:537-556 sparse branch) when the counts were stored sparse and not densified.  Only what the
+    class below touches: ``values`` (the CSR matrix), ``index``, ``columns``, ``shape``."""
+
+    def __init__(self, values, index, columns):
+        self.values, self.index, self.columns = values, pd.Index(index), pd.Index(columns)
+        self.shape = values.shape
+
+
 class cNMF:
     # the R x R distance matrix only leaves the device when a consumer exists (the reference's plotting block,
     # integration/hip_backend.py sets this): 8 R^2 bytes of host memory otherwise bought nothing
@@ -220,6 +230,7 @@ class cNMF:
             o = lambda s: os.path.join(d, n, n + s)                  # noqa: E731
             self.paths = {
                 "normalized_counts": t(".norm_counts.df.npz"),
+                "normalized_counts_sparse": t(".norm_counts.csr.npz"),   # sparse normalised counts (CSR + two label files)
                 "nmf_replicate_parameters": t(".nmf_params.df.npz"),
                 "nmf_run_parameters": t(".nmf_idvrun_params.yaml"),
                 "nmf_genes_list": o(".overdispersed_genes.txt"),
@@ -280,12 +291,23 @@ class cNMF:
         self._norm_counts_cache = (None, None)
         self._tpm_sparse_cache = None
 
+    def _nc_path(self):
+        """The file that holds the normalised matrix: the dense frame, or -- when ``prepare_from_matrix`` was handed a
+        scipy.sparse matrix -- the CSR container (the reference's normalized_counts h5ad keeps a sparse X likewise)."""
+        sparse = self.paths["normalized_counts_sparse"]
+        return sparse if os.path.exists(sparse) else self.paths["normalized_counts"]
+
     def _load_norm_counts(self):
         """The normalised matrix file, kept in memory between the stages of one process."""
-        path = self.paths["normalized_counts"]
+        path = self._nc_path()
         key = (path, os.path.getmtime(path))
         if getattr(self, "_norm_counts_cache", (None, None))[0] != key:
-            self._norm_counts_cache = (key, load_df_from_npz(path))
+            if path == self.paths["normalized_counts_sparse"]:
+                obj = SparseFrame(load_csr(path), open(path + ".cells.txt").read().split("\n"),
+                                  open(path + ".genes.txt").read().split("\n"))
+            else:
+                obj = load_df_from_npz(path)
+            self._norm_counts_cache = (key, obj)
         return self._norm_counts_cache[1]
 
     # ------------------------------------------------------------------ ledger (cnmf.py:564-658)
@@ -344,11 +366,31 @@ class cNMF:
         The object keeps REFERENCES to ``norm_counts`` and to the arrays of a sparse ``tpm`` (so that factorize / consensus of
         this process need not read back what was just written: 0.8 GB at 50 000 x 2 000): do not modify them in place
         afterwards -- the files on disk would no longer be what this process computes on.  Pass copies if you must."""
-        if not isinstance(norm_counts, pd.DataFrame):
-            norm_counts = pd.DataFrame(np.asarray(norm_counts),
-                                       index=["cell%d" % i for i in range(np.shape(norm_counts)[0])],
-                                       columns=["gene%d" % j for j in range(np.shape(norm_counts)[1])])
-        zerocells = np.array(norm_counts.values.sum(axis=1) == 0).reshape(-1)
+        import scipy.sparse as _sp
+        sparse_in = None
+        if isinstance(norm_counts, tuple) and len(norm_counts) == 3 and _sp.issparse(norm_counts[0]):
+            sparse_in = norm_counts                              # (matrix, cell names, gene names)
+        elif _sp.issparse(norm_counts):
+            sparse_in = (norm_counts, ["cell%d" % i for i in range(norm_counts.shape[0])],
+                         ["gene%d" % j for j in range(norm_counts.shape[1])])
+        if sparse_in is not None:
+            # the reference's sparse branch (cnmf.py:537-539, 550-556): norm_counts.X stays a scipy.sparse matrix and is
+            # handed to scikit-learn as stored; here it is uploaded as CSR and walked on its stored entries by the
+            # Kullback-Leibler paths (a coordinate-descent run forms the dense image on the device)
+            mat = _sp.csr_matrix(sparse_in[0])
+            if mat.dtype not in (np.float32, np.float64):
+                mat = mat.astype(np.float64)
+            if not mat.has_canonical_format:
+                mat = mat.copy()
+                mat.sum_duplicates()
+            norm_counts = SparseFrame(mat, [str(c) for c in sparse_in[1]], [str(g) for g in sparse_in[2]])
+            zerocells = np.asarray(mat.sum(axis=1)).ravel() == 0
+        else:
+            if not isinstance(norm_counts, pd.DataFrame):
+                norm_counts = pd.DataFrame(np.asarray(norm_counts),
+                                           index=["cell%d" % i for i in range(np.shape(norm_counts)[0])],
+                                           columns=["gene%d" % j for j in range(np.shape(norm_counts)[1])])
+            zerocells = np.array(norm_counts.values.sum(axis=1) == 0).reshape(-1)
         if zerocells.sum() > 0:
             examples = norm_counts.index[np.ravel(zerocells)]
             raise Exception("Error: %d cells have zero counts of overdispersed genes. E.g. %s. Filter those cells "
@@ -356,10 +398,21 @@ class cNMF:
                             % (zerocells.sum(), ", ".join(map(str, examples[:4]))))
         self._initialize_dirs()
         self._forget_results()
-        save_df_to_npz_fast(norm_counts, self.paths["normalized_counts"], sibling_ok=True)
+        sp_path = self.paths["normalized_counts_sparse"]
+        for stale in (self.paths["normalized_counts"], self.paths["normalized_counts"] + ".data.npy", sp_path,
+                      sp_path + ".cells.txt", sp_path + ".genes.txt") + tuple("%s.%s.npy" % (sp_path, part) for part in ("data", "indices", "indptr")):
+            if os.path.exists(stale):
+                os.remove(stale)                                 # (one form of the matrix on disk, never a stale other one)
+        if sparse_in is not None:
+            save_csr_fast(sp_path, norm_counts.values)
+            with open(sp_path + ".cells.txt", "w") as F:
+                F.write("\n".join(norm_counts.index))
+            with open(sp_path + ".genes.txt", "w") as F:
+                F.write("\n".join(norm_counts.columns))
+        else:
+            save_df_to_npz_fast(norm_counts, self.paths["normalized_counts"], sibling_ok=True)
         # this process holds what it just wrote: factorize() / consensus() need not read the 8 N G bytes back
-        self._norm_counts_cache = ((self.paths["normalized_counts"], os.path.getmtime(self.paths["normalized_counts"])),
-                                   norm_counts)
+        self._norm_counts_cache = ((self._nc_path(), os.path.getmtime(self._nc_path())), norm_counts)
         with open(self.paths["nmf_genes_list"], "w") as F:
             F.write("\n".join(map(str, norm_counts.columns)))
         for stale in (self.paths["tpm"], self.paths["tpm_sparse"], self.paths["tpm_sparse_genes"]) + tuple(
@@ -430,8 +483,7 @@ class cNMF:
                                  alpha_usage=alpha_usage, alpha_spectra=alpha_spectra, init=init,
                                  max_NMF_iter=max_NMF_iter, tpm=tpm)
         # the matrix just written is the one already resident: factorize() in this process skips the upload
-        self._engine_key = ("norm_counts", self.paths["normalized_counts"],
-                            os.path.getmtime(self.paths["normalized_counts"]))
+        self._engine_key = ("norm_counts", self._nc_path(), os.path.getmtime(self._nc_path()))
         eng.x_mean, eng.x_dtype = x_mean, x_dtype
         return norm_counts
 
@@ -454,7 +506,7 @@ class cNMF:
         NNLS refit when ``update_H=False`` (then ``H`` must have X's dtype, sklearn _nmf.py:1221)."""
         kw = dict(nmf_kwargs)
         self._check_kwargs(kw)
-        Xv = X.values if isinstance(X, pd.DataFrame) else X
+        Xv = X.values if isinstance(X, (pd.DataFrame, SparseFrame)) else X
         # (the matrix object consensus()/factorize() made resident is not uploaded again; anything else is)
         if self._resident_obj is not None and X is self._resident_obj and self._engine is not None:
             eng = self._engine
@@ -529,8 +581,7 @@ class cNMF:
         self.last_factorize_jobs = [int(j) for j in jobs]     # ledger rows THIS call ran (dist.factorize_distributed)
         if not jobs:
             return
-        eng = self._get_engine(norm_counts.values, ("norm_counts", self.paths["normalized_counts"],
-                                                    os.path.getmtime(self.paths["normalized_counts"])))
+        eng = self._get_engine(norm_counts.values, ("norm_counts", self._nc_path(), os.path.getmtime(self._nc_path())))
         _t.append(_time.perf_counter())
         sub = run_params.iloc[jobs]
         ks = [int(v) for v in sub["n_components"].values]
@@ -722,7 +773,7 @@ class cNMF:
         if skip_density_and_return_after_stats:
             density_threshold_str = "2"
         density_threshold_repl = density_threshold_str.replace(".", "_")
-        nc_key = ("norm_counts", self.paths["normalized_counts"], os.path.getmtime(self.paths["normalized_counts"]))
+        nc_key = ("norm_counts", self._nc_path(), os.path.getmtime(self._nc_path()))
         eng = self._get_engine(norm_counts.values, nc_key)
         self._resident_obj = norm_counts                      # the refit below reuses this upload
         R = merged_spectra.shape[0]
@@ -913,7 +964,7 @@ class cNMF:
         ks = sorted(set(int(k) for k in run_params.n_components))
         kw = yaml.load(open(self.paths["nmf_run_parameters"]), Loader=yaml.FullLoader)
         if batched and kw.get("solver", "cd") == "cd":
-            nc_key = ("norm_counts", self.paths["normalized_counts"], os.path.getmtime(self.paths["normalized_counts"]))
+            nc_key = ("norm_counts", self._nc_path(), os.path.getmtime(self._nc_path()))
             eng = self._get_engine(norm_counts.values, nc_key)
             self._resident_obj = norm_counts
             merged, srows = {}, {}

@@ -437,8 +437,37 @@ extern "C" int cnmf_prediction_error(cnmf_ctx* ctx, int k, const double* W, cons
 {
     using namespace cnmf;
     if (!ctx || !W || !H || !err_out || k < 1) { SET_ERR(ctx, "bad argument"); return CNMF_EINVAL; }
-    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     if (k > KMAX) { SET_ERR(ctx, "k=%d > %d", k, KMAX); return CNMF_EUNSUPPORTED; }
+    if (!ctx->X && ctx->csr_ptr) {
+        // a matrix that lives as compressed rows only (round 5; the reference densifies it here, cnmf.py:927-928):
+        // ||X - W H||^2 = sum_stored [(x - wh)^2 - (wh)^2] + tr(W^T W . H H^T), float64
+        CONS_TRY(hipSetDevice(ctx->device));
+        hipStream_t st_ = ctx->stream;
+        const int N_ = (int)ctx->N, G_ = (int)ctx->G;
+        std::vector<double> ht((size_t)G_ * k), wtw((size_t)k * k, 0.0), hht((size_t)k * k, 0.0);
+        for (int c = 0; c < k; ++c) for (int j = 0; j < G_; ++j) ht[(size_t)j * k + c] = H[(size_t)c * G_ + j];
+        for (int i = 0; i < N_; ++i) { const double* w = W + (size_t)i * k; for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) wtw[a * k + b] += w[a] * w[b]; }
+        for (int j = 0; j < G_; ++j) { const double* h = ht.data() + (size_t)j * k; for (int a = 0; a < k; ++a) for (int b = 0; b < k; ++b) hht[a * k + b] += h[a] * h[b]; }
+        double tr = 0.0;
+        for (int a = 0; a < k * k; ++a) tr += wtw[a] * hht[a];
+        DevPool pool_;
+        double* dW_ = pool_.get<double>((size_t)N_ * k);
+        double* dHt_ = pool_.get<double>((size_t)G_ * k);
+        double* dpart_ = pool_.get<double>(N_);
+        double* dsum_ = pool_.get<double>(1);
+        if (pool_.err) { SET_ERR(ctx, "device allocation failed"); return CNMF_ENOMEM; }
+        CONS_TRY(hipMemcpyAsync(dW_, W, (size_t)N_ * k * sizeof(double), hipMemcpyHostToDevice, st_));
+        CONS_TRY(hipMemcpyAsync(dHt_, ht.data(), (size_t)G_ * k * sizeof(double), hipMemcpyHostToDevice, st_));
+        csr_residual_rows_kernel<<<(N_ + 3) / 4, 256, 0, st_>>>(ctx->csr_ptr, ctx->csr_idx, ctx->csr_val, N_, dW_, dHt_, k, dpart_);
+        sum_kernel<<<1, 256, 0, st_>>>(dpart_, N_, dsum_);
+        CONS_TRY(hipGetLastError());
+        double s_ = 0.0;
+        CONS_TRY(hipMemcpyAsync(&s_, dsum_, sizeof(double), hipMemcpyDeviceToHost, st_));
+        CONS_TRY(hipStreamSynchronize(st_));
+        *err_out = s_ + tr;
+        return CNMF_OK;
+    }
+    if (int rcd_ = ensure_dense(ctx)) return rcd_;
     CONS_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int N = (int)ctx->N, G = (int)ctx->G;

@@ -177,6 +177,30 @@ __global__ __launch_bounds__(256) void csc_xtw_f64_kernel(const long long* __res
     }
 }
 
+
+// sum over the STORED entries of row i of  (x - w_i.h_j)^2 - (w_i.h_j)^2  (float64): with  ||W H||_F^2 = tr(W^T W . H H^T)  added
+// by the host this is ||X - W H||_F^2 without ever touching the zeros of X.  Ht: [G][k].  A wavefront per row.
+__global__ __launch_bounds__(256) void csr_residual_rows_kernel(const long long* __restrict__ ptr, const int* __restrict__ idx,
+                                                                const float* __restrict__ val, int N, const double* __restrict__ W,
+                                                                const double* __restrict__ Ht, int k, double* __restrict__ part)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const long long b = ptr[row], e = ptr[row + 1];
+    const double* w = W + (size_t)row * k;
+    double acc = 0.0;
+    for (long long p = b + lane; p < e; p += 64) {
+        const double* h = Ht + (size_t)idx[p] * k;
+        double s = 0.0;
+        for (int c = 0; c < k; ++c) s = fma(w[c], h[c], s);
+        const double d = (double)val[p] - s;
+        acc += d * d - s * s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) part[row] = acc;
+}
+
 }  // namespace cnmf
 
 static void free_csr(cnmf_ctx* c)

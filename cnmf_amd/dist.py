@@ -168,7 +168,7 @@ def factorize_distributed(obj, rank, world, device=None, gather="rccl", **factor
             rows.append((idx, key[0], key[1]))
             spectra.append(np.asarray(obj.spectra_cache[key]))
     if genes is None:
-        genes = load_df_from_npz(obj.paths["normalized_counts"]).columns
+        genes = obj._load_norm_counts().columns
     hdr, blk = pack_local(rows, spectra, len(genes))
     if gather == "rccl":
         merged = allgather_spectra_rccl(obj.engine, hdr, blk, len(genes))

@@ -265,7 +265,8 @@ int cnmf_pairwise_distances(cnmf_ctx* ctx, const double* rows, int R, int G, con
                             double* dist_out, double* silhouette_out);
 
 /* sum((X - W.H)^2) over the resident matrix: the prediction error of cnmf.py:926-930
- * (W [N][k], H [k][G], float64). */
+ * (W [N][k], H [k][G], float64).  A matrix that lives as compressed rows only is NOT densified (the reference calls
+ * todense() there): sum over the stored entries of (x - wh)^2 - (wh)^2, plus tr(W^T W . H H^T). */
 int cnmf_prediction_error(cnmf_ctx* ctx, int k, const double* W, const double* H, double* err_out);
 
 /* ---- products with the resident matrix ----------------------------------------------------

@@ -381,7 +381,71 @@ def test_gene_statistics_and_ols_product_on_the_compressed_rows(engine):
     ref = W.T @ ((X64 - X64.mean(axis=0)) / np.sqrt(np.where(X64.var(axis=0) < 1e-12, 1e-12, X64.var(axis=0))))
     assert np.abs(out - ref).max() <= 1e-9 * np.abs(ref).max()
     assert np.abs(plain - W.T @ X64).max() <= 1e-12 * np.abs(W.T @ X64).max()
+    # the prediction error of the statistics branch (cnmf.py:926-930; the reference densifies a sparse matrix there):
+    # sum over the stored entries of (x - wh)^2 - (wh)^2, plus tr(W^T W . H H^T)
+    Hs = np.abs(rs.standard_normal((21, 450)))
+    pe = engine.prediction_error(W, Hs)
+    assert not engine.matrix_images()["dense"]
+    ref_pe = ((X64 - W @ Hs) ** 2).sum()
+    assert abs(pe - ref_pe) <= 1e-10 * ref_pe
     engine.set_matrix(X)                                          # the dense kernels on the same matrix
+    assert abs(engine.prediction_error(W, Hs) - pe) <= 1e-10 * pe
     mean_d, var_d = engine.col_mean_var()
     out_d = engine.xt_matmul_f64(W, mean=mean_d, std=np.sqrt(np.where(var_d < 1e-12, 1e-12, var_d)))
     assert np.abs(mean - mean_d).max() <= 1e-13 * np.abs(mean_d).max() and np.abs(out - out_d).max() <= 1e-9 * np.abs(out_d).max()
+
+
+@pytest.mark.parametrize("beta_loss", ["kullback-leibler", "frobenius"])
+def test_mirror_class_on_sparse_normalised_counts(engine, tmp_path, beta_loss):
+    """The reference's sparse branch end to end through the mirror class: normalised counts AND the TPM matrix handed over
+    as scipy.sparse (what `prepare(densify=False)` keeps for a sparse counts file, cnmf.py:537-556).  The same run on the
+    dense forms of the same matrices is the yardstick; under the Kullback-Leibler loss the device never forms a dense
+    image of either matrix (restarts, k selection's refits, the consensus tail), under 'frobenius' it forms them on
+    demand."""
+    # a count matrix as sparse as a real one (~10 % non-zero): 200 of its 500 genes normalised like prepare does, TPM over all
+    C, _ = synth.topic_counts(700, 500, 5, 4.0, 0.4, 17)
+    C = C[:, C.sum(axis=0) > 0]
+    hv = np.argsort(-C.var(axis=0), kind="stable")[:200]
+    hv.sort()
+    keep = C[:, hv].sum(axis=1) > 0
+    C = C[keep].astype(np.float64)
+    NC = C[:, hv] / C[:, hv].std(axis=0, ddof=1)
+    TPM = C / C.sum(axis=1, keepdims=True) * 1e6
+    assert (NC != 0).mean() < 0.25
+    cells = ["c%d" % i for i in range(C.shape[0])]
+    tg = ["g%d" % j for j in range(C.shape[1])]
+    genes = [tg[j] for j in hv]
+    runs = {}
+    for form in ("sparse", "dense"):
+        obj = cNMF(output_dir=str(tmp_path / form), name="sp", engine=engine)
+        if form == "sparse":
+            nc, tpm = (sp.csr_matrix(NC), cells, genes), (sp.csr_matrix(TPM), tg)
+        else:
+            nc, tpm = pd.DataFrame(NC, index=cells, columns=genes), pd.DataFrame(TPM, index=cells, columns=tg)
+        obj.prepare_from_matrix(nc, components=[4, 5], n_iter=6, seed=14, beta_loss=beta_loss, tpm=tpm)
+        obj.factorize()
+        if form == "sparse" and beta_loss != "frobenius":
+            assert not engine.matrix_images()["dense"], engine.matrix_images()
+        obj.combine()
+        stats = obj.k_selection_stats()
+        if form == "sparse" and beta_loss != "frobenius":          # k selection: float64 refits + prediction errors on the stored entries
+            assert engine.shape == NC.shape and not engine.matrix_images()["dense"], engine.matrix_images()
+        med, usages = obj.consensus(5, density_threshold=2.0)
+        if form == "sparse" and beta_loss != "frobenius":
+            im = engine.matrix_images()
+            assert im["csr"] and not im["dense"] and not im["dense_transpose"], im
+        rep = "2_0"
+        runs[form] = (load_df_from_npz(obj.paths["merged_spectra"] % 5).values, stats, med, usages,
+                      load_df_from_npz(obj.paths["gene_spectra_tpm"] % (5, rep)).values,
+                      load_df_from_npz(obj.paths["gene_spectra_score"] % (5, rep)).values)
+        assert list(usages.index) == cells and list(med.columns) == genes
+    a, b = runs["sparse"], runs["dense"]
+    # (scipy's sparse mean and numpy's dense mean differ in the last bit, and with them the init scale: float32 round-off apart)
+    for it in range(6):
+        maxabs, relfro = nmf_cd.spectra_error(b[0][it * 5:(it + 1) * 5], a[0][it * 5:(it + 1) * 5])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (it, maxabs, relfro)
+    assert np.abs(a[1]["silhouette"].values - b[1]["silhouette"].values).max() < 5e-3
+    assert np.abs(a[1]["prediction_error"].values / b[1]["prediction_error"].values - 1).max() < 1e-3
+    assert ((a[2].values - b[2].values) ** 2).sum() < TOLERANCE
+    assert np.abs(a[3].values - b[3].values).max() <= 2e-3 * np.abs(b[3].values).max()
+    assert np.abs(a[4] - b[4]).max() <= 2e-3 * np.abs(b[4]).max() and np.abs(a[5] - b[5]).max() < 5e-3

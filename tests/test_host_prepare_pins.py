@@ -53,3 +53,30 @@ def test_prepare_artefacts_match_the_reference(tmp_path, sparse_tpm):
     else:
         got = load_df_from_npz(obj.paths["tpm"]).values
     assert ((got - g["tpm"]) ** 2).sum() < TOLERANCE
+
+
+def test_sparse_normalised_counts_round_trip_and_zero_cell_error(tmp_path):
+    """Round 5: `prepare_from_matrix` takes the normalised counts as a scipy.sparse matrix -- the reference's sparse branch
+    (cnmf.py:537-556: `norm_counts.X` stays sparse and goes to scikit-learn as stored).  The CSR container + label files
+    replace the dense frame (never both on disk), the loader hands back the same matrix and labels, the zero-cell error is
+    the reference's, and a later dense prepare removes the sparse form."""
+    from cnmf_amd.cnmf import SparseFrame
+    g = dict(np.load(GOLD, allow_pickle=False))
+    cells = ["c%d" % i for i in range(g["norm_counts"].shape[0])]
+    genes = list(g["genes"])
+    X = sp.csr_matrix(g["norm_counts"])
+    obj = cNMF(output_dir=str(tmp_path), name="sp")
+    obj.prepare_from_matrix((X, cells, genes), components=[4, 5], n_iter=3, seed=14, beta_loss="kullback-leibler")
+    assert os.path.exists(obj.paths["normalized_counts_sparse"]) and not os.path.exists(obj.paths["normalized_counts"])
+    assert open(obj.paths["nmf_genes_list"]).read().split("\n") == genes
+    fresh = cNMF(output_dir=str(tmp_path), name="sp")           # another process: reads the files
+    nc = fresh._load_norm_counts()
+    assert isinstance(nc, SparseFrame) and list(nc.index) == cells and list(nc.columns) == genes and nc.shape == X.shape
+    assert nc.values.dtype == np.float64 and (nc.values != X).nnz == 0
+    bad = X.tolil(); bad[3, :] = 0
+    with pytest.raises(Exception, match="Error: 1 cells have zero counts of overdispersed genes. E.g. c3"):
+        cNMF(output_dir=str(tmp_path), name="spbad").prepare_from_matrix((bad.tocsr(), cells, genes), components=[4], n_iter=2, seed=1)
+    # a dense prepare on the same run directory removes the sparse container (one form on disk, never a stale other one)
+    obj.prepare_from_matrix(pd.DataFrame(g["norm_counts"], index=cells, columns=genes), components=[4], n_iter=2, seed=1)
+    assert os.path.exists(obj.paths["normalized_counts"]) and not os.path.exists(obj.paths["normalized_counts_sparse"])
+    assert isinstance(obj._load_norm_counts(), pd.DataFrame)
