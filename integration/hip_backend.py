@@ -23,6 +23,7 @@ import os
 
 import numpy as np
 import pandas as pd
+import scipy.sparse as sp
 import yaml
 
 import cnmf.cnmf as _ref                      # the UNMODIFIED reference module
@@ -36,6 +37,7 @@ _DEVICE_SOLVERS = {("cd", "frobenius"), ("cd", 2), ("mu", "kullback-leibler"), (
 
 class cNMF(_ref.cNMF):
     _engine = None
+    _untransposed = None          # set by refit_spectra around the inherited call
     _resident = None              # STRONG reference to the matrix object that is on the device (identity check)
 
     # -- engine plumbing ---------------------------------------------------------------------------
@@ -43,21 +45,53 @@ class cNMF(_ref.cNMF):
         d = dict(self.__dict__)
         d.pop("_engine", None)
         d.pop("_resident", None)
+        d.pop("_untransposed", None)
         return d
+
+    def _is_resident(self, X):
+        """The same object, or another view of the same buffers with the same layout (``X.T.T`` of the resident matrix)."""
+        R = self._resident
+        if R is None or X is R:
+            return R is not None
+        if type(X) is not type(R) or getattr(X, "shape", None) != getattr(R, "shape", None) or X.dtype != R.dtype:
+            return False
+        ptr = lambda a: (a.__array_interface__["data"][0], a.shape, a.strides)          # noqa: E731
+        if sp.issparse(X):
+            return all(ptr(getattr(X, n)) == ptr(getattr(R, n)) for n in ("data", "indices", "indptr"))
+        return isinstance(X, np.ndarray) and ptr(X) == ptr(R)
 
     def _eng(self, X):
         if self._engine is None:
             self._engine = Engine(int(os.environ.get("CNMF_DEVICE", "0")))
-        if self._resident is None or X is not self._resident:
+        if not self._is_resident(X):
             self._engine.set_matrix(X)
             self._resident = X
         return self._engine
+
+    # -- cnmf.py:805-820 ---------------------------------------------------------------------------
+    def refit_spectra(self, X, usage):
+        """The reference's one-liner ``refit_usage(X.T, usage.T).T``, with a note for ``_nmf`` of which matrix the
+        transposed view belongs to (array inputs; DataFrames take the inherited route unchanged)."""
+        if isinstance(X, pd.DataFrame):
+            return super().refit_spectra(X, usage)
+        self._untransposed = X
+        try:
+            return super().refit_spectra(X, usage)
+        finally:
+            self._untransposed = None
 
     # -- cnmf.py:661-674 ---------------------------------------------------------------------------
     def _nmf(self, X, nmf_kwargs):
         kw = dict(nmf_kwargs)
         if (kw.get("solver", "cd"), kw.get("beta_loss", "frobenius")) not in _DEVICE_SOLVERS:
             raise NotImplementedError("solver=%r beta_loss=%r is not implemented on the device" % (kw.get("solver"), kw.get("beta_loss")))
+        transposed = False
+        U = self._untransposed
+        if U is not None and kw.get("update_H", True) is False and X.shape == U.shape[::-1]:
+            # refit_spectra handed over ``U.T`` (cnmf.py:820): the cells x genes matrix U itself goes to the device (the layout
+            # every kernel is built for; nothing is re-uploaded if it is resident already) and the refit runs on the
+            # transposed problem there
+            X, transposed = U, True
         eng = self._eng(X)
         xdt = X.dtype if X.dtype in (np.float32, np.float64) else np.dtype(np.float64)
         common = dict(tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 200), alpha_W=kw.get("alpha_W", 0.0),
@@ -68,7 +102,14 @@ class cNMF(_ref.cNMF):
             if H.dtype != xdt:
                 raise TypeError("H should have the same dtype as X. Got H.dtype = {}.".format(H.dtype))
             # (scikit-learn solves in X's dtype: float64 matrices get the float64 device refit)
-            if mu and kw["beta_loss"] in ("kullback-leibler", 1):
+            if transposed and mu and kw["beta_loss"] in ("kullback-leibler", 1):
+                W, _, _ = eng.mu_refit_f64(H, transposed=True, **common)       # rows = genes, on the column-compressed image
+            elif transposed and not mu:
+                Hs, _ = eng.nnls_spectra(np.ascontiguousarray(H.T), **common)  # k x genes on the resident matrix
+                W = np.ascontiguousarray(Hs.T)
+            elif transposed:
+                raise NotImplementedError("beta_loss=%r refit of the spectra is not implemented on the device" % (kw["beta_loss"],))
+            elif mu and kw["beta_loss"] in ("kullback-leibler", 1):
                 # float64 on the stored entries of the matrix (cnmf_mu_refit_f64), like scikit-learn on float64 input
                 W, _, _ = eng.mu_refit_f64(H, **common)
             elif mu:

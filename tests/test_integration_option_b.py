@@ -53,6 +53,13 @@ class RecorderEngine:
         RecorderEngine.calls.append(("nnls_f64", np.shape(H)))
         return nmf_cd.nnls(self.X, np.asarray(H, dtype=np.float64), tol=tol, max_iter=max_iter, alpha_W=alpha_W, l1_ratio=l1_ratio)
 
+    def nnls_spectra(self, W, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0, **kw):
+        from oracle import nmf_cd
+        RecorderEngine.calls.append(("nnls_spectra", np.shape(W)))
+        Wt, n = nmf_cd.nnls(np.ascontiguousarray(self.X.T), np.ascontiguousarray(np.asarray(W, dtype=np.float64).T), tol=tol,
+                            max_iter=max_iter, alpha_W=alpha_W, l1_ratio=l1_ratio)
+        return np.ascontiguousarray(Wt.T), n
+
     def pairwise_distances(self, rows, labels=None, return_dist=True):
         from oracle import consensus as oc
         rows = np.asarray(rows, dtype=np.float64)
@@ -114,6 +121,10 @@ def test_option_b_subclass_runs_the_reference_pipeline(tmp_path, monkeypatch):
     assert kinds.count("nmf_batch") == 1 and ("nmf_batch", 8, 1e-4, 1000) in RecorderEngine.calls    # ONE batched call: 2 k x 4 iters
     # float64 matrices (the shim's h5ad stand-in keeps float64): the float64 device refit, like scikit-learn's dtype rule
     assert "nnls_f64" in kinds and "nnls" not in kinds and "consensus" in kinds
+    # refit_spectra's ``X.T`` never goes up transposed: the cells x genes matrix is what is resident and the spectra are
+    # solved on it (every upload has the 200 cells as its rows)
+    ups = [c[1] for c in RecorderEngine.calls if c[0] == "set_matrix"]
+    assert kinds.count("nnls_spectra") == 2 and all(u[0] == 200 for u in ups), ups
     # show_clustering=True: the distance matrix comes from the distance entry point -- no k = 1 consensus behind it
     assert ("pairwise_distances", (16, 120), False, True) in RecorderEngine.calls
     assert not any(c[0] == "consensus" and c[2] == 1 for c in RecorderEngine.calls)
