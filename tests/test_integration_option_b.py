@@ -60,6 +60,24 @@ class RecorderEngine:
                             max_iter=max_iter, alpha_W=alpha_W, l1_ratio=l1_ratio)
         return np.ascontiguousarray(Wt.T), n
 
+    def nmf_mu_batch(self, ks, beta_loss="kullback-leibler", seeds=None, W0=None, H0=None, tol=1e-4, max_iter=1000,
+                     alpha_W=0.0, alpha_H=0.0, l1_ratio=0.0, return_W=False, **kw):
+        from oracle import nmf_mu
+        RecorderEngine.calls.append(("nmf_mu_batch", len(ks), beta_loss, tol, max_iter))
+        H, W, n = [], [], []
+        for i, k in enumerate(ks):
+            w, h, it = nmf_mu.nmf_mu(self.X, int(k), seed=int(seeds[i]), beta_loss=beta_loss, tol=tol, max_iter=max_iter,
+                                     alpha_W=alpha_W, alpha_H=alpha_H, l1_ratio=l1_ratio)
+            H.append(h); W.append(w); n.append(it)
+        return H, (W if return_W else None), np.array(n), np.zeros(len(ks))
+
+    def mu_refit_f64(self, H, transposed=False, tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0, **kw):
+        from oracle import nmf_mu
+        RecorderEngine.calls.append(("mu_refit_f64", np.shape(H), bool(transposed)))
+        X = np.ascontiguousarray(self.X.T) if transposed else self.X
+        W, n = nmf_mu.nnls_mu(X, np.asarray(H, dtype=np.float64), tol=tol, max_iter=max_iter, alpha_W=alpha_W, l1_ratio=l1_ratio)
+        return W, n, 0.0
+
     def pairwise_distances(self, rows, labels=None, return_dist=True):
         from oracle import consensus as oc
         rows = np.asarray(rows, dtype=np.float64)
@@ -79,17 +97,17 @@ class RecorderEngine:
         return out
 
 
-def _run(cls, tmp, name, counts_fn):
+def _run(cls, tmp, name, counts_fn, beta_loss="frobenius", n_iter=4, thr5=0.5):
     obj = cls(output_dir=str(tmp), name=name)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        obj.prepare(counts_fn, components=[4, 5], n_iter=4, densify=True, seed=14, num_highvar_genes=120, beta_loss="frobenius")
+        obj.prepare(counts_fn, components=[4, 5], n_iter=n_iter, densify=True, seed=14, num_highvar_genes=120, beta_loss=beta_loss)
         obj.factorize(worker_i=0, total_workers=1)
         obj.combine()
         obj.k_selection_plot(close_fig=True)
         # exactly the CLI's call (cnmf.py:1290-1291): positional up to build_ref
         obj.consensus(4, 2.0, 0.30, True, False, close_clustergram_fig=True)
-        obj.consensus(5, 0.5, 0.30, False, False, close_clustergram_fig=True)
+        obj.consensus(5, thr5, 0.30, False, False, close_clustergram_fig=True)
     return obj
 
 
@@ -148,3 +166,48 @@ def test_option_b_subclass_runs_the_reference_pipeline(tmp_path, monkeypatch):
     n0 = len(RecorderEngine.calls)
     factorize_mp_signature((0, 1, clone))
     assert os.path.exists(b.paths["iter_spectra"] % (4, 0)) and RecorderEngine.calls[n0][0] == "create"
+
+
+def test_option_b_kullback_leibler_route(tmp_path, monkeypatch):
+    """The same pipeline prepared with ``beta_loss='kullback-leibler'`` (cnmf.py:618-631 -> solver='mu'): restarts through
+    ``nmf_mu_batch``, ``refit_usage`` through the float64 refit on the stored entries, ``refit_spectra`` through the same
+    entry point on the transposed problem of the RESIDENT matrix -- artefact by artefact against the plain reference."""
+    sys.path.insert(0, ROOT)
+    from oracle import scanpy_shim
+    scanpy_shim.install()
+    import cnmf as ref
+    from cnmf.cnmf import load_df_from_npz, save_df_to_npz
+    from cnmf_amd import synth
+    import cnmf_amd.engine
+    monkeypatch.setattr(cnmf_amd.engine, "Engine", RecorderEngine)
+    sys.modules.pop("integration.hip_backend", None)
+    from integration import hip_backend
+    monkeypatch.setattr(hip_backend, "Engine", RecorderEngine)
+
+    C, _ = synth.topic_counts(200, 300, 4, mu_lib=7.0, sigma_lib=0.3, seed=11)
+    C = C[:, C.sum(axis=0) > 0]
+    counts = pd.DataFrame(C.astype(np.int64), index=["c%d" % i for i in range(C.shape[0])], columns=["g%d" % j for j in range(C.shape[1])])
+    counts_fn = str(tmp_path / "counts.df.npz")
+    save_df_to_npz(counts, counts_fn)
+
+    RecorderEngine.calls = []
+    a = _run(ref.cNMF, tmp_path, "plain_kl", counts_fn, beta_loss="kullback-leibler", n_iter=4, thr5=2.0)
+    assert RecorderEngine.calls == []
+    b = _run(hip_backend.cNMF, tmp_path, "hip_kl", counts_fn, beta_loss="kullback-leibler", n_iter=4, thr5=2.0)
+    calls = RecorderEngine.calls
+    kinds = [c[0] for c in calls]
+    assert ("nmf_mu_batch", 8, "kullback-leibler", 1e-4, 1000) in calls and "nmf_batch" not in kinds
+    assert not {"nnls", "nnls_f64", "nnls_spectra"} & set(kinds)
+    refits = [c for c in calls if c[0] == "mu_refit_f64"]
+    # per consensus(): usages on the normalised counts, spectra on the TPM matrix (transposed problem), usages on the scaled TPM
+    assert [c[2] for c in refits if c[1][1] != 120] == [True, True] and all(c[1][1] == 200 for c in refits if c[2])
+    assert all(u[0] == 200 for u in (c[1] for c in calls if c[0] == "set_matrix"))          # never uploaded transposed
+    for k, rep in ((4, "2_0"), (5, "2_0")):
+        A, B = load_df_from_npz(a.paths["merged_spectra"] % k), load_df_from_npz(b.paths["merged_spectra"] % k)
+        assert list(A.index) == list(B.index) and np.abs(A.values - B.values).max() < 1e-9
+        for key in ("consensus_spectra", "consensus_usages", "gene_spectra_tpm", "gene_spectra_score"):
+            A, B = load_df_from_npz(a.paths[key] % (k, rep)), load_df_from_npz(b.paths[key] % (k, rep))
+            assert A.shape == B.shape and list(A.columns) == list(B.columns)
+            assert ((A.values - B.values) ** 2).sum() < 1e-4 * (1e6 if key == "gene_spectra_tpm" else 1.0), key
+    A, B = load_df_from_npz(a.paths["k_selection_stats"]), load_df_from_npz(b.paths["k_selection_stats"])
+    assert np.allclose(A.values.astype(float), B.values.astype(float), rtol=1e-7, atol=1e-9)
