@@ -110,6 +110,37 @@ def comm_bootstrap_file(engine, rank, world, path, timeout=300.0):
             pass
 
 
+def agree_on_outcome(path, rank, world, ok, message="", timeout=120.0, poll=0.05):
+    """Every rank reports whether a collective set-up step succeeded for IT, then waits for the reports of all ranks, so that
+    all of them take the SAME decision afterwards (a communicator that formed on a subset of the ranks must not be used
+    by that subset while the others go elsewhere: that is a dead-lock until the launcher's timeout, not an error message).
+    Reports travel like the RCCL id does -- files ``<path>.status.<rank>`` written atomically.  Returns
+    ``[(rank, ok, message), ...]`` for all ranks; raises ``TimeoutError`` naming the ranks that never reported (stuck
+    inside the collective, or dead)."""
+    tmp = "%s.status.%d.tmp.%d" % (path, rank, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump({"ok": bool(ok), "message": str(message)}, f)
+    os.replace(tmp, "%s.status.%d" % (path, rank))
+    t0 = time.time()
+    reports = {}
+    while len(reports) < world:
+        for r in range(world):
+            if r in reports:
+                continue
+            try:
+                with open("%s.status.%d" % (path, r)) as f:
+                    reports[r] = json.load(f)
+            except (OSError, ValueError):
+                pass
+        if len(reports) < world:
+            if time.time() - t0 > timeout:
+                missing = [r for r in range(world) if r not in reports]
+                raise TimeoutError("ranks %s never reported the outcome of the communicator set-up within %.0f s "
+                                   "(stuck inside the collective, or dead)" % (missing, timeout))
+            time.sleep(poll)
+    return [(r, bool(reports[r]["ok"]), reports[r]["message"]) for r in range(world)]
+
+
 def comm_bootstrap_torch(engine):
     """Same, when a torch.distributed process group already exists (bench.py's launcher):
     the id is broadcast through it; the data path stays inside the library."""

@@ -55,3 +55,72 @@ def test_bench_has_no_torch_in_its_default_path():
     assert "import torch" not in src.split("def main")[0]                  # nothing at module level, nothing in the spawner
     code = [ln for ln in src.splitlines() if "torch.distributed.run" in ln and not ln.lstrip().startswith(("#", "launcher", "\"", "rank"))]
     assert all("Popen" not in ln and "subprocess" not in ln for ln in code)  # mentioned in prose only, never executed
+
+
+def test_rccl_init_failure_exits_non_zero_on_every_rank_by_default():
+    """Round-5 review, item 6: the first real N > 1 run must not be able to turn "the in-library RCCL communicator did not
+    form" into a green number.  The set-up fails on rank 1 of 3: the ranks agree on that (status files beside the RCCL id),
+    EVERY rank exits non-zero, stdout carries no JSON line."""
+    p = _run(["--gpus", "3", "--spawn-selftest"], env={"CNMF_BENCH_SELFTEST_RCCL_FAIL_RANKS": "1"})
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "did not form on 1 of 3 ranks" in p.stderr and "simulated failure on rank 1" in p.stderr
+    assert "No number is reported" in p.stderr
+
+
+def test_rccl_init_failure_with_explicit_fallback_reports_under_another_metric():
+    """--allow-transport-fallback: ALL ranks switch together (no rank keeps a communicator the others left), and the
+    line's metric cannot be mistaken for the headline."""
+    p = _run(["--gpus", "2", "--spawn-selftest", "--allow-transport-fallback"], env={"CNMF_BENCH_SELFTEST_RCCL_FAIL_RANKS": "0"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["gather"] == "torch" and "rank 0" in d["gather_fallback"]
+    assert "TRANSPORT FALLBACK" in d["metric"] and not d["metric"].startswith("NMF restarts/sec (")
+
+
+def test_every_rank_takes_the_same_transport_decision(tmp_path):
+    """The healthy ranks must not go on alone over a communicator the failed rank never joined (round-5 advice): with the
+    fallback allowed ALL three return "torch" with the same reason; without it ALL three stop."""
+    import importlib.util
+    import threading
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def run(allow, sub):
+        res = [None] * 3
+
+        def one(rank):
+            def boot():
+                if rank == 2:
+                    raise RuntimeError("boom")
+            try:
+                res[rank] = bench.form_transport(boot, rank, 3, str(tmp_path / sub / "id"), allow, timeout=20.0)
+            except SystemExit as e:
+                res[rank] = ("exit", str(e))
+        os.makedirs(tmp_path / sub)
+        th = [threading.Thread(target=one, args=(r,)) for r in range(3)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return res
+    res = run(True, "a")
+    assert [r[0] for r in res] == ["torch"] * 3 and len({r[1] for r in res}) == 1 and "rank 2" in res[0][1]
+    res = run(False, "b")
+    assert [r[0] for r in res] == ["exit"] * 3 and all("did not form on 1 of 3 ranks" in r[1] for r in res)
+
+
+def test_rccl_init_success_keeps_the_library_transport_and_the_headline_metric():
+    p = _run(["--gpus", "2", "--spawn-selftest"], env={"CNMF_BENCH_SELFTEST_RCCL_FAIL_RANKS": ""})
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout)
+    assert d["gather"] == "rccl" and d["gather_fallback"] is None and d["metric"].startswith("NMF restarts/sec (")
+
+
+def test_agree_on_outcome_times_out_naming_the_silent_ranks(tmp_path):
+    """A rank stuck inside ncclCommInitRank never reports: the others stop with its name instead of waiting for the
+    launcher's timeout."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    from cnmf_amd import dist as cd
+    with pytest.raises(TimeoutError, match=r"ranks \[1, 2\] never reported"):
+        cd.agree_on_outcome(str(tmp_path / "rccl_id"), 0, 3, True, timeout=0.3)

@@ -252,8 +252,104 @@ def make_c4_stop():
     np.savez_compressed(os.path.join(OUT, "ref_c4_stop.npz"), **out)
 
 
+C3PIPE_KS = (7, 9, 11)
+C3PIPE_NITER = 8
+C3PIPE_TMP = os.environ.get("C3PIPE_TMP", "/tmp/work/c3pipe_parts")
+_C3X = {}
+
+
+def _c3pipe_one(job):
+    """One scikit-learn restart of the C3 pipeline golden (its own file: a long job loses nothing when a later one fails)."""
+    k, it, seed, dt = job
+    path = os.path.join(C3PIPE_TMP, "k%d_it%d_%s.npz" % (k, it, dt))
+    if os.path.exists(path):
+        return True
+    from threadpoolctl import threadpool_limits
+    t0 = time.time()
+    with threadpool_limits(1):
+        H, _, n = sklearn_ref.nmf(_C3X[dt], k, seed)
+    np.savez(path, H=H.astype(np.float64), n=n)
+    print("C3 pipeline k=%d iter=%d seed=%d %s: n_iter=%d (%.0f s)" % (k, it, seed, dt, n, time.time() - t0), flush=True)
+    return True
+
+
+def _c3pipe_consensus(X, led, dt):
+    """merged spectra (iter asc, topic asc: cnmf.py:765-770) -> consensus core at the defaults (density threshold 0.5,
+    local neighbourhood 0.30) and the stats branch (no density filter: cnmf.py:884-886, 922-936), per K."""
+    from oracle import consensus as oc
+    out = {}
+    for K in C3PIPE_KS:
+        parts = [np.load(os.path.join(C3PIPE_TMP, "k%d_it%d_%s.npz" % (k, it, dt))) for (k, it, _) in led if k == K]
+        merged = np.concatenate([p["H"] for p in parts], axis=0)
+        t0 = time.time()
+        core = oc.consensus_core(merged, X, K, density_threshold=0.5)
+        stats = oc.consensus_core(merged, X, K, stats_mode=True)
+        W = core["rf_usages"]
+        out[K] = dict(n_iter=np.array([int(p["n"]) for p in parts], dtype=np.int32), merged=merged,
+                      local_density=core["local_density"], density_filter=core["density_filter"],
+                      median_spectra=core["median_spectra"], usage_colsum=np.array([W.sum(axis=0), (W * W).sum(axis=0)]),
+                      usage_rows=W[::97].copy(), silhouette=np.array([stats["silhouette"]]),
+                      prediction_error=np.array([stats["prediction_error"]]),
+                      stats_median_spectra=stats["median_spectra"])
+        print("C3 pipeline K=%d %s: iterations %s, kept %d of %d, silhouette %.6f, prediction error %.9g (%.0f s)"
+              % (K, dt, out[K]["n_iter"].tolist(), int(core["density_filter"].sum()), merged.shape[0],
+                 stats["silhouette"], stats["prediction_error"], time.time() - t0), flush=True)
+    return out
+
+
+def make_c3_pipeline():
+    """Round 6 (review item 1): the WHOLE pipeline at the headline shape on the CPU reference path.  The C3 matrix
+    (50 000 x 2000), the reference's ledger for components 7, 9, 11 with n_iter = 8 and seed 14 (cnmf.py:593-610), every
+    restart by scikit-learn in FLOAT64 to the stopping rule (tol 1e-4, max_iter 1000: the call of cnmf.py:672) -> merged
+    spectra -> oracle/consensus.py core (cnmf.py:871-920: density filter, KMeans, medians, usage refit) and stats branch
+    (cnmf.py:922-936).  tests/test_gpu_golden_big.py runs the same ledger on the device, the device's merged spectra
+    through the device's consensus, and compares the consensus spectra at the reference's bar (sum of squared differences
+    < 1e-4, tests/test_reproducibility.py:12, 96-115).  scikit-learn's own float32 pipeline is run beside it as the
+    calibration of what the working precision alone moves (`c3pipe32`; optional entries)."""
+    import multiprocessing as mp
+    from oracle import nmf_cd
+    X32 = synth.make_config("C3", dtype=np.float32)
+    _C3X["float64"] = X32.astype(np.float64)
+    _C3X["float32"] = X32
+    X = _C3X["float64"]
+    led = sklearn_ref.ledger(list(C3PIPE_KS), C3PIPE_NITER, 14)
+    os.makedirs(C3PIPE_TMP, exist_ok=True)
+    dts = ["float64"] + (["float32"] if "c3pipe32" in sys.argv else [])
+    # longest first: k = 11 restarts run to ~1000 iterations
+    jobs = sorted([(k, it, seed, dt) for (k, it, seed) in led for dt in dts], key=lambda j: (-j[0], j[3] == "float32"))
+    with mp.get_context("fork").Pool(int(os.environ.get("C3PIPE_PROCS", min(8, os.cpu_count() or 1)))) as pool:
+        pool.map(_c3pipe_one, jobs, chunksize=1)
+    out = {"x_checksum": np.array([X.sum(), (X * X).sum()]), "shape": np.array(X.shape),
+           "ks": np.array(C3PIPE_KS), "n_iter_per_k": np.array([C3PIPE_NITER]),
+           "ledger": np.array(led, dtype=np.int64)}
+    res = _c3pipe_consensus(X, led, "float64")
+    for K, d in res.items():
+        for name, v in d.items():
+            if name == "merged":
+                v = v.astype(np.float32)               # the float64 restarts' spectra, for diagnostics (float32: size)
+            out["k%d_%s" % (K, name)] = v
+    if "float32" in dts:
+        res32 = _c3pipe_consensus(X, led, "float32")
+        for K in C3PIPE_KS:
+            ref, m32 = res[K]["median_spectra"], res32[K]["median_spectra"]
+            perm, cos = nmf_cd.match_components(ref, m32)
+            m32 = m32[perm]
+            drift = np.array([((m32 - ref) ** 2).sum(), np.linalg.norm(m32 - ref) / np.linalg.norm(ref),
+                              np.abs(m32 - ref).max() / np.abs(ref).max(), cos.min(),
+                              abs(int(res32[K]["density_filter"].sum()) - int(res[K]["density_filter"].sum())),
+                              abs(res32[K]["silhouette"][0] - res[K]["silhouette"][0]),
+                              abs(res32[K]["prediction_error"][0] / res[K]["prediction_error"][0] - 1.0)])
+            out["k%d_f32_drift" % K] = drift
+            out["k%d_f32_n_iter" % K] = res32[K]["n_iter"]
+            print("C3 pipeline K=%d: sklearn float32 pipeline vs float64: sum sq %.3g, rel fro %.3g, rel max %.3g, min cos "
+                  "%.6f, |delta kept| %d, |delta silhouette| %.3g, rel delta prediction error %.3g" % (K, *drift), flush=True)
+    np.savez_compressed(os.path.join(OUT, "ref_c3_pipeline.npz"), **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3", "c4", "c4counts"]
+    if "c3pipe" in which or "c3pipe32" in which:
+        make_c3_pipeline()
     if "c4stop" in which:
         make_c4_stop()
     if "c4kl" in which:
