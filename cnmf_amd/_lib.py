@@ -156,7 +156,7 @@ def load():
     lib.cnmf_spectra_fetch_rows.restype = i32
     lib.cnmf_spectra_fetch_rows.argtypes = [vp, i64, i64, f32p]
     lib.cnmf_mu_refit_f64.restype = i32
-    lib.cnmf_mu_refit_f64.argtypes = [vp, i32, i32, dblp, dblp, C.c_double, C.POINTER(CdParams), dblp, i32p, dblp]
+    lib.cnmf_mu_refit_f64.argtypes = [vp, i32, i32, i32, dblp, dblp, C.c_double, C.POINTER(CdParams), dblp, i32p, dblp]
     lib.cnmf_get_iteration_means.restype = i32
     lib.cnmf_get_iteration_means.argtypes = [vp, dblp]
     lib.cnmf_set_iteration_hints.restype = i32

@@ -518,14 +518,12 @@ class cNMF:
             xdt = Xv.dtype if Xv.dtype in (np.float32, np.float64) else np.dtype(np.float64)
             if H.dtype != xdt:
                 raise TypeError("H should have the same dtype as X. Got H.dtype = {}.".format(H.dtype))
-            if mu and kw["beta_loss"] in ("kullback-leibler", 1):
-                # float64 on the stored entries, like scikit-learn on the reference's float64 matrices (cnmf.py:534)
+            if mu:
+                # float64 on the stored entries, like scikit-learn on the reference's float64 matrices (cnmf.py:534); both
+                # beta losses (Itakura-Saito: a strictly positive matrix -- scikit-learn's rule -- stores every entry)
                 W, _, _ = eng.mu_refit_f64(H, tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 200),
-                                           alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
-            elif mu:
-                W, _ = eng.nnls_mu(H, beta_loss=kw["beta_loss"], tol=kw.get("tol", 1e-4),
-                                   max_iter=kw.get("max_iter", 200), alpha_W=kw.get("alpha_W", 0.0),
-                                   l1_ratio=kw.get("l1_ratio", 0.0))
+                                           alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0),
+                                           beta_loss=kw["beta_loss"])
             else:
                 # scikit-learn solves in X's dtype (sklearn _nmf.py:1221-1233): float64 matrices get the float64 refit
                 # (product, Gram matrix and sweeps), float32 ones the float32 matrix-pipe path
@@ -881,17 +879,14 @@ class cNMF:
             solver_kw = dict(tol=kw.get("tol", 1e-4), max_iter=kw.get("max_iter", 1000),
                              alpha_W=kw.get("alpha_W", 0.0), l1_ratio=kw.get("l1_ratio", 0.0))
             mu_tail = kw.get("solver", "cd") == "mu"
-            kl_tail = mu_tail and kw.get("beta_loss") in ("kullback-leibler", 1)
-            if kl_tail:
-                # refit_spectra = the Kullback-Leibler refit of tpm.X^T against usages^T (cnmf.py:805-820): float64 on the
+            if mu_tail:
+                # refit_spectra = the multiplicative-update refit of tpm.X^T against usages^T (cnmf.py:805-820): float64 on the
                 # compressed rows of X^T, built on the device from the resident matrix -- no todense(), no transposed upload
+                # (Kullback-Leibler: the stored entries; Itakura-Saito, round 6: the matrix is strictly positive by
+                # scikit-learn's rule, every entry is stored)
+                solver_kw["beta_loss"] = kw.get("beta_loss")
                 Wt, _, _ = eng.mu_refit_f64(norm_usages.values.T, transposed=True, **solver_kw)
                 spectra_tpm = Wt.T
-            elif mu_tail:
-                # (Itakura-Saito touches every element: the generic path, transposed upload)
-                spectra_tpm = self.refit_spectra(np.asarray(tpm_x.todense()) if have_sparse else tpm_x.astype(tdt),
-                                                 norm_usages.values.astype(tdt))
-                eng = self._get_engine(tpm_x, None)
             else:
                 spectra_tpm, _ = eng.nnls_spectra(norm_usages.values.astype(tdt), **solver_kw)
             spectra_tpm = pd.DataFrame(np.asarray(spectra_tpm, dtype=tdt), index=rf_usages.columns, columns=tpm_genes)
@@ -916,7 +911,7 @@ class cNMF:
                 Hrf = spectra_tpm_rf.values.astype(np.float64)
                 H_prod = np.zeros((Hrf.shape[0], len(tpm_genes)), dtype=np.float64)
                 H_prod[:, hidx] = Hrf / std1
-                if kl_tail:
+                if mu_tail:
                     # the same refit on tpm[:, hvgs] / std without forming that matrix: the resident TPM's entries divided
                     # by the gene's std on the fly, the other columns dropped; W0 = sqrt(mean(tpm[:, hvgs] / std) / k)
                     div = np.zeros(len(tpm_genes))
@@ -925,9 +920,6 @@ class cNMF:
                     H_full[:, hidx] = Hrf
                     w0 = float(np.sqrt((mean[hidx] / std1).mean() / Hrf.shape[0]))
                     rf, _, _ = eng.mu_refit_f64(H_full, col_divisor=div, w_init=w0, n_features=len(hvgs), **solver_kw)
-                elif mu_tail:
-                    norm_tpm = (np.asarray(tpm_x[:, hidx].todense()) if have_sparse else tpm_x[:, hidx]).astype(np.float64) / std1
-                    rf = self.refit_usage(norm_tpm, Hrf.astype(norm_tpm.dtype))
                 elif tdt == np.float64:
                     rf, _ = eng.nnls_f64(H_prod, gram=Hrf @ Hrf.T, n_features=len(hvgs), **solver_kw)
                 else:

@@ -198,12 +198,13 @@ static int wait_snapshot(cnmf_ctx* ctx, const SlotDesc* sp, int n, int stamp)
 // 256 / 512 / 1024 columns, 50 000 x 2000); the batch narrows in 256-column steps once the queue is dry (compact()).
 // kc_max: 0 = auto, else an upper bound (multiple of 32; above 256 in steps of 256, up to CNMF_KC_LIMIT).
 constexpr int CNMF_KC_LIMIT_DEFAULT = 1024;
-static int kc_limit()                  // (CNMF_KC_LIMIT: A/B knob, up to 2048 = the 64 tile bits of the live mask)
-{
-    static const int v = getenv("CNMF_KC_LIMIT") ? atoi(getenv("CNMF_KC_LIMIT")) : CNMF_KC_LIMIT_DEFAULT;
+static int kc_limit(const cnmf_ctx* ctx)   // (CNMF_KC_LIMIT: A/B knob, up to 2048 = the 64 tile bits of the live mask; read from
+{                                          //  the context's snapshot of the environment like every per-call switch)
+    const char* s = ctx_getenv(ctx, "CNMF_KC_LIMIT");
+    const int v = s ? atoi(s) : CNMF_KC_LIMIT_DEFAULT;
     return std::max(256, std::min(2048, (v / 256) * 256));
 }
-#define CNMF_KC_LIMIT kc_limit()
+#define CNMF_KC_LIMIT kc_limit(ctx)
 static int pick_kc(const cnmf_ctx* ctx, int64_t total_k, int max_k, int kc_max, bool wide_ok)
 {
     bool forced = false;
@@ -245,7 +246,7 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
 {
     if (!ctx) { SET_ERR(ctx, "ctx is NULL"); return CNMF_EINVAL; }
     if (int rcd_ = ensure_dense(ctx)) return rcd_;
-    refresh_gemm3_mode();
+    refresh_gemm3_mode(ctx);
     int rc = validate_params(ctx, prm);
     if (rc) return rc;
     if (n < 0 || (n > 0 && !kk)) { SET_ERR(ctx, "bad restart list"); return CNMF_EINVAL; }
@@ -269,7 +270,12 @@ static int run_batch(cnmf_ctx* ctx, int n, const int32_t* kk, int init_mode, con
     }
     // (wide batches need the whole-tile matrix-pipe kernels and a matrix large enough to be worth them)
     const bool wide_can = gemm3_mode() != 0 && gemm3_enabled(ctx, 512);
-    const bool wide_auto = wide_can && (int64_t)ctx->N_pad * ctx->G_pad >= (1ll << 24);
+    // round 6: a SMALL matrix (BASELINE config 2: 2 700 x 2 000) is launch-latency-bound -- an iteration costs its six
+    // launches whatever the width -- so a job of >= 512 columns also runs wide there (C2: 1 000 columns in one batch instead
+    // of four 256-column rounds, 17 -> 8 ms per job); CNMF_WIDE_SMALL=0: the round-5 rule (A/B)
+    const char* ws_ = ctx_getenv(ctx, "CNMF_WIDE_SMALL");
+    const bool wide_small = total_k >= 512 && !(ws_ && atoi(ws_) == 0);
+    const bool wide_auto = wide_can && ((int64_t)ctx->N_pad * ctx->G_pad >= (1ll << 24) || wide_small);
     int KC = pick_kc(ctx, total_k, max_k, prm->kc_max, (prm->kc_max > 256 || ctx_getenv(ctx, "CNMF_KC")) ? wide_can : wide_auto);
     // 65..128 columns of a count-structured matrix: the 256-column integer-plane kernels (half empty) are still
     // faster than 128 columns on the f32 pipe

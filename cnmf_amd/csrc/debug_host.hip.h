@@ -97,7 +97,7 @@ extern "C" int cnmf_debug_gemm3(cnmf_ctx* ctx, const float* A, const float* B, f
 {
     if (!ctx || !A || !B || !C) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
     if (KC % 256 || K % 16 || J < 1 || nsplit < 1) { SET_ERR(ctx, "debug_gemm3 needs KC %% 256 == 0, K %% 16 == 0"); return CNMF_EINVAL; }
-    refresh_gemm3_mode();
+    refresh_gemm3_mode(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int Jp = round_up(J, gemm3_jw()), Kb = K / 16;

@@ -25,6 +25,11 @@ static hipError_t launch_gemm_t(hipStream_t st, const float* A, int lda, const f
     return hipGetLastError();
 }
 
+// A/B knobs of the launch planning, read ONCE per process (they are not part of the per-context snapshot: cnmf_reload_env
+// does not refresh them -- documented as process-lifetime in include/cnmf_hip.h)
+static bool no_streamk_env() { static const bool v = getenv("CNMF_NO_STREAMK") != nullptr; return v; }
+static const bool s_mtw2 = getenv("CNMF_S_MTW2") != nullptr;
+
 template <bool NN>
 static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int lda, const float* B,
                               int ldb, float* C, int ldc, long long cstride, int KC, int Ktot,
@@ -37,7 +42,7 @@ static hipError_t launch_gemm(hipStream_t st, int variant, const float* A, int l
     if (variant == 3 && KC < 64) variant = 2;
     switch (variant) {
         case 1:  // S: 4 waves x (MTW tiles of 32 comps), 32 j
-            if (KC % 256 == 0 && KC >= 256 && getenv("CNMF_S_MTW2")) GO(2, 4, 1);
+            if (KC % 256 == 0 && KC >= 256 && s_mtw2) GO(2, 4, 1);
             GO(1, 4, 1);
         case 3:  // 2x2
             if (KC % 128 == 0) GO(2, 2, 2);
@@ -145,7 +150,7 @@ struct StreamK {
 static StreamK plan_streamk(int KC, int N_pad, int G_pad, int n_wg_slots)
 {
     StreamK sk;
-    if (KC % 128 != 0 || getenv("CNMF_NO_STREAMK")) return sk;
+    if (KC % 128 != 0 || no_streamk_env()) return sk;
     sk.MG = KC / sk.mw;
     sk.T = sk.MG * (N_pad / 128);
     sk.nk = G_pad / BK;                                    // stages per tile, as the kernel counts them
@@ -204,13 +209,13 @@ static hipError_t launch_split3(hipStream_t st, const float* src, int ld, int ro
 // ping-pong workgroup per CU; 3 (default) = 2, plus the count-structured path (one integer plane for X, 3 MFMAs
 // per product on 256 x 256 tiles) whenever the resident matrix has that structure; 4 (default) = 3 on the f16 matrix
 // pipe (kernels_gemm2h.hip.h): counts <= 2048 in one f16 plane, the factor as two f16 planes with a per-row exponent,
-// 2 MFMAs per product.  Read on every call so that tests can switch it.
+// 2 MFMAs per product.  Read at every call from the context's snapshot (cnmf_reload_env re-reads it): tests switch it.
 // (Tried and dropped, all within 3 % of variant 2 at the 50k x 2000 shape: the same ping-pong with register
 //  staging; 256 x 256 tiles with the two wave groups half a block apart (2/3 of the DMA bytes per flop).)
 static thread_local int g_gemm3_mode = CNMF_GEMM3_DEFAULT;
-static void refresh_gemm3_mode()            // at every API entry that launches GEMMs (not inside the hot loop)
-{
-    const char* e = getenv("CNMF_GEMM3");
+static void refresh_gemm3_mode(const cnmf_ctx* ctx)   // at every API entry that launches GEMMs (not inside the hot loop): from the
+{                                                      // context's snapshot of the environment, like every per-call switch
+    const char* e = ctx_getenv(ctx, "CNMF_GEMM3");
     const int mode = e ? atoi(e) : CNMF_GEMM3_DEFAULT;
     g_gemm3_mode = (mode < 0 || mode > 4) ? CNMF_GEMM3_DEFAULT : mode;
 }
@@ -270,7 +275,7 @@ static StreamK3 plan_streamk3(int KC, int N_pad, int G_pad, int n_wg_slots, int 
     sk.T = sk.MG * (N_pad / jw);
     sk.Kb = G_pad / (G3_BK * unit);
     sk.P = n_wg_slots;
-    if (sk.T < sk.P / 2 + sk.P / 4 || sk.P > 2 * sk.T || getenv("CNMF_NO_STREAMK")) return sk;   // few tiles: K split + reduce instead
+    if (sk.T < sk.P / 2 + sk.P / 4 || sk.P > 2 * sk.T || no_streamk_env()) return sk;   // few tiles: K split + reduce instead
     sk.on = true;
     sk.flags.assign(sk.T, 0);
     const long long U = (long long)sk.T * sk.Kb;

@@ -185,10 +185,21 @@ static int mu_sparse_prepare(cnmf_ctx* ctx, int KP, bool* use)
     const int mode = ev ? atoi(ev) : -1;
     if (mode == 0 || (KP != 16 && KP != 32)) return CNMF_OK;
     const int N = (int)ctx->N, G = (int)ctx->G, idx = KP == 16 ? 0 : 1, BS = SP_LDS_BYTES / (KP * 4);
-    int rc = ensure_csr(ctx);                                   // (kept from the CSR upload, or two passes over the dense image)
-    if (rc == CNMF_ENOMEM && mode != 1) return CNMF_OK;
-    if (rc) return rc;
-    ctx->x_nnz = ctx->csr_nnz;
+    // how many entries are stored?  From the compressed rows when the matrix came as CSR; a dense upload is only COUNTED here
+    // (N + 1 counters) -- its compressed rows (12 B per entry) are built below, once the density and memory rules have chosen
+    // this path, and not at all when they send the call back to the dense kernels (round-5 advice)
+    int rc = CNMF_OK;
+    if (ctx->csr_ptr) ctx->x_nnz = ctx->csr_nnz;
+    else if (ctx->x_nnz < 0) {
+        long long* cnt = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&cnt, ((size_t)N + 1) * sizeof(long long)));
+        csr_count_dense_kernel<<<(N + 3) / 4, 256, 0, ctx->stream>>>(ctx->X, ctx->G_pad, N, G, cnt);
+        long long nnz = 0;
+        rc = hipGetLastError() == hipSuccess ? csr_scan_to_ptr(ctx, cnt, (size_t)N, &nnz) : CNMF_EHIP;
+        hipFree(cnt);
+        if (rc) return rc;
+        ctx->x_nnz = nnz;
+    }
     if (mode != 1 && (double)ctx->x_nnz > 0.25 * (double)N * (double)G) return CNMF_OK;
     if (!ctx->spA[idx].ent || !ctx->spB[idx].ent) {
         // the partial numerators of a half-step whose other side needs several blocks ([blocks][own rows][KP] per slot), the
@@ -203,6 +214,9 @@ static int mu_sparse_prepare(cnmf_ctx* ctx, int KP, bool* use)
             return CNMF_OK;
         }
     }
+    rc = ensure_csr(ctx);                                       // (kept from the CSR upload, or two passes over the dense image)
+    if (rc == CNMF_ENOMEM && mode != 1) return CNMF_OK;
+    if (rc) return rc;
     if (!ctx->spA[idx].ent) rc = sp_build_image(ctx, ctx->csr_ptr, ctx->csr_idx, ctx->csr_val, N, G, BS, ctx->spA[idx]);
     if (!rc && !ctx->spB[idx].ent) {
         rc = ensure_csc(ctx);

@@ -28,12 +28,19 @@ constexpr double MU_EPS32 = 1.1920928955078125e-07;        // scikit-learn's EPS
 // x'_ij = x_ij / coldiv[j], coldiv[j] == 0 drops column j (the column subset of the final usage refit);
 // W: [nrows][KP] in / out;  hsum: [KP] = sum_j Ht[j][c] over the columns that count;
 // err_part[row] = sum_{x' > eps} (x' log(x' / max(wh, eps)) - x') + sum_c w_c hsum_c   after the last iteration
-template <int KP>
+// BETA = 0 (Itakura-Saito, round 6): scikit-learn refuses beta_loss <= 0 on a matrix that contains a zero (_nmf.py:1679-1684),
+// so every entry of the walked matrix is a STORED entry and the same walk covers the dense update
+//     w_i <- w_i * sqrt( (sum_j x_ij / s_ij^2 h_j) / (sum_j 1 / s_ij h_j + l1 + l2 w_i) ),   s_ij = max(w_i . h_j, eps32)
+// (`_multiplicative_update_w` :575-631 with gamma = 1 / (2 - beta) = 1/2, :848-851; W < eps64 -> 0, :858-860); a dropped
+// column (coldiv == 0) has x' = 0 and h = 0 and adds nothing to either sum.  Divergence: sum (x / s - log(x / s)) - rows x
+// columns (`_beta_divergence` :158-161; ncount = the column count of the matrix meant).
+template <int KP, int BETA = 1>
 __global__ __launch_bounds__(256) void mu_refit_f64_kernel(const long long* __restrict__ ptr, const int* __restrict__ idx,
                                                            const float* __restrict__ val, int nrows,
                                                            const double* __restrict__ Ht, const double* __restrict__ coldiv,
                                                            double* __restrict__ W, const double* __restrict__ hsum,
-                                                           double l1, double l2, int n_inner, double* __restrict__ err_part)
+                                                           double l1, double l2, int n_inner, double* __restrict__ err_part,
+                                                           double ncount = 0.0)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nrows) return;
@@ -45,6 +52,7 @@ __global__ __launch_bounds__(256) void mu_refit_f64_kernel(const long long* __re
         double acc[KP];
 #pragma unroll
         for (int c = 0; c < KP; ++c) acc[c] = 0.0;
+        if constexpr (BETA == 1) {
         for (long long p = b + lane; p < e; p += 64) {
             const int j = idx[p];
             double x = (double)val[p];
@@ -78,6 +86,36 @@ __global__ __launch_bounds__(256) void mu_refit_f64_kernel(const long long* __re
             if (den == 0.0) den = MU_EPS32;
             w[c] *= a / den;
         }
+        } else {
+        double dacc[KP];
+#pragma unroll
+        for (int c = 0; c < KP; ++c) dacc[c] = 0.0;
+        for (long long p = b + lane; p < e; p += 64) {
+            const int j = idx[p];
+            double x = (double)val[p];
+            if (coldiv) { const double d = coldiv[j]; x = d != 0.0 ? x / d : 0.0; }
+            const double* h = Ht + (size_t)j * KP;
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < KP; ++c) s += w[c] * h[c];
+            s = fmax(s, MU_EPS32);
+            const double r = 1.0 / s;               // numerator: WH ** -1, ** 2, * X (_nmf.py:590-595); denominator: WH ** (beta - 1) (:618)
+            const double q = (r * r) * x;
+#pragma unroll
+            for (int c = 0; c < KP; ++c) { const double hv = h[c]; acc[c] += q * hv; dacc[c] += r * hv; }
+        }
+#pragma unroll
+        for (int c = 0; c < KP; ++c) {
+            double a = acc[c], d = dacc[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); d += __shfl_xor(d, o, 64); }
+            double den = d + l1 + l2 * w[c];
+            if (den == 0.0) den = MU_EPS32;
+            double nw = w[c] * sqrt(a / den);
+            if (nw < 2.220446049250313e-16) nw = 0.0;
+            w[c] = nw;
+        }
+        }
     }
     if (n_inner > 0 && lane == 0) {
 #pragma unroll
@@ -94,15 +132,20 @@ __global__ __launch_bounds__(256) void mu_refit_f64_kernel(const long long* __re
             double s = 0.0;
 #pragma unroll
             for (int c = 0; c < KP; ++c) s += w[c] * h[c];
-            r += x * log(x / fmax(s, MU_EPS32)) - x;
+            if constexpr (BETA == 1) r += x * log(x / fmax(s, MU_EPS32)) - x;
+            else { const double dv = x / fmax(s, MU_EPS32); r += dv - log(dv); }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
         if (lane == 0) {
-            double swh = 0.0;
+            if constexpr (BETA == 1) {
+                double swh = 0.0;
 #pragma unroll
-            for (int c = 0; c < KP; ++c) swh += w[c] * hsum[c];
-            err_part[row] = r + swh;
+                for (int c = 0; c < KP; ++c) swh += w[c] * hsum[c];
+                err_part[row] = r + swh;
+            } else {
+                err_part[row] = r - ncount;          // - prod(X.shape), one row's share
+            }
         }
     }
 }
@@ -133,11 +176,12 @@ __global__ __launch_bounds__(256) void mu_refit_fill_kernel(double* __restrict__
 // side 0: rows = cells (H is k x n_genes); side 1: rows = genes of the resident matrix, i.e. the problem on X^T (H is
 // k x n_cells).  W_out: [rows][k] float64.  w_init: scikit-learn's avg = sqrt(X.mean() / k) of the matrix the caller MEANS
 // (with coldiv: of the divided column subset).  prm: tol, max_iter, l1_reg_W, l2_reg_W.
-extern "C" int cnmf_mu_refit_f64(cnmf_ctx* ctx, int side, int k, const double* H, const double* coldiv, double w_init,
+extern "C" int cnmf_mu_refit_f64(cnmf_ctx* ctx, int side, int beta, int k, const double* H, const double* coldiv, double w_init,
                                  const cnmf_cd_params* prm, double* W_out, int32_t* n_iter_out, double* err_out)
 {
     using namespace cnmf;
     if (!ctx || !H || !prm || !W_out) { SET_ERR(ctx, "null argument"); return CNMF_EINVAL; }
+    if (beta != 0 && beta != 1) { SET_ERR(ctx, "beta must be 1 (Kullback-Leibler) or 0 (Itakura-Saito)"); return CNMF_EINVAL; }
     if (!ctx->X && !ctx->csr_ptr) { SET_ERR(ctx, "cnmf_set_matrix has not been called"); return CNMF_ESTATE; }
     if (k < 1 || k > CNMF_MU_KMAX) { SET_ERR(ctx, "rank %d outside 1..%d (multiplicative updates)", k, CNMF_MU_KMAX); return CNMF_EUNSUPPORTED; }
     if (side != 0 && side != 1) { SET_ERR(ctx, "side must be 0 (rows = cells) or 1 (rows = genes)"); return CNMF_EINVAL; }
@@ -150,6 +194,17 @@ extern "C" int cnmf_mu_refit_f64(cnmf_ctx* ctx, int side, int k, const double* H
     const int* idx = side == 0 ? ctx->csr_idx : ctx->csc_idx;
     const float* val = side == 0 ? ctx->csr_val : ctx->csc_val;
     const int KP = k <= 8 ? 8 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64));
+    if (beta == 0) {
+        // scikit-learn's own refusal (_nmf.py:1679-1684): every entry must be positive, i.e. every entry is stored
+        long long nnz = 0;
+        HIP_TRY(ctx, hipMemcpy(&nnz, ptr + nrows, sizeof(long long), hipMemcpyDeviceToHost));
+        if (nnz != (long long)nrows * ncols) {
+            SET_ERR(ctx, "When beta_loss <= 0 and X contains zeros, the solver may diverge. Please add small values to X, or use a positive beta_loss.");
+            return CNMF_EINVAL;
+        }
+    }
+    double ncount = 0.0;                            // columns of the matrix meant (Itakura-Saito divergence: - prod(X.shape))
+    for (int j = 0; j < ncols; ++j) ncount += (coldiv && coldiv[j] == 0.0) ? 0.0 : 1.0;
     // the fixed factor, one row per column of the walked matrix; its row sums over the columns that count
     std::vector<double> ht((size_t)ncols * KP, 0.0), hsum(KP, 0.0);
     for (int c = 0; c < k; ++c) {
@@ -180,12 +235,24 @@ extern "C" int cnmf_mu_refit_f64(cnmf_ctx* ctx, int side, int k, const double* H
     const double l1 = prm->l1_reg_W, l2 = prm->l2_reg_W;
     auto step = [&](int n_inner, double* err) -> int {
         const unsigned grid = (unsigned)((nrows + 3) / 4);
-        switch (KP) {
-            case 8:  mu_refit_f64_kernel<8><<<grid, 256, 0, st>>>(ptr, idx, val, nrows, dHt, dDiv, dW, dHs, l1, l2, n_inner, err ? dPart : nullptr); break;
-            case 16: mu_refit_f64_kernel<16><<<grid, 256, 0, st>>>(ptr, idx, val, nrows, dHt, dDiv, dW, dHs, l1, l2, n_inner, err ? dPart : nullptr); break;
-            case 32: mu_refit_f64_kernel<32><<<grid, 256, 0, st>>>(ptr, idx, val, nrows, dHt, dDiv, dW, dHs, l1, l2, n_inner, err ? dPart : nullptr); break;
-            default: mu_refit_f64_kernel<64><<<grid, 256, 0, st>>>(ptr, idx, val, nrows, dHt, dDiv, dW, dHs, l1, l2, n_inner, err ? dPart : nullptr); break;
+#define CNMF_MU_REFIT_LAUNCH(KPV, BV) mu_refit_f64_kernel<KPV, BV><<<grid, 256, 0, st>>>(ptr, idx, val, nrows, dHt, dDiv, dW, dHs, l1, l2, \
+                                                                                     n_inner, err ? dPart : nullptr, ncount)
+        if (beta == 1) {
+            switch (KP) {
+                case 8:  CNMF_MU_REFIT_LAUNCH(8, 1); break;
+                case 16: CNMF_MU_REFIT_LAUNCH(16, 1); break;
+                case 32: CNMF_MU_REFIT_LAUNCH(32, 1); break;
+                default: CNMF_MU_REFIT_LAUNCH(64, 1); break;
+            }
+        } else {
+            switch (KP) {
+                case 8:  CNMF_MU_REFIT_LAUNCH(8, 0); break;
+                case 16: CNMF_MU_REFIT_LAUNCH(16, 0); break;
+                case 32: CNMF_MU_REFIT_LAUNCH(32, 0); break;
+                default: CNMF_MU_REFIT_LAUNCH(64, 0); break;
+            }
         }
+#undef CNMF_MU_REFIT_LAUNCH
         HIP_TRY(ctx, hipGetLastError());
         if (err) {
             double res = 0.0;

@@ -91,6 +91,7 @@ class Engine:
         self.shape = None
         self._x_mean, self._x_mean_src = None, None
         self.x_dtype = None
+        self.x_has_zero = False            # (scikit-learn refuses beta_loss <= 0 on a matrix that contains a zero)
         self.last_stats = None
         self.store_gen = 0                 # generation of the resident spectra store (bumped by spectra_reset)
         self.last_store_offsets = None     # first store row of every restart of the last resident batch
@@ -172,9 +173,16 @@ class Engine:
             # scipy's sparse mean (what scikit-learn's init='random' divides by) copies, divides and sums the whole matrix:
             # 0.17 s at 50 000 x 2 000 -- taken only when a restart asks for it (the TPM upload of consensus() never does)
             self._x_mean, self._x_mean_src = None, X
+            self.x_has_zero = bool(X.nnz < X.shape[0] * X.shape[1] or (data.size and data.min() == 0))
+            vals = np.ascontiguousarray(data, dtype=np.float32)
+            if vals.size and not vals.all():
+                # a STORED zero (explicit, or a float64 value that underflows in float32) would make the library treat the
+                # arrays as non-canonical and form the dense image of the whole matrix (round-5 advice): compact them here
+                Xc = sp.csr_matrix((vals, X.indices, X.indptr), shape=X.shape)
+                Xc.eliminate_zeros()
+                X, vals = Xc, np.ascontiguousarray(Xc.data, dtype=np.float32)
             indptr = np.ascontiguousarray(X.indptr, dtype=np.int32)
             indices = np.ascontiguousarray(X.indices, dtype=np.int32)
-            vals = np.ascontiguousarray(data, dtype=np.float32)
             ip = C.POINTER(C.c_int32)
             self._check(self._lib.cnmf_set_matrix_csr(self._ctx, indptr.ctypes.data_as(ip),
                                                       indices.ctypes.data_as(ip), _fp(vals),
@@ -190,6 +198,7 @@ class Engine:
             if X.size and X.min() < 0:
                 raise ValueError("Negative values in data passed to NMF (input X)")
             self.x_dtype = X.dtype
+            self.x_has_zero = bool(X.size and X.min() == 0)
             self.x_mean = X.mean()                  # numpy scalar of X's dtype, like sklearn's X.mean()
             Xf = np.ascontiguousarray(X, dtype=np.float32)
             self._check(self._lib.cnmf_set_matrix(self._ctx, _fp(Xf), Xf.shape[0], Xf.shape[1]))
@@ -372,6 +381,7 @@ class Engine:
             raise RuntimeError("set_matrix() has not been called")
         if beta_loss not in self._BETA:
             raise NotImplementedError("beta_loss=%r is not implemented on the device" % (beta_loss,))
+        self._refuse_zeros(beta_loss)
         N, G = self.shape
         ks = np.ascontiguousarray(ks, dtype=np.int32).ravel()
         n = int(ks.size)
@@ -406,8 +416,8 @@ class Engine:
     def nnls_mu(self, H, beta_loss="kullback-leibler", tol=1e-4, max_iter=1000, alpha_W=0.0, l1_ratio=0.0,
                 warn=True):
         """Refit with fixed H and ``solver='mu'``: W starts from avg everywhere (sklearn _nmf.py:1229-1231).
-        Kullback-Leibler: the float64 refit on the stored entries (:meth:`mu_refit_f64`; result cast to float32 like the
-        other refits of this class); Itakura-Saito: the dense float32 matrix-pipe kernels."""
+        Both losses: the float64 refit on the stored entries (:meth:`mu_refit_f64`; result cast to float32 like the
+        other refits of this class)."""
         if self.shape is None:
             raise RuntimeError("set_matrix() has not been called")
         N, G = self.shape
@@ -418,31 +428,26 @@ class Engine:
             raise ValueError("Negative values in data passed to NMF (input H)")
         if H.max() == 0:
             raise ValueError("Array passed to NMF (input H) is full of zeros.")
-        if self._BETA[beta_loss] == 1:
-            W, n, _ = self.mu_refit_f64(H, tol=tol, max_iter=max_iter, alpha_W=alpha_W, l1_ratio=l1_ratio, warn=warn)
-            return W.astype(np.float32), n
-        k = int(H.shape[0])
-        ks = np.array([k], dtype=np.int32)
-        Hf = np.ascontiguousarray(H, dtype=np.float32)
-        avg = np.array([self.init_scale(k)], dtype=np.float64)
-        prm = self._params(tol, max_iter, alpha_W, 0.0, l1_ratio)
-        W = np.empty((N, k), dtype=np.float32)
-        n_iter = np.zeros(1, dtype=np.int32)
-        err = np.zeros(1, dtype=np.float64)
-        i32p, dblp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
-        self._check(self._lib.cnmf_nmf_mu_batch(self._ctx, 1, ks.ctypes.data_as(i32p), 0, None,
-                                                avg.ctypes.data_as(dblp), None, _fp(Hf), self._BETA[beta_loss], 0,
-                                                C.byref(prm), None, _fp(W), n_iter.ctypes.data_as(i32p),
-                                                err.ctypes.data_as(dblp)))
-        if warn and tol > 0 and n_iter[0] == max_iter:
-            warnings.warn("Maximum number of iterations %d reached. Increase it to improve convergence."
-                          % max_iter, ConvergenceWarning)
-        return W, int(n_iter[0])
+        W, n, _ = self.mu_refit_f64(H, tol=tol, max_iter=max_iter, alpha_W=alpha_W, l1_ratio=l1_ratio, warn=warn,
+                                    beta_loss=beta_loss)
+        return W.astype(np.float32), n
+
+    _ZERO_MSG = ("When beta_loss <= 0 and X contains zeros, the solver may diverge. Please add small values to X, or use a "
+                 "positive beta_loss.")
+
+    def _refuse_zeros(self, beta_loss):
+        """scikit-learn's own refusal (``_fit_transform``, _nmf.py:1679-1684): ``beta_loss <= 0`` on a matrix that contains a
+        zero raises ValueError -- what the reference's ``factorize`` / ``refit_usage`` do for every ordinary count matrix under
+        ``--beta-loss itakura-saito``."""
+        if self._BETA[beta_loss] <= 0 and self.x_has_zero:
+            raise ValueError(self._ZERO_MSG)
 
     def mu_refit_f64(self, H, transposed=False, col_divisor=None, w_init=None, tol=1e-4, max_iter=1000, alpha_W=0.0,
-                     l1_ratio=0.0, n_features=None, warn=True):
-        """``non_negative_factorization(X, H=H, update_H=False, solver='mu', beta_loss='kullback-leibler')`` in float64 on
+                     l1_ratio=0.0, n_features=None, warn=True, beta_loss="kullback-leibler"):
+        """``non_negative_factorization(X, H=H, update_H=False, solver='mu', beta_loss=...)`` in float64 on
         the stored entries of the resident matrix (cnmf_mu_refit_f64): returns ``(W float64, n_iter, err)``.
+        ``beta_loss='itakura-saito'`` (round 6): the matrix must be strictly positive (scikit-learn's rule), so every entry
+        is a stored entry.
 
         ``transposed=False``: X = the resident cells x genes matrix, ``H`` [k, n_genes], W [n_cells, k] (refit_usage,
         cnmf.py:776-802).  ``transposed=True``: the problem on X^T -- ``H`` [k, n_cells] (usages^T), W [n_genes, k]
@@ -453,6 +458,9 @@ class Engine:
         self._sync_env()
         if self.shape is None:
             raise RuntimeError("set_matrix() has not been called")
+        if beta_loss not in self._BETA:
+            raise NotImplementedError("beta_loss=%r is not implemented on the device" % (beta_loss,))
+        self._refuse_zeros(beta_loss)
         N, G = self.shape
         rows, cols = (G, N) if transposed else (N, G)
         H = np.ascontiguousarray(H, dtype=np.float64)
@@ -481,7 +489,7 @@ class Engine:
         W = np.empty((rows, k), dtype=np.float64)
         n_iter = C.c_int32(0)
         err = C.c_double(0.0)
-        self._check(self._lib.cnmf_mu_refit_f64(self._ctx, 1 if transposed else 0, k, H.ctypes.data_as(dblp),
+        self._check(self._lib.cnmf_mu_refit_f64(self._ctx, 1 if transposed else 0, self._BETA[beta_loss], k, H.ctypes.data_as(dblp),
                                                 div.ctypes.data_as(dblp) if div is not None else None, float(w_init),
                                                 C.byref(prm), W.ctypes.data_as(dblp), C.byref(n_iter), C.byref(err)))
         if warn and tol > 0 and n_iter.value == max_iter:

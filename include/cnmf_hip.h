@@ -88,7 +88,11 @@ void        cnmf_destroy(cnmf_ctx* ctx);
 const char* cnmf_last_error(const cnmf_ctx* ctx);
 /* The CNMF_* environment variables (INTEGRATION.md "Runtime switches") that steer per-call host decisions are read ONCE,
  * when the context is created, into the context; cnmf_reload_env re-reads them (A/B tools, tests).  A knob therefore
- * cannot change between two calls on one context unless the caller asks for it.                                   */
+ * cannot change between two calls on one context unless the caller asks for it.  In the snapshot: the GEMM operand
+ * scheme (CNMF_GEMM3), the batch width (CNMF_KC, CNMF_KC_LIMIT, CNMF_NO_WIDE, CNMF_WIDE_SMALL), CNMF_LAG, the consensus and
+ * multiplicative-update switches.  PROCESS-LIFETIME (read once per process, NOT refreshed by cnmf_reload_env): the A/B
+ * knobs of the kernel launch planning and instruction streams -- CNMF_NO_STREAMK, CNMF_S_MTW2, CNMF_G2_*, CNMF_WG_SLOTS,
+ * CNMF_FUSE_W, CNMF_G2G, CNMF_SPIN_QUERY, CNMF_NO_COUNTS -- set them before the library is loaded.                    */
 int cnmf_reload_env(cnmf_ctx* ctx);
 const char* cnmf_version(void);
 
@@ -102,10 +106,12 @@ int cnmf_set_matrix(cnmf_ctx* ctx, const float* X, int64_t n_cells, int64_t n_ge
  * multiplies the exact integer planes; enabled = 0 keeps every matrix on the general float32-operand path.      */
 int cnmf_set_count_detection(cnmf_ctx* ctx, int enabled);
 /* CSR input (scipy.sparse.csr_matrix of float32, int32 indices/indptr) -- the reference hands `norm_counts.X` / `tpm.X`
- * to scikit-learn as stored (cnmf.py:726, 873, 950).  The dense image is formed on the device (duplicates summed like
- * .toarray()); round 5: the arrays also STAY on the device and serve the paths that walk the stored entries
- * (cnmf_mu_refit_f64, the non-zero images of cnmf_nmf_mu_batch) -- as uploaded when every row lists strictly increasing
- * columns without stored zeros (scipy's canonical format), otherwise rebuilt from the dense image on first use.
+ * to scikit-learn as stored (cnmf.py:726, 873, 950).  The arrays STAY on the device and serve the paths that walk the
+ * stored entries (cnmf_mu_refit_f64, the non-zero images of cnmf_nmf_mu_batch) -- as uploaded when every row lists
+ * strictly increasing columns without stored zeros (scipy's canonical format after eliminate_zeros(); the Python
+ * wrapper compacts stored zeros before the call).  The dense float32 image is formed on the device ONLY when a path
+ * that multiplies the dense matrix asks for it (coordinate descent, NNLS, Itakura-Saito restarts; duplicates summed like
+ * .toarray()); arrays that are not canonical form it at once and the compressed rows are rebuilt from it on first use.
  * A column index outside [0, n_genes): CNMF_EINVAL.                                                              */
 int cnmf_set_matrix_csr(cnmf_ctx* ctx, const int32_t* indptr, const int32_t* indices,
                         const float* data, int64_t n_cells, int64_t n_genes);
@@ -199,10 +205,14 @@ int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n_restarts, const int32_t* k, int init_
                       int beta, int update_H, const cnmf_cd_params* params,
                       float* H_out, float* W_out, int32_t* n_iter_out, double* err_out);
 
-/* Kullback-Leibler refit in FLOAT64 on the stored entries (round 5, mu_refit_host.hip.h): the three
- *   non_negative_factorization(X, H=..., update_H=False, solver='mu', beta_loss='kullback-leibler')
- * calls of a consensus run with the Kullback-Leibler loss (cnmf.py:776-820 via :920, :952, :972) on float64 matrices --
+/* Multiplicative-update refit in FLOAT64 on the stored entries (round 5, mu_refit_host.hip.h): the three
+ *   non_negative_factorization(X, H=..., update_H=False, solver='mu', beta_loss=...)
+ * calls of a consensus run with a beta loss (cnmf.py:776-820 via :920, :952, :972) on float64 matrices --
  * scikit-learn's `_fit_multiplicative_update` with H fixed (sklearn:_nmf.py:731-893, :526-631, :84-194).
+ *   beta 1: Kullback-Leibler (only the stored entries count, like scikit-learn on scipy.sparse input);
+ *   beta 0: Itakura-Saito (round 6).  scikit-learn refuses beta_loss <= 0 on a matrix that contains a zero
+ *           (sklearn:_nmf.py:1679-1684), so must the caller's matrix be strictly positive: every entry is then a stored entry
+ *           and the same walk is the dense update.  A matrix with a zero: CNMF_EINVAL with scikit-learn's message.
  *   side 0: rows = cells   (refit_usage):   H [k][n_genes],  W_out [n_cells][k]
  *   side 1: rows = GENES   (refit_spectra = the problem on X^T, cnmf.py:820): H = usages^T [k][n_cells], W_out [n_genes][k];
  *           walks the compressed rows of X^T built on the device -- no todense(), no transposed upload.
@@ -211,7 +221,7 @@ int cnmf_nmf_mu_batch(cnmf_ctx* ctx, int n_restarts, const int32_t* k, int init_
  * w_init: W starts from this value everywhere (sklearn:_nmf.py:1229-1231: sqrt(X.mean() / k) of the matrix meant).
  * params: tol, max_iter, l1_reg_W, l2_reg_W.  n_iter_out as scikit-learn counts (a multiple of 10 or max_iter),
  * err_out = sqrt(2 x divergence) of the final factors.  Ranks above CNMF_MU_KMAX: CNMF_EUNSUPPORTED.             */
-int cnmf_mu_refit_f64(cnmf_ctx* ctx, int side, int k, const double* H, const double* coldiv, double w_init,
+int cnmf_mu_refit_f64(cnmf_ctx* ctx, int side, int beta, int k, const double* H, const double* coldiv, double w_init,
                       const cnmf_cd_params* params, double* W_out, int32_t* n_iter_out, double* err_out);
 
 /* ---- NNLS refit ---------------------------------------------------------------------

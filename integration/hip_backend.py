@@ -102,18 +102,14 @@ class cNMF(_ref.cNMF):
             if H.dtype != xdt:
                 raise TypeError("H should have the same dtype as X. Got H.dtype = {}.".format(H.dtype))
             # (scikit-learn solves in X's dtype: float64 matrices get the float64 device refit)
-            if transposed and mu and kw["beta_loss"] in ("kullback-leibler", 1):
-                W, _, _ = eng.mu_refit_f64(H, transposed=True, **common)       # rows = genes, on the column-compressed image
-            elif transposed and not mu:
+            if mu:
+                # float64 on the stored entries of the matrix (cnmf_mu_refit_f64), like scikit-learn on float64 input; the
+                # transposed problem walks the column-compressed image (rows = genes).  Both beta losses: an Itakura-Saito
+                # run's matrices are strictly positive (scikit-learn refuses anything else), every entry is stored
+                W, _, _ = eng.mu_refit_f64(H, transposed=transposed, beta_loss=kw["beta_loss"], **common)
+            elif transposed:
                 Hs, _ = eng.nnls_spectra(np.ascontiguousarray(H.T), **common)  # k x genes on the resident matrix
                 W = np.ascontiguousarray(Hs.T)
-            elif transposed:
-                raise NotImplementedError("beta_loss=%r refit of the spectra is not implemented on the device" % (kw["beta_loss"],))
-            elif mu and kw["beta_loss"] in ("kullback-leibler", 1):
-                # float64 on the stored entries of the matrix (cnmf_mu_refit_f64), like scikit-learn on float64 input
-                W, _, _ = eng.mu_refit_f64(H, **common)
-            elif mu:
-                W, _ = eng.nnls_mu(H, beta_loss=kw["beta_loss"], **common)
             else:
                 W, _ = (eng.nnls_f64 if xdt == np.float64 else eng.nnls)(H, **common)
             return H, W.astype(xdt, copy=False)

@@ -24,8 +24,10 @@ def test_repeated_batches_are_bit_identical(engine):
 
     def run():
         H, W, n, err = engine.nmf_mu_batch(ks, seeds=seeds, max_iter=30, return_W=True, warn=False)
+        engine.set_matrix(X + np.float32(1e-3))     # (scikit-learn refuses beta_loss <= 0 on a matrix with zeros; so does the engine)
         Hi, Wi, ni, _ = engine.nmf_mu_batch(ks[:6], seeds=seeds[:6], beta_loss="itakura-saito", max_iter=20,
                                             return_W=True, warn=False)
+        engine.set_matrix(X)
         Hc, _, nc, _ = engine.nmf_batch(ks * 4, seeds=list(range(500, 500 + 4 * len(ks))), max_iter=50, warn=False)
         return [np.concatenate([a.ravel() for a in part]) for part in (H, W, Hi, Wi, Hc)] + [n.copy(), ni.copy(), nc.copy(), np.asarray(err)]
 

@@ -323,7 +323,9 @@ def test_sparse_upload_stays_sparse_on_the_kl_route(engine, monkeypatch):
     np.testing.assert_array_equal(Hc_s[0], Hc_d[0])
     np.testing.assert_array_equal(engine.get_matrix(), X)
     # Itakura-Saito touches every element: the dense kernels (and their transposed copy) on demand as well
-    engine.set_matrix(Xs)
+    # (a strictly positive matrix -- scikit-learn's rule for beta_loss <= 0, mirrored by the engine -- handed over as CSR)
+    engine.set_matrix(sp.csr_matrix(X + np.float32(1.0)))
+    assert not engine.matrix_images()["dense"]
     engine.nmf_mu_batch([5], seeds=[3], beta_loss="itakura-saito", max_iter=10, warn=False)
     im = engine.matrix_images()
     assert im["dense"] and im["dense_transpose"], im
@@ -449,3 +451,31 @@ def test_mirror_class_on_sparse_normalised_counts(engine, tmp_path, beta_loss):
     assert ((a[2].values - b[2].values) ** 2).sum() < TOLERANCE
     assert np.abs(a[3].values - b[3].values).max() <= 2e-3 * np.abs(b[3].values).max()
     assert np.abs(a[4] - b[4]).max() <= 2e-3 * np.abs(b[4]).max() and np.abs(a[5] - b[5]).max() < 5e-3
+
+
+def test_stored_zeros_and_dense_matrices_do_not_cost_extra_images(engine):
+    """Round-5 advice (low): (i) a CSR upload with a STORED zero (explicit, or a float64 value that underflows in float32)
+    is compacted by the wrapper and stays on the no-dense-image route instead of silently forming the N x G image;
+    (ii) a dense upload that the density rule sends back to the dense kernels is only COUNTED -- no compressed rows
+    (12 B per entry) are left behind."""
+    X = _counts(1500, 600, 4.6, seed=21)                    # ~10 % non-zero
+    Xs = sp.csr_matrix(X.astype(np.float64))
+    Xz = Xs.copy()
+    Xz.data[::17] = 1e-60                                   # underflows to 0 in float32
+    Xz.data[5] = 0.0                                        # an explicit stored zero
+    engine.set_matrix(Xz)
+    im = engine.matrix_images()
+    assert im["csr"] and not im["dense"], im
+    H, _, n, _ = engine.nmf_mu_batch([5], seeds=[3], max_iter=30, warn=False)
+    assert not engine.matrix_images()["dense"]
+    Xc = Xz.copy(); Xc.data = Xc.data.astype(np.float32).astype(np.float64); Xc.eliminate_zeros()
+    engine.set_matrix(Xc)
+    H2, _, n2, _ = engine.nmf_mu_batch([5], seeds=[3], max_iter=30, warn=False)
+    assert list(n) == list(n2) and np.array_equal(H[0], H2[0])
+    # (ii) mostly non-zero, dense upload: the dense kernels run, nothing compressed is kept
+    Xd = synth.make_config("C1", dtype=np.float32, n_cells=600)
+    assert (Xd != 0).mean() > 0.25
+    engine.set_matrix(Xd)
+    engine.nmf_mu_batch([5], seeds=[3], max_iter=20, warn=False)
+    im = engine.matrix_images()
+    assert im["dense"] and not im["csr"] and not im["csr_of_transpose"], im

@@ -98,10 +98,13 @@ def test_kl_path_selection_and_matrix_change(engine, monkeypatch):
     monkeypatch.setenv("CNMF_MU_SPARSE", "1")                                 # forced: allowed on any matrix
     H1, _, n1, _ = engine.nmf_mu_batch([5, 9], seeds=[3, 4], max_iter=40, warn=False)
     Hb, _, nb, _ = engine.nmf_mu_batch([40], seeds=[3], max_iter=20, warn=False)                 # rank 40: dense kernels
-    Hi, _, ni, _ = engine.nmf_mu_batch([5], seeds=[3], beta_loss="itakura-saito", max_iter=20, warn=False)
     monkeypatch.setenv("CNMF_MU_SPARSE", "0")
     Hb0, _, _, _ = engine.nmf_mu_batch([40], seeds=[3], max_iter=20, warn=False)
+    # Itakura-Saito needs a strictly positive matrix (scikit-learn's rule, mirrored by the engine)
+    engine.set_matrix(Xd + np.float32(1e-3))
     Hi0, _, _, _ = engine.nmf_mu_batch([5], seeds=[3], beta_loss="itakura-saito", max_iter=20, warn=False)
+    monkeypatch.setenv("CNMF_MU_SPARSE", "1")
+    Hi, _, ni, _ = engine.nmf_mu_batch([5], seeds=[3], beta_loss="itakura-saito", max_iter=20, warn=False)
     monkeypatch.delenv("CNMF_MU_SPARSE")
     for a, b in zip(H, H0):
         np.testing.assert_array_equal(a, b)

@@ -18,6 +18,7 @@ not exist:
 
 Run:  python tools/make_golden.py          (takes ~1 min; needs /root/reference)
       python tools/make_golden.py --beta-loss kullback-leibler      -> golden/ref_small_kl.npz
+      python tools/make_golden.py --beta-loss itakura-saito         -> golden/ref_small_is.npz   (round 6)
 """
 import os
 import shutil
@@ -42,13 +43,20 @@ def main(beta_loss="frobenius"):
 
     # round 5: the same pipeline under beta_loss='kullback-leibler' (solver 'mu' for the restarts AND for the three refits
     # of the consensus tail, cnmf.py:618-631) -> golden/ref_small_kl.npz
-    out_path = os.path.join(ROOT, "tests", "golden", "ref_small.npz" if beta_loss == "frobenius" else "ref_small_kl.npz")
+    out_path = os.path.join(ROOT, "tests", "golden", {"frobenius": "ref_small.npz", "kullback-leibler": "ref_small_kl.npz",
+                                                           "itakura-saito": "ref_small_is.npz"}[beta_loss])
     tmp = tempfile.mkdtemp(prefix="cnmf_golden_")
     try:
         # seeded synthetic counts: 240 cells x 400 genes, 5 programmes
         C, _ = synth.topic_counts(240, 400, 5, mu_lib=7.0, sigma_lib=0.3, seed=7)
         keep = C.sum(axis=0) > 0
         C = C[:, keep]
+        if beta_loss == "itakura-saito":
+            # scikit-learn REFUSES beta_loss <= 0 on a matrix that contains a zero (sklearn _nmf.py:1679-1684: "the solver
+            # may diverge"), i.e. the unmodified reference raises ValueError in factorize() for every ordinary count
+            # matrix under --beta-loss itakura-saito.  The only inputs that reach the solver are strictly positive ones:
+            # one pseudo-count everywhere.
+            C = C + 1
         counts = pd.DataFrame(C.astype(np.int64), index=["c%d" % i for i in range(C.shape[0])],
                               columns=["g%d" % j for j in range(C.shape[1])])
         counts_fn = os.path.join(tmp, "counts.df.npz")

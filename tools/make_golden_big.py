@@ -326,7 +326,7 @@ def make_c3_pipeline():
     for K, d in res.items():
         for name, v in d.items():
             if name == "merged":
-                v = v.astype(np.float32)               # the float64 restarts' spectra, for diagnostics (float32: size)
+                continue                               # (1.7 MB of per-restart spectra: not committed)
             out["k%d_%s" % (K, name)] = v
     if "float32" in dts:
         res32 = _c3pipe_consensus(X, led, "float32")
