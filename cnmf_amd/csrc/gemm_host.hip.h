@@ -213,11 +213,14 @@ static hipError_t launch_split3(hipStream_t st, const float* src, int ld, int ro
 // (Tried and dropped, all within 3 % of variant 2 at the 50k x 2000 shape: the same ping-pong with register
 //  staging; 256 x 256 tiles with the two wave groups half a block apart (2/3 of the DMA bytes per flop).)
 static thread_local int g_gemm3_mode = CNMF_GEMM3_DEFAULT;
+static thread_local int g_g2_gvar = 4;      // instruction stream of the general-matrix GEMMs (CNMF_G2_GVAR, refreshed below)
 static void refresh_gemm3_mode(const cnmf_ctx* ctx)   // at every API entry that launches GEMMs (not inside the hot loop): from the
 {                                                      // context's snapshot of the environment, like every per-call switch
     const char* e = ctx_getenv(ctx, "CNMF_GEMM3");
     const int mode = e ? atoi(e) : CNMF_GEMM3_DEFAULT;
     g_gemm3_mode = (mode < 0 || mode > 4) ? CNMF_GEMM3_DEFAULT : mode;
+    const char* gv = ctx_getenv(ctx, "CNMF_G2_GVAR");
+    g_g2_gvar = (gv && atoi(gv) == 0) ? 0 : 4;
 }
 static int gemm3_mode() { return g_gemm3_mode; }
 // (CNMF_WG_SLOTS: fewer persistent GEMM workgroups than CUs -- leaves whole CUs to the kernels of another stream)
@@ -408,6 +411,8 @@ static int g2_nsub()
 #ifndef CNMF_G2_VAR_DEFAULT
 #define CNMF_G2_VAR_DEFAULT 4
 #endif
+// general matrices (GEN): 4 = the spread instruction stream (round 6, default), 0 = the burst loop (A/B; same bits)
+static int g2_gvar() { return g_g2_gvar; }
 static int g2_var()
 {
     static const int v = getenv("CNMF_G2_VAR") ? atoi(getenv("CNMF_G2_VAR")) : CNMF_G2_VAR_DEFAULT;
@@ -452,9 +457,13 @@ static hipError_t launch_gemm2h(hipStream_t st, const unsigned char* A2, const u
     const bool part = (livemask & g2_full_mask(KC)) != g2_full_mask(KC);
     // general matrices (cscale != nullptr: X as two f16 planes) multiply three of the four plane pairs (GEN); CNMF_G2_GEN4=1: all four (A/B)
     static const bool gen4 = getenv("CNMF_G2_GEN4") != nullptr;
-    if (Bhi && cscale && !gen4)
-        return part ? launch_gemm2h_t<1, true, 0, true, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale, livemask)
-                    : launch_gemm2h_t<1, true, 0, false, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale);
+    if (Bhi && cscale && !gen4) {
+        if (g2_gvar() == 0)                 // (A/B: the burst loop of rounds 3-5; bit-identical results)
+            return part ? launch_gemm2h_t<1, true, 0, true, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale, livemask)
+                        : launch_gemm2h_t<1, true, 0, false, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale);
+        return part ? launch_gemm2h_t<1, true, 4, true, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale, livemask)
+                    : launch_gemm2h_t<1, true, 4, false, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale);
+    }
     if (Bhi) return part ? launch_gemm2h_t<1, true, 0, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale, livemask)
                          : launch_gemm2h_t<1, true>(st, A2, B1, Bhi, hiflag, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit, cscale);
     if (cscale) return hipErrorInvalidValue;              // a column scale exists only on the two-plane operand path
@@ -470,6 +479,7 @@ static hipError_t launch_gemm2h(hipStream_t st, const unsigned char* A2, const u
             default: return launch_gemm2h_t<2, false, 0>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
         }
     }
+    if (g2_var() >= 1) return launch_gemm2h_t<1, false, 4>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
     return launch_gemm2h_t<1, false>(st, A2, B1, nullptr, nullptr, rscale, Kb, C, ldc, cstride, KC, Jpad, nsplit);
 }
 static int gemm2h_nsub(bool hi, int Kb) { return (!hi && g2_nsub() == 2 && Kb % 2 == 0) ? 2 : 1; }
@@ -485,7 +495,12 @@ static hipError_t launch_gemm2h_streamk_t(hipStream_t st, const StreamK3& sk, co
     {
         if (hipError_t e_ = dyn_lds_optin((const void*)gemm2h_streamk_kernel<NSUB, HI, VAR, NTB, PART, GEN>, lds)) return e_;
     }
-    static const int xmap = getenv("CNMF_G2_XMAP") ? atoi(getenv("CNMF_G2_XMAP")) : 1;      // (0: A/B, the identity order)
+    // XCD mapping of the persistent workgroups (kernel comment).  Count path: every XCD inside ONE component group (1).  General
+    // path (GEN: both X planes, 410 MB at 50 000 x 2 000, re-streamed per component group): the identity order (0) -- the four
+    // groups of a row tile share it in one L2 -- measured +1.3 % (133.7 / 134.1 vs 131.9 / 132.4 restarts/s, round 6); the
+    // count path measured -2 % with it (round 3).  CNMF_G2_XMAP=0|1 forces either.
+    static const int xmap_env = getenv("CNMF_G2_XMAP") ? atoi(getenv("CNMF_G2_XMAP")) : -1;
+    const int xmap = xmap_env >= 0 ? xmap_env : (GEN ? 0 : 1);
     gemm2h_streamk_kernel<NSUB, HI, VAR, NTB, PART, GEN><<<sk.P, 512, lds, st>>>(A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, sk.MG, sk.T, xmap, cscale, livemask);
     return hipGetLastError();
 }
@@ -504,9 +519,14 @@ static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, cons
     const bool shared = sk.MG > 1 && !force_nt;
     static const bool gen4 = getenv("CNMF_G2_GEN4") != nullptr;
     if (Bhi && cscale && !gen4) {          // general matrices: three of the four plane pairs (GEN)
-        if (part) return launch_gemm2h_streamk_t<1, true, 0, false, true, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale, livemask);
-        return shared ? launch_gemm2h_streamk_t<1, true, 0, false, false, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale)
-                      : launch_gemm2h_streamk_t<1, true, 0, true, false, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale);
+        if (g2_gvar() == 0) {              // (A/B: the burst loop of rounds 3-5; bit-identical results)
+            if (part) return launch_gemm2h_streamk_t<1, true, 0, false, true, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale, livemask);
+            return shared ? launch_gemm2h_streamk_t<1, true, 0, false, false, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale)
+                          : launch_gemm2h_streamk_t<1, true, 0, true, false, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale);
+        }
+        if (part) return launch_gemm2h_streamk_t<1, true, 4, false, true, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale, livemask);
+        return shared ? launch_gemm2h_streamk_t<1, true, 4, false, false, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale)
+                      : launch_gemm2h_streamk_t<1, true, 4, true, false, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale);
     }
     if (Bhi) {
         if (part) return launch_gemm2h_streamk_t<1, true, 0, false, true>(st, sk, A2, B1, Bhi, hiflag, rscale, Kb, C0, C1, C2, ldc, cscale, livemask);
@@ -528,6 +548,9 @@ static hipError_t launch_gemm2h_streamk(hipStream_t st, const StreamK3& sk, cons
             default: return launch_gemm2h_streamk_t<2, false, 0>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
         }
     }
+    if (g2_var() >= 1)                     // (CNMF_G2_NSUB=1 A/B: the one-block spread stream on the count plane)
+        return shared ? launch_gemm2h_streamk_t<1, false, 4, false>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc)
+                      : launch_gemm2h_streamk_t<1, false, 4, true>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
     return launch_gemm2h_streamk_t<1, false>(st, sk, A2, B1, nullptr, nullptr, rscale, Kb, C0, C1, C2, ldc);
 }
 

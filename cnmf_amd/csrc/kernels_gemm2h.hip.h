@@ -575,6 +575,11 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
     f16x8 bq[NSUB][2], bh[NSUB][2], aq[NSUB][4][2];
     constexpr int AHEAD = IMGS - 1;                      // steps requested ahead of the one being multiplied
     constexpr bool SPREAD = VAR >= 1 && NSUB == 2 && !HI;
+    // round 6, general matrices (GEN: both X planes in every block, flags all set): the count kernels' spread stream for the
+    // one-block-per-step instantiation -- the four LDS-DMA pieces of step s + 3 ride between the MFMA groups instead of a
+    // burst behind the X barrier, the fragment reads come in two batches (8 + 4).  Same MFMA order per accumulator as the
+    // burst loop below: results are bit-identical (tests/test_gpu_nmf.py).
+    constexpr bool SPREADG = VAR >= 1 && NSUB == 1 && ((HI && GEN) || !HI);   // (!HI: the count plane alone, A/B via CNMF_G2_NSUB=1)
     constexpr bool PRIO = false;
     constexpr bool NOMFMA = VAR == 2, NODMA = VAR == 3 || VAR == 6 || VAR == 7, SPLITRD = VAR >= 4, ASMDMA = VAR == 5;
     constexpr bool NOREAD = VAR == 6 || VAR == 7;         // timing ablations: fragments read once / ... and no barriers
@@ -586,7 +591,71 @@ __device__ __forceinline__ void gemm2h_segment(const unsigned char* __restrict__
     // step 0 landed (everything issued after it may stay in flight)
     if (AHEAD > 2 && nst > 2) G2_WAIT_AHEAD(2) else if (nst > 1) G2_WAIT_AHEAD(1) else G2_WAIT_AHEAD(0)
     if (grp == 1) G3_RAW_BARRIER()
-    if constexpr (!SPREAD) {
+    if constexpr (SPREADG) {
+        static_assert(!SPREADG || (IMGS == 4 && NA == 2 && NB == 1), "one-block spread stream: four images, pieces A0 A1 B (Bhi)");
+#define G2G_PIECE(s_, i_)                                                                          \
+        {                                                                                          \
+            unsigned char* d_ = smem + ((s_) % IMGS) * IMG + wave * 1024;                          \
+            if ((i_) < NA)                                                                         \
+                __builtin_amdgcn_global_load_lds(G3_AS1(abase + (size_t)(s_) * G2_A + (i_) * 8192), \
+                                                 G3_AS3(d_ + (i_) * 8192), 16, 0, 0);              \
+            else if ((i_) == NA)                                                                   \
+                __builtin_amdgcn_global_load_lds(G3_AS1(bbase + (size_t)(s_) * G2_B), G3_AS3(d_ + OFF_B), 16, 0, NTB ? 2 : 0); \
+            else if constexpr (HI)                                                                 \
+                __builtin_amdgcn_global_load_lds(G3_AS1(hbase + (size_t)(s_) * G2_B), G3_AS3(d_ + OFF_H), 16, 0, NTB ? 2 : 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }
+#define G2G_READ_A(s_)                                                                             \
+        {                                                                                          \
+            const unsigned char* bb = smem + ((s_) % IMGS) * IMG;                                  \
+            _Pragma("unroll") for (int n = 0; n < 2; ++n) bq[0][n] = G2_FRAG(bb + b_off + n * 32 * 32); \
+            _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                        \
+                aq[0][m][1] = G2_FRAG(bb + a_row + m * 32 * G2_ROWB + a_s1);                       \
+                aq[0][m][0] = G2_FRAG(bb + a_row + m * 32 * G2_ROWB + a_s0);                       \
+            }                                                                                      \
+            if constexpr (HI) { _Pragma("unroll") for (int n = 0; n < 2; ++n) bh[0][n] = G2_FRAG(bb + b_off + G2_B + n * 32 * 32); } \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }
+#define G2G_READ_B(s_)                                                                             \
+        {                                                                                          \
+            const unsigned char* bb = smem + ((s_) % IMGS) * IMG;                                  \
+            _Pragma("unroll") for (int m = 2; m < 4; ++m) {                                        \
+                aq[0][m][1] = G2_FRAG(bb + a_row + m * 32 * G2_ROWB + a_s1);                       \
+                aq[0][m][0] = G2_FRAG(bb + a_row + m * 32 * G2_ROWB + a_s0);                       \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }
+#define G2G_STEP(MORE_)                                                                            \
+        {                                                                                          \
+            G3_RAW_BARRIER()                                        /* X_s: image (s + 3) % 4 = (s - 1) % 4 is free */ \
+            G2G_READ_A(s)                                                                          \
+            G2_MFMA(bq, 0, 0, 1) G2_MFMA(bq, 0, 1, 1)                                              \
+            if (MORE_) G2G_PIECE(s + AHEAD, 0)                                                     \
+            G2_MFMA(bq, 0, 0, 0) G2_MFMA(bq, 0, 1, 0)                                              \
+            G2G_READ_B(s)                                                                          \
+            if (MORE_) G2G_PIECE(s + AHEAD, 1)                                                     \
+            if constexpr (HI) { G2_MFMA(bh, 0, 0, 0) G2_MFMA(bh, 0, 1, 0) }                        \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+            /* step s+1 must have landed before Y_s; step s+2 (4 / 3 pieces) and the two pieces of step s+3 just issued may stay in flight */ \
+            if (s + 1 < nst) { if (MORE_) { if constexpr (HI) G3_WAIT_VM(6); else G3_WAIT_VM(5); } else G3_WAIT_VM(0); } \
+            G3_RAW_BARRIER()                                        /* Y_s */                      \
+            G2_MFMA(bq, 0, 2, 1) G2_MFMA(bq, 0, 3, 1)                                              \
+            if (MORE_) G2G_PIECE(s + AHEAD, 2)                                                     \
+            G2_MFMA(bq, 0, 2, 0) G2_MFMA(bq, 0, 3, 0)                                              \
+            if constexpr (HI) { if (MORE_) G2G_PIECE(s + AHEAD, 3)                                 \
+                                G2_MFMA(bh, 0, 2, 0) G2_MFMA(bh, 0, 3, 0) }                        \
+        }
+        {
+            int s = 0;
+            const int n_main = nst - AHEAD;                         // steps that still have a step to request
+            for (; s < n_main; ++s) G2G_STEP(true)
+            for (; s < nst; ++s) G2G_STEP(false)
+        }
+#undef G2G_STEP
+#undef G2G_READ_B
+#undef G2G_READ_A
+#undef G2G_PIECE
+    } else if constexpr (!SPREAD) {
         for (int s = 0; s < nst; ++s) {
             bool hi_blk[NSUB];
 #pragma unroll

@@ -178,8 +178,8 @@ class Engine:
             if vals.size and not vals.all():
                 # a STORED zero (explicit, or a float64 value that underflows in float32) would make the library treat the
                 # arrays as non-canonical and form the dense image of the whole matrix (round-5 advice): compact them here
-                Xc = sp.csr_matrix((vals, X.indices, X.indptr), shape=X.shape)
-                Xc.eliminate_zeros()
+                Xc = sp.csr_matrix((vals, X.indices.copy(), X.indptr.copy()), shape=X.shape)    # (eliminate_zeros works in place:
+                Xc.eliminate_zeros()                                                            #  never on the caller's arrays)
                 X, vals = Xc, np.ascontiguousarray(Xc.data, dtype=np.float32)
             indptr = np.ascontiguousarray(X.indptr, dtype=np.int32)
             indices = np.ascontiguousarray(X.indices, dtype=np.int32)

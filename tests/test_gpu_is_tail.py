@@ -74,6 +74,7 @@ def test_is_refit_f64_vs_oracle(engine, n, g_, k):
     got = []
     for M in (X, sp.csr_matrix(X)):
         engine.set_matrix(M)
+        engine.x_mean = X64.mean()                  # (numpy's dense and scipy's sparse float32 means differ in the last bits)
         W, it, err = engine.mu_refit_f64(H, beta_loss=IS, max_iter=200, warn=False)
         Wt, itt, _ = engine.mu_refit_f64(U.T, transposed=True, beta_loss=IS, max_iter=200, warn=False)
         assert it == n_ref and itt == nt_ref, (it, n_ref, itt, nt_ref)

@@ -237,6 +237,31 @@ def test_general_matrix_on_the_f16_pipe_matches_oracle(engine):
     # against the 3 x 3 bf16 planes of rounds 1-2 (CNMF_G2G=0 is read once per process: compared through the oracle only)
 
 
+def test_general_path_spread_stream_is_bit_identical_to_the_burst_loop(engine, monkeypatch):
+    """Round 6: the general-matrix GEMMs (gemm_mode 5) issue their LDS-DMA pieces between the MFMA groups and read their
+    fragments in two batches (the count kernels' spread stream, kernels_gemm2h.hip.h SPREADG) -- the MFMA order per accumulator
+    is the burst loop's, so every bit of every result must be (CNMF_G2_GVAR=0: the burst loop).  A 256-column batch (pass B
+    split-K, pass A stream-K with cut tiles) and a 1024-column one (four component groups, the identity XCD mapping), with
+    refill, narrowing and partial tiles in the tail."""
+    X = synth.make_config("C3", dtype=np.float32, n_cells=9000)
+    rs = np.random.RandomState(5)
+    X = (X * np.exp(0.3 * rs.standard_normal((X.shape[0], 1)))).astype(np.float32) + np.float32(0.003)
+    engine.set_matrix(X)
+    for n_restarts, kc in ((40, 256), (150, 1024)):
+        ks = [int(k) for k in rs.randint(5, 14, size=n_restarts)]
+        seeds = [int(s) for s in rs.randint(1, 2**31 - 1, size=n_restarts)]
+        H, _, n_iter, viol = engine.nmf_batch(ks, seeds=seeds, max_iter=60, warn=False, kc_max=kc)
+        assert engine.last_stats["kc"] == kc and engine.last_stats["gemm_mode"] == 5, engine.last_stats
+        monkeypatch.setenv("CNMF_G2_GVAR", "0")
+        H0, _, n0, viol0 = engine.nmf_batch(ks, seeds=seeds, max_iter=60, warn=False, kc_max=kc)
+        monkeypatch.delenv("CNMF_G2_GVAR")
+        assert list(n0) == list(n_iter) and np.array_equal(viol, viol0)
+        assert all(np.array_equal(a, b) for a, b in zip(H, H0))
+    _, H_ref, _ = nmf_cd.nmf(X.astype(np.float64), ks[0], seed=seeds[0], max_iter=60)
+    maxabs, relfro = nmf_cd.spectra_error(H_ref, H[0])
+    assert maxabs <= 1e-4 and relfro <= 1e-3, (maxabs, relfro)
+
+
 @pytest.mark.parametrize("g3mode", ["0", "1", "2", "3", "4"])
 def test_full_width_batch_matches_oracle_in_every_gemm_mode(engine, monkeypatch, g3mode):
     """256 packed columns (the width at which the split-operand GEMM takes over): every restart
