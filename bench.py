@@ -411,7 +411,7 @@ def pmc_traffic(key, gemm_mode):
     collected in separate rocprofv3 --pmc passes (tools/gpu_pmc_bench.sh) and committed under
     profiles/ -- counters cannot be read from inside an un-profiled run.  (detail, usable)."""
     name = {0: "r1_pmc_traffic.json", 1: "r1_pmc_traffic_split.json", 2: "r1_pmc_traffic_split.json",
-            3: "r1_pmc_traffic_counts.json", 4: "r5_pmc_traffic_f16.json", 5: "r5_pmc_traffic_general.json"}[gemm_mode]
+            3: "r1_pmc_traffic_counts.json", 4: "r6_pmc_traffic_f16.json", 5: "r6_pmc_traffic_general.json"}[gemm_mode]
     d, verdict = load_profile(name)
     if d is None or key not in d:
         return None, False
@@ -1021,11 +1021,11 @@ def main():
             # measured ceiling of THIS instruction stream with everything but the MFMAs removed (tools/
             # probe_gemm2h_ablate.py var 7): the matrix pipe on non-zero data at the clock the power budget allows --
             # not a roofline, but the reason `frac` cannot approach 1.  Read from a stamped profile, never a literal.
-            abl, verdict = load_profile("r5_gemm2h_ablation.json")
+            abl, verdict = load_profile("r6_gemm2h_ablation.json")
             if abl and "mfma_only_tflops_issued" in abl:
                 issued = ach * per_product * agg["col_iters"] / max(agg["rc_iters"], 1)
                 roof["mfma_only_ablation"] = {"tflops_issued": abl["mfma_only_tflops_issued"],
-                                              "source": "profiles/r5_gemm2h_ablation.json (production pass-B launch shape, random operands)", "stale": verdict,
+                                              "source": "profiles/r6_gemm2h_ablation.json (production pass-B launch shape, random operands)", "stale": verdict,
                                               "issued_over_mfma_only": (issued / abl["mfma_only_tflops_issued"]) if verdict is None else None,
                                               "production_over_mfma_only_on_the_probes_data": (abl.get("production_tflops_issued", 0.0) / abl["mfma_only_tflops_issued"]),
                                               "note": "the ablation probe multiplies RANDOM operands (the chip clocks to its power budget: the "

@@ -86,7 +86,8 @@ def build(force=False, verbose=False, out=None):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     product = os.environ.get("CNMF_PRODUCT_BUILD", "0") not in ("", "0")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-unused-result"] + ([] if product else ["-DCNMF_DEBUG_ABI"]) + [
+           "-Wno-unused-value", "-Wno-unused-result"] + ([] if product else ["-DCNMF_DEBUG_ABI"]) + (
+           os.environ.get("CNMF_HIPCC_FLAGS", "").split()) + [          # (A/B builds: tools/, e.g. -DCNMF_SP_PF=1)
            # MFMA accumulators in plain VGPRs (gfx950 has one unified file): no v_accvgpr moves around the
            # elementwise work between chained MFMAs (kernels_mu_mfma.hip.h)
            "-mllvm", "-amdgpu-mfma-vgpr-form=1",

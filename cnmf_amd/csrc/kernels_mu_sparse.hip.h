@@ -35,6 +35,10 @@ struct BSellDev {
 
 constexpr int SP_WAVES = 16;                      // slices per workgroup (1024 threads: 4 waves per SIMD, one workgroup per CU)
 constexpr int SP_LDS_BYTES = 128 * 1024;
+#ifndef CNMF_SP_PF
+#define CNMF_SP_PF 1                              // (2 measured in round 6: 128 registers + 4-5 spilled, 117 vs 113-115 us per
+#endif                                            //  restart-iteration at 200 000 x 2 000 / 9 %: profiles/r6_mu_sparse_prefetch_ab.txt)
+constexpr int SP_PF = CNMF_SP_PF;                 // trips the entry stream is requested ahead of the gathers
 constexpr int SP_UNROLL = 4;                      // lengths are padded to it: up to four entries per lane and trip
 
 // ---- build, pass 1: non-zeros of every row of M [R][ld] inside every block of BS columns
@@ -266,14 +270,26 @@ __device__ __forceinline__ void sp_slices(const BSellDev& A, const MuSlotDev& sd
         const int L = __builtin_amdgcn_readfirstlane(A.len[(size_t)s * A.nblk + blk]);
         const uint2* ep = A.ent + A.off[(size_t)s * A.nblk + blk] + lane;
         constexpr int U = NQ <= 4 ? 4 : (NQ <= 5 ? 2 : 1);                  // gathers in flight per lane (registers: no spills)
-        uint2 nxt[U];
+        // the entry stream runs SP_PF trips ahead of the gathers (-DCNMF_SP_PF=2: two trips, an A/B build -- measured no faster)
+        uint2 nxt[U], nx2[SP_PF > 1 ? U : 1];
 #pragma unroll
         for (int u = 0; u < U; ++u) nxt[u] = L > 0 ? ep[(size_t)u * 64] : uint2{0u, 0u};
+        if constexpr (SP_PF > 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nx2[u] = U < L ? ep[(size_t)(U + u) * 64] : uint2{0u, 0u};
+        }
         for (int t = 0; t < L; t += U) {
             uint2 e[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) e[u] = nxt[u];
-            if (t + U < L) {
+            if constexpr (SP_PF > 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) nxt[u] = nx2[u];
+                if (t + 2 * U < L) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) nx2[u] = ep[(size_t)(t + 2 * U + u) * 64];
+                }
+            } else if (t + U < L) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) nxt[u] = ep[(size_t)(t + U + u) * 64];
             }
