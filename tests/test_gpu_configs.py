@@ -27,6 +27,9 @@ def test_C2_full_ledger_sampled_parity(engine):
     ks = [k for k, _, _ in led]
     seeds = [s for _, _, s in led]
     H, _, n_iter, viol = engine.nmf_batch(ks, seeds=seeds, warn=False)
+    # round 6: a job of >= 512 columns runs wide on a small matrix too (1 000 columns in ONE 1024-column batch on the f16
+    # count kernels instead of four 256-column rounds: 17.5 -> 8.6 ms per job)
+    assert engine.last_stats["kc"] == 1024 and engine.last_stats["gemm_mode"] == 4, engine.last_stats
     assert len(H) == 100 and all(h.shape == (10, X.shape[1]) for h in H)
     assert (n_iter >= 1).all() and (n_iter <= 1000).all()
     conv = n_iter < 1000
@@ -237,3 +240,25 @@ def test_C2_full_pipeline_consensus_spectra_vs_cpu_reference(engine, K):
     assert ((med - ref) ** 2).sum() < 1e-4                              # the reference's TOLERANCE
     assert np.linalg.norm(med - ref) <= 1e-3 * np.linalg.norm(ref)
     assert np.abs(med - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("wide", ["1", "0"])
+def test_small_matrix_wide_batch_matches_oracle(engine, monkeypatch, wide):
+    """Round 6 (`wide_small` in batch_host.hip.h): the tutorial-sized matrix (1000 x 500 -> 1024 x 512 padded: four cell tiles,
+    two gene tiles) with a job of 120 restarts (~840 columns): the batch is as wide as the job (CNMF_WIDE_SMALL=0: 256 columns,
+    the round-5 rule), every sampled restart against its float64 oracle run, and the two widths agree restart by restart."""
+    monkeypatch.setenv("CNMF_WIDE_SMALL", wide)
+    X = synth.make_config("C1", dtype=np.float64)
+    engine.set_matrix(X)
+    rs = np.random.RandomState(23)
+    ks = [int(k) for k in rs.randint(5, 10, size=120)]
+    seeds = [int(s) for s in rs.randint(1, 2**31 - 1, size=120)]
+    H, _, n_iter, viol = engine.nmf_batch(ks, seeds=seeds, warn=False)
+    st = engine.last_stats
+    assert st["kc"] == (1024 if wide == "1" else 256) and st["gemm_mode"] == 4, st
+    assert (viol[n_iter < 1000] <= 1e-4).all()
+    for r in range(0, 120, 9):
+        _, H_ref, n_ref = nmf_cd.nmf(X, ks[r], seed=seeds[r])
+        maxabs, relfro = nmf_cd.spectra_error(H_ref, H[r])
+        assert abs(int(n_iter[r]) - n_ref) <= max(3, n_ref // 100), (r, n_iter[r], n_ref)
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (r, maxabs, relfro)
