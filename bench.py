@@ -690,6 +690,11 @@ def form_transport(bootstrap, rank, world, id_path, allow_fallback, explicit=Fal
       headline."""
     from cnmf_amd import dist as cd
     err = None
+    if world > 1:
+        try:
+            os.remove("%s.status.%d" % (id_path, rank))      # (a stale report of an earlier launch under the same name)
+        except OSError:
+            pass
     try:
         bootstrap()
     except Exception as e:                           # noqa: BLE001 -- whatever the library / the rendezvous raised
@@ -1132,6 +1137,11 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
     barrier()
+    if multi and world > 1:
+        try:                                      # (every rank is past the barrier: nobody reads the reports any more)
+            os.remove("%s.status.%d" % (id_path, rank))
+        except (OSError, NameError):
+            pass
     if dist is not None:
         dist.destroy_process_group()
     if gather_mode == "rccl":

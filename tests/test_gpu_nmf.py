@@ -257,6 +257,12 @@ def test_general_path_spread_stream_is_bit_identical_to_the_burst_loop(engine, m
         monkeypatch.delenv("CNMF_G2_GVAR")
         assert list(n0) == list(n_iter) and np.array_equal(viol, viol0)
         assert all(np.array_equal(a, b) for a, b in zip(H, H0))
+        # the opt-in partial-tile passes of the tail (CNMF_PART=1: dead 32-column tiles are neither multiplied nor stored) on
+        # the same stream: what a live restart computes does not change
+        monkeypatch.setenv("CNMF_PART", "1")
+        Hp, _, n_p, violp = engine.nmf_batch(ks, seeds=seeds, max_iter=60, warn=False, kc_max=kc)
+        monkeypatch.delenv("CNMF_PART")
+        assert list(n_p) == list(n_iter) and all(np.array_equal(a, b) for a, b in zip(H, Hp))
     _, H_ref, _ = nmf_cd.nmf(X.astype(np.float64), ks[0], seed=seeds[0], max_iter=60)
     maxabs, relfro = nmf_cd.spectra_error(H_ref, H[0])
     assert maxabs <= 1e-4 and relfro <= 1e-3, (maxabs, relfro)
