@@ -89,6 +89,9 @@ struct PlaneOut {
 // PSUM: the products arrive as `sp.mgroups` split-K partial planes (stride sp.tile_rows * 2^20 + sp.tile_cols floats,
 // see psum_info) that are summed here in split order and scaled by the per-row constant sp.split (reinterpreted as
 // const double*) -- the work of reduce_splits_kernel folded into the H half-step (no extra launch, no extra pass).
+#ifndef CNMF_SWEEP_PF
+#define CNMF_SWEEP_PF 0
+#endif
 template <int KP, bool RMX, bool PSUM = false, bool PLN = false>
 __device__ __forceinline__ void sweep_body(
     float* __restrict__ V, int ldv, int L, const float* __restrict__ P, const SplitInfo& sp,
@@ -132,6 +135,20 @@ __device__ __forceinline__ void sweep_body(
 #pragma unroll
     for (int c = 0; c < (RMX ? KP : 1); ++c) mx[c] = 0.f;
 
+    // Software prefetch (round 6 experiment, -DCNMF_SWEEP_PF=1; W half-step only; NOT adopted): the factor and product values
+    // of chunk ch + 1 are requested before chunk ch is computed.  Same arithmetic, same bits; 2 KP more registers = 128 + 20
+    // spilled and 4 instead of 5 waves per SIMD: 217.6 against 228.9 restarts/s (profiles/r6_sweep_prefetch_ab.txt).
+    constexpr bool PF = (CNMF_SWEEP_PF != 0) && !PSUM;
+    float wn[PF ? KP : 1], pn[PF ? KP : 1];
+    if constexpr (PF) {
+        const int rowc0 = min((int)(blockIdx.x * chunks_per_block) * 256 + tid, L - 1);
+#pragma unroll
+        for (int c = 0; c < KP; ++c) {
+            const size_t idx = (size_t)(off + min(c, k - 1)) * ldv + rowc0;
+            wn[c] = V[idx];
+            pn[c] = P[idx];
+        }
+    }
     for (int ch = 0; ch < chunks_per_block; ++ch) {
         const int row = (blockIdx.x * chunks_per_block + ch) * 256 + tid;
         const bool live = row < L;
@@ -155,11 +172,25 @@ __device__ __forceinline__ void sweep_body(
             // clamped (always valid) addresses; the values of dead lanes / columns >= k are
             // discarded by selects.  (Per-column branches serialise the memory latency.)
             const int rowc = min(row, L - 1);
+            if constexpr (PF) {
+#pragma unroll
+                for (int c = 0; c < KP; ++c) { w[c] = wn[c]; p[c] = pn[c]; }
+                if (ch + 1 < chunks_per_block) {                 // (uniform over the workgroup)
+                    const int rown = min(row + 256, L - 1);
+#pragma unroll
+                    for (int c = 0; c < KP; ++c) {
+                        const size_t idx = (size_t)(off + min(c, k - 1)) * ldv + rown;
+                        wn[c] = V[idx];
+                        pn[c] = P[idx];
+                    }
+                }
+            } else {
 #pragma unroll
             for (int c = 0; c < KP; ++c) {
                 const size_t idx = (size_t)(off + min(c, k - 1)) * ldv + rowc;
                 w[c] = V[idx];
                 p[c] = P[idx];
+            }
             }
             if constexpr (PSUM) {
                 const int nsplit = sp.mgroups;
