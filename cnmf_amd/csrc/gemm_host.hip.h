@@ -321,7 +321,7 @@ static int ensure_planes(cnmf_ctx* ctx)
     HIP_TRY(ctx, hipMalloc(&ctx->X3, bA));
     HIP_TRY(ctx, hipMalloc(&ctx->Xt3, bB));
     HIP_TRY(ctx, launch_split3(ctx->stream, ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->X3, TR));
-    dim3 grid((ctx->G_pad + 255) / 256, ctx->N_pad / 16);
+    dim3 grid(ctx->N_pad / 16, (ctx->G_pad + 255) / 256);
     split3_transpose_kernel<<<grid, 256, 0, ctx->stream>>>(ctx->X, ctx->G_pad, ctx->N_pad, ctx->G_pad, ctx->N_pad,
                                                             TR, (unsigned short*)ctx->Xt3);
     HIP_TRY(ctx, hipGetLastError());
@@ -359,7 +359,7 @@ static int ensure_x2planes(cnmf_ctx* ctx)
         const long long total = (long long)Np * (Gp / 16);
         x2h_planes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(ctx->X, Gp, N, G, Np, Gp, G3C_JW, shA,
                                                                             (unsigned short*)a, (unsigned short*)am);
-        x2h_planes_transpose_kernel<<<dim3((Gp + 255) / 256, Np / 16), 256, 0, st>>>(ctx->X, Gp, N, G, Gp, Np, G3C_JW, shB,
+        x2h_planes_transpose_kernel<<<dim3(Np / 16, (Gp + 255) / 256), 256, 0, st>>>(ctx->X, Gp, N, G, Gp, Np, G3C_JW, shB,
                                                                                     (unsigned short*)b, (unsigned short*)bm);
         e = hipGetLastError();
     }
@@ -660,7 +660,7 @@ static int ensure_counts(cnmf_ctx* ctx)
     }
     {
         const long long total = (long long)ctx->N_pad * (ctx->G_pad / 16);
-        dim3 gt((ctx->G_pad + 255) / 256, ctx->N_pad / 16);
+        dim3 gt(ctx->N_pad / 16, (ctx->G_pad + 255) / 256);
         if (fmt == 4) {
             count_planes_f16_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
                 ctx->X, ctx->G_pad, N, G, ctx->N_pad, ctx->G_pad, G3C_JW, unit, (unsigned short*)ctx->C1,
@@ -686,9 +686,11 @@ static int ensure_counts(cnmf_ctx* ctx)
 // the split-operand path needs whole 256 x 128 tiles
 static bool gemm3_enabled(const cnmf_ctx* ctx, int KC)
 {
-    // (the plane builders index 16-cell blocks with blockIdx.y: up to 65 535 x 16 cells)
+    // (round 6: the plane builders carry the 16-cell blocks on grid.x, so matrices beyond 65 535 x 16 = 1 048 560 cells keep the
+    //  matrix-pipe path -- probed at 1 100 000 x 2 000, 2.25e9 padded elements: tools/probe_big_matrix.py; bounded at 2^24 cells
+    //  only because nothing larger has been run; the gene side still rides on grid.y of those builders: G_pad / 256 <= 65 535)
     return gemm3_mode() != 0 && KC % G3_MW == 0 && ctx->G_pad % gemm3_jw() == 0 && ctx->N_pad % gemm3_jw() == 0 &&
-           ctx->N_pad / 16 <= 65535 && ctx->G_pad / 16 <= 65535;
+           ctx->N_pad <= (1 << 24) && ctx->G_pad / 256 <= 65535;
 }
 
 static int pick_nsplit3(const cnmf_ctx* ctx, int KC, int jw)

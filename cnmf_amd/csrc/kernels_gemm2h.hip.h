@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void count_planes_f16_transpose_kernel(const f
                                                                          unsigned short* __restrict__ dst_hi,
                                                                          unsigned int* __restrict__ hiflag)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int kb = blockIdx.y;
+    const int j = blockIdx.y * 256 + threadIdx.x;       // (grid = (16-k blocks, row groups): the long dimension on x -- no 65 535 limit)
+    const int kb = blockIdx.x;
     if (j >= rows_pad) return;
     const int Kb = K / 16;
     const float u = (j < G) ? unit[j] : 0.f;
@@ -379,8 +379,8 @@ __global__ __launch_bounds__(256) void x2h_planes_transpose_kernel(const float* 
                                                                    unsigned short* __restrict__ dst_h,
                                                                    unsigned short* __restrict__ dst_m)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int kb = blockIdx.y;
+    const int j = blockIdx.y * 256 + threadIdx.x;       // (grid = (16-k blocks, row groups): the long dimension on x -- no 65 535 limit)
+    const int kb = blockIdx.x;
     if (j >= rows_pad) return;
     const int Kb = K / 16;
     const int s = shift[j];

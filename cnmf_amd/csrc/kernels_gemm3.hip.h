@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s
 __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ src, int ld, int src_rows,
                                                                int J, int K, int TR, unsigned short* __restrict__ dst)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int kb = blockIdx.y;
+    const int j = blockIdx.y * 256 + threadIdx.x;       // (grid = (16-k blocks, row groups): the long dimension on x -- no 65 535 limit)
+    const int kb = blockIdx.x;
     if (j >= J) return;
     const int Kb = K / 16;
     unsigned short p[3][16];

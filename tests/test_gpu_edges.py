@@ -4,6 +4,7 @@ regularisation strong enough to zero a factor (violation_init == 0 path)."""
 import numpy as np
 import pytest
 
+from cnmf_amd import synth
 from oracle import nmf_cd
 
 pytestmark = pytest.mark.gpu
@@ -275,3 +276,39 @@ def test_round4_entry_points_at_their_edges(engine):
     big = np.empty(-need, dtype=np.uint8)
     n = lib.cnmf_format_rows_f64(v.ctypes.data_as(C.POINTER(C.c_double)), 4, 3, b"\t", None, 0, big.ctypes.data_as(C.c_void_p), big.size)
     assert bytes(big[:n]).decode() == "".join("\t".join(repr(float(x)) for x in row) + "\n" for row in v)
+
+
+def test_matrix_beyond_2_31_padded_elements_keeps_the_matrix_pipe_path(engine):
+    """Maximum sizes (round 6): 1 100 000 cells x 2 000 genes = 2.25e9 padded elements, count planes of 4.5 GB -- beyond the
+    65 535 x 16 cells the plane builders' launch grid allowed until round 6 (such a matrix silently fell back to the
+    exact-f32 pipe at 256 columns).  The default f16 count path at 1024 packed columns against the SAME restarts on the
+    exact-f32 matrix pipe at 32 columns (other kernels, other index arithmetic): a 32-bit overflow in either shows as a
+    mismatch or a fault; the LAST cells take part through a usage refit checked in float64.  (tools/probe_big_matrix.py is
+    the same with independently drawn cells.)"""
+    avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
+    if avail < 48:
+        pytest.skip("needs ~30 GB of host memory (%.0f GB available)" % avail)
+    base = synth.make_config("C3", dtype=np.float32, n_cells=100_000)
+    n_tiles, n_cells = 11, 1_100_000
+    X = np.empty((n_cells, base.shape[1]), dtype=np.float32)
+    for t in range(n_tiles):                                  # distinct row order per tile: a wrong-tile read is a wrong row
+        X[t * 100_000:(t + 1) * 100_000] = np.roll(base, 7919 * t, axis=0)
+    del base
+    engine.set_matrix(X)
+    ks = [9] * 100 + [13] * 10                                # 1 030 columns: a 1024-wide batch with a queue
+    seeds = list(range(7, 7 + len(ks)))
+    H, _, n, _ = engine.nmf_batch(ks, seeds=seeds, max_iter=5, tol=0.0, warn=False)
+    st = engine.last_stats
+    assert st["kc"] == 1024 and st["gemm_mode"] == 4, st
+    sel = [0, 57, 105]
+    H32, _, _, _ = engine.nmf_batch([ks[i] for i in sel], seeds=[seeds[i] for i in sel], max_iter=5, tol=0.0, warn=False, kc_max=32)
+    assert engine.last_stats["gemm_mode"] == 0
+    for j, i in enumerate(sel):
+        maxabs, relfro = nmf_cd.spectra_error(H32[j].astype(np.float64), H[i])
+        assert maxabs <= 1e-4 and relfro <= 1e-3, (i, maxabs, relfro)
+    Hn = H[0] / H[0].sum(axis=1, keepdims=True)
+    Wd, _ = engine.nnls(Hn, max_iter=30, warn=False)
+    tail = slice(n_cells - 2000, n_cells)
+    W_ref, _ = nmf_cd.nnls(X[tail].astype(np.float64), Hn.astype(np.float64), max_iter=30)
+    assert np.abs(Wd[tail] - W_ref).max() <= 2e-3 * np.abs(W_ref).max()
+    engine.set_matrix(np.ones((4, 4), dtype=np.float32))      # release the 9 GB image and its planes for the tests that follow
