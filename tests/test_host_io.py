@@ -82,3 +82,24 @@ def test_text_writer_is_byte_identical_to_pandas(tmp_path):
         m.save_df_to_text(df, got)
         df.to_csv(ref, sep="\t")
         assert open(got, "rb").read() == open(ref, "rb").read(), name
+
+
+def test_large_float_tables_are_stored_not_deflated_and_read_back_identically(tmp_path):
+    """save_df_to_npz keeps the reference's container (cnmf.py:31-32: three members data / index / columns read back with
+    np.load) -- a float ``data`` member of a megabyte or more is stored instead of deflated (zlib gains ~1 % on float64
+    mantissas and was the critical path of consensus()'s artefact writes); small tables are deflated as before."""
+    import zipfile
+    from cnmf_amd.cnmf import save_df_to_npz, load_df_from_npz
+    rs = np.random.RandomState(0)
+    big = pd.DataFrame(rs.rand(20000, 9), index=["cell%d" % i for i in range(20000)], columns=np.arange(1, 10))
+    small = pd.DataFrame(rs.rand(9, 300), index=np.arange(1, 10), columns=["g%d" % j for j in range(300)])
+    for name, df, stored in (("big", big, True), ("small", small, False)):
+        fn = str(tmp_path / (name + ".df.npz"))
+        save_df_to_npz(df, fn)
+        with zipfile.ZipFile(fn) as zf:
+            info = {i.filename: i.compress_type for i in zf.infolist()}
+        assert set(info) == {"data.npy", "index.npy", "columns.npy"}
+        assert (info["data.npy"] == zipfile.ZIP_STORED) == stored and info["index.npy"] == zipfile.ZIP_DEFLATED
+        with np.load(fn, allow_pickle=True) as f:                  # exactly the reference's load_df_from_npz (cnmf.py:36-38)
+            back = pd.DataFrame(**f)
+        assert back.equals(df) and load_df_from_npz(fn).equals(df)
