@@ -756,8 +756,9 @@ def main():
             def fake_bootstrap():
                 if rank in bad:
                     raise RuntimeError("ncclCommInitRank: simulated failure on rank %d" % rank)
-            mode, fb = form_transport(fake_bootstrap, rank, world, os.environ["CNMF_RCCL_ID_FILE"], args.allow_transport_fallback,
-                                      timeout=20.0)
+            idp = os.environ.get("CNMF_RCCL_ID_FILE") or os.path.join(
+                "/tmp", "cnmf_rccl_id.%d.%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))     # (as the real path below)
+            mode, fb = form_transport(fake_bootstrap, rank, world, idp, args.allow_transport_fallback, timeout=20.0)
             if rank == 0:
                 print(json.dumps({"n_gpus": world, "gather": mode, "gather_fallback": fb,
                                   "metric": (FALLBACK_METRIC if fb else "NMF restarts/sec") + " (selftest)"}))
